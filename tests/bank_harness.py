@@ -1,0 +1,62 @@
+"""The modal render harness of the reference's audio tests, restated (tests/ModalBench.h:14-81):
+SampleStrip / MakeModes / ImpactEvent / ModalScene.  OracleScene drives the CPU oracle; tests/test_bank_gpu.py
+drives the HIP bank through the same interface.
+"""
+import numpy as np
+
+SAMPLE_RATE = 48000.0
+BLOCK = 512
+SAMPLE_POINTS = 4
+
+
+def sample_strip():
+    """tests/ModalBench.h:19-24: a strip of alternating depth so consecutive triples form triangles."""
+    pos = np.array([[p * 0.01, 0.0, 0.02 if p % 2 else 0.0] for p in range(SAMPLE_POINTS)], np.float32)
+    idx = np.array([[p, p + 1, p + 2] for p in range(SAMPLE_POINTS - 2)], np.uint32).reshape(-1)
+    return pos, idx
+
+
+def make_modes(mode_count, longest_t60, shape_scale=1.0, freq_scale=1.0):
+    """tests/ModalBench.h:26-40 (float arithmetic as the reference)."""
+    k = np.arange(mode_count, dtype=np.float32)
+    freqs = (np.float32(40.0) * (k + np.float32(1)) * np.float32(1.031) * np.float32(freq_scale)).astype(np.float32)
+    t60s = (np.float32(longest_t60) / (k + np.float32(1))).astype(np.float32)
+    pos, idx = sample_strip()
+    shapes = np.zeros((SAMPLE_POINTS, mode_count, 3), np.float32)
+    for p in range(SAMPLE_POINTS):
+        a = ((k + np.float32(1)) * np.float32(0.37) + np.float32(p)).astype(np.float32)
+        s = np.stack([np.sin(a), np.cos(a * np.float32(1.7)), np.sin(a * np.float32(2.3))], -1).astype(np.float32)
+        shapes[p] = s * np.float32(0.01) * np.float32(shape_scale)
+    return {"freqs": freqs, "t60s": t60s, "shapes": shapes, "positions": pos, "indices": idx}
+
+
+def impact_event(oracle, obj, impulse, ex_pos=0, pulse_step=1.0 / 300.0):
+    """tests/ModalBench.h:42-44"""
+    return oracle.Event(0, obj, ex_pos, impulse, 0.5 * impulse, 0.0, pulse_step, 20.0, 0.0, 0.0, 0.0, 0.0)
+
+
+class OracleScene:
+    """tests/ModalBench.h:47-81 over the CPU oracle."""
+
+    def __init__(self, oracle, object_count, mode_count, longest_t60, renderers, sample_rate=SAMPLE_RATE, use_double=False, modes=None):
+        self.dtype = np.float64 if use_double else np.float32
+        self.bank = oracle.Bank(sample_rate, use_double)
+        self.bank.set_renderers(renderers)
+        modes = modes or make_modes(mode_count, longest_t60)
+        self.objects = []
+        for o in range(object_count):
+            slot = self.bank.add_object(o, modes["shapes"], modes["positions"], modes["indices"])
+            self.bank.tune_object(slot, modes["freqs"], modes["t60s"])
+            self.bank.set_gains(slot, 1.0, 1.0)
+            self.objects.append(slot)
+        self.bank.install()
+        self.bank.render(np.zeros(BLOCK, self.dtype))
+
+    def enqueue(self, ev):
+        return self.bank.enqueue(ev)
+
+    def render(self, blocks, frames):
+        sig = np.zeros(blocks * frames, self.dtype)
+        for b in range(blocks):
+            self.bank.render(sig[b * frames:(b + 1) * frames])
+        return sig
