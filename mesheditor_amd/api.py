@@ -1,0 +1,292 @@
+"""Python binding of the C ABI (include/modalhip.h) plus mesh2modes(), the same orchestration the C++ mirror of
+modal::mesh2modes performs (reference src/audio/mesh2modes.cpp:605-658): FilterDegenerate/BuildQuadMesh/Assemble on
+the device, excitation sampling, eigensolve, shape gather, PostprocessModes.  Used by tests and bench.py."""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import Material, Profile, SolverConfig  # noqa: F401
+
+ERRORS = {1: "EINVAL", 2: "EHIP", 3: "ECANCELLED", 4: "ENOTCONVERGED", 5: "EFACTOR", 6: "EEMPTY"}
+
+
+class ModalHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"modalhip {ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def material(density, young, poisson, alpha=0.0, beta=0.0):
+    return Material(density, young, poisson, alpha, beta)
+
+
+def default_config(**kw):
+    cfg = SolverConfig()
+    _lib.lib().mh_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if k == "fundamental_freq":
+            cfg.has_fundamental, cfg.fundamental_freq = (0, 0.0) if v is None else (1, v)
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.mh_context_create(device, C.byref(h))
+        if rc != 0:
+            raise ModalHipError(rc, "mh_context_create failed (no MI355X visible?)")
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            raise ModalHipError(rc, (self.L.mh_last_error(self.h) or b"").decode())
+
+    def synchronize(self):
+        self.check(self.L.mh_context_synchronize(self.h))
+
+    def time_kernels(self, enable=True):
+        self.check(self.L.mh_context_time_kernels(self.h, int(enable)))
+
+    def kernel_stats(self):
+        n, ms, by = C.c_uint64(0), C.c_double(0), C.c_double(0)
+        self.check(self.L.mh_context_kernel_stats(self.h, C.byref(n), C.byref(ms), C.byref(by)))
+        return {"launches": n.value, "total_ms": ms.value, "total_bytes": by.value}
+
+    @property
+    def stream(self):
+        return self.L.mh_context_stream(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.mh_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mesh:
+    def __init__(self, ctx, points, tets):
+        self.ctx = ctx
+        self.points = np.ascontiguousarray(points, dtype=np.float64)
+        self.tets = np.ascontiguousarray(tets, dtype=np.uint32)
+        h = C.c_void_p()
+        ctx.check(ctx.L.mh_mesh_create(ctx.h, len(self.points), _p(self.points), len(self.tets), _p(self.tets), C.byref(h)))
+        self.h = h
+
+    def nearest_points(self, positions):
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        out = np.zeros(len(pos), np.uint32)
+        self.ctx.check(self.ctx.L.mh_nearest_points(self.ctx.h, self.h, len(pos), _p(pos), _p(out)))
+        return out
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.mh_mesh_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class System:
+    """mh_assemble: K (3x3 node blocks) and M (node scalars) resident in HBM."""
+
+    def __init__(self, ctx, mesh, mat):
+        self.ctx, self.mesh, self.mat = ctx, mesh, mat
+        h = C.c_void_p()
+        ctx.check(ctx.L.mh_assemble(ctx.h, mesh.h, C.byref(mat), C.byref(h)))
+        self.h = h
+        dofs, nodes, kept, nb = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        ctx.check(ctx.L.mh_system_dims(h, C.byref(dofs), C.byref(nodes), C.byref(kept), C.byref(nb)))
+        self.n, self.node_count, self.kept_tets, self.node_blocks = dofs.value, nodes.value, kept.value, nb.value
+
+    def element_nodes(self):
+        out = np.zeros((self.kept_tets, 10), np.uint32)
+        self.ctx.check(self.ctx.L.mh_system_element_nodes(self.h, _p(out)))
+        return out
+
+    def export_blocks(self):
+        nb = self.node_blocks
+        r, c, k, m = np.zeros(nb, np.uint32), np.zeros(nb, np.uint32), np.zeros((nb, 3, 3)), np.zeros(nb)
+        self.ctx.check(self.ctx.L.mh_system_export_blocks(self.h, _p(r), _p(c), _p(k), _p(m)))
+        return r, c, k, m
+
+    def to_scipy(self):
+        """(K, M) as scipy CSR in the reference's DOF order."""
+        import scipy.sparse as sp
+        r, c, k, m = self.export_blocks()
+        rows = (3 * r[:, None, None] + np.arange(3)[None, :, None]) + 0 * np.arange(3)[None, None, :]
+        cols = (3 * c[:, None, None] + np.arange(3)[None, None, :]) + 0 * np.arange(3)[None, :, None]
+        K = sp.coo_matrix((k.ravel(), (rows.ravel(), cols.ravel())), shape=(self.n, self.n)).tocsr()
+        Mn = sp.coo_matrix((m, (r, c)), shape=(self.node_count, self.node_count)).tocsr()
+        return K, sp.kron(Mn, sp.identity(3), format="csr")
+
+    def matvec(self, which, x):
+        x = np.asfortranarray(np.atleast_2d(np.asarray(x, dtype=np.float64).T).T if np.ndim(x) == 1 else x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1, order="F")
+        y = np.zeros_like(x, order="F")
+        self.ctx.check(self.ctx.L.mh_system_matvec(self.h, which, _p(x), _p(y), x.shape[1]))
+        return y
+
+    def eigs(self, nev, sigma=-(2 * np.pi * 20.0) ** 2, residual_tol=1e-6, max_iters=200, seed_basis=None):
+        ev = np.zeros(nev)
+        prof = Profile()
+        seed, rows, cols = None, 0, 0
+        if seed_basis is not None:
+            seed = np.asfortranarray(seed_basis, dtype=np.float32)
+            rows, cols = seed.shape
+        self.ctx.check(self.ctx.L.mh_eigs(self.h, nev, sigma, residual_tol, max_iters, _p(seed), rows, cols, None, None, _p(ev), C.byref(prof)))
+        return ev, prof.as_dict()
+
+    def gather_shapes(self, nodes, ncols):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+        out = np.zeros((len(nodes), ncols, 3), np.float32)
+        self.ctx.check(self.ctx.L.mh_system_gather_shapes(self.h, len(nodes), _p(nodes), ncols, _p(out)))
+        return out
+
+    def basis(self, ncols):
+        out = np.zeros((self.n, ncols), np.float32, order="F")
+        self.ctx.check(self.ctx.L.mh_system_basis(self.h, ncols, _p(out)))
+        return out
+
+    def eigenvectors(self, ncols):
+        out = np.zeros((self.n, ncols), np.float64, order="F")
+        self.ctx.check(self.ctx.L.mh_system_eigenvectors(self.h, ncols, _p(out)))
+        return out
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.mh_system_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mass_properties(points, tets, density, scale=(1, 1, 1), length_to_si=1.0):
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    tets = np.ascontiguousarray(tets, dtype=np.uint32)
+    sc = np.asarray(scale, np.float32)
+    mp = _lib.MassProps()
+    rc = _lib.lib().mh_compute_mass_properties(len(points), _p(points), len(tets), _p(tets), density, _p(sc), length_to_si, C.byref(mp))
+    if rc:
+        raise ModalHipError(rc, "mh_compute_mass_properties")
+    return mp.mass, np.array(mp.center_of_mass), np.array(mp.inertia_diagonal), np.array(mp.inertia_orientation_wxyz)
+
+
+def postprocess_modes(eigenvalues, shapes, shape_scale, mat, cfg):
+    ev = np.ascontiguousarray(eigenvalues, dtype=np.float64)
+    sh = np.ascontiguousarray(shapes, dtype=np.float32)
+    npos, n = sh.shape[0], len(ev)
+    freqs, t60s, out = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(npos * n * 3, np.float32)
+    k, orig = C.c_uint32(0), C.c_float(0)
+    rc = _lib.lib().mh_postprocess_modes(n, _p(ev), npos, _p(sh), shape_scale, C.byref(mat), C.byref(cfg), C.byref(k), _p(freqs), _p(t60s), _p(out), C.byref(orig))
+    if rc:
+        raise ModalHipError(rc, "mh_postprocess_modes")
+    k = k.value
+    return freqs[:k].copy(), t60s[:k].copy(), out[: npos * k * 3].reshape(npos, k, 3).copy(), orig.value
+
+
+def rescale_modes(eigenvalues, summary_shapes, solved, edited, cfg):
+    ev = np.ascontiguousarray(eigenvalues, dtype=np.float64)
+    sh = np.ascontiguousarray(summary_shapes, dtype=np.float32)
+    npos, n = sh.shape[0], len(ev)
+    freqs, t60s, out = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(npos * n * 3, np.float32)
+    k, orig, ok = C.c_uint32(0), C.c_float(0), C.c_int(0)
+    rc = _lib.lib().mh_rescale_modes(n, _p(ev), npos, _p(sh), C.byref(solved), C.byref(edited), C.byref(cfg), C.byref(ok), C.byref(k), _p(freqs), _p(t60s), _p(out), C.byref(orig))
+    if rc:
+        raise ModalHipError(rc, "mh_rescale_modes")
+    if not ok.value:
+        return None
+    k = k.value
+    return freqs[:k].copy(), t60s[:k].copy(), out[: npos * k * 3].reshape(npos, k, 3).copy(), orig.value
+
+
+@dataclass
+class ModalResult:
+    freqs: np.ndarray
+    t60s: np.ndarray
+    shapes: np.ndarray
+    positions: np.ndarray
+    original_fundamental: float
+    eigenvalues: np.ndarray
+    summary_shapes: np.ndarray
+    mass: float
+    center_of_mass: np.ndarray
+    inertia_diagonal: np.ndarray
+    inertia_orientation_wxyz: np.ndarray
+    profile: dict
+    sample_point_of_excitation: np.ndarray
+    basis: np.ndarray = field(default=None)
+    system: object = field(default=None, repr=False)
+
+
+def residual_tolerance(cfg):
+    """SolverConfig::Tolerance is Spectra's Ritz-value tolerance; a relative residual r gives an eigenvalue error ~ r^2,
+    so sqrt(tol)/10 meets it with margin (1e-5 for the default 1e-8)."""
+    return float(min(1e-4, max(1e-9, 0.1 * np.sqrt(cfg.tolerance))))
+
+
+def mesh2modes(ctx, points, tets, mat, excite_positions, baked_scale=(1.0, 1.0, 1.0), config=None, seed_basis=None, keep_basis=False, mesh=None, keep_system=False):
+    """modal::mesh2modes over the C ABI.  Failure/cancel -> empty result, as the reference."""
+    cfg = config or default_config()
+    scale = np.asarray(baked_scale, dtype=np.float32)
+    length_to_si = (float(scale[0]) + float(scale[1]) + float(scale[2])) / 3.0
+    own_mesh = mesh is None
+    mesh = mesh or Mesh(ctx, points, tets)
+    mass, com, inertia, quat = mass_properties(mesh.points, mesh.tets, mat.density, scale, length_to_si)
+    system = System(ctx, mesh, mat)
+    ex = np.ascontiguousarray(excite_positions, dtype=np.float32).reshape(-1, 3)
+    nearest = mesh.nearest_points(ex)
+    # first-seen de-duplication (mesh2modes.cpp:637-642)
+    sample_of, pts, remap = {}, [], np.zeros(len(ex), np.uint32)
+    for i, v in enumerate(nearest):
+        if int(v) not in sample_of:
+            sample_of[int(v)] = len(pts)
+            pts.append(int(v))
+        remap[i] = sample_of[int(v)]
+    pts = np.array(pts, np.uint32)
+    positions = (mesh.points[pts] / scale.astype(np.float64)).astype(np.float32) if len(pts) else np.zeros((0, 3), np.float32)
+    n = system.n
+    nev = min(cfg.num_fem_modes, n - 1)
+    sigma = -float(np.float64(2 * np.pi * np.float64(cfg.min_mode_freq)) ** 2)
+    empty = ModalResult(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros((len(pts), 0, 3), np.float32), positions, 0.0, np.zeros(0),
+                        np.zeros((len(pts), 0, 3), np.float32), mass, com, inertia, quat, {}, remap)
+    try:
+        warm = seed_basis is not None and seed_basis.shape[0] == n and seed_basis.shape[1] >= nev
+        tol = float(min(1e-2, max(1e-9, np.sqrt(cfg.warm_tolerance) * 1e-2))) if warm else residual_tolerance(cfg)
+        ev, prof = system.eigs(nev, sigma, tol, max(cfg.max_restarts, 1) * 3, seed_basis if warm else None)
+    except ModalHipError as e:
+        if e.code == _lib.MH_EFACTOR:
+            raise RuntimeError("Modal shift-invert factorization failed.") from e
+        empty.profile = {"error": str(e)}
+        return empty
+    sshapes = system.gather_shapes(pts, nev)
+    freqs, t60s, shapes, orig = postprocess_modes(ev, sshapes, 1.0, mat, cfg)
+    basis = system.basis(nev) if keep_basis else None
+    res = ModalResult(freqs, t60s, shapes, positions, orig, ev, sshapes, mass, com, inertia, quat, prof, remap, basis, system if keep_system else None)
+    if not keep_system:
+        system.close()
+    if own_mesh:
+        mesh.close()
+    return res

@@ -1,0 +1,226 @@
+// Shared internals of libmodalhip: context (stream, library handles, device memory pool), error plumbing,
+// device-side data structures of the assembled system.
+#pragma once
+#include "../../include/modalhip.h"
+
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct MhError : std::runtime_error {
+    int code;
+    MhError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void mh_throw(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw MhError(code, buf);
+}
+
+#define HIP_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) mh_throw(MH_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define ROCBLAS_CHECK(expr)                                                                                     \
+    do {                                                                                                        \
+        rocblas_status s_ = (expr);                                                                             \
+        if (s_ != rocblas_status_success) mh_throw(MH_EHIP, "%s failed: rocblas status %d (%s:%d)", #expr, int(s_), __FILE__, __LINE__); \
+    } while (0)
+#define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
+
+// Size-bucketed caching allocator: device buffers are recycled across solves so a steady-state solve performs no
+// hipMalloc/hipFree (which synchronise the device).
+struct DevicePool {
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+    size_t bytes_reserved{0};
+    static size_t round_up(size_t n) {
+        if (n < 256) return 256;
+        if (n < (1u << 20)) return (n + 4095) & ~size_t(4095);
+        return (n + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    }
+    void *alloc(size_t n) {
+        const size_t r = round_up(n);
+        auto it = free_blocks.lower_bound(r);
+        if (it != free_blocks.end() && it->first <= r + r / 4 + (size_t(1) << 20)) {
+            void *p = it->second;
+            live[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, r));
+        bytes_reserved += r;
+        live[p] = r;
+        return p;
+    }
+    void release(void *p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.emplace(it->second, p);
+        live.erase(it);
+    }
+    void trim() {
+        for (auto &kv : free_blocks) (void)hipFree(kv.second), bytes_reserved -= kv.first;
+        free_blocks.clear();
+    }
+    ~DevicePool() {
+        trim();
+        for (auto &kv : live) (void)hipFree(kv.first);
+    }
+};
+
+struct mh_context {
+    int device{0};
+    hipStream_t stream{nullptr};
+    rocblas_handle blas{nullptr};
+    DevicePool pool;
+    std::string last_error;
+    hipEvent_t ev0{nullptr}, ev1{nullptr};
+    void *gram_ws{nullptr}; // partial-Gram workspace of mh_gram, grown on demand
+    size_t gram_ws_bytes{0};
+    // Optional per-launch timing of the level-2 SpMM (the path's dominant kernel): HIP events on this stream around
+    // every launch, resolved lazily.  Totals feed bench.py's roofline object.
+    bool time_kernels{false};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timer_events;
+    std::vector<double> timer_bytes;
+    size_t timer_used{0};
+    double spmm_ms{0}, spmm_bytes{0};
+    uint64_t spmm_launches{0};
+};
+void mh_timer_flush(mh_context *ctx); // mh_spmm.hip
+
+// RAII device array bound to a context's pool.
+template<typename T> struct DevArray {
+    mh_context *ctx{nullptr};
+    T *ptr{nullptr};
+    size_t count{0};
+    DevArray() = default;
+    DevArray(mh_context *c, size_t n) { reset(c, n); }
+    DevArray(const DevArray &) = delete;
+    DevArray &operator=(const DevArray &) = delete;
+    DevArray(DevArray &&o) noexcept : ctx(o.ctx), ptr(o.ptr), count(o.count) { o.ptr = nullptr; o.count = 0; }
+    DevArray &operator=(DevArray &&o) noexcept {
+        if (this != &o) {
+            free();
+            ctx = o.ctx; ptr = o.ptr; count = o.count;
+            o.ptr = nullptr; o.count = 0;
+        }
+        return *this;
+    }
+    ~DevArray() { free(); }
+    void reset(mh_context *c, size_t n) {
+        free();
+        ctx = c;
+        count = n;
+        ptr = n ? static_cast<T *>(c->pool.alloc(n * sizeof(T))) : nullptr;
+    }
+    void free() {
+        if (ptr && ctx) ctx->pool.release(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    T *get() const { return ptr; }
+    operator T *() const { return ptr; }
+    void zero() const { if (ptr) HIP_CHECK(hipMemsetAsync(ptr, 0, count * sizeof(T), ctx->stream)); }
+    void upload(const T *src, size_t n) const { HIP_CHECK(hipMemcpyAsync(ptr, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream)); }
+    void download(T *dst, size_t n) const {
+        HIP_CHECK(hipMemcpyAsync(dst, ptr, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<T> to_host() const {
+        std::vector<T> h(count);
+        if (count) download(h.data(), count);
+        return h;
+    }
+};
+
+struct mh_mesh {
+    mh_context *ctx;
+    uint32_t n_points{0}, n_tets{0};
+    DevArray<double> points; // n_points x 3
+    DevArray<uint32_t> tets; // n_tets x 4
+};
+
+// One level of the operator hierarchy: symmetric matrix in 3x3 node blocks (BSR), rows and columns in the level's
+// internal (Morton) numbering.
+struct BsrLevel {
+    uint32_t n_nodes{0};
+    uint64_t n_blocks{0};
+    DevArray<uint32_t> row_ptr; // n_nodes + 1
+    DevArray<uint32_t> col; // n_blocks
+    DevArray<double> kval; // n_blocks x 9, row-major 3x3 (stiffness K)
+    DevArray<double> mval; // n_blocks (mass scalar of the node block)
+    DevArray<double> aval; // n_blocks x 9: K - sigma*M, filled by the eigensolver set-up
+    DevArray<double> dinv; // 3*n_nodes: 1 / diag(A)
+    double lmax{0}; // spectral radius estimate of D^-1 A
+};
+
+struct mh_system {
+    mh_context *ctx;
+    mh_material material{};
+    uint32_t n_points{0}, kept_tets{0}, n_nodes{0}, n_edges{0};
+    DevArray<double> points; // copy of mesh points (P1 node coordinates), reference numbering
+    DevArray<uint32_t> elem_nodes_ref; // kept_tets x 10, reference numbering
+    DevArray<uint32_t> elem_nodes; // kept_tets x 10, internal numbering
+    DevArray<double> elem_basis; // kept_tets x 13: volume, Phig[4][3]
+    DevArray<uint32_t> perm; // internal -> reference node id
+    DevArray<uint32_t> inv_perm; // reference -> internal
+    DevArray<double> node_xyz; // n_nodes x 3, internal numbering
+    // P2 <- P1 interpolation: internal P2 node -> its one (corner) or two (midside) P1 parents, internal P1 ids
+    DevArray<uint32_t> parent_a, parent_b;
+    // P1 node -> the midside P2 nodes of its edges (CSR), for the transposed interpolation
+    DevArray<uint32_t> p1_edge_ptr, p1_edge_mid;
+    DevArray<uint32_t> p1_corner; // P1 internal id -> internal P2 id of the same point
+    DevArray<double> p1_xyz; // n_points x 3, P1 internal numbering
+    BsrLevel L2, L1;
+    // level 0: rigid-body aggregates (runs of agg_size consecutive P1 nodes), dense Cholesky factor
+    uint32_t agg_size{32}, n_agg{0};
+    DevArray<double> agg_t; // n_points x 18: the 3x6 tentative-prolongator block of each P1 node (row-major)
+    DevArray<double> a0; // (6 n_agg)^2 column-major: the coarse operator, replaced by its explicit inverse at set-up
+    double sigma_built{0};
+    bool hierarchy_ready{false};
+    // eigensolver result (internal numbering, row-major n x ncols)
+    DevArray<double> evecs;
+    uint32_t evec_cols{0};
+    mh_profile profile{};
+};
+
+inline int mh_guard(mh_context *ctx, const std::exception &e) {
+    if (ctx) ctx->last_error = e.what();
+    if (auto *m = dynamic_cast<const MhError *>(&e)) return m->code;
+    return MH_EHIP;
+}
+
+#define MH_TRY(ctx_expr, body)                         \
+    mh_context *ctx_guard_ = (ctx_expr);               \
+    try {                                              \
+        body;                                          \
+        return MH_OK;                                  \
+    } catch (const std::exception &e) {                \
+        return mh_guard(ctx_guard_, e);                \
+    }
+
+inline unsigned div_up(size_t a, size_t b) { return unsigned((a + b - 1) / b); }
+
+// ---- stage entry points implemented across the .hip files ----
+void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &mat, mh_system *sys); // mh_pipeline.hip
+void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
+// y (n x w row-major, ld = w) = A x with A given by 9-value blocks; optionally y2 = M x from the scalar blocks.
+// G (wa x wb, column-major, ld) = X^T Y for row-major panels (fp64 MFMA, deterministic two-stage reduction).  mh_dense.hip
+void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld);
+void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

@@ -1,0 +1,701 @@
+// Generalised eigensolve K x = lambda M x for the lowest pairs, on the device.
+//
+// Replaces the reference's Spectra SymGEigsShiftSolver over an Accelerate sparse Cholesky (cold branch,
+// src/audio/mesh2modes.cpp:470,485-491; CholeskyShiftInvert.cpp) and its warm-started SubspaceIterate (:339-428)
+// by a block LOBPCG (Knyazev 2001; basis handling after Hetmaniuk & Lehoucq 2006) on the same shifted pencil
+// (A, M), A = K - sigma M, sigma = -(2 pi MinModeFreq)^2 (:460), preconditioned by one symmetric three-level cycle:
+//   level 2  P2 operator, Chebyshev-Jacobi smoothing (SpMM-bound)
+//   level 1  its exact Galerkin restriction to the corner nodes (P1 subset of P2), two cycles
+//   level 0  rigid-body modes of node aggregates, dense Cholesky (rocSOLVER potrf, rocBLAS trsm)
+// Dense tall-skinny products go through rocBLAS dgemm, the small Rayleigh-Ritz problem through rocSOLVER sygvd.
+#include "mh_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+__global__ void k_shift_values(const double *kval, const double *mval, size_t nblocks, double sigma, double *aval);
+__global__ void k_diag_inverse(const uint32_t *row_ptr, const uint32_t *col, const double *aval, uint32_t nnodes, double *dinv);
+__global__ void k_coarse_matrix(const uint32_t *row_ptr, const uint32_t *col, const double *aval, const double *tmat, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *a0);
+__global__ void k_fix_coarse_diag(double *a0, uint32_t n0, double rel);
+
+namespace {
+constexpr int TB = 256;
+
+struct Timer {
+    mh_context *ctx;
+    hipEvent_t a, b;
+    explicit Timer(mh_context *c) : ctx(c) {
+        HIP_CHECK(hipEventCreate(&a));
+        HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, ctx->stream));
+    }
+    double stop() {
+        HIP_CHECK(hipEventRecord(b, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        return ms * 1e-3;
+    }
+    ~Timer() {
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+};
+
+// ---- elementwise panel kernels (n x w row-major, flat index) ------------------------------------------------
+__global__ void k_random_panel(double *__restrict__ x, size_t count, uint64_t seed) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    auto mix = [](uint64_t z) {
+        z += 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    const uint64_t a = mix(seed + 2 * i), b = mix(seed + 2 * i + 1);
+    const double u1 = (double(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = double(b >> 11) * (1.0 / 9007199254740992.0);
+    x[i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+// Chebyshev first step: r = b - t (t optional), d = dinv * r / theta, x = d or x += d.
+__global__ void k_cheb_init(const double *__restrict__ b, const double *__restrict__ t, const double *__restrict__ dinv, double inv_theta,
+                            double *__restrict__ r, double *__restrict__ d, double *__restrict__ x, int accumulate, size_t rows, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const double rv = t ? b[i] - t[i] : b[i];
+    const double dv = dinv[i / w] * rv * inv_theta;
+    r[i] = rv;
+    d[i] = dv;
+    x[i] = accumulate ? x[i] + dv : dv;
+}
+__global__ void k_cheb_step(const double *__restrict__ t, const double *__restrict__ dinv, double c1, double c2, double *__restrict__ r,
+                            double *__restrict__ d, double *__restrict__ x, size_t rows, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const double rv = r[i] - t[i];
+    const double dv = c1 * d[i] + c2 * dinv[i / w] * rv;
+    r[i] = rv;
+    d[i] = dv;
+    x[i] += dv;
+}
+
+// r1 = P^T (b - t): corner value plus half of every incident edge's midside value.
+__global__ void k_restrict_p1(const double *__restrict__ b, const double *__restrict__ t, const uint32_t *__restrict__ p1_corner,
+                              const uint32_t *__restrict__ eptr, const uint32_t *__restrict__ emid, double *__restrict__ r1, uint32_t npts, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(npts) * 3 * w) return;
+    const uint32_t c = uint32_t(i % w), comp = uint32_t((i / w) % 3), p = uint32_t(i / (size_t(3) * w));
+    auto res = [&](uint32_t node) {
+        const size_t o = (size_t(3) * node + comp) * w + c;
+        return b[o] - t[o];
+    };
+    double s = res(p1_corner[p]);
+    double h = 0;
+    for (uint32_t e = eptr[p]; e < eptr[p + 1]; ++e) h += res(emid[e]);
+    r1[i] = s + 0.5 * h;
+}
+// x2 += P x1
+__global__ void k_prolong_p1(const double *__restrict__ x1, const uint32_t *__restrict__ pa, const uint32_t *__restrict__ pb, double *__restrict__ x2,
+                             uint32_t nnodes, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nnodes) * 3 * w) return;
+    const uint32_t c = uint32_t(i % w), comp = uint32_t((i / w) % 3), node = uint32_t(i / (size_t(3) * w));
+    const uint32_t a = pa[node], bb = pb[node];
+    const double va = x1[(size_t(3) * a + comp) * w + c];
+    x2[i] += a == bb ? va : 0.5 * (va + x1[(size_t(3) * bb + comp) * w + c]);
+}
+// r0 = T^T (b - t) per aggregate (6 rows each), one thread per (aggregate dof, column)
+__global__ void k_restrict_agg(const double *__restrict__ b, const double *__restrict__ t, const double *__restrict__ tmat, double *__restrict__ r0,
+                               uint32_t npts, uint32_t agg_size, uint32_t nagg, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nagg) * 6 * w) return;
+    const uint32_t c = uint32_t(i % w), q = uint32_t((i / w) % 6), a = uint32_t(i / (size_t(6) * w));
+    const uint32_t i0 = a * agg_size, i1 = a == nagg - 1 ? npts : (a + 1) * agg_size;
+    double s = 0;
+    for (uint32_t nd = i0; nd < i1; ++nd) {
+        const double *tm = tmat + 18 * size_t(nd);
+        for (int p = 0; p < 3; ++p) {
+            const size_t o = (size_t(3) * nd + p) * w + c;
+            s += tm[6 * p + q] * (b[o] - t[o]);
+        }
+    }
+    r0[i] = s;
+}
+// x1 += T x0
+__global__ void k_prolong_agg(const double *__restrict__ x0, const double *__restrict__ tmat, double *__restrict__ x1, uint32_t npts, uint32_t agg_size,
+                              uint32_t nagg, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(npts) * 3 * w) return;
+    const uint32_t c = uint32_t(i % w), p = uint32_t((i / w) % 3), nd = uint32_t(i / (size_t(3) * w));
+    const uint32_t a = min(nd / agg_size, nagg - 1);
+    const double *tm = tmat + 18 * size_t(nd) + 6 * p;
+    double s = 0;
+    for (int q = 0; q < 6; ++q) s += tm[q] * x0[(size_t(6) * a + q) * w + c];
+    x1[i] += s;
+}
+
+// R[:, k] = AX[:, idx[k]] - theta[idx[k]] * MX[:, idx[k]]
+__global__ void k_residual(const double *__restrict__ ax, const double *__restrict__ mx, const double *__restrict__ theta, const uint32_t *__restrict__ idx,
+                           double *__restrict__ r, size_t rows, uint32_t b, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const uint32_t k = uint32_t(i % w);
+    const size_t row = i / w;
+    const uint32_t src = idx ? idx[k] : k;
+    r[i] = ax[row * b + src] - theta[src] * mx[row * b + src];
+}
+
+// Column sums of squares, two deterministic stages.
+__global__ void k_colsumsq_partial(const double *__restrict__ x, size_t rows, uint32_t w, double *__restrict__ partial, uint32_t rows_per_block) {
+    const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= w) return;
+    const size_t r0 = size_t(blockIdx.x) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    double s = 0;
+    for (size_t r = r0; r < r1; ++r) {
+        const double v = x[r * w + c];
+        s += v * v;
+    }
+    partial[size_t(blockIdx.x) * w + c] = s;
+}
+// one 256-thread block per column: strided partial sums, then a fixed binary tree in LDS
+__global__ void k_colsumsq_final(const double *__restrict__ partial, uint32_t nblocks, uint32_t w, double *__restrict__ out) {
+    __shared__ double s[256];
+    const uint32_t c = blockIdx.x;
+    double acc = 0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256) acc += partial[size_t(b) * w + c];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (int(threadIdx.x) < h) s[threadIdx.x] += s[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = s[0];
+}
+__global__ void k_scale_cols_inv_sqrt(double *__restrict__ x, const double *__restrict__ sumsq, size_t rows, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const double s = sumsq[i % w];
+    x[i] *= s > 0 ? rsqrt(s) : 0.0;
+}
+__global__ void k_dinv_mul(const double *__restrict__ t, const double *__restrict__ dinv, double *__restrict__ v, size_t rows, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < rows * w) v[i] = dinv[i / w] * t[i];
+}
+
+// ---- small dense helpers (column-major, leading dimension ld) ------------------------------------------------
+__global__ void k_set_identity_blocks(double *__restrict__ ga, double *__restrict__ gm, const double *__restrict__ theta, uint32_t b, uint32_t ld) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b) return;
+    ga[size_t(i) * ld + i] = theta[i];
+    gm[size_t(i) * ld + i] = 1.0;
+}
+// d = 1/sqrt(diag G); Gs = D G D written to the w x w block that follows G in memory (ld = w for both)
+__global__ void k_scale_gram(double *__restrict__ g, uint32_t w, uint32_t ld, double *__restrict__ dscale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * w) return;
+    const uint32_t r = i % w, c = i / w;
+    const double dr = g[size_t(r) * ld + r], dc = g[size_t(c) * ld + c];
+    const double sr = dr > 0 ? rsqrt(dr) : 0.0, sc = dc > 0 ? rsqrt(dc) : 0.0;
+    if (r == c) dscale[r] = sr;
+    g[size_t(w) * ld + size_t(c) * ld + r] = g[size_t(c) * ld + r] * sr * sc;
+}
+// L <- diag(1/d) L (lower triangle), so that W L^-T applies the column scaling as well
+__global__ void k_unscale_chol(double *__restrict__ l, uint32_t w, uint32_t ld, const double *__restrict__ dscale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * w) return;
+    const uint32_t r = i % w, c = i / w;
+    if (r < c) { l[size_t(c) * ld + r] = 0; return; }
+    const double d = dscale[r];
+    l[size_t(c) * ld + r] = d > 0 ? l[size_t(c) * ld + r] / d : (r == c ? 1.0 : 0.0);
+}
+// Cp[r][k] = r < b ? 0 : C[r][idx[k]]
+__global__ void k_build_cp(const double *__restrict__ c, const uint32_t *__restrict__ idx, uint32_t b, uint32_t m, uint32_t w, uint32_t ldc,
+                           double *__restrict__ cp, uint32_t ldp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * w) return;
+    const uint32_t r = i % m, k = i / m;
+    cp[size_t(k) * ldp + r] = r < b ? 0.0 : c[size_t(idx[k]) * ldc + r];
+}
+__global__ void k_gather_cols(const double *__restrict__ src, const uint32_t *__restrict__ idx, double *__restrict__ dst, size_t rows, uint32_t wsrc, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    dst[i] = src[(i / w) * wsrc + idx[i % w]];
+}
+// seed basis (column-major float, reference DOF order) -> leading columns of a row-major internal-order panel
+__global__ void k_load_seed(const float *__restrict__ seed, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t ncols, uint32_t b, double *__restrict__ x) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nnodes) * 3 * ncols) return;
+    const uint32_t c = uint32_t(i % ncols), comp = uint32_t((i / ncols) % 3), node = uint32_t(i / (size_t(3) * ncols));
+    x[(size_t(3) * node + comp) * b + c] = double(seed[size_t(c) * (size_t(3) * nnodes) + size_t(3) * perm[node] + comp]);
+}
+__global__ void k_copy_cols(const double *__restrict__ src, uint32_t wsrc, double *__restrict__ dst, uint32_t wdst, size_t rows, uint32_t ncols) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * ncols) return;
+    dst[(i / ncols) * wdst + i % ncols] = src[(i / ncols) * wsrc + i % ncols];
+}
+// dense path: BSR -> dense column-major (both A-values and M scalars)
+__global__ void k_bsr_to_dense(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ v9, const double *__restrict__ ms,
+                               uint32_t nnodes, double *__restrict__ a, double *__restrict__ m) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nnodes) return;
+    const size_t n = size_t(3) * nnodes;
+    for (uint32_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+        const uint32_t c = col[p];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) a[(size_t(3) * c + j) * n + size_t(3) * r + i] = v9[9 * size_t(p) + 3 * i + j];
+            m[(size_t(3) * c + i) * n + size_t(3) * r + i] = ms[p];
+        }
+    }
+}
+__global__ void k_colmajor_to_panel(const double *__restrict__ z, size_t n, uint32_t ncols, double *__restrict__ x) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n * ncols) return;
+    x[i] = z[size_t(i % ncols) * n + i / ncols];
+}
+
+// upper triangle <- lower triangle (column-major n x n, ld)
+__global__ void k_symmetrize_lower(double *__restrict__ a, uint32_t n, uint32_t ld) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(n) * n) return;
+    const uint32_t r = uint32_t(i % n), c = uint32_t(i / n);
+    if (r < c) a[size_t(c) * ld + r] = a[size_t(r) * ld + c];
+}
+
+unsigned grid1(size_t count) { return div_up(count, TB); }
+
+// ---- rocBLAS wrappers over row-major panels ------------------------------------------------------------------
+// G (wa x wb, column-major, ld) = Xa^T Yb for panels Xa (n x wa), Yb (n x wb): hand-written MFMA kernel (mh_dense.hip)
+void gram(mh_context *ctx, size_t n, const double *xa, uint32_t wa, const double *yb, uint32_t wb, double *g, uint32_t ld) {
+    mh_gram(ctx, n, xa, wa, yb, wb, g, ld);
+}
+// Z (n x wz) = alpha * X (n x wa) * C (wa x wz, column-major ld) + beta * Z
+void panel_mul(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *c, uint32_t ld, double *z, uint32_t wz, double alpha, double beta) {
+    if (!wz) return;
+    if (!wa) return;
+    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wz, rocblas_int(n), wa, &alpha, c, ld, x, wa, &beta, z, wz));
+}
+// W (n x w) <- W L^-T  (L lower, column-major)
+void panel_trsm(mh_context *ctx, size_t n, double *wp, uint32_t w, const double *l, uint32_t ld) {
+    const double one = 1;
+    ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, w, rocblas_int(n), &one, l, ld, wp, w));
+}
+
+
+// Small generalised symmetric eigenproblem gA c = theta gM c (lower triangles given, order m, ld m):
+// Cholesky reduction + rocSOLVER syevd (rocSOLVER's sygvd reduces with an unblocked sygs2 that launches O(m) tiny
+// kernels; this form measured 2.3x faster at m = 225).  On return gA holds the gM-orthonormal eigenvectors.
+int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info) {
+    const double one = 1;
+    int hinfo = 0;
+    k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gA, m, m);
+    KERNEL_CHECK();
+    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, m, gM, m, info));
+    info.download(&hinfo, 1);
+    if (hinfo != 0) return hinfo;
+    ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
+    ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
+    ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
+    info.download(&hinfo, 1);
+    if (hinfo != 0) return hinfo;
+    ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
+    return 0;
+}
+
+void colsumsq(mh_context *ctx, const double *x, size_t rows, uint32_t w, double *out, DevArray<double> &scratch) {
+    const uint32_t rpb = 256;
+    const uint32_t nb = div_up(rows, rpb);
+    if (scratch.count < size_t(nb) * w) scratch.reset(ctx, size_t(nb) * w);
+    dim3 grid(nb, div_up(w, 64));
+    k_colsumsq_partial<<<grid, 64, 0, ctx->stream>>>(x, rows, w, scratch, rpb);
+    KERNEL_CHECK();
+    k_colsumsq_final<<<w, 256, 0, ctx->stream>>>(scratch, nb, w, out);
+    KERNEL_CHECK();
+}
+
+// ---- multilevel preconditioner ---------------------------------------------------------------------------------
+struct Precond {
+    mh_system *sys;
+    mh_context *ctx;
+    uint32_t wmax;
+    int deg2{2}, deg1{3}, gamma{3};
+    double ratio{8.0};
+    DevArray<double> d2, t2, r2, r1, x1, d1, t1, rr1, r0, x0;
+    Precond(mh_system *s, uint32_t w) : sys(s), ctx(s->ctx), wmax(w) {
+        const size_t n2 = size_t(3) * s->n_nodes, n1 = size_t(3) * s->n_points, n0 = size_t(6) * s->n_agg;
+        d2.reset(ctx, n2 * w); t2.reset(ctx, n2 * w); r2.reset(ctx, n2 * w);
+        r1.reset(ctx, n1 * w); x1.reset(ctx, n1 * w); d1.reset(ctx, n1 * w); t1.reset(ctx, n1 * w); rr1.reset(ctx, n1 * w);
+        r0.reset(ctx, n0 * w);
+        x0.reset(ctx, n0 * w);
+        if (const char *e = getenv("MH_DEG2")) deg2 = std::max(1, atoi(e));
+        if (const char *e = getenv("MH_DEG1")) deg1 = std::max(1, atoi(e));
+        if (const char *e = getenv("MH_GAMMA")) gamma = std::max(1, atoi(e));
+    }
+    void cheb(const BsrLevel &lvl, int deg, const double *b, double *x, bool zero_init, double *r, double *d, double *t, uint32_t w) {
+        const size_t rows = size_t(3) * lvl.n_nodes;
+        const double lmax = lvl.lmax, lmin = lvl.lmax / ratio;
+        const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig = theta / delta;
+        double rho = 1.0 / sig;
+        if (!zero_init) mh_spmm(ctx, lvl, lvl.aval, x, t, nullptr, nullptr, w);
+        k_cheb_init<<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, lvl.dinv, 1.0 / theta, r, d, x, zero_init ? 0 : 1, rows, w);
+        KERNEL_CHECK();
+        for (int k = 1; k < deg; ++k) {
+            mh_spmm(ctx, lvl, lvl.aval, d, t, nullptr, nullptr, w);
+            const double rho_new = 1.0 / (2 * sig - rho);
+            k_cheb_step<<<grid1(rows * w), TB, 0, ctx->stream>>>(t, lvl.dinv, rho_new * rho, 2 * rho_new / delta, r, d, x, rows, w);
+            KERNEL_CHECK();
+            rho = rho_new;
+        }
+    }
+    // z = B r for an n2 x w panel
+    void apply(const double *r, double *z, uint32_t w) {
+        const uint32_t nn = sys->n_nodes, np = sys->n_points, na = sys->n_agg;
+        const size_t n1 = size_t(3) * np, n0 = size_t(6) * na;
+        const double one = 1, zero = 0;
+        cheb(sys->L2, deg2, r, z, true, r2, d2, t2, w);
+        mh_spmm(ctx, sys->L2, sys->L2.aval, z, t2, nullptr, nullptr, w);
+        k_restrict_p1<<<grid1(n1 * w), TB, 0, ctx->stream>>>(r, t2, sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1, np, w);
+        KERNEL_CHECK();
+        for (int g = 0; g < gamma; ++g) {
+            cheb(sys->L1, deg1, r1, x1, g == 0, rr1, d1, t1, w);
+            mh_spmm(ctx, sys->L1, sys->L1.aval, x1, t1, nullptr, nullptr, w);
+            k_restrict_agg<<<grid1(n0 * w), TB, 0, ctx->stream>>>(r1, t1, sys->agg_t, r0, np, sys->agg_size, na, w);
+            KERNEL_CHECK();
+            // r0 is (6 na) x w row-major = w x (6 na) column-major: x0 = r0 * A0^-1 (A0^-1 symmetric, explicit)
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, rocblas_int(n0), rocblas_int(n0), &one, r0, w, sys->a0, rocblas_int(n0), &zero, x0, w));
+            k_prolong_agg<<<grid1(n1 * w), TB, 0, ctx->stream>>>(x0, sys->agg_t, x1, np, sys->agg_size, na, w);
+            KERNEL_CHECK();
+            cheb(sys->L1, deg1, r1, x1, false, rr1, d1, t1, w);
+        }
+        k_prolong_p1<<<grid1(size_t(3) * nn * w), TB, 0, ctx->stream>>>(x1, sys->parent_a, sys->parent_b, z, nn, w);
+        KERNEL_CHECK();
+        cheb(sys->L2, deg2, r, z, false, r2, d2, t2, w);
+    }
+};
+
+double estimate_lmax(mh_context *ctx, BsrLevel &lvl) {
+    const uint32_t w = 8;
+    const size_t rows = size_t(3) * lvl.n_nodes;
+    DevArray<double> v(ctx, rows * w), t(ctx, rows * w), nrm(ctx, w), scratch;
+    k_random_panel<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, rows * w, 0x5eedull);
+    KERNEL_CHECK();
+    colsumsq(ctx, v, rows, w, nrm, scratch);
+    k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
+    KERNEL_CHECK();
+    for (int it = 0; it < 12; ++it) {
+        mh_spmm(ctx, lvl, lvl.aval, v, t, nullptr, nullptr, w);
+        k_dinv_mul<<<grid1(rows * w), TB, 0, ctx->stream>>>(t, lvl.dinv, v, rows, w);
+        KERNEL_CHECK();
+        colsumsq(ctx, v, rows, w, nrm, scratch);
+        if (it + 1 < 12) {
+            k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
+            KERNEL_CHECK();
+        }
+    }
+    auto h = nrm.to_host();
+    double m = 0;
+    for (double s : h) m = std::max(m, std::sqrt(s));
+    return 1.1 * m;
+}
+} // namespace
+
+void mh_build_hierarchy(mh_system *sys, double sigma) {
+    mh_context *ctx = sys->ctx;
+    if (sys->hierarchy_ready && sys->sigma_built == sigma) return;
+    for (BsrLevel *lvl : {&sys->L2, &sys->L1}) {
+        lvl->aval.reset(ctx, lvl->n_blocks * 9);
+        lvl->dinv.reset(ctx, size_t(3) * lvl->n_nodes);
+        k_shift_values<<<grid1(lvl->n_blocks * 9), TB, 0, ctx->stream>>>(lvl->kval, lvl->mval, lvl->n_blocks, sigma, lvl->aval);
+        KERNEL_CHECK();
+        k_diag_inverse<<<grid1(lvl->n_nodes), TB, 0, ctx->stream>>>(lvl->row_ptr, lvl->col, lvl->aval, lvl->n_nodes, lvl->dinv);
+        KERNEL_CHECK();
+        lvl->lmax = estimate_lmax(ctx, *lvl);
+    }
+    const size_t n0 = size_t(6) * sys->n_agg;
+    sys->a0.reset(ctx, n0 * n0);
+    sys->a0.zero();
+    k_coarse_matrix<<<grid1(sys->n_points), TB, 0, ctx->stream>>>(sys->L1.row_ptr, sys->L1.col, sys->L1.aval, sys->agg_t, sys->n_points, sys->agg_size, sys->n_agg, sys->a0);
+    KERNEL_CHECK();
+    k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), 1e-12);
+    KERNEL_CHECK();
+    DevArray<int> info(ctx, 1);
+    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
+    int hinfo = 0;
+    info.download(&hinfo, 1);
+    if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (potrf info %d): shift must be negative", hinfo);
+    // Explicit inverse: the coarse solve becomes one dense product per application (2.5x faster than two triangular
+    // solves at these sizes, and free of their O(n0/128) dependent launches).
+    ROCBLAS_CHECK(rocsolver_dpotri(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
+    info.download(&hinfo, 1);
+    if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse inverse failed (potri info %d)", hinfo);
+    k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
+    KERNEL_CHECK();
+    sys->sigma_built = sigma;
+    sys->hierarchy_ready = true;
+}
+
+namespace {
+// Tiny problems: one dense generalised eigensolve on the device.
+void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues) {
+    mh_context *ctx = sys->ctx;
+    const size_t n = size_t(3) * sys->n_nodes;
+    auto &lvl = sys->L2;
+    DevArray<double> a(ctx, n * n), m(ctx, n * n), d(ctx, n), e(ctx, n);
+    DevArray<int> info(ctx, 1);
+    a.zero();
+    m.zero();
+    lvl.aval.reset(ctx, lvl.n_blocks * 9);
+    k_shift_values<<<grid1(lvl.n_blocks * 9), TB, 0, ctx->stream>>>(lvl.kval, lvl.mval, lvl.n_blocks, sigma, lvl.aval);
+    KERNEL_CHECK();
+    k_bsr_to_dense<<<grid1(lvl.n_nodes), TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, lvl.mval, lvl.n_nodes, a, m);
+    KERNEL_CHECK();
+    ROCBLAS_CHECK(rocsolver_dsygvd(ctx->blas, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_lower, rocblas_int(n), a, rocblas_int(n), m, rocblas_int(n), d, e, info));
+    int hinfo = 0;
+    info.download(&hinfo, 1);
+    if (hinfo != 0) mh_throw(hinfo > int(n) ? MH_EFACTOR : MH_ENOTCONVERGED, "dense sygvd failed (info %d)", hinfo);
+    std::vector<double> th(n);
+    d.download(th.data(), n);
+    for (uint32_t i = 0; i < nev; ++i) eigenvalues[i] = th[i] + sigma;
+    sys->evecs.reset(ctx, n * nev);
+    sys->evec_cols = nev;
+    k_colmajor_to_panel<<<grid1(n * nev), TB, 0, ctx->stream>>>(a, n, nev, sys->evecs);
+    KERNEL_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+} // namespace
+
+static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
+                      uint32_t seed_cols, const volatile int *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
+    {
+        mh_context *ctx = sys->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * sys->n_nodes;
+        if (nev >= n) mh_throw(MH_EINVAL, "nev %u must be below the %zu unknowns", nev, n);
+        if (!(sigma < 0)) mh_throw(MH_EFACTOR, "shift must be negative for a positive-definite shifted operator");
+        mh_profile prof = sys->profile;
+        prof.dofs = uint32_t(n);
+        // the reference counts the lower triangle of K (Eigen nonZeros of the lower-stored matrix, mesh2modes.cpp:615)
+        prof.stiffness_nonzeros = uint32_t((sys->L2.n_blocks - sys->n_nodes) / 2 * 9 + uint64_t(6) * sys->n_nodes);
+        if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
+        uint32_t b = nev + std::max(10u, nev / 10);
+        if (n <= 768 || n < size_t(5) * b) {
+            Timer t(ctx);
+            dense_eigs(sys, nev, sigma, eigenvalues);
+            prof.iterate = t.stop();
+            prof.restarts = 1;
+            sys->profile = prof;
+            if (profile) *profile = prof;
+        } else {
+            {
+                Timer t(ctx);
+                mh_build_hierarchy(sys, sigma);
+                prof.factorize = t.stop();
+            }
+            if (progress) *progress = 0.3f;
+            Timer t_iter(ctx);
+            double precond_seconds = 0;
+            hipStream_t st = ctx->stream;
+            const uint32_t mmax = 3 * b;
+            // panels
+            DevArray<double> X(ctx, n * b), AX(ctx, n * b), MX(ctx, n * b), Xn(ctx, n * b), AXn(ctx, n * b), MXn(ctx, n * b);
+            DevArray<double> W(ctx, n * b), AW(ctx, n * b), MW(ctx, n * b), P(ctx, n * b), AP(ctx, n * b), MP(ctx, n * b);
+            DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
+            DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), evals(ctx, mmax), ework(ctx, mmax);
+            DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
+            DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch;
+            DevArray<uint32_t> idx_d(ctx, b);
+            DevArray<int> info(ctx, 1);
+            Precond prec(sys, b);
+
+            // --- initial block: seed columns (warm start), then Gaussian noise; M-orthonormalise; Rayleigh-Ritz
+            k_random_panel<<<grid1(n * b), TB, 0, st>>>(X, n * b, 20260710ull);
+            KERNEL_CHECK();
+            const bool warm = seed_basis && seed_rows == n && seed_cols >= nev;
+            if (warm) {
+                const uint32_t ncols = std::min(seed_cols, b);
+                DevArray<float> seed(ctx, n * ncols);
+                seed.upload(seed_basis, n * ncols);
+                k_load_seed<<<grid1(n * ncols), TB, 0, st>>>(seed, sys->perm, sys->n_nodes, ncols, b, X);
+                KERNEL_CHECK();
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w) -> bool {
+                // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
+                gram(ctx, n, V, w, MV, w, G, w);
+                k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
+                KERNEL_CHECK();
+                double *Gs = G.get() + size_t(w) * w;
+                ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                int hinfo = 0;
+                info.download(&hinfo, 1);
+                if (hinfo != 0) return false;
+                k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
+                KERNEL_CHECK();
+                panel_trsm(ctx, n, V, w, Gs, w);
+                if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
+                if (AV) panel_trsm(ctx, n, AV, w, Gs, w);
+                return true;
+            };
+            mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
+            if (!chol_orthonormalise(X, MX, nullptr, b)) mh_throw(MH_ENOTCONVERGED, "initial block is rank deficient");
+            mh_spmm(ctx, sys->L2, sys->L2.aval, X, AX, sys->L2.mval, MX, b);
+            std::vector<double> theta(b);
+            {
+                gram(ctx, n, X, b, AX, b, gA, b);
+                gram(ctx, n, X, b, MX, b, gM, b);
+                const int hinfo = rr_solve(ctx, gA, gM, b, evals, ework, info);
+                if (hinfo != 0) mh_throw(MH_ENOTCONVERGED, "initial Rayleigh-Ritz failed (info %d)", hinfo);
+                panel_mul(ctx, n, X, b, gA, b, Xn, b, 1.0, 0.0);
+                panel_mul(ctx, n, AX, b, gA, b, AXn, b, 1.0, 0.0);
+                panel_mul(ctx, n, MX, b, gA, b, MXn, b, 1.0, 0.0);
+                std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
+                evals.download(theta.data(), b);
+            }
+            uint32_t wp = 0; // width of P
+            uint32_t iters = 0, nconv = 0;
+            std::vector<double> rn(b), mn(b);
+            std::vector<uint32_t> act;
+            bool converged = false;
+            for (uint32_t it = 0; it <= max_iters; ++it) {
+                if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
+                theta_d.upload(theta.data(), b);
+                k_residual<<<grid1(n * b), TB, 0, st>>>(AX, MX, theta_d, nullptr, R, n, b, b);
+                KERNEL_CHECK();
+                colsumsq(ctx, R, n, b, rn_d, scratch);
+                colsumsq(ctx, MX, n, b, mn_d, scratch);
+                rn_d.download(rn.data(), b);
+                mn_d.download(mn.data(), b);
+                act.clear();
+                nconv = 0;
+                for (uint32_t i = 0; i < b; ++i) {
+                    const double rel = std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]));
+                    const bool ok = rel < residual_tol;
+                    if (!ok) act.push_back(i);
+                    if (ok && i < nev) ++nconv;
+                }
+                if (progress) *progress = 0.3f + 0.65f * float(nconv) / float(nev);
+                iters = it;
+                if (nconv >= nev) { converged = true; break; }
+                if (it == max_iters) break;
+                const uint32_t w = uint32_t(act.size());
+                idx_d.upload(act.data(), w);
+                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
+                KERNEL_CHECK();
+                {
+                    Timer tp(ctx);
+                    prec.apply(Rw, W, w);
+                    precond_seconds += tp.stop();
+                    prof.op_applications += w;
+                }
+                // W <- (I - X X^T M - P P^T M) W, twice, keeping M W alongside; then M-orthonormalise.
+                mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
+                bool ok = true;
+                for (int pass = 0; pass < 2 && ok; ++pass) {
+                    gram(ctx, n, MX, b, W, w, H, b); // b x w
+                    panel_mul(ctx, n, X, b, H, b, W, w, -1.0, 1.0);
+                    panel_mul(ctx, n, MX, b, H, b, MW, w, -1.0, 1.0);
+                    if (wp) {
+                        gram(ctx, n, MP, wp, W, w, H, wp);
+                        panel_mul(ctx, n, P, wp, H, wp, W, w, -1.0, 1.0);
+                        panel_mul(ctx, n, MP, wp, H, wp, MW, w, -1.0, 1.0);
+                    }
+                    ok = chol_orthonormalise(W, MW, nullptr, w);
+                }
+                if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+                mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
+                // Gram matrices of S = [X W P] (lower triangles), X block known: diag(theta) and I
+                uint32_t m = b + w + wp;
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    HIP_CHECK(hipMemsetAsync(gA, 0, size_t(m) * m * sizeof(double), st));
+                    HIP_CHECK(hipMemsetAsync(gM, 0, size_t(m) * m * sizeof(double), st));
+                    k_set_identity_blocks<<<grid1(b), TB, 0, st>>>(gA, gM, theta_d, b, m);
+                    KERNEL_CHECK();
+                    gram(ctx, n, W, w, AX, b, gA.get() + b, m);
+                    gram(ctx, n, W, w, MX, b, gM.get() + b, m);
+                    gram(ctx, n, W, w, AW, w, gA.get() + size_t(b) * m + b, m);
+                    gram(ctx, n, W, w, MW, w, gM.get() + size_t(b) * m + b, m);
+                    if (wp) {
+                        gram(ctx, n, P, wp, AX, b, gA.get() + b + w, m);
+                        gram(ctx, n, P, wp, MX, b, gM.get() + b + w, m);
+                        gram(ctx, n, P, wp, AW, w, gA.get() + size_t(b) * m + b + w, m);
+                        gram(ctx, n, P, wp, MW, w, gM.get() + size_t(b) * m + b + w, m);
+                        gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(b + w) * m + b + w, m);
+                        gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(b + w) * m + b + w, m);
+                    }
+                    HIP_CHECK(hipMemcpyAsync(gM0, gM, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info);
+                    if (hinfo == 0) break;
+                    if (attempt == 1 || wp == 0) mh_throw(MH_ENOTCONVERGED, "Rayleigh-Ritz failed at iteration %u (info %d)", it, hinfo);
+                    wp = 0; // drop the previous directions and retry on [X W]
+                    m = b + w;
+                }
+                evals.download(theta.data(), b);
+                // New directions in coefficient space: the [W P] part of the active Ritz vectors, made
+                // gM-orthonormal against the new X coefficients and among themselves.
+                const double one = 1, zero = 0, mone = -1;
+                uint32_t wp_new = w;
+                k_build_cp<<<grid1(size_t(m) * w), TB, 0, st>>>(gA, idx_d, b, m, w, m, Cp, m);
+                KERNEL_CHECK();
+                ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, b, w, m, &one, gA, m, T1, m, &zero, H, b));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, b, &mone, gA, m, H, b, &one, Cp, m));
+                ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, T1, m, &zero, G, w));
+                k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
+                KERNEL_CHECK();
+                {
+                    double *Gs = G.get() + size_t(w) * w;
+                    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                    int hinfo = 0;
+                    info.download(&hinfo, 1);
+                    if (hinfo != 0) {
+                        wp_new = 0;
+                    } else {
+                        k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
+                        KERNEL_CHECK();
+                        ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, w, &one, Gs, w, Cp, m));
+                    }
+                }
+                // X <- S Cx, P <- S Cp (and the A-, M-images)
+                auto combine = [&](const double *x, const double *wv, const double *pv, const double *c, uint32_t wout, double *out) {
+                    panel_mul(ctx, n, x, b, c, m, out, wout, 1.0, 0.0);
+                    panel_mul(ctx, n, wv, w, c + b, m, out, wout, 1.0, 1.0);
+                    if (wp) panel_mul(ctx, n, pv, wp, c + b + w, m, out, wout, 1.0, 1.0);
+                };
+                combine(X, W, P, gA, b, Xn);
+                combine(AX, AW, AP, gA, b, AXn);
+                combine(MX, MW, MP, gA, b, MXn);
+                if (wp_new) {
+                    combine(X, W, P, Cp, wp_new, Pn);
+                    combine(AX, AW, AP, Cp, wp_new, APn);
+                    combine(MX, MW, MP, Cp, wp_new, MPn);
+                }
+                std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
+                std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
+                wp = wp_new;
+            }
+            prof.restarts = iters;
+            prof.op_solve = precond_seconds;
+            if (!converged) mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged in %u iterations", nconv, nev, iters);
+            for (uint32_t i = 0; i < nev; ++i) eigenvalues[i] = theta[i] + sigma;
+            sys->evecs.reset(ctx, n * nev);
+            sys->evec_cols = nev;
+            k_copy_cols<<<grid1(n * nev), TB, 0, st>>>(X, b, sys->evecs, nev, n, nev);
+            KERNEL_CHECK();
+            prof.iterate = t_iter.stop();
+            sys->profile = prof;
+            if (profile) *profile = prof;
+        }
+    }
+}
+
+extern "C" int mh_eigs(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
+                       uint32_t seed_cols, const volatile int *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
+    if (!sys || !eigenvalues || nev == 0) return MH_EINVAL;
+    try {
+        eigs_impl(sys, nev, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, eigenvalues, profile);
+        return MH_OK;
+    } catch (const std::exception &e) {
+        return mh_guard(sys->ctx, e);
+    }
+}

@@ -1,0 +1,127 @@
+// Sparse block kernels of the eigensolver (gfx950): BSR 3x3 fp64 SpMM over row-major n x w panels.
+//
+// Panels are row-major (one row of w contiguous doubles per DOF) so that a wavefront's 64 lanes map to panel
+// columns: the gather of x for a node block is three coalesced w*8-byte segments and the 3x3 block values are
+// wave-uniform (scalar loads).  HBM-bound: algorithmic bytes per launch = 76 B per node block (9 values + column
+// index) + 4 B per row pointer + 2 * 8 * n * w for reading x and writing y once.
+#include "mh_common.h"
+
+namespace {
+constexpr int TB = 256;
+
+// CW = panel columns per row group (power of two <= 64); a wave covers 64/CW block rows.
+// NC = columns per lane (stride 64) so that panels up to 64*NC wide read the matrix once.
+template<int CW, int NC, bool WITH_M, bool WITH_A>
+__global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ vals9,
+                                            const double *__restrict__ mscal, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ y2,
+                                            uint32_t nnodes, uint32_t w) {
+    constexpr int RPW = 64 / CW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c0 = blockIdx.y * (CW * NC) + (lane % CW);
+    uint32_t row = (blockIdx.x * (TB / 64) + wave) * RPW + lane / CW;
+    if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+    if (row >= nnodes) return;
+    bool active[NC];
+    uint32_t cc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        active[k] = c0 + 64 * k < w;
+        cc[k] = active[k] ? c0 + 64 * k : 0;
+    }
+    double a0[NC], a1[NC], a2[NC], m0[NC], m1[NC], m2[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) a0[k] = a1[k] = a2[k] = m0[k] = m1[k] = m2[k] = 0;
+    const uint32_t p0 = row_ptr[row], p1 = row_ptr[row + 1];
+    for (uint32_t p = p0; p < p1; ++p) {
+        const uint32_t j = col[p];
+        const double *xr = x + size_t(3) * j * w;
+        double v[9];
+        if (WITH_A) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) v[e] = vals9[size_t(9) * p + e];
+        }
+        const double m = WITH_M ? mscal[p] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double x0 = xr[cc[k]], x1 = xr[w + cc[k]], x2 = xr[2 * size_t(w) + cc[k]];
+            if (WITH_A) {
+                a0[k] += v[0] * x0 + v[1] * x1 + v[2] * x2;
+                a1[k] += v[3] * x0 + v[4] * x1 + v[5] * x2;
+                a2[k] += v[6] * x0 + v[7] * x1 + v[8] * x2;
+            }
+            if (WITH_M) {
+                m0[k] += m * x0;
+                m1[k] += m * x1;
+                m2[k] += m * x2;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (!active[k]) continue;
+        const size_t o = size_t(3) * row * w + c0 + 64 * k;
+        if (WITH_A) { y[o] = a0[k]; y[o + w] = a1[k]; y[o + 2 * size_t(w)] = a2[k]; }
+        if (WITH_M) { y2[o] = m0[k]; y2[o + w] = m1[k]; y2[o + 2 * size_t(w)] = m2[k]; }
+    }
+}
+
+template<bool WITH_M, bool WITH_A>
+void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
+    const uint32_t n = lvl.n_nodes;
+    auto go = [&](auto cw_tag, auto nc_tag) {
+        constexpr int CW = decltype(cw_tag)::value, NC = decltype(nc_tag)::value;
+        constexpr int RPW = 64 / CW;
+        dim3 grid(div_up(n, (TB / 64) * RPW), div_up(w, CW * NC));
+        k_spmm<CW, NC, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, n, w);
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    if (w <= 8) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+    else if (w <= 16) go(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+    else if (w <= 32) go(std::integral_constant<int, 32>{}, std::integral_constant<int, 1>{});
+    else if (w <= 64) go(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
+    else if (w <= 128) go(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
+    KERNEL_CHECK();
+}
+} // namespace
+
+void mh_timer_flush(mh_context *ctx) {
+    if (!ctx->timer_used) return;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->timer_used; ++i) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->timer_events[i].first, ctx->timer_events[i].second));
+        ctx->spmm_ms += ms;
+        ctx->spmm_bytes += ctx->timer_bytes[i];
+        ++ctx->spmm_launches;
+    }
+    ctx->timer_used = 0;
+}
+
+void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
+    if (w == 0) return;
+    // Timed launches: the stiffness-pattern products on large levels (the P2 operator), A-values only.
+    const bool timed = ctx->time_kernels && vals9 && !mscal && lvl.n_blocks >= 100000;
+    size_t slot = 0;
+    if (timed) {
+        if (ctx->timer_used == ctx->timer_events.size()) {
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a));
+            HIP_CHECK(hipEventCreate(&b));
+            ctx->timer_events.emplace_back(a, b);
+            ctx->timer_bytes.push_back(0);
+        }
+        slot = ctx->timer_used++;
+        // algorithmic bytes: 9 values + column index per node block, row pointers, x read once, y written once
+        ctx->timer_bytes[slot] = 76.0 * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + 2.0 * 8.0 * 3.0 * double(lvl.n_nodes) * w;
+        HIP_CHECK(hipEventRecord(ctx->timer_events[slot].first, ctx->stream));
+    }
+    struct Stop {
+        mh_context *c; bool on; size_t s;
+        ~Stop() { if (on) (void)hipEventRecord(c->timer_events[s].second, c->stream); }
+    } stop{ctx, timed, slot};
+    if (vals9 && mscal) launch_spmm<true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
+    else if (vals9) launch_spmm<false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
+    else launch_spmm<true, false>(ctx, lvl, nullptr, x, nullptr, mscal, y2, w);
+}

@@ -454,10 +454,12 @@ struct EigResult {
     uint OpApplications{0}, Restarts{0};
 };
 
-// Restarted shift-invert Lanczos (Spectra SymGEigsShiftSolver<..., ShiftInvert>::compute(LargestMagn, maxit, tol, SmallestAlge)).
-EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double sigma, double tol, uint max_restarts) {
+// One restarted Lanczos run on OP = (K - sigma M)^-1 M in the M inner product, optionally deflated against the
+// M-orthonormal vectors Q (every Krylov vector is kept M-orthogonal to them).  Returns the `nev` Ritz pairs of
+// largest |theta| (theta = 1/(lambda - sigma)) in `theta_out` / `vec_out` (n x nev), or false when not converged.
+bool LanczosRun(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double tol, uint max_restarts, const std::vector<double> &Q,
+                const std::vector<double> &MQ, uint nq, uint64_t seed, std::vector<double> &theta_out, std::vector<double> &vec_out, uint &ops, uint &restarts) {
     const size_t n = size_t(op.rows());
-    EigResult result;
     std::vector<double> V(n * (ncv + 1)), MV(n * (ncv + 1)), T(size_t(ncv) * ncv, 0.0);
     std::vector<double> w(n), Mw(n), h(ncv + 1), theta(ncv), S(size_t(ncv) * ncv);
     auto col = [&](std::vector<double> &a, size_t j) { return a.data() + j * n; };
@@ -466,14 +468,24 @@ EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uin
         for (size_t i = 0; i < n; ++i) s += x[i] * mx[i];
         return std::sqrt(std::max(s, 0.0));
     };
+    auto deflate = [&](double *x) { // x -= Q (MQ^T x), twice
+        for (int pass = 0; pass < 2 && nq; ++pass)
+            for (uint i = 0; i < nq; ++i) {
+                const double *mq = MQ.data() + size_t(i) * n, *q = Q.data() + size_t(i) * n;
+                double s = 0;
+                for (size_t r = 0; r < n; ++r) s += mq[r] * x[r];
+                for (size_t r = 0; r < n; ++r) x[r] -= s * q[r];
+            }
+    };
     // Start vector: fixed-seed uniform noise pushed through the operator once (into the range of OP).
     {
-        std::mt19937_64 rng{0};
+        std::mt19937_64 rng{seed};
         std::uniform_real_distribution<double> uni(-0.5, 0.5);
         for (size_t i = 0; i < n; ++i) w[i] = uni(rng);
         SymMatVec(M, w.data(), Mw.data());
         op.perform_op(Mw.data(), col(V, 0));
-        ++result.OpApplications;
+        ++ops;
+        deflate(col(V, 0));
         SymMatVec(M, col(V, 0), col(MV, 0));
         const double nrm = mnorm(col(V, 0), col(MV, 0));
         for (size_t i = 0; i < n; ++i) {
@@ -485,10 +497,12 @@ EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uin
     uint k = 0; // retained Ritz vectors at the head of V
     double beta_last = 0;
     std::vector<uint> wanted(ncv);
+    uint local_restarts = 0;
     for (;;) {
         for (uint j = k; j < ncv; ++j) {
             op.perform_op(col(MV, j), w.data());
-            ++result.OpApplications;
+            ++ops;
+            deflate(w.data());
             // Two passes of classical Gram-Schmidt in the M inner product against everything so far.
             std::fill(h.begin(), h.end(), 0.0);
             for (int pass = 0; pass < 2; ++pass) {
@@ -516,7 +530,7 @@ EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uin
                 beta_last = beta;
             }
         }
-        if (!sym_eig(int(ncv), T.data(), theta.data(), S.data())) return {};
+        if (!sym_eig(int(ncv), T.data(), theta.data(), S.data())) return false;
         std::iota(wanted.begin(), wanted.end(), 0u);
         std::stable_sort(wanted.begin(), wanted.end(), [&](uint a, uint b) { return std::abs(theta[a]) > std::abs(theta[b]); });
         uint nconv = 0;
@@ -525,11 +539,12 @@ EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uin
             const double res = std::abs(beta_last * S[size_t(c) * ncv + (ncv - 1)]);
             if (res < tol * std::max(eps23, std::abs(theta[c]))) ++nconv;
         }
-        if (nconv >= nev || result.Restarts >= max_restarts) {
-            if (nconv < nev) return {};
+        if (nconv >= nev || local_restarts >= max_restarts) {
+            if (nconv < nev) return false;
             break;
         }
-        ++result.Restarts;
+        ++local_restarts;
+        ++restarts;
         uint keep = nev + std::min(nconv, (ncv - nev) / 2);
         if (nev == 1 && ncv >= 6) keep = ncv / 2;
         else if (nev == 1 && ncv > 2) keep = 2;
@@ -562,22 +577,66 @@ EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uin
         }
         k = keep;
     }
-    // lambda = sigma + 1/theta for the nev wanted, ascending.
-    std::vector<uint> order(wanted.begin(), wanted.begin() + nev);
-    std::vector<double> lambda(ncv);
-    for (uint c : order) lambda[c] = sigma + 1.0 / theta[c];
-    std::stable_sort(order.begin(), order.end(), [&](uint a, uint b) { return lambda[a] < lambda[b]; });
-    result.Eigenvalues.resize(nev);
-    result.Eigenvectors.assign(n * nev, 0.0);
+    theta_out.resize(nev);
+    vec_out.assign(n * nev, 0.0);
     for (uint c = 0; c < nev; ++c) {
-        result.Eigenvalues[c] = lambda[order[c]];
-        const double *s = S.data() + size_t(order[c]) * ncv;
-        double *out = result.Eigenvectors.data() + size_t(c) * n;
+        theta_out[c] = theta[wanted[c]];
+        const double *s = S.data() + size_t(wanted[c]) * ncv;
+        double *out = vec_out.data() + size_t(c) * n;
         for (uint i = 0; i < ncv; ++i) {
             const double si = s[i];
             const double *v = col(V, i);
             for (size_t r = 0; r < n; ++r) out[r] += si * v[r];
         }
+    }
+    return true;
+}
+
+// Restarted shift-invert Lanczos (Spectra SymGEigsShiftSolver<..., ShiftInvert>::compute(LargestMagn, maxit, tol, SmallestAlge)).
+//
+// Multiplicity safeguard (not part of Spectra): a single-vector Krylov space holds one copy of a repeated
+// eigenvalue, and the test bodies here (cubes, square bars, balls) have exact symmetries.  After the main run, short
+// verification runs deflated against everything found so far look for eigenvalues below the largest one returned;
+// any they find replace the tail.  On meshes without exact multiplicities the first verification run finds nothing.
+EigResult ShiftInvertLanczos(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double sigma, double tol, uint max_restarts) {
+    const size_t n = size_t(op.rows());
+    EigResult result;
+    std::vector<double> theta, vecs;
+    if (!LanczosRun(op, M, nev, ncv, tol, max_restarts, {}, {}, 0, 0, theta, vecs, result.OpApplications, result.Restarts)) return {};
+    auto mprod = [&](const std::vector<double> &X, uint cols) {
+        std::vector<double> Y(n * cols);
+        for (uint j = 0; j < cols; ++j) SymMatVec(M, X.data() + size_t(j) * n, Y.data() + size_t(j) * n);
+        return Y;
+    };
+    const uint nv = std::min(8u, nev), ncv_v = uint(std::min<size_t>(std::max(nv + 20u, 20u), n > nev ? n - nev : 1));
+    for (uint round = 0; round < 16 && ncv_v > nv && size_t(nev) + ncv_v < n; ++round) {
+        const std::vector<double> MQ = mprod(vecs, uint(theta.size()));
+        std::vector<double> th2, v2;
+        if (!LanczosRun(op, M, nv, ncv_v, tol, max_restarts, vecs, MQ, uint(theta.size()), 1 + round, th2, v2, result.OpApplications, result.Restarts)) break;
+        // smallest theta currently kept among the first nev (largest lambda)
+        std::vector<uint> order(theta.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint a, uint b) { return theta[a] > theta[b]; });
+        const double cutoff = theta[order[nev - 1]];
+        uint added = 0;
+        for (uint i = 0; i < nv; ++i) {
+            if (th2[i] > cutoff * (1 + 1e-9)) {
+                theta.push_back(th2[i]);
+                vecs.insert(vecs.end(), v2.begin() + size_t(i) * n, v2.begin() + size_t(i + 1) * n);
+                ++added;
+            }
+        }
+        if (added == 0) break;
+    }
+    // lambda = sigma + 1/theta for the nev largest theta, ascending in lambda.
+    std::vector<uint> order(theta.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint a, uint b) { return theta[a] > theta[b]; });
+    result.Eigenvalues.resize(nev);
+    result.Eigenvectors.assign(n * nev, 0.0);
+    for (uint c = 0; c < nev; ++c) {
+        result.Eigenvalues[c] = sigma + 1.0 / theta[order[c]];
+        std::copy(vecs.begin() + size_t(order[c]) * n, vecs.begin() + size_t(order[c] + 1) * n, result.Eigenvectors.begin() + size_t(c) * n);
     }
     return result;
 }

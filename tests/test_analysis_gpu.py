@@ -1,0 +1,227 @@
+"""GPU parity tests of the analysis half, through the C ABI (include/modalhip.h): HIP assembly / SpMM / eigensolve
+against the CPU oracle on the same seeded inputs, the reference's closed-form bar answers, the glTF golden vectors,
+and size-independent properties at the full BASELINE.json sizes."""
+import numpy as np
+import pytest
+
+from mesheditor_amd import meshes
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+SIGMA = -(2 * np.pi * 20.0) ** 2
+
+
+@pytest.fixture(scope="module")
+def api():
+    from mesheditor_amd import api as _api
+    return _api
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _mats(api, oracle, m):
+    return api.material(*m), oracle.material(*m)
+
+
+@pytest.mark.parametrize("name", ["cube_small", "bar_thin"])
+def test_assembly_matches_oracle(api, ctx, oracle, name):
+    """K and M entry by entry (fp64, 1e-12 of the largest entry; the sums differ from Eigen's only in order)."""
+    pts, tets, m, _ = meshes.workload(name)
+    mg, mo = _mats(api, oracle, m)
+    mesh = api.Mesh(ctx, pts, tets)
+    sysg = api.System(ctx, mesh, mg)
+    syso = oracle.System(pts, tets, mo)
+    assert sysg.n == syso.n and sysg.node_count == syso.node_count and sysg.kept_tets == syso.kept_tets
+    assert np.array_equal(sysg.element_nodes(), syso.element_nodes())
+    K, M = sysg.to_scipy()
+    Ko, Mo = syso.full(0), syso.full(1)
+    assert (K != 0).sum() <= (Ko != 0).sum() + 9 * sysg.node_blocks  # same pattern family
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert abs(M - Mo).max() <= 1e-13 * abs(Mo).max()
+    assert abs(K - K.T).max() <= 1e-12 * abs(Ko).max()
+
+
+def test_degenerate_and_ragged_inputs(api, ctx, oracle):
+    pts, tets = meshes.kuhn_box(3, 2, 2, 0.3, 0.2, 0.2)
+    extra = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]]) + 5.0  # a flat tet on its own points
+    pts2 = np.vstack([pts, extra])
+    flat = np.array([[len(pts), len(pts) + 1, len(pts) + 2, len(pts) + 3]], dtype=np.uint32)
+    tets2 = np.vstack([tets[:7], flat, tets[7:], flat])
+    m = meshes.MATERIALS["Glass"]
+    mg, mo = _mats(api, oracle, m)
+    sysg = api.System(ctx, api.Mesh(ctx, pts2, tets2), mg)
+    syso = oracle.System(pts2, tets2, mo)
+    assert sysg.kept_tets == len(tets) == syso.kept_tets
+    assert np.array_equal(sysg.element_nodes(), syso.element_nodes())
+    # every tet degenerate -> EEMPTY
+    with pytest.raises(api.ModalHipError) as e:
+        api.System(ctx, api.Mesh(ctx, pts2, flat), mg)
+    assert e.value.code == 6
+    # out-of-range tet index -> EINVAL
+    with pytest.raises(api.ModalHipError) as e:
+        api.Mesh(ctx, pts, np.array([[0, 1, 2, 10 ** 6]], np.uint32))
+    assert e.value.code == 1
+
+
+def test_spmm_matches_oracle(api, ctx, oracle):
+    pts, tets, m, _ = meshes.workload("cube_small")
+    mg, mo = _mats(api, oracle, m)
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
+    syso = oracle.System(pts, tets, mo)
+    rng = np.random.default_rng(3)
+    for width in (1, 5, 33, 70, 130):
+        x = rng.standard_normal((sysg.n, width))
+        for which in (0, 1):
+            y = sysg.matvec(which, x)
+            ref = np.stack([syso.matvec(which, x[:, j]) for j in range(width)], 1)
+            assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max() * 10
+
+
+@pytest.mark.parametrize("name,nev", [("cube_small", 45), ("bar_square", 45), ("bar_thin", 30)])
+def test_eigenvalues_match_oracle(api, ctx, oracle, name, nev):
+    """BASELINE north star: eigenvalues within 1e-6 relative of the shift-invert reference algorithm (fp64)."""
+    pts, tets, m, _ = meshes.workload(name)
+    mg, mo = _mats(api, oracle, m)
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
+    syso = oracle.System(pts, tets, mo)
+    ev, prof = sysg.eigs(nev, SIGMA, 1e-6)
+    evo, veco, _ = syso.eigs(nev)
+    assert np.all(np.diff(ev) >= -1e-9 * abs(ev[-1]))
+    elastic = evo > 1e-6 * evo[-1]
+    assert elastic.sum() == nev - 6  # six rigid-body modes
+    rel = np.abs(ev[elastic] - evo[elastic]) / evo[elastic]
+    assert rel.max() < 1e-6, rel.max()
+    assert np.abs(ev[~elastic]).max() < 1e-6 * evo[6]
+    # eigenvectors: M-orthonormal, small residuals, same invariant subspaces as the oracle's
+    V = sysg.eigenvectors(nev)
+    Ko, Mo = syso.full(0), syso.full(1)
+    G = V.T @ (Mo @ V)
+    assert np.abs(G - np.eye(nev)).max() < 1e-8
+    R = Ko @ V - (Mo @ V) * ev
+    assert (np.linalg.norm(R, axis=0) / (np.abs(ev - SIGMA) * np.linalg.norm(Mo @ V, axis=0))).max() < 2e-6
+    # compare subspaces cluster by cluster (eigenvectors inside a multiplet are an arbitrary rotation)
+    order, start = np.arange(nev), 6
+    while start < nev:
+        end = start + 1
+        while end < nev and (evo[end] - evo[end - 1]) < 1e-4 * evo[end]:
+            end += 1
+        if end < nev:  # a cluster cut by the end of the window cannot be compared
+            assert helpers.subspace_angle_sin(V[:, start:end], veco[:, start:end], Mo) < 1e-3, (start, end)
+        start = end
+    assert prof["restarts"] > 0 and prof["dofs"] == sysg.n
+
+
+def test_square_bar_closed_forms(api, ctx):
+    """G1 (reference tests/ModalSolverTest.cpp:228-245) through the whole device path."""
+    pts, tets, m, _ = meshes.workload("bar_square")
+    r = api.mesh2modes(ctx, pts, tets, api.material(*m), pts.astype(np.float32))
+    L, W, T = 0.3, 0.05, 0.05
+    fam = helpers.families(r.freqs, r.positions, r.shapes, L, W, T, 20)
+    speed = np.sqrt(m[1] / m[0])
+    helpers.check_family(fam["longitudinal"], [speed / (2 * L) * n for n in (1, 2, 3)], 0.01)
+    tors = np.sqrt(m[1] / 2 / m[0] * 0.140577 * 6) / (2 * L)
+    helpers.check_family(fam["torsional"], [tors * n for n in (1, 2, 3)], 0.05)
+    bending = sorted(fam.get("bending", []) + fam.get("bending_y", []) + fam.get("bending_z", []))[:2]
+    helpers.check_family(bending, helpers.bending_theory(m[1], m[0], L, T, 2), 0.10)
+    assert len(r.freqs) == 30 and r.profile["dofs"] == 9963
+
+
+def test_thin_bar_closed_forms(api, ctx):
+    """G2 (reference tests/ModalSolverTest.cpp:249-261)."""
+    pts, tets, m, _ = meshes.workload("bar_thin")
+    r = api.mesh2modes(ctx, pts, tets, api.material(*m), pts.astype(np.float32))
+    L, W, T = 0.3, 0.05, 0.01
+    fam = helpers.families(r.freqs, r.positions, r.shapes, L, W, T, 30)
+    speed = np.sqrt(m[1] / m[0])
+    helpers.check_family(fam["longitudinal"], [speed / (2 * L) * n for n in (1, 2, 3)], 0.01)
+    helpers.check_family(fam["bending_y"], helpers.bending_theory(m[1], m[0], L, W, 1)[:1], 0.10, 1)
+    helpers.check_family(fam["bending_z"], helpers.bending_theory(m[1], m[0], L, T, 1), 0.05)
+
+
+def test_mesh2modes_matches_oracle_field_by_field(api, ctx, oracle, golden):
+    """The glTF 'Solved box' body (G3) through both implementations: every ModalResult field."""
+    model = golden["Solved box"]
+    lo, hi = np.array(model["positionMin"]), np.array(model["positionMax"])
+    pts, tets = meshes.kuhn_box(12, 3, 1, *(hi - lo), origin=tuple(lo))
+    pts = pts.astype(np.float32).astype(np.float64)
+    m = meshes.MATERIALS["Ceramic"]
+    ex = pts.astype(np.float32)
+    cfg_g, cfg_o = api.default_config(), oracle.default_config()
+    rg = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=cfg_g, keep_basis=True)
+    ro = oracle.mesh2modes(pts, tets, oracle.material(*m), ex, config=cfg_o, keep_basis=True)
+    assert len(rg.freqs) == len(ro.freqs) == 10
+    assert np.allclose(rg.freqs, ro.freqs, rtol=1e-6) and np.allclose(rg.t60s, ro.t60s, rtol=2e-6)
+    assert abs(rg.original_fundamental - ro.original_fundamental) < 1e-3
+    assert np.array_equal(rg.sample_point_of_excitation, ro.sample_point_of_excitation)
+    assert np.array_equal(rg.positions, ro.positions)
+    assert abs(rg.mass - ro.mass) <= 1e-15 * ro.mass and np.allclose(rg.center_of_mass, ro.center_of_mass, atol=1e-9)
+    assert np.allclose(rg.inertia_diagonal, ro.inertia_diagonal, rtol=1e-6)
+    # shapes: simple (non-degenerate) modes agree up to sign
+    for k in range(4):
+        a, b = rg.shapes[:, k, :].ravel(), ro.shapes[:, k, :].ravel()
+        s = np.sign(a @ b)
+        assert np.abs(a - s * b).max() < 1e-3 * np.abs(b).max()
+    assert rg.basis.shape == ro.basis.shape
+    # against the reference's own committed output (different tetrahedralisation): 3.5e-4 on the first four modes
+    gold = np.array(model["frequencies"])
+    assert (np.abs(rg.freqs[:4] - gold[:4]) / gold[:4]).max() < 3.5e-4
+    assert abs(rg.mass - model["massProperties"]["mass"]) < 2e-6 * rg.mass
+
+
+def test_warm_start_and_rescale(api, ctx, oracle):
+    pts, tets, m, _ = meshes.workload("cube_small")
+    mat = api.material(*m)
+    ex = pts[:: max(1, len(pts) // 10)].astype(np.float32)
+    cfg = api.default_config(num_modes=10, num_fem_modes=25, max_mode_freq=1e6)
+    cold = api.mesh2modes(ctx, pts, tets, mat, ex, config=cfg, keep_basis=True)
+    warm = api.mesh2modes(ctx, pts, tets, mat, ex, config=cfg, seed_basis=cold.basis)
+    assert len(warm.freqs) == len(cold.freqs) == 10
+    assert abs(float(warm.freqs[0]) - float(cold.freqs[0])) < 0.05  # reference bench criterion
+    assert warm.profile["restarts"] < cold.profile["restarts"]
+    # RescaleModes against the oracle's
+    solved, edited = api.material(*m), api.material(m[0] * 2, m[1] * 3, m[2], m[3], m[4])
+    got = api.rescale_modes(cold.eigenvalues, cold.summary_shapes, solved, edited, cfg)
+    ref = oracle.rescale_modes(cold.eigenvalues, cold.summary_shapes, oracle.material(*m), oracle.material(m[0] * 2, m[1] * 3, m[2], m[3], m[4]),
+                               oracle.default_config(num_modes=10, num_fem_modes=25, max_mode_freq=1e6))
+    for a, b in zip(got[:3], ref[:3]):
+        assert np.array_equal(a, b)
+    assert api.rescale_modes(cold.eigenvalues, cold.summary_shapes, solved, api.material(m[0], m[1], 0.3), cfg) is None
+
+
+def test_nearest_points_first_minimum(api, ctx):
+    pts, tets = meshes.kuhn_box(6, 5, 4, 1.0, 1.0, 1.0)
+    mesh = api.Mesh(ctx, pts, tets)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-0.2, 1.2, (500, 3)).astype(np.float32)
+    q[:50] = ((pts[:50] + pts[1:51]) / 2).astype(np.float32)  # exact ties between two points
+    got = mesh.nearest_points(q)
+    d = ((q[:, None, :].astype(np.float64) - pts[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(got, d.argmin(1).astype(np.uint32))
+
+
+def test_full_size_properties(api, ctx):
+    """BASELINE configs[1] size (ball ~10k tets, 65 eigenpairs) and the 100k-tet metric config: residuals,
+    M-orthonormality via the device SpMM, rigid-body count -- properties that need no CPU reference."""
+    for name in ("ball_s10k", "cube_s100k"):
+        pts, tets, m, kw = meshes.workload(name)
+        mesh = api.Mesh(ctx, pts, tets)
+        sysg = api.System(ctx, mesh, api.material(*m))
+        nev = kw["num_fem_modes"]
+        ev, prof = sysg.eigs(nev, SIGMA, 1e-5)
+        assert (np.abs(ev[:6]) < 1e-6 * ev[6]).all() and ev[6] > 0 and np.all(np.diff(ev[6:]) >= 0)
+        V = sysg.eigenvectors(nev)
+        KV, MV = sysg.matvec(0, V), sysg.matvec(1, V)
+        G = V.T @ MV
+        assert np.abs(G - np.eye(nev)).max() < 1e-7
+        res = np.linalg.norm(KV - MV * ev, axis=0) / (np.abs(ev - SIGMA) * np.linalg.norm(MV, axis=0))
+        assert res.max() < 1.5e-5, res.max()
+        # Rayleigh quotients reproduce the eigenvalues
+        rq = np.einsum("ij,ij->j", V, KV)
+        assert np.allclose(rq[6:], ev[6:], rtol=1e-8)
+        sysg.close()
+        mesh.close()
