@@ -99,6 +99,10 @@ int mh_system_export_blocks(const mh_system *, uint32_t *row_node, uint32_t *col
  * DOF order (3*node + component).  The SpMM kernel of the eigensolver, exposed for parity and roofline measurement. */
 int mh_system_matvec(mh_system *, int which, const double *x, double *y, uint32_t width);
 
+/* Measurement aid: average device time of `reps` back-to-back K x products over a resident n x width panel, and the
+ * algorithmic bytes of one launch (76 B per node block + 4 B per row pointer + 16 B per panel entry). */
+int mh_system_bench_spmm(mh_system *, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes);
+
 /* The nearest tet point to each excitation position, first minimum wins (mesh2modes.cpp:626-636). */
 int mh_nearest_points(mh_context *, const mh_mesh *, uint32_t n, const float *positions_xyz, uint32_t *nearest);
 
@@ -106,11 +110,11 @@ int mh_nearest_points(mh_context *, const mh_mesh *, uint32_t n, const float *po
  * M-orthonormal.  Replaces Spectra SymGEigsShiftSolver + CholeskyShiftInvert (cold) and SubspaceIterate (warm, when
  * seed_basis has n rows and >= nev columns; column-major float as ModalResult::Basis) with a block LOBPCG on the
  * shifted pencil (K - sigma M, M) preconditioned by a three-level cycle.  residual_tol is the relative residual
- * ||K x - lambda M x|| / (|lambda - sigma| ||M x||) every returned pair meets.  cancel (nullable) is polled between
- * iterations; progress (nullable) receives 0.3 + 0.65 * converged / nev as the reference's warm path does. */
+ * ||K x - lambda M x|| / (|lambda - sigma| ||M x||) every returned pair meets.  cancel (nullable; one byte, the storage of JobMonitor's
+ * std::atomic<bool>) is polled between iterations; progress (nullable) receives 0.3 + 0.65 * converged / nev as the reference's warm path does. */
 int mh_eigs(mh_system *, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters,
             const float *seed_basis, uint32_t seed_rows, uint32_t seed_cols,
-            const volatile int *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile);
+            const volatile unsigned char *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile);
 /* shapes[node][column][xyz] = eigenvector rows 3*node + {0,1,2} (mesh2modes.cpp:498-504), as float. */
 int mh_system_gather_shapes(const mh_system *, uint32_t n_nodes, const uint32_t *nodes, uint32_t n_cols, float *shapes);
 /* ModalResult::Basis: n x n_cols column-major float, rows in the reference's DOF order (mesh2modes.cpp:509). */
@@ -167,11 +171,12 @@ int mh_bank_zero_state(mh_bank *, uint32_t first_mode, uint32_t count);
  * deal_objects[deal_offset[r] .. deal_offset[r+1]) in that order, each with mode count render_count[i] (Tuned when the
  * object has impacts, Live otherwise).  impacts is updated in place (phase, samples_left, click state).
  * Per dealt object the device returns its post-block energy, its audible prefix (chunk-granular `live`) and whether
- * it fell silent (no impacts and gain-weighted energy below 1e-12: its state was zeroed, ModalAudio.cpp:141-144). */
+ * it fell silent (no impacts and gain-weighted energy below 1e-12: its state was zeroed, ModalAudio.cpp:141-144), plus
+ * its share of the modal-energy diagnostic over its tuned_count modes (ModalAudio.cpp:564-577; nullable). */
 int mh_bank_render(mh_bank *, uint32_t frames, float click_gain, uint32_t n_impacts, mh_impact *impacts,
                    uint32_t n_renderers, const uint32_t *deal_offset, const uint32_t *deal_objects, const uint32_t *render_count,
-                   const float *out_gain, const float *listener_gain, void *out, double *object_energy, uint32_t *object_live,
-                   uint8_t *object_silenced);
+                   const uint32_t *tuned_count, const float *out_gain, const float *listener_gain, void *out, double *object_energy,
+                   uint32_t *object_live, uint8_t *object_silenced, double *object_modal_energy);
 /* Read back state columns (for parity tests and the modal-energy diagnostic, ModalAudio.cpp:564-577). */
 int mh_bank_read_state(const mh_bank *, uint32_t first, uint32_t count, double *state_re, double *state_im);
 

@@ -64,7 +64,7 @@ def lib():
         "mh_assemble": (i32, [vp, vp, C.POINTER(Material), pp]), "mh_system_destroy": (None, [vp]),
         "mh_system_dims": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]),
         "mh_system_element_nodes": (i32, [vp, vp]), "mh_system_export_blocks": (i32, [vp, vp, vp, vp, vp]),
-        "mh_system_matvec": (i32, [vp, i32, vp, vp, u32]), "mh_nearest_points": (i32, [vp, vp, u32, vp, vp]),
+        "mh_system_matvec": (i32, [vp, i32, vp, vp, u32]), "mh_system_bench_spmm": (i32, [vp, u32, u32, C.POINTER(f64), C.POINTER(f64)]), "mh_nearest_points": (i32, [vp, vp, u32, vp, vp]),
         "mh_eigs": (i32, [vp, u32, f64, f64, u32, vp, u32, u32, vp, vp, vp, C.POINTER(Profile)]),
         "mh_system_gather_shapes": (i32, [vp, u32, vp, u32, vp]), "mh_system_basis": (i32, [vp, u32, vp]),
         "mh_system_eigenvectors": (i32, [vp, u32, vp]),
@@ -74,7 +74,7 @@ def lib():
         "mh_bank_create": (i32, [vp, i32, u32, u32, u32, vp, vp, vp, vp, vp, vp, pp]), "mh_bank_destroy": (None, [vp]),
         "mh_bank_set_coefficients": (i32, [vp, u32, u32, vp, vp, vp, vp, vp]), "mh_bank_set_shapes": (i32, [vp, u32, u32, vp, vp, vp]),
         "mh_bank_zero_state": (i32, [vp, u32, u32]),
-        "mh_bank_render": (i32, [vp, u32, C.c_float, u32, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "mh_bank_render": (i32, [vp, u32, C.c_float, u32, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "mh_bank_read_state": (i32, [vp, u32, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():

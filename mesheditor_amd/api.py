@@ -145,6 +145,11 @@ class System:
         self.ctx.check(self.ctx.L.mh_system_matvec(self.h, which, _p(x), _p(y), x.shape[1]))
         return y
 
+    def bench_spmm(self, width, reps=20):
+        ms, by = C.c_double(0), C.c_double(0)
+        self.ctx.check(self.ctx.L.mh_system_bench_spmm(self.h, width, reps, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
     def eigs(self, nev, sigma=-(2 * np.pi * 20.0) ** 2, residual_tol=1e-6, max_iters=200, seed_basis=None):
         ev = np.zeros(nev)
         prof = Profile()

@@ -1,0 +1,143 @@
+// Flat C wrapper over the C++ host mirror, for the Python test-suite (ctypes cannot call C++ directly).
+// Every function forwards to the reference-named API in modal/*.hpp.
+#include "modal/bank.hpp"
+#include "modal/contact.hpp"
+#include "modal/solver.hpp"
+
+#include <cstring>
+#include <exception>
+#include <string>
+
+namespace {
+thread_local std::string g_error;
+ModalModes MakeModes(uint32_t n_modes, uint32_t n_pos, const float *freqs, const float *t60s, const float *shapes, const float *positions, uint32_t n_idx, const uint32_t *idx) {
+    ModalModes m;
+    if (freqs) m.Freqs.assign(freqs, freqs + n_modes); else m.Freqs.assign(n_modes, 0.f);
+    if (t60s) m.T60s.assign(t60s, t60s + n_modes); else m.T60s.assign(n_modes, 0.f);
+    m.Shapes.assign(n_pos, std::vector<vec3>(n_modes));
+    for (uint32_t p = 0; p < n_pos; ++p)
+        for (uint32_t k = 0; k < n_modes; ++k) m.Shapes[p][k] = {shapes[(size_t(p) * n_modes + k) * 3], shapes[(size_t(p) * n_modes + k) * 3 + 1], shapes[(size_t(p) * n_modes + k) * 3 + 2]};
+    if (positions)
+        for (uint32_t p = 0; p < n_pos; ++p) m.Positions.push_back({positions[3 * p], positions[3 * p + 1], positions[3 * p + 2]});
+    if (idx) m.Indices.assign(idx, idx + n_idx);
+    return m;
+}
+} // namespace
+
+struct mhx_scene {
+    ModalAudio audio;
+    ModalBank next;
+};
+
+extern "C" {
+const char *mhx_last_error() { return g_error.c_str(); }
+
+mhx_scene *mhx_scene_create(float sample_rate, int device) {
+    auto *s = new mhx_scene;
+    s->next.SampleRate = sample_rate;
+    s->audio.Device = device;
+    return s;
+}
+void mhx_scene_destroy(mhx_scene *s) { delete s; }
+uint32_t mhx_add_object(mhx_scene *s, uint32_t entity, uint32_t n_modes, uint32_t n_pos, const float *shapes, const float *positions, uint32_t n_idx, const uint32_t *idx) {
+    return AddModalObject(s->next, entt::entity{entity}, MakeModes(n_modes, n_pos, nullptr, nullptr, shapes, positions, n_idx, idx));
+}
+void mhx_tune_object(mhx_scene *s, int live, uint32_t object, uint32_t n, const float *freqs, const float *t60s, float radius_scale) {
+    TuneModalObject(live ? LiveBank(s->audio) : s->next, object, std::span<const float>(freqs, n), std::span<const float>(t60s, n), radius_scale);
+}
+int mhx_set_shapes(mhx_scene *s, int live, uint32_t object, uint32_t n_modes, uint32_t n_pos, const float *shapes) {
+    return SetModalObjectShapes(live ? LiveBank(s->audio) : s->next, object, MakeModes(n_modes, n_pos, nullptr, nullptr, shapes, nullptr, 0, nullptr)) ? 1 : 0;
+}
+void mhx_set_gains(mhx_scene *s, int live, uint32_t object, float out_gain, float listener_gain) {
+    auto &b = live ? LiveBank(s->audio) : s->next;
+    b.OutGain[object] = out_gain;
+    b.ListenerGain[object] = listener_gain;
+}
+int mhx_install(mhx_scene *s) {
+    try {
+        InstallModalBank(s->audio, s->next);
+        s->next = ModalBank{};
+        s->next.SampleRate = LiveBank(s->audio).SampleRate;
+        return 0;
+    } catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+void mhx_set_renderers(mhx_scene *s, uint32_t n) { s->audio.RenderPool.SetSize(n); }
+void mhx_set_click_gain(mhx_scene *s, float g) { s->audio.ClickGain.store(g); }
+void mhx_set_max_impacts(mhx_scene *s, uint32_t n) { s->audio.MaxImpacts.store(n); }
+int mhx_enqueue(mhx_scene *s, const ModalEvent *e) {
+    const auto before = s->audio.EventsDropped;
+    EnqueueModalEvent(s->audio, *e);
+    return s->audio.EventsDropped == before ? 1 : 0;
+}
+int mhx_render(mhx_scene *s, float *out, uint32_t frames) {
+    try {
+        RenderModal(s->audio, out, frames);
+        return 0;
+    } catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+uint32_t mhx_num_objects(mhx_scene *s) { return uint32_t(LiveBank(s->audio).Entities.size()); }
+uint32_t mhx_active_impacts(mhx_scene *s) { return s->audio.ActiveImpacts.load(); }
+double mhx_modal_energy(mhx_scene *s) { return s->audio.ModalEnergy.load(); }
+float mhx_render_share(mhx_scene *s) { return s->audio.RenderShare.load(); }
+int mhx_find_object(mhx_scene *s, uint32_t entity) {
+    const auto o = FindModalObject(LiveBank(s->audio), entt::entity{entity});
+    return o ? int(*o) : -1;
+}
+// which: as oracle mo_bank_column
+uint32_t mhx_column(mhx_scene *s, int live, int which, double *out) {
+    if (live && (which == 2 || which == 3)) SyncModalState(s->audio);
+    const auto &b = live ? LiveBank(s->audio) : s->next;
+    const std::vector<float> *cols[] = {&b.CoeffRe, &b.CoeffIm, &b.StateRe, &b.StateIm, &b.RadiationGain, &b.RadiationArea, &b.DeflectionGain, &b.OutPhaseIm,
+                                        &b.OutPhaseRe, &b.QuadCompliance, &b.QuadDriveScale, &b.ShapeX, &b.ShapeY, &b.ShapeZ, &b.OutGain, &b.ListenerGain,
+                                        &b.RadiantRadius, &b.DeflectionScale};
+    if (which < 0 || which >= 18) return 0;
+    const auto &c = *cols[which];
+    if (out) for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
+    return uint32_t(c.size());
+}
+void mhx_object_state(mhx_scene *s, uint32_t *tuned, uint32_t *live, uint8_t *ringing) {
+    const auto &b = LiveBank(s->audio);
+    for (size_t o = 0; o < b.Entities.size(); ++o) {
+        if (tuned) tuned[o] = b.TunedModeCount[o];
+        if (live) live[o] = b.LiveModeCount[o];
+        if (ringing) ringing[o] = b.Ringing[o];
+    }
+}
+void mhx_recoil_click_filter(double radius, double volume, double mass, double sample_rate, float out3[3]) {
+    const auto f = RecoilClickFilter(radius, volume, mass, sample_rate);
+    out3[0] = f.B0; out3[1] = f.A1; out3[2] = f.A2;
+}
+void mhx_recoil_object_filter(double radius, double volume, double sample_rate, float out6[6]) {
+    const auto f = RecoilObjectFilter(radius, volume, sample_rate);
+    out6[0] = f.RadB0; out6[1] = f.AirB0; out6[2] = f.AirB1; out6[3] = f.AirB2; out6[4] = f.A1; out6[5] = f.A2;
+}
+double mhx_estimate_contact_time(double mass, const float inv_inertia9[9], const float arm[3], const float dir[3], double speed, const double object_mat[5],
+                                 double object_curvature, double area, const double impactor_mat[5], double impactor_curvature, double impactor_inv_mass,
+                                 double scale, double roughness) {
+    ContactDynamics d;
+    d.Mass = mass;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) d.InverseInertia[c][r] = inv_inertia9[c * 3 + r];
+    d.ContactArm = {vec3{arm[0], arm[1], arm[2]}};
+    const AcousticMaterialProperties om{object_mat[0], object_mat[1], object_mat[2], object_mat[3], object_mat[4]};
+    const Impactor imp{{impactor_mat[0], impactor_mat[1], impactor_mat[2], impactor_mat[3], impactor_mat[4]}, impactor_curvature, impactor_inv_mass};
+    return EstimateContactTime(d, 0, vec3{dir[0], dir[1], dir[2]}, speed, om, object_curvature, area, imp, scale, roughness);
+}
+double mhx_striker_mass(double density, float tip_radius, float length) {
+    Striker s;
+    s.Material.Properties.Density = density;
+    s.TipRadius = tip_radius;
+    s.Length = length;
+    return StrikerMass(s);
+}
+void mhx_inverse_inertia_tensor(const float diag[3], const float q[4], float out9[9]) {
+    MassProperties mp;
+    mp.InertiaDiagonal = {diag[0], diag[1], diag[2]};
+    mp.InertiaOrientation = {q[0], q[1], q[2], q[3]};
+    const auto m = InverseInertiaTensor(mp);
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) out9[c * 3 + r] = m[c][r];
+}
+double mhx_saturation_penetration(double curvature, double area) { return SaturationPenetration(curvature, area); }
+double mhx_punch_stiffness(double inv_modulus, double area) { return PunchStiffness(inv_modulus, area); }
+}

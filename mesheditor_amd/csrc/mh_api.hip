@@ -242,6 +242,35 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+int mh_system_bench_spmm(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes) {
+    if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * s->n_nodes;
+        DevArray<double> x(ctx, n * width), y(ctx, n * width);
+        std::vector<double> hx(n * width);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        x.upload(hx.data(), hx.size());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int warm = 0; warm < 2; ++warm) mh_spmm(ctx, s->L2, s->L2.kval, x, y, nullptr, nullptr, width);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t r = 0; r < reps; ++r) mh_spmm(ctx, s->L2, s->L2.kval, x, y, nullptr, nullptr, width);
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
+        if (algorithmic_bytes) *algorithmic_bytes = 76.0 * double(s->L2.n_blocks) + 4.0 * (double(s->n_nodes) + 1) + 16.0 * double(n) * width;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 int mh_nearest_points(mh_context *ctx, const mh_mesh *mesh, uint32_t n, const float *positions_xyz, uint32_t *nearest) {
     if (!ctx || !mesh || (n && (!positions_xyz || !nearest))) return MH_EINVAL;
     if (n == 0) return MH_OK;

@@ -153,7 +153,7 @@ template<typename Real>
 __global__ void k_bank_objects(BankCols<Real> b, const uint32_t *__restrict__ deal_objects, const uint32_t *__restrict__ render_count,
                                const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ imp_ptr, const Real *__restrict__ out_gain,
                                const Real *__restrict__ chunk_energy, uint32_t n_dealt, double *__restrict__ energy_out, uint32_t *__restrict__ live_out,
-                               uint8_t *__restrict__ silenced) {
+                               uint8_t *__restrict__ silenced, const uint32_t *__restrict__ tuned_count, double *__restrict__ modal_energy) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_dealt) return;
     const uint32_t o = deal_objects[d], count = render_count[d];
@@ -178,6 +178,19 @@ __global__ void k_bank_objects(BankCols<Real> b, const uint32_t *__restrict__ de
     energy_out[d] = double(energy);
     live_out[d] = live;
     silenced[d] = silent ? 1 : 0;
+    // Mechanical energy behind the pressure-unit states (the diagnostic of ModalAudio.cpp:564-577), in double.
+    double me = 0;
+    if (!silent) {
+        const uint32_t k0 = b.mode_offset[o], n = tuned_count[d];
+        for (uint32_t k = 0; k < n; ++k) {
+            const double g = double(b.rad_gain[k0 + k]);
+            if (g > 0) {
+                const double re = double(b.state_re[k0 + k]), im = double(b.state_im[k0 + k]);
+                me += 0.5 * (re * re + im * im) / (g * g);
+            }
+        }
+    }
+    modal_energy[d] = me;
 }
 
 // Renderer r's private buffer: its chunks' partial signals added in order (ModalAudio.cpp:130).
@@ -212,7 +225,8 @@ template<typename Real> struct BankImpl {
     DevArray<Real> force, click, partial, chunk_energy, gain_scratch, rout, d_out, d_out_gain, d_listener_gain;
     DevArray<WaveDesc> d_waves;
     DevArray<uint32_t> d_deal_objects, d_render_count, d_chunk_base, d_imp_ptr, d_imp_idx, d_renderer_chunk_ptr, d_live;
-    DevArray<double> d_energy;
+    DevArray<double> d_energy, d_modal_energy;
+    DevArray<uint32_t> d_tuned;
     DevArray<uint8_t> d_silenced;
     BankCols<Real> cols() {
         return {coeff_re, coeff_im, state_re, state_im, rad_gain, phase_im, phase_re, shape_x, shape_y, shape_z, mode_offset, mode_count, shape_offset};
@@ -233,8 +247,8 @@ void upload_converted(mh_context *ctx, DevArray<Real> &dst, size_t offset, const
 
 template<typename Real>
 void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t n_impacts, mh_impact *impacts, uint32_t n_renderers, const uint32_t *deal_offset,
-                 const uint32_t *deal_objects, const uint32_t *render_count, const float *out_gain, const float *listener_gain, void *out_v,
-                 double *object_energy, uint32_t *object_live, uint8_t *object_silenced) {
+                 const uint32_t *deal_objects, const uint32_t *render_count, const uint32_t *tuned_count, const float *out_gain, const float *listener_gain,
+                 void *out_v, double *object_energy, uint32_t *object_live, uint8_t *object_silenced, double *object_modal_energy) {
     mh_context *ctx = B.ctx;
     hipStream_t st = ctx->stream;
     Real *out = static_cast<Real *>(out_v);
@@ -301,6 +315,9 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
         ensure(ctx, B.chunk_energy, n_chunks + 1);
         ensure(ctx, B.gain_scratch, size_t(n_waves + 1) * max_imp * WAVE);
         ensure(ctx, B.d_energy, n_dealt);
+        ensure(ctx, B.d_modal_energy, n_dealt);
+        ensure(ctx, B.d_tuned, n_dealt);
+        HIP_CHECK(hipMemcpyAsync(B.d_tuned.get(), tuned_count, n_dealt * 4, hipMemcpyHostToDevice, st));
         ensure(ctx, B.d_live, n_dealt);
         ensure(ctx, B.d_silenced, n_dealt);
         if (n_waves) HIP_CHECK(hipMemcpyAsync(B.d_waves.get(), waves.data(), n_waves * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
@@ -317,7 +334,7 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
             KERNEL_CHECK();
         }
         k_bank_objects<Real><<<div_up(n_dealt, 64), 64, 0, st>>>(B.cols(), B.d_deal_objects, B.d_render_count, B.d_chunk_base, B.d_imp_ptr, B.d_out_gain,
-                                                                  B.chunk_energy, n_dealt, B.d_energy, B.d_live, B.d_silenced);
+                                                                  B.chunk_energy, n_dealt, B.d_energy, B.d_live, B.d_silenced, B.d_tuned, B.d_modal_energy);
         KERNEL_CHECK();
         dim3 grid(div_up(frames, 64), n_renderers);
         k_bank_renderer_sum<Real><<<grid, 64, 0, st>>>(B.partial, B.d_renderer_chunk_ptr, frames, B.rout);
@@ -334,6 +351,7 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
         HIP_CHECK(hipMemcpyAsync(object_energy, B.d_energy.get(), n_dealt * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(object_live, B.d_live.get(), n_dealt * 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(object_silenced, B.d_silenced.get(), n_dealt, hipMemcpyDeviceToHost, st));
+        if (object_modal_energy) HIP_CHECK(hipMemcpyAsync(object_modal_energy, B.d_modal_energy.get(), n_dealt * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HIP_CHECK(hipStreamSynchronize(st));
     for (uint32_t i = 0; i < n_impacts; ++i) {
@@ -452,14 +470,15 @@ int mh_bank_zero_state(mh_bank *bank, uint32_t first, uint32_t count) {
     } catch (const std::exception &e) { return mh_guard(bank->ctx, e); }
 }
 int mh_bank_render(mh_bank *bank, uint32_t frames, float click_gain, uint32_t n_impacts, mh_impact *impacts, uint32_t n_renderers, const uint32_t *deal_offset,
-                   const uint32_t *deal_objects, const uint32_t *render_count, const float *out_gain, const float *listener_gain, void *out,
-                   double *object_energy, uint32_t *object_live, uint8_t *object_silenced) {
+                   const uint32_t *deal_objects, const uint32_t *render_count, const uint32_t *tuned_count, const float *out_gain, const float *listener_gain,
+                   void *out, double *object_energy, uint32_t *object_live, uint8_t *object_silenced, double *object_modal_energy) {
     if (!bank || !out || (n_impacts && !impacts) || (n_renderers && !deal_offset) || !out_gain || !listener_gain) return MH_EINVAL;
+    if (n_renderers && deal_offset[n_renderers] && (!deal_objects || !render_count || !tuned_count || !object_energy || !object_live || !object_silenced)) return MH_EINVAL;
     if (frames == 0) return MH_OK;
     try {
         HIP_CHECK(hipSetDevice(bank->ctx->device));
-        if (bank->dbl) render_impl(*bank->d, frames, click_gain, n_impacts, impacts, n_renderers, deal_offset, deal_objects, render_count, out_gain, listener_gain, out, object_energy, object_live, object_silenced);
-        else render_impl(*bank->f, frames, click_gain, n_impacts, impacts, n_renderers, deal_offset, deal_objects, render_count, out_gain, listener_gain, out, object_energy, object_live, object_silenced);
+        if (bank->dbl) render_impl(*bank->d, frames, click_gain, n_impacts, impacts, n_renderers, deal_offset, deal_objects, render_count, tuned_count, out_gain, listener_gain, out, object_energy, object_live, object_silenced, object_modal_energy);
+        else render_impl(*bank->f, frames, click_gain, n_impacts, impacts, n_renderers, deal_offset, deal_objects, render_count, tuned_count, out_gain, listener_gain, out, object_energy, object_live, object_silenced, object_modal_energy);
         return MH_OK;
     } catch (const std::exception &e) { return mh_guard(bank->ctx, e); }
 }

@@ -159,6 +159,7 @@ struct mh_mesh {
 // One level of the operator hierarchy: symmetric matrix in 3x3 node blocks (BSR), rows and columns in the level's
 // internal (Morton) numbering.
 struct BsrLevel {
+    int id{0}; // 2 = P2 operator, 1 = P1 operator
     uint32_t n_nodes{0};
     uint64_t n_blocks{0};
     DevArray<uint32_t> row_ptr; // n_nodes + 1

@@ -465,7 +465,7 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues)
 } // namespace
 
 static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
-                      uint32_t seed_cols, const volatile int *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
+                      uint32_t seed_cols, const volatile unsigned char *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
     {
         mh_context *ctx = sys->ctx;
         HIP_CHECK(hipSetDevice(ctx->device));
@@ -690,7 +690,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
 }
 
 extern "C" int mh_eigs(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
-                       uint32_t seed_cols, const volatile int *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
+                       uint32_t seed_cols, const volatile unsigned char *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
     if (!sys || !eigenvalues || nev == 0) return MH_EINVAL;
     try {
         eigs_impl(sys, nev, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, eigenvalues, profile);

@@ -605,6 +605,8 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
     DevArray<double> tq_dev(ctx, tq.size()), tl_dev(ctx, tl.size());
     tq_dev.upload(tq.data(), tq.size());
     tl_dev.upload(tl.data(), tl.size());
+    sys->L2.id = 2;
+    sys->L1.id = 1;
     build_level<10>(ctx, tmp, sys->elem_nodes, nt, nn, sys->elem_basis, tq_dev, mat, sys->L2);
     build_level<4>(ctx, tmp, elem_p1, nt, npts, sys->elem_basis, tl_dev, mat, sys->L1);
 

@@ -14,11 +14,15 @@ constexpr int TB = 256;
 template<int CW, int NC, bool WITH_M, bool WITH_A>
 __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ vals9,
                                             const double *__restrict__ mscal, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ y2,
-                                            uint32_t nnodes, uint32_t w) {
+                                            uint32_t nnodes, uint32_t w, int xcd_remap) {
     constexpr int RPW = 64 / CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c0 = blockIdx.y * (CW * NC) + (lane % CW);
-    uint32_t row = (blockIdx.x * (TB / 64) + wave) * RPW + lane / CW;
+    // Workgroups are dealt round-robin over the 8 XCDs; remap so that each XCD walks one contiguous eighth of the
+    // (Morton-ordered) rows and the gathered x rows are shared inside one L2.
+    const uint32_t nb = gridDim.x, per = (nb + 7) / 8;
+    const uint32_t bid = xcd_remap ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    uint32_t row = (bid * (TB / 64) + wave) * RPW + lane / CW;
     if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
     if (row >= nnodes) return;
     bool active[NC];
@@ -31,31 +35,59 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
     double a0[NC], a1[NC], a2[NC], m0[NC], m1[NC], m2[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) a0[k] = a1[k] = a2[k] = m0[k] = m1[k] = m2[k] = 0;
-    const uint32_t p0 = row_ptr[row], p1 = row_ptr[row + 1];
-    for (uint32_t p = p0; p < p1; ++p) {
-        const uint32_t j = col[p];
-        const double *xr = x + size_t(3) * j * w;
-        double v[9];
-        if (WITH_A) {
+    const uint32_t p1 = row_ptr[row + 1];
+    uint32_t p = row_ptr[row];
+    // U node blocks per step: all column indices, then all x gathers, then all block values are issued before the
+    // first FMA, so a wave keeps 3*U*NC gathers in flight instead of one dependent load chain per block.
+    auto step = [&](auto u_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        uint32_t j[U];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) v[e] = vals9[size_t(9) * p + e];
+        for (int u = 0; u < U; ++u) j[u] = col[p + u];
+        double xv[U][NC][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double *xr = x + size_t(3) * j[u] * w;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                xv[u][k][0] = xr[cc[k]];
+                xv[u][k][1] = xr[w + cc[k]];
+                xv[u][k][2] = xr[2 * size_t(w) + cc[k]];
+            }
         }
-        const double m = WITH_M ? mscal[p] : 0.0;
+        double v[U][9], m[U];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const double x0 = xr[cc[k]], x1 = xr[w + cc[k]], x2 = xr[2 * size_t(w) + cc[k]];
+        for (int u = 0; u < U; ++u) {
             if (WITH_A) {
-                a0[k] += v[0] * x0 + v[1] * x1 + v[2] * x2;
-                a1[k] += v[3] * x0 + v[4] * x1 + v[5] * x2;
-                a2[k] += v[6] * x0 + v[7] * x1 + v[8] * x2;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) v[u][e] = vals9[size_t(9) * (p + u) + e];
             }
-            if (WITH_M) {
-                m0[k] += m * x0;
-                m1[k] += m * x1;
-                m2[k] += m * x2;
+            m[u] = WITH_M ? mscal[p + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const double x0 = xv[u][k][0], x1 = xv[u][k][1], x2 = xv[u][k][2];
+                if (WITH_A) {
+                    a0[k] += v[u][0] * x0 + v[u][1] * x1 + v[u][2] * x2;
+                    a1[k] += v[u][3] * x0 + v[u][4] * x1 + v[u][5] * x2;
+                    a2[k] += v[u][6] * x0 + v[u][7] * x1 + v[u][8] * x2;
+                }
+                if (WITH_M) {
+                    m0[k] += m[u] * x0;
+                    m1[k] += m[u] * x1;
+                    m2[k] += m[u] * x2;
+                }
             }
         }
-    }
+        p += U;
+    };
+    constexpr int UMAX = NC >= 4 ? 2 : (NC == 2 ? 4 : 8);
+    while (p + UMAX <= p1) step(std::integral_constant<int, UMAX>{});
+    if (UMAX >= 8 && p + 4 <= p1) step(std::integral_constant<int, 4>{});
+    if (UMAX >= 4 && p + 2 <= p1) step(std::integral_constant<int, 2>{});
+    while (p < p1) step(std::integral_constant<int, 1>{});
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         if (!active[k]) continue;
@@ -71,8 +103,10 @@ void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, cons
     auto go = [&](auto cw_tag, auto nc_tag) {
         constexpr int CW = decltype(cw_tag)::value, NC = decltype(nc_tag)::value;
         constexpr int RPW = 64 / CW;
-        dim3 grid(div_up(n, (TB / 64) * RPW), div_up(w, CW * NC));
-        k_spmm<CW, NC, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, n, w);
+        static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+        // grid.x padded to a multiple of 8 so the XCD remap is a bijection onto [0, 8*per)
+        dim3 grid((div_up(n, (TB / 64) * RPW) + 7) / 8 * 8, div_up(w, CW * NC));
+        k_spmm<CW, NC, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, n, w, xcd);
     };
     using I = std::integral_constant<int, 0>;
     (void)sizeof(I);
@@ -101,8 +135,8 @@ void mh_timer_flush(mh_context *ctx) {
 
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
     if (w == 0) return;
-    // Timed launches: the stiffness-pattern products on large levels (the P2 operator), A-values only.
-    const bool timed = ctx->time_kernels && vals9 && !mscal && lvl.n_blocks >= 100000;
+    // Timed launches: products with the P2 operator's 3x3 blocks (A-values only).
+    const bool timed = ctx->time_kernels && vals9 && !mscal && lvl.id == 2;
     size_t slot = 0;
     if (timed) {
         if (ctx->timer_used == ctx->timer_events.size()) {

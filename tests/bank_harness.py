@@ -60,3 +60,31 @@ class OracleScene:
         for b in range(blocks):
             self.bank.render(sig[b * frames:(b + 1) * frames])
         return sig
+
+
+class DeviceScene:
+    """tests/ModalBench.h:47-81 over the HIP bank (libmodalhost.so -> libmodalhip.so)."""
+
+    def __init__(self, object_count, mode_count, longest_t60, renderers, sample_rate=SAMPLE_RATE, modes=None, device=0):
+        from mesheditor_amd import bank as hipbank
+        self.dtype = np.float32
+        self.bank = hipbank.Scene(sample_rate, device)
+        self.bank.set_renderers(renderers)
+        modes = modes or make_modes(mode_count, longest_t60)
+        self.objects = []
+        for o in range(object_count):
+            slot = self.bank.add_object(o, modes["shapes"], modes["positions"], modes["indices"])
+            self.bank.tune_object(slot, modes["freqs"], modes["t60s"])
+            self.bank.set_gains(slot, 1.0, 1.0)
+            self.objects.append(slot)
+        self.bank.install()
+        self.bank.render(np.zeros(BLOCK, self.dtype))
+
+    def enqueue(self, ev):
+        return self.bank.enqueue(ev)
+
+    def render(self, blocks, frames):
+        sig = np.zeros(blocks * frames, self.dtype)
+        for b in range(blocks):
+            self.bank.render(sig[b * frames:(b + 1) * frames])
+        return sig
