@@ -169,7 +169,15 @@ struct BsrLevel {
     DevArray<double> aval; // n_blocks x 9: K - sigma*M, filled by the eigensolver set-up
     DevArray<double> dinv; // 3*n_nodes: 1 / diag(A)
     double lmax{0}; // spectral radius estimate of D^-1 A
+    // Row tiles of TILE_ROWS consecutive rows for the LDS-staged SpMM: the sorted union of each tile's column nodes
+    // and, per node block, its column's position in that union.
+    uint32_t n_tiles{0};
+    DevArray<uint32_t> tile_uptr; // n_tiles + 1
+    DevArray<uint32_t> tile_ucols; // tile_uptr[n_tiles]
+    DevArray<uint16_t> block_local; // n_blocks
+    bool tiled{false};
 };
+constexpr uint32_t MH_TILE_ROWS = 64;
 
 struct mh_system {
     mh_context *ctx;

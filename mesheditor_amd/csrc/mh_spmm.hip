@@ -118,6 +118,132 @@ void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, cons
     else go(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
     KERNEL_CHECK();
 }
+
+// ---- LDS-staged variant ---------------------------------------------------------------------------------------
+// One 1024-thread workgroup per tile of 64 consecutive rows; wave v owns rows 4v..4v+3 and keeps their accumulators in
+// registers.  The tile's sorted unique column nodes are walked in segments of S nodes: the segment's x rows (3*w
+// doubles each, contiguous) are staged in LDS once and every node block of the tile that points into the segment
+// reads its x from there.  Each x row therefore leaves L2 once per tile instead of once per node block (~5x fewer
+// gathered bytes on P2 tetrahedral meshes in Morton order); the block values and column ranks stream through scalar
+// loads exactly once.
+template<int NC>
+__global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict__ row_ptr, const uint16_t *__restrict__ local, const double *__restrict__ vals9,
+                                                    const uint32_t *__restrict__ tile_uptr, const uint32_t *__restrict__ tile_ucols,
+                                                    const double *__restrict__ x, double *__restrict__ y, uint32_t nnodes, uint32_t w, uint32_t seg_nodes,
+                                                    uint32_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const uint32_t per = (gridDim.x + 7) / 8;
+    const uint32_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8; // XCD-contiguous tiles
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w3 = 3 * w;
+    const uint32_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
+    uint32_t cc[NC];
+    bool active[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        active[k] = uint32_t(lane) + 64 * k < w;
+        cc[k] = active[k] ? lane + 64 * k : 0;
+    }
+    uint32_t pcur[4], pend[4];
+    double acc[4][NC][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t r = tile * MH_TILE_ROWS + wave * 4 + q;
+        pcur[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r] : 0);
+        pend[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r + 1] : 0);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[q][k][0] = acc[q][k][1] = acc[q][k][2] = 0;
+    }
+    for (uint32_t base = 0; base < nu; base += seg_nodes) {
+        const uint32_t cnt = min(seg_nodes, nu - base);
+        // stage: wave v copies x rows v, v+16, ... of the segment (each 3*w contiguous doubles)
+        for (uint32_t k = wave; k < cnt; k += 16) {
+            const uint32_t node = tile_ucols[u0 + base + k];
+            const double *src = x + size_t(node) * w3;
+            double *dst = xs + size_t(k) * w3;
+            for (uint32_t off = lane; off < w3; off += 64) dst[off] = src[off];
+        }
+        __syncthreads();
+        const uint32_t lim = base + cnt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            for (;;) {
+                const uint32_t rem = pend[q] - pcur[q];
+                if (rem == 0) break;
+                const uint32_t lv = uint32_t(lane) < rem ? uint32_t(local[pcur[q] + lane]) : 0xffffu;
+                const uint32_t n = __popcll(__ballot(lv < lim));
+                uint32_t p = pcur[q];
+                auto step = [&](auto u_tag, uint32_t first) {
+                    constexpr int U = decltype(u_tag)::value;
+                    double v[U][9];
+                    uint32_t li[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        li[u] = __builtin_amdgcn_readlane(int(lv), int(first) + u) - base;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) v[u][e] = vals9[size_t(9) * (p + u) + e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const double *xr = xs + size_t(li[u]) * w3;
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) {
+                            const double x0 = xr[cc[k]], x1 = xr[w + cc[k]], x2 = xr[2 * w + cc[k]];
+                            acc[q][k][0] += v[u][0] * x0 + v[u][1] * x1 + v[u][2] * x2;
+                            acc[q][k][1] += v[u][3] * x0 + v[u][4] * x1 + v[u][5] * x2;
+                            acc[q][k][2] += v[u][6] * x0 + v[u][7] * x1 + v[u][8] * x2;
+                        }
+                    }
+                    p += U;
+                };
+                uint32_t done = 0;
+                while (done + 4 <= n) { step(std::integral_constant<int, 4>{}, done); done += 4; }
+                while (done < n) { step(std::integral_constant<int, 1>{}, done); done += 1; }
+                pcur[q] = p;
+                if (n < 64) break;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t r = tile * MH_TILE_ROWS + wave * 4 + q;
+        if (r >= nnodes) continue;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if (!active[k]) continue;
+            const size_t o = size_t(r) * w3 + lane + 64 * k;
+            y[o] = acc[q][k][0];
+            y[o + w] = acc[q][k][1];
+            y[o + 2 * size_t(w)] = acc[q][k][2];
+        }
+    }
+}
+
+bool launch_spmm_tiled(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, uint32_t w) {
+    static const bool enabled = getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) != 0; // not yet pipelined: slower than the plain kernel
+    if (!enabled || !lvl.tiled || w < 24 || w > 256) return false; // narrow panels: the plain kernel packs several rows per wave
+    static const int lds_kb = getenv("MH_SPMM_LDS_KB") ? atoi(getenv("MH_SPMM_LDS_KB")) : 64;
+    uint32_t seg = uint32_t(size_t(lds_kb) * 1024 / (size_t(24) * w));
+    seg = std::max(4u, std::min(seg, 64u));
+    const size_t lds = size_t(seg) * 3 * w * sizeof(double);
+    const unsigned grid = (lvl.n_tiles + 7) / 8 * 8;
+    auto go = [&](auto nc_tag) {
+        constexpr int NC = decltype(nc_tag)::value;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_tiled<NC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        k_spmm_tiled<NC><<<grid, 1024, lds, ctx->stream>>>(lvl.row_ptr, lvl.block_local, vals9, lvl.tile_uptr, lvl.tile_ucols, x, y, lvl.n_nodes, w, seg, lvl.n_tiles);
+    };
+    if (w <= 64) go(std::integral_constant<int, 1>{});
+    else if (w <= 128) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 4>{});
+    KERNEL_CHECK();
+    return true;
+}
 } // namespace
 
 void mh_timer_flush(mh_context *ctx) {
@@ -156,6 +282,8 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
         ~Stop() { if (on) (void)hipEventRecord(c->timer_events[s].second, c->stream); }
     } stop{ctx, timed, slot};
     if (vals9 && mscal) launch_spmm<true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
-    else if (vals9) launch_spmm<false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
+    else if (vals9) {
+        if (!launch_spmm_tiled(ctx, lvl, vals9, x, y, w)) launch_spmm<false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
+    }
     else launch_spmm<true, false>(ctx, lvl, nullptr, x, nullptr, mscal, y2, w);
 }

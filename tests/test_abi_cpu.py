@@ -1,0 +1,116 @@
+"""CPU-side checks of the boundary: libmodalhip.so / libmodalhost.so load and export every symbol the headers declare
+(no compute calls without a GPU), the host-side scalar stages agree with the oracle, and the device entry points fail
+loudly when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mesheditor_amd import meshes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def core():
+    from mesheditor_amd import _lib
+    _lib.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(core):
+    L = core.lib()
+    header = open(os.path.join(ROOT, "include", "modalhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 30
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    # the binding declares a signature for every exported function it uses
+    assert set(L._declared) <= set(declared)
+
+
+def test_no_gpu_fails_loudly(core):
+    L = core.lib()
+    h = C.c_void_p()
+    rc = L.mh_context_create(0, C.byref(h))
+    if rc == 0:
+        L.mh_context_destroy(h)
+        pytest.skip("a GPU is present")
+    assert rc == core.MH_EHIP and not h.value
+    from mesheditor_amd import api
+    with pytest.raises(api.ModalHipError):
+        api.Context(0)
+
+
+def test_host_stages_match_oracle(core, oracle):
+    from mesheditor_amd import api
+    pts, tets = meshes.kuhn_box(5, 3, 2, 0.5, 0.3, 0.2, origin=(-0.25, -0.15, -0.1))
+    for scale, si in (((1, 1, 1), 1.0), ((2, 2, 2), 2.0), ((1.5, 1.0, 0.5), 1.0)):
+        mg = api.mass_properties(pts, tets, 2700.0, scale, si)
+        mo = oracle.mass_properties(pts, tets, 2700.0, scale, si)
+        assert mg[0] == mo[0]
+        assert np.array_equal(mg[1], mo[1])
+        assert np.allclose(mg[2], mo[2], rtol=1e-6)
+        # principal frames agree up to axis sign (eigenvector signs are arbitrary in the reference too)
+        def rot(q):
+            w, x, y, z = q
+            return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                             [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                             [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(np.abs(rot(mg[3]).T @ rot(mo[3])), np.eye(3), atol=1e-4)
+    mat_g, mat_o = api.material(*meshes.MATERIALS["Glass"]), oracle.material(*meshes.MATERIALS["Glass"])
+    rng = np.random.default_rng(2)
+    lam = np.sort(np.concatenate([rng.uniform(-1e-7, 1e-6, 6), (2 * np.pi * rng.uniform(5, 30000, 40)) ** 2]))
+    shapes = rng.standard_normal((5, len(lam), 3)).astype(np.float32)
+    for kw in ({}, {"num_modes": 7}, {"fundamental_freq": 440.0}, {"min_mode_freq": 100.0, "max_mode_freq": 5000.0}):
+        a = api.postprocess_modes(lam, shapes, 0.5, mat_g, api.default_config(**kw))
+        b = oracle.postprocess_modes(lam, shapes, 0.5, mat_o, oracle.default_config(**kw))
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(x, y)
+        assert a[3] == b[3]
+    edited = meshes.MATERIALS["Glass"]
+    e_g, e_o = api.material(edited[0] * 1.3, edited[1] * 0.7, *edited[2:]), oracle.material(edited[0] * 1.3, edited[1] * 0.7, *edited[2:])
+    a = api.rescale_modes(lam, shapes, mat_g, e_g, api.default_config())
+    b = oracle.rescale_modes(lam, shapes, mat_o, e_o, oracle.default_config())
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert api.rescale_modes(lam, shapes, mat_g, api.material(2600, 6.2e10, 0.21), api.default_config()) is None
+    # nothing in band -> empty result
+    assert len(api.postprocess_modes(lam[:6], shapes[:, :6], 1.0, mat_g, api.default_config())[0]) == 0
+
+
+def test_host_mirror_contact_model(oracle):
+    """libmodalhost.so (C++ mirror of src/audio/ContactModel.h) against the oracle and the reference's known answers."""
+    from mesheditor_amd import bank as hipbank
+    hipbank_path = hipbank.SO_PATH
+    if not os.path.exists(hipbank_path):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "mesheditor_amd", "cpp")])
+    H, O = hipbank.lib(), oracle.lib()
+    polymer = np.array([1000.0, 1e9, 0.3, 0.0, 0.0])
+    null = np.array([1e6, 1e30, 0.0, 0.0, 0.0])
+    inv = np.eye(3, dtype=np.float32).reshape(-1)
+    arm, direction = np.zeros(3, np.float32), np.array([0, 0, 1], np.float32)
+    smass = H.mhx_striker_mass(1e6, 1e6, 1e6)
+    assert smass == O.mo_striker_mass(1e6, 1e6, 1e6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for curv, area, speed, scale in ((100.0, 0.0, 1.0, 1.0), (0.0, 1e-4, 1.0, 1.0), (10.0, 1e-5, 3.0, 2.0), (100.0, 0.0, 32.0, 1e-6)):
+        a = H.mhx_estimate_contact_time(1.0, p(inv), p(arm), p(direction), speed, p(polymer), curv, area, p(null), 1e-6, 1.0 / smass, scale, 0.0)
+        b = O.mo_estimate_contact_time(1.0, p(inv), p(arm), p(direction), speed, oracle.material(*polymer), curv, area, oracle.material(*null), 1e-6, 1.0 / smass, scale, 0.0)
+        assert a == b
+    tau = H.mhx_estimate_contact_time(1.0, p(inv), p(arm), p(direction), 1.0, p(polymer), 100.0, 0.0, p(null), 1e-6, 1.0 / smass, 1.0, 0.0)
+    assert abs(tau - 1.744e-3) < 2e-2 * 1.744e-3  # tests/ContactModelTest.cpp:55-60
+    assert abs(H.mhx_saturation_penetration(10.0, 1e-5) - 3.183e-5) < 1e-3 * 3.183e-5
+    q = np.array([0.3, 0.1, -0.5, 0.8], np.float32)
+    q /= np.linalg.norm(q)
+    diag = np.array([2.0, 5.0, 9.0], np.float32)
+    a9, b9 = np.zeros(9, np.float32), np.zeros(9, np.float32)
+    H.mhx_inverse_inertia_tensor(p(diag), p(q), p(a9))
+    O.mo_inverse_inertia_tensor(p(diag), p(q), p(b9))
+    assert np.array_equal(a9, b9)
+    fa, fb = np.zeros(6, np.float32), np.zeros(6, np.float32)
+    H.mhx_recoil_object_filter(0.05, 5e-4, 48000.0, p(fa))
+    O.mo_recoil_object_filter(0.05, 5e-4, 48000.0, p(fb))
+    assert np.array_equal(fa, fb) and fa[0] != 0
