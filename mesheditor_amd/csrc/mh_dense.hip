@@ -9,7 +9,7 @@
 #include "mh_common.h"
 
 namespace {
-constexpr int KC = 16; // rows staged per step
+constexpr int KC = 32; // rows staged per step
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -19,10 +19,11 @@ __host__ __device__ inline int pad_pitch(int w) { // smallest p >= w with p = 16
     return p;
 }
 
-template<int WAVES, int MAXT>
+template<int WAVES, int MAXT, int MAXC>
 __global__ void __launch_bounds__(WAVES * 64) k_gram(const double *__restrict__ X, int wa, const double *__restrict__ Y, int wb, size_t n, size_t rows_per_wg,
                                                     double *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NTH = WAVES * 64;
     const int pa = pad_pitch(wa), pb = pad_pitch(wb);
     double *Xs = smem, *Ys = smem + KC * pa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,19 +34,44 @@ __global__ void __launch_bounds__(WAVES * 64) k_gram(const double *__restrict__ 
     const size_t r_begin = size_t(blockIdx.x) * rows_per_wg;
     const size_t r_end = min(n, r_begin + rows_per_wg);
     const int kk_lane = lane >> 4, c_lane = lane & 15;
+    // staging map: 16 threads per row, NTH/16 rows per pass; elements a thread carries per chunk (registers)
+    constexpr int RPP = NTH / 16; // rows per pass
+    constexpr int PASSES = KC / RPP > 0 ? KC / RPP : 1;
+    const int srow = tid >> 4, scol = tid & 15;
+    double px[PASSES][MAXC], py[PASSES][MAXC];
+    const int nca = (wa + 15) / 16, ncb = (wb + 15) / 16; // column strips actually loaded
+    auto fetch = [&](size_t r0) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const size_t r = r0 + ps * RPP + srow;
+            const bool rok = r < r_end && ps * RPP + srow < KC;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int col = scol + 16 * c;
+                if (c < nca) px[ps][c] = (rok && col < wa) ? X[r * wa + col] : 0.0;
+                if (c < ncb) py[ps][c] = (rok && col < wb) ? Y[r * wb + col] : 0.0;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int k = ps * RPP + srow;
+            if (k < KC) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int col = scol + 16 * c;
+                    if (c < nca) Xs[k * pa + col] = px[ps][c];
+                    if (c < ncb) Ys[k * pb + col] = py[ps][c];
+                }
+            }
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
     for (size_t r0 = r_begin; r0 < r_end; r0 += KC) {
-        // stage KC rows (zero beyond the panel / the row range)
-        for (int i = tid; i < KC * pa; i += WAVES * 64) {
-            const int k = i / pa, c = i % pa;
-            const size_t r = r0 + k;
-            Xs[i] = (c < wa && r < r_end) ? X[r * wa + c] : 0.0;
-        }
-        for (int i = tid; i < KC * pb; i += WAVES * 64) {
-            const int k = i / pb, c = i % pb;
-            const size_t r = r0 + k;
-            Ys[i] = (c < wb && r < r_end) ? Y[r * wb + c] : 0.0;
-        }
+        commit();
         __syncthreads();
+        if (r0 + KC < r_end) fetch(r0 + KC); // in flight while the MFMAs below run
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             const double *xr = Xs + (kk + kk_lane) * pa + c_lane;
@@ -91,6 +117,84 @@ __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int w
         g[size_t(idx / wa) * ld + idx % wa] = t;
     }
 }
+
+// ---- fused basis update ----------------------------------------------------------------------------------------
+// Z = [X | W | P] * C for row-major panels X (n x wx), W (n x ww), P (n x wp) and a coefficient matrix C given
+// row-major (k-major) as Ct[(wx+ww+wp)][nc]; the first n1 output columns go to out1 (n x n1), the rest to out2
+// (n x (nc - n1)).  One launch replaces six rocBLAS dgemm calls of the LOBPCG update (new Ritz vectors and new search
+// directions from the same basis) and reads the basis once.  A workgroup owns 64 rows (16 per wave) and all nc <= 256
+// output columns; the basis rows and the matching coefficient rows are staged through LDS in K-chunks of 32 and
+// multiplied with v_mfma_f64_16x16x4_f64.  Bound: 2 n m nc flops on fp64 MFMA vs 8 n (m + nc) bytes of HBM.
+constexpr int CK = 32; // K chunk
+template<int NT> // 16-column output tiles per wave (nc <= 16 * NT)
+__global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, const double *__restrict__ W, int ww, const double *__restrict__ P, int wp,
+                                                const double *__restrict__ Ct, int nc, size_t n, double *__restrict__ out1, int n1, double *__restrict__ out2) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = wx + ww + wp;
+    const int ncp = ((nc + 15) / 16) * 16;
+    const int cpitch = (ncp % 32 == 16) ? ncp : ncp + 16; // = 16 (mod 32): conflict-free B reads
+    double *Ss = smem; // 64 rows x (CK + 1) (odd pitch: A reads walk rows)
+    double *Cs = smem + 64 * (CK + 1); // CK x cpitch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t r0 = size_t(blockIdx.x) * 64;
+    double4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = double4_t{0, 0, 0, 0};
+    const int ntile = ncp / 16;
+    for (int k0 = 0; k0 < m; k0 += CK) {
+        // stage S[r0 .. r0+64)[k0 .. k0+CK): thread (row = tid / 4, 8 consecutive k each)
+        {
+            const int row = tid >> 2, kk0 = (tid & 3) * 8;
+            const size_t r = r0 + row;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + kk0 + j;
+                double v = 0.0;
+                if (r < n && k < m) {
+                    if (k < wx) v = X[r * wx + k];
+                    else if (k < wx + ww) v = W[r * ww + (k - wx)];
+                    else v = P[r * wp + (k - wx - ww)];
+                }
+                Ss[row * (CK + 1) + kk0 + j] = v;
+            }
+        }
+        // stage Ct[k0 .. k0+CK)[0 .. nc)
+        for (int i = tid; i < CK * ncp; i += 256) {
+            const int k = i / ncp, c = i % ncp;
+            Cs[k * cpitch + c] = (k0 + k < m && c < nc) ? Ct[size_t(k0 + k) * nc + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < CK; kk += 4) {
+            const double a = Ss[(wave * 16 + (lane & 15)) * (CK + 1) + kk + (lane >> 4)];
+            const double *brow = Cs + (kk + (lane >> 4)) * cpitch + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[t * 16], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t >= ntile) continue;
+        const int c = t * 16 + (lane & 15);
+        if (c >= nc) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const size_t r = r0 + wave * 16 + (lane >> 4) + 4 * reg;
+            if (r >= n) continue;
+            if (c < n1) out1[r * n1 + c] = acc[t][reg];
+            else out2[r * (nc - n1) + (c - n1)] = acc[t][reg];
+        }
+    }
+}
+__global__ void k_transpose_small(const double *__restrict__ c, int rows, int cols, int ld, double *__restrict__ ct, int col_off, int ct_cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = i % rows, cc = i / rows;
+    ct[size_t(r) * ct_cols + col_off + cc] = c[size_t(cc) * ld + r];
+}
 } // namespace
 
 // G (wa x wb, column-major, leading dimension ld) = X^T Y
@@ -98,7 +202,11 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
     if (!wa || !wb) return;
     const int ntiles = int((wa + 15) / 16) * int((wb + 15) / 16);
     if (ntiles > 256) mh_throw(MH_EINVAL, "gram: block width %u x %u exceeds 256 x 256", wa, wb);
-    int nwg = int(std::min<size_t>(256, (n + KC - 1) / KC));
+    // ~4 workgroups per CU for the 256-thread variant, fewer for the wide ones (their workgroups fill a CU alone)
+    const uint32_t wmax = std::max(wa, wb);
+    const bool small = ntiles <= 32 && wmax <= 96;
+    const size_t target = small ? 1024 : (ntiles <= 64 && wmax <= 128 ? 512 : 256);
+    int nwg = int(std::min<size_t>(target, (n + KC - 1) / KC));
     size_t rows_per_wg = ((n + nwg - 1) / nwg + KC - 1) / KC * KC;
     nwg = int((n + rows_per_wg - 1) / rows_per_wg);
     const size_t need = size_t(nwg) * wa * wb * sizeof(double);
@@ -109,14 +217,52 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
     }
     double *workspace = static_cast<double *>(ctx->gram_ws);
     const size_t lds = size_t(KC) * (pad_pitch(int(wa)) + pad_pitch(int(wb))) * sizeof(double);
-    if (ntiles <= 32) {
-        k_gram<4, 8><<<nwg, 256, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-    } else if (ntiles <= 64) {
-        k_gram<8, 8><<<nwg, 512, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+    if (small) {
+        k_gram<4, 8, 6><<<nwg, 256, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+    } else if (ntiles <= 64 && wmax <= 128) {
+        k_gram<8, 8, 8><<<nwg, 512, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
     } else {
-        k_gram<16, 16><<<nwg, 1024, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+        k_gram<16, 16, 16><<<nwg, 1024, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
     }
     KERNEL_CHECK();
     k_gram_reduce<<<div_up(size_t(wa) * wb, 32), 256, 0, ctx->stream>>>(workspace, nwg, int(wa), int(wb), g, int(ld));
+    KERNEL_CHECK();
+}
+
+// Row-major (k-major) packing of two column-major coefficient blocks side by side: ct[m][n1 + n2]
+void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct) {
+    if (n1) {
+        k_transpose_small<<<div_up(size_t(m) * n1, 256), 256, 0, ctx->stream>>>(c1, int(m), int(n1), int(ld), ct, 0, int(n1 + n2));
+        KERNEL_CHECK();
+    }
+    if (n2) {
+        k_transpose_small<<<div_up(size_t(m) * n2, 256), 256, 0, ctx->stream>>>(c2, int(m), int(n2), int(ld), ct, int(n1), int(n1 + n2));
+        KERNEL_CHECK();
+    }
+}
+
+// out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct
+void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
+                double *out1, uint32_t n1, double *out2) {
+    if (!nc) return;
+    if (nc > 256) mh_throw(MH_EINVAL, "combine: %u output columns exceed 256", nc);
+    const int ncp = int((nc + 15) / 16) * 16;
+    const int cpitch = (ncp % 32 == 16) ? ncp : ncp + 16;
+    const size_t lds = (size_t(64) * (CK + 1) + size_t(CK) * cpitch) * sizeof(double);
+    const unsigned grid = div_up(n, 64);
+    auto go = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        k_combine<NT><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
+    };
+    const int ntile = ncp / 16;
+    if (ntile <= 4) go(std::integral_constant<int, 4>{});
+    else if (ntile <= 8) go(std::integral_constant<int, 8>{});
+    else if (ntile <= 12) go(std::integral_constant<int, 12>{});
+    else go(std::integral_constant<int, 16>{});
     KERNEL_CHECK();
 }

@@ -502,7 +502,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
             DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), evals(ctx, mmax), ework(ctx, mmax);
             DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
-            DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch;
+            DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
             DevArray<uint32_t> idx_d(ctx, b);
             DevArray<int> info(ctx, 1);
             Precond prec(sys, b);
@@ -656,19 +656,26 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, w, &one, Gs, w, Cp, m));
                     }
                 }
-                // X <- S Cx, P <- S Cp (and the A-, M-images)
-                auto combine = [&](const double *x, const double *wv, const double *pv, const double *c, uint32_t wout, double *out) {
-                    panel_mul(ctx, n, x, b, c, m, out, wout, 1.0, 0.0);
-                    panel_mul(ctx, n, wv, w, c + b, m, out, wout, 1.0, 1.0);
-                    if (wp) panel_mul(ctx, n, pv, wp, c + b + w, m, out, wout, 1.0, 1.0);
-                };
-                combine(X, W, P, gA, b, Xn);
-                combine(AX, AW, AP, gA, b, AXn);
-                combine(MX, MW, MP, gA, b, MXn);
-                if (wp_new) {
-                    combine(X, W, P, Cp, wp_new, Pn);
-                    combine(AX, AW, AP, Cp, wp_new, APn);
-                    combine(MX, MW, MP, Cp, wp_new, MPn);
+                // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
+                if (b + wp_new <= 256) {
+                    mh_pack_coefficients(ctx, gA, b, Cp, wp_new, m, m, Ct);
+                    mh_combine(ctx, n, X, b, W, w, P, wp, Ct, b + wp_new, Xn, b, Pn);
+                    mh_combine(ctx, n, AX, b, AW, w, AP, wp, Ct, b + wp_new, AXn, b, APn);
+                    mh_combine(ctx, n, MX, b, MW, w, MP, wp, Ct, b + wp_new, MXn, b, MPn);
+                } else {
+                    auto combine = [&](const double *x, const double *wv, const double *pv, const double *c, uint32_t wout, double *out) {
+                        panel_mul(ctx, n, x, b, c, m, out, wout, 1.0, 0.0);
+                        panel_mul(ctx, n, wv, w, c + b, m, out, wout, 1.0, 1.0);
+                        if (wp) panel_mul(ctx, n, pv, wp, c + b + w, m, out, wout, 1.0, 1.0);
+                    };
+                    combine(X, W, P, gA, b, Xn);
+                    combine(AX, AW, AP, gA, b, AXn);
+                    combine(MX, MW, MP, gA, b, MXn);
+                    if (wp_new) {
+                        combine(X, W, P, Cp, wp_new, Pn);
+                        combine(AX, AW, AP, Cp, wp_new, APn);
+                        combine(MX, MW, MP, Cp, wp_new, MPn);
+                    }
                 }
                 std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
                 std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);

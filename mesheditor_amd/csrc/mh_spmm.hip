@@ -124,14 +124,16 @@ void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, cons
 // registers.  The tile's sorted unique column nodes are walked in segments of S nodes: the segment's x rows (3*w
 // doubles each, contiguous) are staged in LDS once and every node block of the tile that points into the segment
 // reads its x from there.  Each x row therefore leaves L2 once per tile instead of once per node block (~5x fewer
-// gathered bytes on P2 tetrahedral meshes in Morton order); the block values and column ranks stream through scalar
-// loads exactly once.
-template<int NC>
+// gathered bytes on P2 tetrahedral meshes in Morton order).  The next segment's rows are fetched into registers
+// before the current segment is consumed and written to LDS after it (issue-early / write-late), so the gather latency
+// hides under the FMAs; block values stream through scalar loads exactly once.
+template<int NC, int MAXR>
 __global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict__ row_ptr, const uint16_t *__restrict__ local, const double *__restrict__ vals9,
                                                     const uint32_t *__restrict__ tile_uptr, const uint32_t *__restrict__ tile_ucols,
                                                     const double *__restrict__ x, double *__restrict__ y, uint32_t nnodes, uint32_t w, uint32_t seg_nodes,
                                                     uint32_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) double xs[];
+    constexpr int SI = 3 * NC; // 64-lane strips per staged x row (3*w <= 192*NC doubles)
     const uint32_t per = (gridDim.x + 7) / 8;
     const uint32_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8; // XCD-contiguous tiles
     if (tile >= ntiles) return;
@@ -145,42 +147,70 @@ __global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict_
         active[k] = uint32_t(lane) + 64 * k < w;
         cc[k] = active[k] ? lane + 64 * k : 0;
     }
-    uint32_t pcur[4], pend[4];
+    uint32_t pstart[4], pend[4], lv[4], used[4];
     double acc[4][NC][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t r = tile * MH_TILE_ROWS + wave * 4 + q;
-        pcur[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r] : 0);
+        pstart[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r] : 0);
         pend[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r + 1] : 0);
+        lv[q] = pstart[q] + lane < pend[q] ? uint32_t(local[pstart[q] + lane]) : 0xffffu;
+        used[q] = 0;
 #pragma unroll
         for (int k = 0; k < NC; ++k) acc[q][k][0] = acc[q][k][1] = acc[q][k][2] = 0;
     }
+    double pre[MAXR][SI];
+    auto fetch = [&](uint32_t base) { // this wave's rows of the segment starting at `base` -> registers
+        const uint32_t cnt = min(seg_nodes, nu - base);
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) {
+            const uint32_t k = wave + 16 * j;
+            if (k < cnt) {
+                const double *src = x + size_t(tile_ucols[u0 + base + k]) * w3;
+#pragma unroll
+                for (int i = 0; i < SI; ++i) {
+                    const uint32_t off = lane + 64 * i;
+                    pre[j][i] = off < w3 ? src[off] : 0.0;
+                }
+            }
+        }
+    };
+    auto commit = [&](uint32_t base) { // registers -> LDS
+        const uint32_t cnt = min(seg_nodes, nu - base);
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) {
+            const uint32_t k = wave + 16 * j;
+            if (k < cnt) {
+#pragma unroll
+                for (int i = 0; i < SI; ++i) {
+                    const uint32_t off = lane + 64 * i;
+                    if (off < w3) xs[size_t(k) * w3 + off] = pre[j][i];
+                }
+            }
+        }
+    };
+    if (nu) fetch(0);
+    if (nu) commit(0);
+    __syncthreads();
     for (uint32_t base = 0; base < nu; base += seg_nodes) {
         const uint32_t cnt = min(seg_nodes, nu - base);
-        // stage: wave v copies x rows v, v+16, ... of the segment (each 3*w contiguous doubles)
-        for (uint32_t k = wave; k < cnt; k += 16) {
-            const uint32_t node = tile_ucols[u0 + base + k];
-            const double *src = x + size_t(node) * w3;
-            double *dst = xs + size_t(k) * w3;
-            for (uint32_t off = lane; off < w3; off += 64) dst[off] = src[off];
-        }
-        __syncthreads();
+        const bool more = base + seg_nodes < nu;
+        if (more) fetch(base + seg_nodes);
         const uint32_t lim = base + cnt;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             for (;;) {
-                const uint32_t rem = pend[q] - pcur[q];
-                if (rem == 0) break;
-                const uint32_t lv = uint32_t(lane) < rem ? uint32_t(local[pcur[q] + lane]) : 0xffffu;
-                const uint32_t n = __popcll(__ballot(lv < lim));
-                uint32_t p = pcur[q];
-                auto step = [&](auto u_tag, uint32_t first) {
+                const uint32_t avail = min(64u, pend[q] - pstart[q]);
+                const uint32_t n = __popcll(__ballot(uint32_t(lane) >= used[q] && uint32_t(lane) < avail && lv[q] < lim));
+                uint32_t p = pstart[q] + used[q];
+                uint32_t first = used[q];
+                auto step = [&](auto u_tag) {
                     constexpr int U = decltype(u_tag)::value;
                     double v[U][9];
                     uint32_t li[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        li[u] = __builtin_amdgcn_readlane(int(lv), int(first) + u) - base;
+                        li[u] = __builtin_amdgcn_readlane(int(lv[q]), int(first) + u) - base;
 #pragma unroll
                         for (int e = 0; e < 9; ++e) v[u][e] = vals9[size_t(9) * (p + u) + e];
                     }
@@ -196,14 +226,24 @@ __global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict_
                         }
                     }
                     p += U;
+                    first += U;
                 };
                 uint32_t done = 0;
-                while (done + 4 <= n) { step(std::integral_constant<int, 4>{}, done); done += 4; }
-                while (done < n) { step(std::integral_constant<int, 1>{}, done); done += 1; }
-                pcur[q] = p;
-                if (n < 64) break;
+                while (done + 4 <= n) { step(std::integral_constant<int, 4>{}); done += 4; }
+                while (done < n) { step(std::integral_constant<int, 1>{}); done += 1; }
+                used[q] += n;
+                // a row longer than 64 node blocks: move the 64-block window once it is used up
+                if (used[q] == 64 && pstart[q] + 64 < pend[q]) {
+                    pstart[q] += 64;
+                    lv[q] = pstart[q] + lane < pend[q] ? uint32_t(local[pstart[q] + lane]) : 0xffffu;
+                    used[q] = 0;
+                    continue;
+                }
+                break;
             }
         }
+        __syncthreads();
+        if (more) commit(base + seg_nodes);
         __syncthreads();
     }
 #pragma unroll
@@ -222,25 +262,25 @@ __global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict_
 }
 
 bool launch_spmm_tiled(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, uint32_t w) {
-    static const bool enabled = getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) != 0; // not yet pipelined: slower than the plain kernel
+    static const bool enabled = !(getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) == 0);
     if (!enabled || !lvl.tiled || w < 24 || w > 256) return false; // narrow panels: the plain kernel packs several rows per wave
-    static const int lds_kb = getenv("MH_SPMM_LDS_KB") ? atoi(getenv("MH_SPMM_LDS_KB")) : 64;
-    uint32_t seg = uint32_t(size_t(lds_kb) * 1024 / (size_t(24) * w));
-    seg = std::max(4u, std::min(seg, 64u));
-    const size_t lds = size_t(seg) * 3 * w * sizeof(double);
+    static const int lds_kb = getenv("MH_SPMM_LDS_KB") ? atoi(getenv("MH_SPMM_LDS_KB")) : 150;
     const unsigned grid = (lvl.n_tiles + 7) / 8 * 8;
-    auto go = [&](auto nc_tag) {
-        constexpr int NC = decltype(nc_tag)::value;
+    auto go = [&](auto nc_tag, auto maxr_tag) {
+        constexpr int NC = decltype(nc_tag)::value, MAXR = decltype(maxr_tag)::value;
+        uint32_t seg = uint32_t(size_t(lds_kb) * 1024 / (size_t(24) * w));
+        seg = std::max(4u, std::min(seg, uint32_t(16 * MAXR)));
+        const size_t lds = size_t(seg) * 3 * w * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_tiled<NC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_tiled<NC, MAXR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        k_spmm_tiled<NC><<<grid, 1024, lds, ctx->stream>>>(lvl.row_ptr, lvl.block_local, vals9, lvl.tile_uptr, lvl.tile_ucols, x, y, lvl.n_nodes, w, seg, lvl.n_tiles);
+        k_spmm_tiled<NC, MAXR><<<grid, 1024, lds, ctx->stream>>>(lvl.row_ptr, lvl.block_local, vals9, lvl.tile_uptr, lvl.tile_ucols, x, y, lvl.n_nodes, w, seg, lvl.n_tiles);
     };
-    if (w <= 64) go(std::integral_constant<int, 1>{});
-    else if (w <= 128) go(std::integral_constant<int, 2>{});
-    else go(std::integral_constant<int, 4>{});
+    if (w <= 64) go(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{});
+    else if (w <= 128) go(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+    else go(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
     KERNEL_CHECK();
     return true;
 }
