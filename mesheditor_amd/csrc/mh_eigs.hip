@@ -190,6 +190,13 @@ __global__ void k_set_identity_blocks(double *__restrict__ ga, double *__restric
     ga[size_t(i) * ld + i] = theta[i];
     gm[size_t(i) * ld + i] = 1.0;
 }
+// dst block (w x w at leading dimension ld) <- src (w x w, ld w), or identity when src is null
+__global__ void k_place_block(double *__restrict__ dst, uint32_t ld, const double *__restrict__ src, uint32_t w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * w) return;
+    const uint32_t r = i % w, c = i / w;
+    dst[size_t(c) * ld + r] = src ? src[size_t(c) * w + r] : (r == c ? 1.0 : 0.0);
+}
 // d = 1/sqrt(diag G); Gs = D G D written to the w x w block that follows G in memory (ld = w for both)
 __global__ void k_scale_gram(double *__restrict__ g, uint32_t w, uint32_t ld, double *__restrict__ dscale) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,7 +521,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> X(ctx, n * b), AX(ctx, n * b), MX(ctx, n * b), Xn(ctx, n * b), AXn(ctx, n * b), MXn(ctx, n * b);
             DevArray<double> W(ctx, n * b), AW(ctx, n * b), MW(ctx, n * b), P(ctx, n * b), AP(ctx, n * b), MP(ctx, n * b);
             DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
-            DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), evals(ctx, mmax), ework(ctx, mmax);
+            DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), gA0(ctx, size_t(mmax) * mmax), App(ctx, size_t(b) * b), evals(ctx, mmax), ework(ctx, mmax);
+            static const bool implicit_p = !(getenv("MH_IMPLICIT_P") && atoi(getenv("MH_IMPLICIT_P")) == 0);
             DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
             DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
             DevArray<uint32_t> idx_d(ctx, b);
@@ -660,13 +668,25 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(b) * m + b, m);
                     gram(ctx, n, W, w, MW, w, gM.get() + size_t(b) * m + b, m);
                     if (wp) {
-                        gram(ctx, n, P, wp, AX, b, gA.get() + b + w, m);
-                        gram(ctx, n, P, wp, MX, b, gM.get() + b + w, m);
                         gram(ctx, n, P, wp, AW, w, gA.get() + size_t(b) * m + b + w, m);
                         gram(ctx, n, P, wp, MW, w, gM.get() + size_t(b) * m + b + w, m);
-                        gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(b + w) * m + b + w, m);
-                        gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(b + w) * m + b + w, m);
+                        if (implicit_p) {
+                            // P = S_prev Cp with Cp gM-orthonormal and gM-orthogonal to the Ritz coefficients Cx, and
+                            // gA Cx = gM Cx Theta: hence P^T M P = I, P^T M X = P^T A X = 0 and P^T A P = Cp^T gA_prev Cp
+                            // (formed last iteration from the small matrices) -- four tall Gram products saved.
+                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gA.get() + size_t(b + w) * m + b + w, m, App, wp);
+                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(b + w) * m + b + w, m, nullptr, wp);
+                            KERNEL_CHECK();
+                        } else {
+                            gram(ctx, n, P, wp, AX, b, gA.get() + b + w, m);
+                            gram(ctx, n, P, wp, MX, b, gM.get() + b + w, m);
+                            gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(b + w) * m + b + w, m);
+                            gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(b + w) * m + b + w, m);
+                        }
                     }
+                    k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, st>>>(gA, m, m);
+                    KERNEL_CHECK();
+                    HIP_CHECK(hipMemcpyAsync(gA0, gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
                     HIP_CHECK(hipMemcpyAsync(gM0, gM, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
                     const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info);
                     if (hinfo == 0) break;
@@ -700,6 +720,10 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         KERNEL_CHECK();
                         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, w, &one, Gs, w, Cp, m));
                     }
+                }
+                if (wp_new && implicit_p) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
+                    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m));
+                    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
                 }
                 // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
                 if (b + wp_new <= 256) {

@@ -510,7 +510,7 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
     KERNEL_CHECK();
     // row tiles for the LDS-staged SpMM (skipped for small levels, where the plain kernel is latency-bound anyway)
     lvl.tiled = false;
-    if (nb >= 200000 && !(getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) == 0)) {
+    if (nb >= 200000 && getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) != 0) {
         const uint32_t ntiles = div_up(nnodes, MH_TILE_ROWS);
         DevArray<uint32_t> ucount(ctx, ntiles), overflow(ctx, 1);
         overflow.zero();

@@ -262,7 +262,9 @@ __global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict_
 }
 
 bool launch_spmm_tiled(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, uint32_t w) {
-    static const bool enabled = !(getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) == 0);
+    // Off by default: correct, but its barriers and per-row serial phases make it slower than the plain kernel on
+    // MI355X (742 us vs 527 us at S100k, w = 64, even with the block values removed); kept for the next round.
+    static const bool enabled = getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) != 0;
     if (!enabled || !lvl.tiled || w < 24 || w > 256) return false; // narrow panels: the plain kernel packs several rows per wave
     static const int lds_kb = getenv("MH_SPMM_LDS_KB") ? atoi(getenv("MH_SPMM_LDS_KB")) : 150;
     const unsigned grid = (lvl.n_tiles + 7) / 8 * 8;
