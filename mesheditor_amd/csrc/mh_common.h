@@ -234,6 +234,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K
 void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld);
 // [X | W | P] * Ct -> out1 (first n1 columns), out2 (the rest); Ct row-major m x nc.  mh_dense.hip
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
-                double *out1, uint32_t n1, double *out2);
+                double *out1, uint32_t n1, double *out2, bool accumulate = false);
+void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

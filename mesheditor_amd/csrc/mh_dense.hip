@@ -125,48 +125,61 @@ __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int w
 // directions from the same basis) and reads the basis once.  A workgroup owns 64 rows (16 per wave) and all nc <= 256
 // output columns; the basis rows and the matching coefficient rows are staged through LDS in K-chunks of 32 and
 // multiplied with v_mfma_f64_16x16x4_f64.  Bound: 2 n m nc flops on fp64 MFMA vs 8 n (m + nc) bytes of HBM.
-constexpr int CK = 32; // K chunk
-template<int NT> // 16-column output tiles per wave (nc <= 16 * NT)
+constexpr int CK = 16; // K chunk
+template<int NT, bool ACCUMULATE> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =
 __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, const double *__restrict__ W, int ww, const double *__restrict__ P, int wp,
                                                 const double *__restrict__ Ct, int nc, size_t n, double *__restrict__ out1, int n1, double *__restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = wx + ww + wp;
     const int ncp = ((nc + 15) / 16) * 16;
     const int cpitch = (ncp % 32 == 16) ? ncp : ncp + 16; // = 16 (mod 32): conflict-free B reads
-    double *Ss = smem; // 64 rows x (CK + 1) (odd pitch: A reads walk rows)
-    double *Cs = smem + 64 * (CK + 1); // CK x cpitch
+    constexpr int SP = CK + 2; // A-tile pitch: rows 2 doubles apart mod 32 -> conflict-free ds_read_b64
+    double *Ss = smem; // 64 rows x SP
+    double *Cs = smem + 64 * SP; // CK x cpitch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t r0 = size_t(blockIdx.x) * 64;
     double4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = double4_t{0, 0, 0, 0};
     const int ntile = ncp / 16;
-    for (int k0 = 0; k0 < m; k0 += CK) {
-        // stage S[r0 .. r0+64)[k0 .. k0+CK): thread (row = tid / 4, 8 consecutive k each)
-        {
-            const int row = tid >> 2, kk0 = (tid & 3) * 8;
-            const size_t r = r0 + row;
+    // staging maps: S tile: thread -> (row = tid / 4, 4 consecutive k); C tile: NT strips of 16 columns per k row
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const int ck = tid >> 4, cc = tid & 15; // 16 k rows x 16 threads, each thread NT columns (stride 16)
+    double ps[4], pc[NT];
+    auto fetch = [&](int k0) {
+        const size_t r = r0 + srow;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + kk0 + j;
-                double v = 0.0;
-                if (r < n && k < m) {
-                    if (k < wx) v = X[r * wx + k];
-                    else if (k < wx + ww) v = W[r * ww + (k - wx)];
-                    else v = P[r * wp + (k - wx - ww)];
-                }
-                Ss[row * (CK + 1) + kk0 + j] = v;
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + sk + j;
+            double v = 0.0;
+            if (r < n && k < m) {
+                if (k < wx) v = X[r * wx + k];
+                else if (k < wx + ww) v = W[r * ww + (k - wx)];
+                else v = P[r * wp + (k - wx - ww)];
             }
+            ps[j] = v;
         }
-        // stage Ct[k0 .. k0+CK)[0 .. nc)
-        for (int i = tid; i < CK * ncp; i += 256) {
-            const int k = i / ncp, c = i % ncp;
-            Cs[k * cpitch + c] = (k0 + k < m && c < nc) ? Ct[size_t(k0 + k) * nc + c] : 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = cc + 16 * t;
+            pc[t] = (t < ntile && k0 + ck < m && c < nc) ? Ct[size_t(k0 + ck) * nc + c] : 0.0;
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ss[srow * SP + sk + j] = ps[j];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < ntile) Cs[ck * cpitch + cc + 16 * t] = pc[t];
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < m; k0 += CK) {
+        commit();
         __syncthreads();
+        if (k0 + CK < m) fetch(k0 + CK); // in flight under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < CK; kk += 4) {
-            const double a = Ss[(wave * 16 + (lane & 15)) * (CK + 1) + kk + (lane >> 4)];
+            const double a = Ss[(wave * 16 + (lane & 15)) * SP + kk + (lane >> 4)];
             const double *brow = Cs + (kk + (lane >> 4)) * cpitch + (lane & 15);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -184,16 +197,16 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
         for (int reg = 0; reg < 4; ++reg) {
             const size_t r = r0 + wave * 16 + (lane >> 4) + 4 * reg;
             if (r >= n) continue;
-            if (c < n1) out1[r * n1 + c] = acc[t][reg];
-            else out2[r * (nc - n1) + (c - n1)] = acc[t][reg];
+            double *dst = c < n1 ? out1 + r * n1 + c : out2 + r * (nc - n1) + (c - n1);
+            *dst = ACCUMULATE ? *dst + acc[t][reg] : acc[t][reg];
         }
     }
 }
-__global__ void k_transpose_small(const double *__restrict__ c, int rows, int cols, int ld, double *__restrict__ ct, int col_off, int ct_cols) {
+__global__ void k_transpose_small(const double *__restrict__ c, int rows, int cols, int ld, double *__restrict__ ct, int col_off, int ct_cols, double scale = 1.0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     const int r = i % rows, cc = i / rows;
-    ct[size_t(r) * ct_cols + col_off + cc] = c[size_t(cc) * ld + r];
+    ct[size_t(r) * ct_cols + col_off + cc] = scale * c[size_t(cc) * ld + r];
 }
 } // namespace
 
@@ -241,23 +254,19 @@ void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const 
     }
 }
 
-// out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct
+// out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct  (+= when accumulate)
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
-                double *out1, uint32_t n1, double *out2) {
+                double *out1, uint32_t n1, double *out2, bool accumulate) {
     if (!nc) return;
     if (nc > 256) mh_throw(MH_EINVAL, "combine: %u output columns exceed 256", nc);
     const int ncp = int((nc + 15) / 16) * 16;
     const int cpitch = (ncp % 32 == 16) ? ncp : ncp + 16;
-    const size_t lds = (size_t(64) * (CK + 1) + size_t(CK) * cpitch) * sizeof(double);
+    const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * cpitch) * sizeof(double);
     const unsigned grid = div_up(n, 64);
     auto go = [&](auto nt_tag) {
         constexpr int NT = decltype(nt_tag)::value;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        k_combine<NT><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
+        if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
+        else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
     };
     const int ntile = ncp / 16;
     if (ntile <= 4) go(std::integral_constant<int, 4>{});
@@ -265,4 +274,16 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     else if (ntile <= 12) go(std::integral_constant<int, 12>{});
     else go(std::integral_constant<int, 16>{});
     KERNEL_CHECK();
+}
+
+// Row-major (k-major) packing of two column-major blocks stacked vertically, scaled: ct[(r1 + r2)][cols]
+void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct) {
+    if (r1) {
+        k_transpose_small<<<div_up(size_t(r1) * cols, 256), 256, 0, ctx->stream>>>(c1, int(r1), int(cols), int(r1), ct, 0, int(cols), scale);
+        KERNEL_CHECK();
+    }
+    if (r2) {
+        k_transpose_small<<<div_up(size_t(r2) * cols, 256), 256, 0, ctx->stream>>>(c2, int(r2), int(cols), int(r2), ct + size_t(r1) * cols, 0, int(cols), scale);
+        KERNEL_CHECK();
+    }
 }

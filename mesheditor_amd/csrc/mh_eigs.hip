@@ -523,7 +523,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
             DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), gA0(ctx, size_t(mmax) * mmax), App(ctx, size_t(b) * b), evals(ctx, mmax), ework(ctx, mmax);
             static const bool implicit_p = !(getenv("MH_IMPLICIT_P") && atoi(getenv("MH_IMPLICIT_P")) == 0);
-            DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
+            DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), H2(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
             DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
             DevArray<uint32_t> idx_d(ctx, b);
             DevArray<int> info(ctx, 1);
@@ -645,12 +645,18 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 static const int ortho_passes = getenv("MH_ORTHO_PASSES") ? std::max(1, atoi(getenv("MH_ORTHO_PASSES"))) : 1;
                 for (int pass = 0; pass < ortho_passes && ok; ++pass) {
                     gram(ctx, n, MX, b, W, w, H, b); // b x w
-                    panel_mul(ctx, n, X, b, H, b, W, w, -1.0, 1.0);
-                    panel_mul(ctx, n, MX, b, H, b, MW, w, -1.0, 1.0);
-                    if (wp) {
-                        gram(ctx, n, MP, wp, W, w, H, wp);
-                        panel_mul(ctx, n, P, wp, H, wp, W, w, -1.0, 1.0);
-                        panel_mul(ctx, n, MP, wp, H, wp, MW, w, -1.0, 1.0);
+                    if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
+                    if (w <= 256) { // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
+                        mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
+                        mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
+                        mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
+                    } else {
+                        panel_mul(ctx, n, X, b, H, b, W, w, -1.0, 1.0);
+                        panel_mul(ctx, n, MX, b, H, b, MW, w, -1.0, 1.0);
+                        if (wp) {
+                            panel_mul(ctx, n, P, wp, H2, wp, W, w, -1.0, 1.0);
+                            panel_mul(ctx, n, MP, wp, H2, wp, MW, w, -1.0, 1.0);
+                        }
                     }
                     ok = chol_orthonormalise(W, MW, nullptr, w);
                 }
