@@ -45,6 +45,29 @@ struct ClickFilter {
 };
 ClickFilter RecoilClickFilter(double radius, double volume, double mass, double sample_rate);
 
+// Not in the reference: the span of per-mode (or shape) entries edited since the device mirror last saw them.
+// TuneModalObject / SetModalObjectShapes mark it (from any thread); the render takes it at block start and uploads
+// just that span.  Code that writes the per-mode columns directly calls MarkModalColumnsEdited.
+struct ModalEditSpan {
+    std::atomic<uint32_t> Lo{UINT32_MAX}, Hi{0};
+    ModalEditSpan() = default;
+    ModalEditSpan(const ModalEditSpan &o) : Lo{o.Lo.load()}, Hi{o.Hi.load()} {}
+    ModalEditSpan &operator=(const ModalEditSpan &o) {
+        Lo.store(o.Lo.load());
+        Hi.store(o.Hi.load());
+        return *this;
+    }
+    void Mark(uint32_t lo, uint32_t hi) {
+        for (auto seen = Lo.load(); lo < seen && !Lo.compare_exchange_weak(seen, lo);) {}
+        for (auto seen = Hi.load(); hi > seen && !Hi.compare_exchange_weak(seen, hi);) {}
+    }
+    bool Take(uint32_t &lo, uint32_t &hi) {
+        hi = Hi.exchange(0);
+        lo = Lo.exchange(UINT32_MAX);
+        return lo < hi;
+    }
+};
+
 struct ModalBank {
     // per mode
     std::vector<float> CoeffRe, CoeffIm, StateRe, StateIm, RadiationGain, RadiationArea, DeflectionGain, OutPhaseIm, OutPhaseRe, QuadCompliance, QuadDriveScale;
@@ -63,7 +86,10 @@ struct ModalBank {
     };
     std::vector<ActiveImpact> Impacts;
     float SampleRate{48'000};
+    ModalEditSpan EditedModes, EditedShapes; // device-mirror bookkeeping (not in the reference)
 };
+inline void MarkModalColumnsEdited(ModalBank &b, uint32_t first_mode, uint32_t end_mode) { b.EditedModes.Mark(first_mode, end_mode); }
+inline void MarkModalShapesEdited(ModalBank &b, uint32_t first, uint32_t end) { b.EditedShapes.Mark(first, end); }
 
 constexpr uint32_t Lanes{8};
 

@@ -15,9 +15,7 @@ struct ModalAudio::DeviceState {
     mh_context *ctx{nullptr};
     mh_bank *bank{nullptr};
     const ModalBank *mirrored{nullptr};
-    // snapshots of the host columns as last uploaded, to push caller edits (TuneModalObject, SetModalObjectShapes,
-    // direct column writes) before a block renders
-    std::vector<float> CoeffRe, CoeffIm, RadiationGain, OutPhaseIm, OutPhaseRe, ShapeX, ShapeY, ShapeZ;
+    std::vector<uint32_t> impacts_on; // active impacts per object, rebuilt once per block
     std::vector<uint32_t> deal_offset, deal_objects, render_count, tuned, live;
     std::vector<double> energy, modal_energy;
     std::vector<uint8_t> silenced;
@@ -111,8 +109,7 @@ void DealObjects(ModalAudio &m, const ModalBank &b, uint32_t count) {
     d.order.clear();
     for (uint32_t o = 0; o < uint32_t(b.Entities.size()); ++o) {
         if (!b.Ringing[o]) continue;
-        bool excited = false;
-        for (const auto &im : b.Impacts) excited = excited || im.Object == o;
+        const bool excited = d.impacts_on[o] != 0;
         d.order.emplace_back(uint64_t(excited ? b.TunedModeCount[o] : b.LiveModeCount[o]), o);
     }
     if (count == 1) {
@@ -145,45 +142,25 @@ void MirrorBank(ModalAudio &m, ModalBank &b) {
                        b.ShapeZ.data(), &d.bank) != MH_OK)
         throw std::runtime_error(std::string("modalhip: ") + mh_last_error(d.ctx));
     mh_bank_set_coefficients(d.bank, 0, n_modes, b.CoeffRe.data(), b.CoeffIm.data(), b.RadiationGain.data(), b.OutPhaseIm.data(), b.OutPhaseRe.data());
-    d.CoeffRe = b.CoeffRe; d.CoeffIm = b.CoeffIm; d.RadiationGain = b.RadiationGain; d.OutPhaseIm = b.OutPhaseIm; d.OutPhaseRe = b.OutPhaseRe;
-    d.ShapeX = b.ShapeX; d.ShapeY = b.ShapeY; d.ShapeZ = b.ShapeZ;
+    uint32_t lo, hi;
+    b.EditedModes.Take(lo, hi);
+    b.EditedShapes.Take(lo, hi);
     d.mirrored = &b;
 }
 
-// Push host-side edits made since the last block (TuneModalObject / SetModalObjectShapes write the host columns).
+// Push host-side edits made since the last block (TuneModalObject / SetModalObjectShapes mark the spans they wrote).
 void SyncEdits(ModalAudio &m, ModalBank &b) {
     auto &d = *m.Dev;
-    const auto n_modes = uint32_t(b.CoeffRe.size());
-    uint32_t lo = n_modes, hi = 0;
-    for (uint32_t k = 0; k < n_modes; ++k) {
-        if (b.CoeffRe[k] != d.CoeffRe[k] || b.CoeffIm[k] != d.CoeffIm[k] || b.RadiationGain[k] != d.RadiationGain[k] || b.OutPhaseIm[k] != d.OutPhaseIm[k] ||
-            b.OutPhaseRe[k] != d.OutPhaseRe[k]) {
-            lo = std::min(lo, k);
-            hi = std::max(hi, k + 1);
-        }
+    uint32_t lo, hi;
+    if (b.EditedModes.Take(lo, hi)) {
+        hi = std::min(hi, uint32_t(b.CoeffRe.size()));
+        if (lo < hi)
+            mh_bank_set_coefficients(d.bank, lo, hi - lo, b.CoeffRe.data() + lo, b.CoeffIm.data() + lo, b.RadiationGain.data() + lo, b.OutPhaseIm.data() + lo,
+                                     b.OutPhaseRe.data() + lo);
     }
-    if (lo < hi) {
-        mh_bank_set_coefficients(d.bank, lo, hi - lo, b.CoeffRe.data() + lo, b.CoeffIm.data() + lo, b.RadiationGain.data() + lo, b.OutPhaseIm.data() + lo,
-                                 b.OutPhaseRe.data() + lo);
-        std::copy(b.CoeffRe.begin() + lo, b.CoeffRe.begin() + hi, d.CoeffRe.begin() + lo);
-        std::copy(b.CoeffIm.begin() + lo, b.CoeffIm.begin() + hi, d.CoeffIm.begin() + lo);
-        std::copy(b.RadiationGain.begin() + lo, b.RadiationGain.begin() + hi, d.RadiationGain.begin() + lo);
-        std::copy(b.OutPhaseIm.begin() + lo, b.OutPhaseIm.begin() + hi, d.OutPhaseIm.begin() + lo);
-        std::copy(b.OutPhaseRe.begin() + lo, b.OutPhaseRe.begin() + hi, d.OutPhaseRe.begin() + lo);
-    }
-    const auto n_shapes = uint32_t(b.ShapeX.size());
-    uint32_t slo = n_shapes, shi = 0;
-    for (uint32_t k = 0; k < n_shapes; ++k) {
-        if (b.ShapeX[k] != d.ShapeX[k] || b.ShapeY[k] != d.ShapeY[k] || b.ShapeZ[k] != d.ShapeZ[k]) {
-            slo = std::min(slo, k);
-            shi = std::max(shi, k + 1);
-        }
-    }
-    if (slo < shi) {
-        mh_bank_set_shapes(d.bank, slo, shi - slo, b.ShapeX.data() + slo, b.ShapeY.data() + slo, b.ShapeZ.data() + slo);
-        std::copy(b.ShapeX.begin() + slo, b.ShapeX.begin() + shi, d.ShapeX.begin() + slo);
-        std::copy(b.ShapeY.begin() + slo, b.ShapeY.begin() + shi, d.ShapeY.begin() + slo);
-        std::copy(b.ShapeZ.begin() + slo, b.ShapeZ.begin() + shi, d.ShapeZ.begin() + slo);
+    if (b.EditedShapes.Take(lo, hi)) {
+        hi = std::min(hi, uint32_t(b.ShapeX.size()));
+        if (lo < hi) mh_bank_set_shapes(d.bank, lo, hi - lo, b.ShapeX.data() + lo, b.ShapeY.data() + lo, b.ShapeZ.data() + lo);
     }
 }
 } // namespace
@@ -285,6 +262,7 @@ void TuneModalObject(ModalBank &b, uint32_t object, std::span<const float> freqs
     while (live > 0 && b.CoeffRe[k0 + live - 1] == 0.f && b.CoeffIm[k0 + live - 1] == 0.f) --live;
     b.TunedModeCount[object] = live;
     b.LiveModeCount[object] = live;
+    b.EditedModes.Mark(k0, k0 + b.ModeCount[object]);
 }
 
 bool SetModalObjectShapes(ModalBank &b, uint32_t object, const ModalModes &modes) {
@@ -300,6 +278,7 @@ bool SetModalObjectShapes(ModalBank &b, uint32_t object, const ModalModes &modes
             b.ShapeZ[i] = shape.z;
             ++i;
         }
+    b.EditedShapes.Mark(begin, end);
     return true;
 }
 
@@ -331,6 +310,8 @@ void RenderModal(ModalAudio &m, float *out, uint32_t frame_count) {
     SyncEdits(m, b);
     const auto click_gain = m.ClickGain.load(std::memory_order_relaxed);
 
+    d.impacts_on.assign(b.Entities.size(), 0);
+    for (const auto &im : b.Impacts) ++d.impacts_on[im.Object];
     const uint32_t width = m.RenderPool.Size();
     DealObjects(m, b, width);
     d.deal_offset.assign(width + 1, 0);
@@ -339,8 +320,7 @@ void RenderModal(ModalAudio &m, float *out, uint32_t frame_count) {
     d.tuned.clear();
     for (uint32_t r = 0; r < width; ++r) {
         for (const auto o : d.renderers[r]) {
-            bool excited = false;
-            for (const auto &im : b.Impacts) excited = excited || im.Object == o;
+            const bool excited = d.impacts_on[o] != 0;
             d.deal_objects.push_back(o);
             d.render_count.push_back(excited ? b.TunedModeCount[o] : b.LiveModeCount[o]);
             d.tuned.push_back(b.TunedModeCount[o]);
@@ -373,8 +353,7 @@ void RenderModal(ModalAudio &m, float *out, uint32_t frame_count) {
     // Per-object bookkeeping of RenderObjectFast's tail (ModalAudio.cpp:141-146).
     for (uint32_t i = 0; i < n_dealt; ++i) {
         const auto o = d.deal_objects[i];
-        bool excited = false;
-        for (const auto &im : b.Impacts) excited = excited || im.Object == o;
+        const bool excited = d.impacts_on[o] != 0;
         if (d.silenced[i]) {
             SilenceObject(m, b, o, true);
             continue;

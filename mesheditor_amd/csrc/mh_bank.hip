@@ -69,7 +69,41 @@ template<typename Real> struct BankCols {
     const uint32_t *mode_offset, *mode_count, *shape_offset;
 };
 
+// Cross-lane moves that stay on the VALU (no LDS crossbar): lane i reads lane i+N of its 16-lane row, and a
+// wave-uniform lane broadcast.
+template<int N> __device__ __forceinline__ float row_shl(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+template<int N> __device__ __forceinline__ double row_shl(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, int(b), 0x100 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, int(b >> 32), 0x100 + N, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ float lane_bcast(float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), int(l))); }
+__device__ __forceinline__ double lane_bcast(double v, uint32_t l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(int(b), int(l)), hi = __builtin_amdgcn_readlane(int(b >> 32), int(l));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// Sum of the 8 lanes of a chunk, lane 0..7 in order, valid in the chunk's first lane (ModalAudio.cpp:121-128).
+template<typename Real> __device__ __forceinline__ Real chunk_sum_in_order(Real term) {
+    Real acc = Real(0) + term;
+    acc += row_shl<1>(term);
+    acc += row_shl<2>(term);
+    acc += row_shl<3>(term);
+    acc += row_shl<4>(term);
+    acc += row_shl<5>(term);
+    acc += row_shl<6>(term);
+    acc += row_shl<7>(term);
+    return acc;
+}
+
 // One wave = 64 consecutive modes of one dealt object = 8 chunks.  partial: [global chunk][frames].
+// Samples run in tiles of TS: during a tile every lane (= mode) advances its resonator sample by sample and drops its
+// output term into an LDS tile [sample][mode]; after the tile the wave turns around -- lane = (chunk group, sample) --
+// and adds each chunk's 8 terms in lane order 0..7, which is the reference's summation order at two LDS reads per
+// mode-sample instead of a cross-lane chain per sample, and makes the partial-signal stores contiguous in the sample.
 template<typename Real>
 __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const WaveDesc *__restrict__ waves, const uint32_t *__restrict__ deal_objects,
                                                     const uint32_t *__restrict__ render_count, const uint32_t *__restrict__ chunk_base,
@@ -77,7 +111,8 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
                                                     const ImpactDev<Real> *__restrict__ impacts, const Real *__restrict__ force,
                                                     const Real *__restrict__ out_gain, const Real *__restrict__ listener_gain, uint32_t frames,
                                                     Real *__restrict__ partial, Real *__restrict__ chunk_energy, Real *__restrict__ gain_scratch, uint32_t max_imp) {
-    __shared__ Real s_tile[CHUNKS_PER_WAVE][WAVE];
+    constexpr uint32_t TS = 32, PITCH = WAVE + 1;
+    __shared__ Real s_term[TS * PITCH];
     const WaveDesc wd = waves[blockIdx.x];
     const uint32_t lane = threadIdx.x;
     const uint32_t o = deal_objects[wd.dealt];
@@ -94,114 +129,212 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
         p_im = b.phase_im[k0 + k]; p_re = b.phase_re[k0 + k];
     }
     const uint32_t i0 = imp_ptr[wd.dealt], n_imp = imp_ptr[wd.dealt + 1] - i0;
-    // Hoisted impact gains (ImpactGainRow, ModalAudio.h:182-188); zero on padded lanes.
-    Real g_reg[4] = {0, 0, 0, 0};
+    // Hoisted impact gains (ImpactGainRow, ModalAudio.h:182-188); zero on padded lanes.  The first IMP_REG impacts of
+    // the object live in registers, further ones (rare) in a scratch row.
+    constexpr uint32_t IMP_REG = 2;
+    Real g_reg[IMP_REG] = {};
+    uint32_t f_row[IMP_REG] = {};
     Real *g_mem = gain_scratch + size_t(blockIdx.x) * max_imp * WAVE;
     for (uint32_t t = 0; t < n_imp; ++t) {
         Real g = 0;
+        const uint32_t ii = imp_idx[i0 + t];
         if (live) {
-            const ImpactDev<Real> &im = impacts[imp_idx[i0 + t]];
+            const ImpactDev<Real> &im = impacts[ii];
             const uint32_t base = shape0 + im.ex_pos * stride + k;
             g = b.rad_gain[k0 + k] * (b.shape_x[base] * im.jx + b.shape_y[base] * im.jy + b.shape_z[base] * im.jz);
         }
-        if (t < 4) g_reg[t] = g;
+        if (t < IMP_REG) { g_reg[t] = g; f_row[t] = ii; }
         else g_mem[size_t(t) * WAVE + lane] = g;
     }
     const Real mix_gain = out_gain[o] * listener_gain[o];
-    const uint32_t chunk_lane0 = lane & ~uint32_t(LANES - 1);
-    for (uint32_t s0 = 0; s0 < frames; s0 += WAVE) {
-        const uint32_t sn = min(uint32_t(WAVE), frames - s0);
-        for (uint32_t ds = 0; ds < sn; ++ds) {
-            const uint32_t s = s0 + ds;
-            Real excite = 0;
-            for (uint32_t t = 0; t < n_imp; ++t) {
-                const Real f = force[size_t(imp_idx[i0 + t]) * frames + s];
-                if (f == Real(0)) continue;
-                const Real g = t < 4 ? g_reg[t] : g_mem[size_t(t) * WAVE + lane];
-                excite += f * g;
+    const uint32_t half = lane / TS, ts = lane % TS; // turn-around mapping: chunks 4*half .. 4*half+3 of sample ts
+
+    // NR = impacts held in registers (0, 1 or 2); EXTRA = the object has more than IMP_REG impacts.
+    auto run = [&](auto nr_tag, auto extra_tag) {
+        constexpr uint32_t NR = decltype(nr_tag)::value;
+        constexpr bool EXTRA = decltype(extra_tag)::value;
+        for (uint32_t s0 = 0; s0 < frames; s0 += TS) {
+            const uint32_t sn = min(TS, frames - s0);
+            Real f_tile[NR > 0 ? NR : 1] = {};
+#pragma unroll
+            for (uint32_t t = 0; t < NR; ++t)
+                if (lane < sn) f_tile[t] = force[size_t(f_row[t]) * frames + s0 + lane];
+            auto sample = [&](uint32_t ds) {
+                Real excite = 0;
+#pragma unroll
+                for (uint32_t t = 0; t < NR; ++t) {
+                    // a zero force sample is skipped by the reference; adding +0 instead is the same bits
+                    const Real f = lane_bcast(f_tile[t], ds);
+                    const Real fg = f * g_reg[t];
+                    excite += f != Real(0) ? fg : Real(0);
+                }
+                if (EXTRA) {
+                    for (uint32_t t = IMP_REG; t < n_imp; ++t) {
+                        const Real f = force[size_t(imp_idx[i0 + t]) * frames + s0 + ds];
+                        if (f == Real(0)) continue;
+                        excite += f * g_mem[size_t(t) * WAVE + lane];
+                    }
+                }
+                const Real re = z_re * c_re - z_im * c_im + excite;
+                z_im = z_re * c_im + z_im * c_re;
+                z_re = re;
+                s_term[ds * PITCH + lane] = p_im * z_im + p_re * re;
+            };
+            if (sn == TS && !EXTRA) {
+#pragma unroll
+                for (uint32_t ds = 0; ds < TS; ++ds) sample(ds);
+            } else {
+                for (uint32_t ds = 0; ds < sn; ++ds) sample(ds);
             }
-            const Real re = z_re * c_re - z_im * c_im + excite;
-            z_im = z_re * c_im + z_im * c_re;
-            z_re = re;
-            const Real term = p_im * z_im + p_re * re;
-            // lanes 0..7 of the chunk, in order
-            Real acc = 0;
-            for (int l = 0; l < LANES; ++l) acc += __shfl(term, int(chunk_lane0) + l, WAVE);
-            if ((lane & (LANES - 1)) == 0) s_tile[lane / LANES][ds] = acc * mix_gain;
+            __syncthreads();
+            if (ts < sn) {
+                const Real *row = s_term + ts * PITCH + half * (4 * LANES);
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    Real acc = 0;
+#pragma unroll
+                    for (uint32_t l = 0; l < LANES; ++l) acc += row[c * LANES + l];
+                    const uint32_t chunk = 4 * half + c;
+                    if (chunk < chunks_here) partial[size_t(chunk0 + chunk) * frames + s0 + ts] = acc * mix_gain;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (uint32_t c = 0; c < chunks_here; ++c)
-            if (lane < sn) partial[size_t(chunk0 + c) * frames + s0 + lane] = s_tile[c][lane];
-        __syncthreads();
-    }
+    };
+    using T0 = std::integral_constant<uint32_t, 0>;
+    using T1 = std::integral_constant<uint32_t, 1>;
+    using T2 = std::integral_constant<uint32_t, 2>;
+    if (n_imp == 0) run(T0{}, std::false_type{});
+    else if (n_imp == 1) run(T1{}, std::false_type{});
+    else if (n_imp == 2) run(T2{}, std::false_type{});
+    else run(T2{}, std::true_type{});
     if (live) {
         b.state_re[k0 + k] = z_re;
         b.state_im[k0 + k] = z_im;
     }
     // chunk energy: sum over the chunk's valid lanes in order (padded lanes hold zero state)
     const Real e = z_re * z_re + z_im * z_im;
-    Real chunk = 0;
-    for (int l = 0; l < LANES; ++l) {
-        const Real el = __shfl(e, int(chunk_lane0) + l, WAVE);
-        if (wd.first_mode + chunk_lane0 + l < count) chunk += el;
-    }
+    const Real chunk = chunk_sum_in_order(live ? e : Real(0));
     if ((lane & (LANES - 1)) == 0 && lane / LANES < chunks_here) chunk_energy[chunk0 + lane / LANES] = chunk;
 }
 
-// Per dealt object: energy, audible prefix, whole-object silence (ModalAudio.cpp:132-146).
+// Per dealt object (one wave each): energy, audible prefix, whole-object silence (ModalAudio.cpp:132-146).  Loads are
+// lane-parallel; every sum runs in the reference's order through wave-uniform lane broadcasts.
 template<typename Real>
-__global__ void k_bank_objects(BankCols<Real> b, const uint32_t *__restrict__ deal_objects, const uint32_t *__restrict__ render_count,
-                               const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ imp_ptr, const Real *__restrict__ out_gain,
-                               const Real *__restrict__ chunk_energy, uint32_t n_dealt, double *__restrict__ energy_out, uint32_t *__restrict__ live_out,
-                               uint8_t *__restrict__ silenced, const uint32_t *__restrict__ tuned_count, double *__restrict__ modal_energy) {
-    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(WAVE) k_bank_objects(BankCols<Real> b, const uint32_t *__restrict__ deal_objects, const uint32_t *__restrict__ render_count,
+                                                      const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ imp_ptr, const Real *__restrict__ out_gain,
+                                                      const Real *__restrict__ chunk_energy, uint32_t n_dealt, double *__restrict__ energy_out,
+                                                      uint32_t *__restrict__ live_out, uint8_t *__restrict__ silenced, const uint32_t *__restrict__ tuned_count,
+                                                      double *__restrict__ modal_energy) {
+    const uint32_t d = blockIdx.x, lane = threadIdx.x;
     if (d >= n_dealt) return;
     const uint32_t o = deal_objects[d], count = render_count[d];
     const Real og = out_gain[o];
     Real energy = 0;
     uint32_t live = 0;
-    const uint32_t nchunks = (count + LANES - 1) / LANES;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        const Real chunk = chunk_energy[chunk_base[d] + c];
-        energy += chunk;
-        if (chunk * og * og >= Real(1e-12f)) live = min(count, (c + 1) * LANES);
+    const uint32_t nchunks = (count + LANES - 1) / LANES, cb = chunk_base[d];
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += WAVE) {
+        const uint32_t m = min(uint32_t(WAVE), nchunks - c0);
+        const Real mine = lane < m ? chunk_energy[cb + c0 + lane] : Real(0);
+        for (uint32_t l = 0; l < m; ++l) {
+            const Real chunk = lane_bcast(mine, l);
+            energy += chunk;
+            if (chunk * og * og >= Real(1e-12f)) live = min(count, (c0 + l + 1) * LANES);
+        }
     }
     const bool no_impacts = imp_ptr[d + 1] == imp_ptr[d];
     const bool silent = no_impacts && energy * og * og < Real(1e-12f);
+    const uint32_t k0 = b.mode_offset[o];
     if (silent) {
-        const uint32_t k0 = b.mode_offset[o], n = b.mode_count[o];
-        for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t n = b.mode_count[o];
+        for (uint32_t k = lane; k < n; k += WAVE) {
             b.state_re[k0 + k] = 0;
             b.state_im[k0 + k] = 0;
         }
     }
-    energy_out[d] = double(energy);
-    live_out[d] = live;
-    silenced[d] = silent ? 1 : 0;
     // Mechanical energy behind the pressure-unit states (the diagnostic of ModalAudio.cpp:564-577), in double.
     double me = 0;
     if (!silent) {
-        const uint32_t k0 = b.mode_offset[o], n = tuned_count[d];
-        for (uint32_t k = 0; k < n; ++k) {
-            const double g = double(b.rad_gain[k0 + k]);
-            if (g > 0) {
-                const double re = double(b.state_re[k0 + k]), im = double(b.state_im[k0 + k]);
-                me += 0.5 * (re * re + im * im) / (g * g);
+        const uint32_t n = tuned_count[d];
+        for (uint32_t q0 = 0; q0 < n; q0 += WAVE) {
+            const uint32_t m = min(uint32_t(WAVE), n - q0);
+            double term = 0;
+            if (lane < m) {
+                const double g = double(b.rad_gain[k0 + q0 + lane]);
+                if (g > 0) {
+                    const double re = double(b.state_re[k0 + q0 + lane]), im = double(b.state_im[k0 + q0 + lane]);
+                    term = 0.5 * (re * re + im * im) / (g * g);
+                }
             }
+            for (uint32_t l = 0; l < m; ++l) me += lane_bcast(term, l);
         }
     }
-    modal_energy[d] = me;
+    if (lane == 0) {
+        energy_out[d] = double(energy);
+        live_out[d] = live;
+        silenced[d] = silent ? 1 : 0;
+        modal_energy[d] = me;
+    }
 }
 
-// Renderer r's private buffer: its chunks' partial signals added in order (ModalAudio.cpp:130).
-template<typename Real>
-__global__ void k_bank_renderer_sum(const Real *__restrict__ partial, const uint32_t *__restrict__ renderer_chunk_ptr, uint32_t frames, Real *__restrict__ rout) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = blockIdx.y;
-    if (s >= frames) return;
+// Renderer r's private buffer: its chunks' partial signals added in chunk order (ModalAudio.cpp:130).  The chain of
+// adds per sample is sequential by contract, so the work is a latency problem: one 1024-thread workgroup per
+// (SW-sample strip, renderer) streams tiles of RPT*1024/SW chunk rows through LDS with all 16 waves loading (next tile
+// in registers while the current one is consumed) and its first wave runs the ordered chain out of LDS.
+template<typename Real, int SW>
+__global__ void __launch_bounds__(1024) k_bank_renderer_sum(const Real *__restrict__ partial, const uint32_t *__restrict__ renderer_chunk_ptr, uint32_t frames,
+                                                           Real *__restrict__ rout) {
+    constexpr int RPT = 8, ROUND = 1024 / SW, TILE = RPT * ROUND;
+    __shared__ Real xs[TILE * SW];
+    const uint32_t tid = threadIdx.x, col = tid % SW, rr = tid / SW;
+    const uint32_t s = blockIdx.x * SW + col, r = blockIdx.y;
+    const uint32_t c_begin = renderer_chunk_ptr[r], c_end = renderer_chunk_ptr[r + 1];
+    const bool in_range = s < frames;
+    Real pre[RPT];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const uint32_t c = base + j * ROUND + rr;
+            pre[j] = (c < c_end && in_range) ? partial[size_t(c) * frames + s] : Real(0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) xs[(j * ROUND + rr) * SW + col] = pre[j];
+    };
     Real acc = 0;
-    for (uint32_t c = renderer_chunk_ptr[r]; c < renderer_chunk_ptr[r + 1]; ++c) acc += partial[size_t(c) * frames + s];
-    rout[size_t(r) * frames + s] = acc;
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        commit();
+    }
+    __syncthreads();
+    for (uint32_t base = c_begin; base < c_end; base += TILE) {
+        const bool more = base + TILE < c_end;
+        if (more) fetch(base + TILE);
+        if (tid < SW) {
+            const uint32_t cnt = min(uint32_t(TILE), c_end - base);
+            uint32_t q = 0;
+            for (; q + 8 <= cnt; q += 8) {
+                Real v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = xs[(q + u) * SW + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; q < cnt; ++q) acc += xs[q * SW + col];
+        }
+        __syncthreads();
+        if (more) commit();
+        __syncthreads();
+    }
+    if (tid < SW && in_range) rout[size_t(r) * frames + s] = acc;
+}
+template<typename Real>
+void launch_renderer_sum(hipStream_t st, const Real *partial, const uint32_t *renderer_chunk_ptr, uint32_t frames, uint32_t n_renderers, Real *rout) {
+    constexpr int SW = 16;
+    dim3 grid(div_up(frames, SW), n_renderers);
+    k_bank_renderer_sum<Real, SW><<<grid, 1024, 0, st>>>(partial, renderer_chunk_ptr, frames, rout);
+    KERNEL_CHECK();
 }
 // out[s] += clicks in impact order, then the renderers' buffers in renderer order (ModalAudio.cpp:531,553-555).
 template<typename Real>
@@ -214,6 +347,33 @@ __global__ void k_bank_mix(const Real *__restrict__ click, uint32_t n_impacts, c
     out[s] = acc;
 }
 
+// Host-pinned staging buffer mirrored by a device buffer: every small per-block array travels in ONE copy each way.
+struct Arena {
+    char *host{nullptr}, *dev{nullptr};
+    size_t cap{0}, used{0};
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        release();
+        cap = n + n / 2 + 4096;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), cap, hipHostMallocDefault));
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), cap));
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        host = dev = nullptr;
+        cap = 0;
+    }
+    size_t take(size_t bytes) {
+        const size_t o = used;
+        used += (bytes + 63) & ~size_t(63);
+        return o;
+    }
+    template<typename T> T *h(size_t off) const { return reinterpret_cast<T *>(host + off); }
+    template<typename T> T *d(size_t off) const { return reinterpret_cast<T *>(dev + off); }
+    ~Arena() { release(); }
+};
+
 template<typename Real> struct BankImpl {
     mh_context *ctx;
     uint32_t n_objects, n_modes, n_shapes;
@@ -221,13 +381,10 @@ template<typename Real> struct BankImpl {
     DevArray<uint32_t> mode_offset, mode_count, shape_offset;
     std::vector<uint32_t> h_mode_count;
     // per-block scratch
-    DevArray<ImpactDev<Real>> d_impacts;
-    DevArray<Real> force, click, partial, chunk_energy, gain_scratch, rout, d_out, d_out_gain, d_listener_gain;
-    DevArray<WaveDesc> d_waves;
-    DevArray<uint32_t> d_deal_objects, d_render_count, d_chunk_base, d_imp_ptr, d_imp_idx, d_renderer_chunk_ptr, d_live;
-    DevArray<double> d_energy, d_modal_energy;
-    DevArray<uint32_t> d_tuned;
-    DevArray<uint8_t> d_silenced;
+    Arena arena;
+    DevArray<Real> force, click, partial, chunk_energy, gain_scratch, rout;
+    std::vector<int32_t> dealt_of_object;
+    std::vector<uint32_t> imp_fill;
     BankCols<Real> cols() {
         return {coeff_re, coeff_im, state_re, state_im, rad_gain, phase_im, phase_re, shape_x, shape_y, shape_z, mode_offset, mode_count, shape_offset};
     }
@@ -253,107 +410,113 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     hipStream_t st = ctx->stream;
     Real *out = static_cast<Real *>(out_v);
     const uint32_t n_dealt = n_renderers ? deal_offset[n_renderers] : 0;
-    // host-side descriptors: waves, chunk bases, per-object impact lists
-    std::vector<WaveDesc> waves;
-    std::vector<uint32_t> chunk_base(n_dealt + 1, 0), imp_ptr(n_dealt + 1, 0), imp_idx, renderer_chunk_ptr(n_renderers + 1, 0);
-    uint32_t max_imp = 1;
+    uint32_t n_waves = 0;
+    for (uint32_t d = 0; d < n_dealt; ++d) n_waves += (render_count[d] + WAVE - 1) / WAVE;
+    // ---- arena layout: [upload only | both ways | download only] ----
+    Arena &A = B.arena;
+    A.used = 0;
+    const size_t o_out_gain = A.take(B.n_objects * sizeof(Real)), o_listener = A.take(B.n_objects * sizeof(Real));
+    const size_t o_waves = A.take((n_waves + 1) * sizeof(WaveDesc)), o_deal = A.take((n_dealt + 1) * 4), o_count = A.take((n_dealt + 1) * 4);
+    const size_t o_tuned = A.take((n_dealt + 1) * 4), o_chunk_base = A.take((n_dealt + 1) * 4), o_imp_ptr = A.take((n_dealt + 1) * 4);
+    const size_t o_imp_idx = A.take((n_impacts + 1) * 4), o_rcp = A.take((n_renderers + 1) * 4);
+    const size_t both_begin = A.used;
+    const size_t o_out = A.take(frames * sizeof(Real)), o_impacts = A.take((n_impacts + 1) * sizeof(ImpactDev<Real>));
+    const size_t both_end = A.used;
+    const size_t o_energy = A.take((n_dealt + 1) * 8), o_modal = A.take((n_dealt + 1) * 8), o_live = A.take((n_dealt + 1) * 4), o_silenced = A.take(n_dealt + 1);
+    const size_t total = A.used;
+    if (total > A.cap) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        A.reserve(total);
+    }
+    // ---- host-side descriptors: waves, chunk bases, per-object impact lists (impact order kept) ----
+    WaveDesc *waves = A.h<WaveDesc>(o_waves);
+    uint32_t *chunk_base = A.h<uint32_t>(o_chunk_base), *imp_ptr = A.h<uint32_t>(o_imp_ptr), *imp_idx = A.h<uint32_t>(o_imp_idx), *rcp = A.h<uint32_t>(o_rcp);
+    B.dealt_of_object.assign(B.n_objects, -1);
+    chunk_base[0] = 0;
     {
-        uint32_t r = 0;
+        uint32_t wv = 0;
         for (uint32_t d = 0; d < n_dealt; ++d) {
-            while (r < n_renderers && d >= deal_offset[r + 1]) ++r;
-            if (d == deal_offset[r]) renderer_chunk_ptr[r] = chunk_base[d];
             const uint32_t count = render_count[d];
             chunk_base[d + 1] = chunk_base[d] + (count + LANES - 1) / LANES;
-            for (uint32_t k = 0; k < count; k += WAVE) waves.push_back({d, k});
-            for (uint32_t i = 0; i < n_impacts; ++i)
-                if (impacts[i].object == deal_objects[d]) imp_idx.push_back(i);
-            imp_ptr[d + 1] = uint32_t(imp_idx.size());
-            max_imp = std::max(max_imp, imp_ptr[d + 1] - imp_ptr[d]);
+            for (uint32_t k = 0; k < count; k += WAVE) waves[wv++] = {d, k};
+            if (deal_objects[d] < B.n_objects) B.dealt_of_object[deal_objects[d]] = int32_t(d);
+            imp_ptr[d + 1] = 0;
         }
-        // renderers with no objects: empty ranges
-        for (uint32_t q = 0; q <= n_renderers; ++q) {
-            const uint32_t d0 = q < n_renderers ? deal_offset[q] : n_dealt;
-            renderer_chunk_ptr[q] = chunk_base[std::min(d0, n_dealt)];
+        imp_ptr[0] = 0;
+    }
+    uint32_t max_imp = 1;
+    if (n_dealt) {
+        for (uint32_t i = 0; i < n_impacts; ++i) {
+            const int32_t d = impacts[i].object < B.n_objects ? B.dealt_of_object[impacts[i].object] : -1;
+            if (d >= 0) ++imp_ptr[d + 1];
+        }
+        for (uint32_t d = 0; d < n_dealt; ++d) {
+            max_imp = std::max(max_imp, imp_ptr[d + 1]);
+            imp_ptr[d + 1] += imp_ptr[d];
+        }
+        B.imp_fill.assign(imp_ptr, imp_ptr + n_dealt);
+        for (uint32_t i = 0; i < n_impacts; ++i) {
+            const int32_t d = impacts[i].object < B.n_objects ? B.dealt_of_object[impacts[i].object] : -1;
+            if (d >= 0) imp_idx[B.imp_fill[d]++] = i;
         }
     }
-    const uint32_t n_chunks = chunk_base[n_dealt], n_waves = uint32_t(waves.size());
-    // uploads
-    ensure(ctx, B.d_out, frames);
-    HIP_CHECK(hipMemcpyAsync(B.d_out.get(), out, frames * sizeof(Real), hipMemcpyHostToDevice, st));
-    {
-        std::vector<Real> og(out_gain, out_gain + B.n_objects), lg(listener_gain, listener_gain + B.n_objects);
-        ensure(ctx, B.d_out_gain, B.n_objects);
-        ensure(ctx, B.d_listener_gain, B.n_objects);
-        HIP_CHECK(hipMemcpyAsync(B.d_out_gain.get(), og.data(), og.size() * sizeof(Real), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(B.d_listener_gain.get(), lg.data(), lg.size() * sizeof(Real), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+    for (uint32_t q = 0; q <= n_renderers; ++q) {
+        const uint32_t d0 = q < n_renderers ? deal_offset[q] : n_dealt;
+        rcp[q] = chunk_base[std::min(d0, n_dealt)];
     }
-    std::vector<ImpactDev<Real>> himp(n_impacts);
+    const uint32_t n_chunks = chunk_base[n_dealt];
+    std::copy(out_gain, out_gain + B.n_objects, A.h<Real>(o_out_gain));
+    std::copy(listener_gain, listener_gain + B.n_objects, A.h<Real>(o_listener));
+    std::copy(deal_objects, deal_objects + n_dealt, A.h<uint32_t>(o_deal));
+    std::copy(render_count, render_count + n_dealt, A.h<uint32_t>(o_count));
+    std::copy(tuned_count, tuned_count + n_dealt, A.h<uint32_t>(o_tuned));
+    std::copy(out, out + frames, A.h<Real>(o_out));
+    ImpactDev<Real> *himp = A.h<ImpactDev<Real>>(o_impacts);
     for (uint32_t i = 0; i < n_impacts; ++i) {
         const mh_impact &m = impacts[i];
         himp[i] = {m.object, m.ex_pos, m.samples_left, 0, Real(m.jx), Real(m.jy), Real(m.jz), Real(m.phase_re), Real(m.phase_im), Real(m.rot_re), Real(m.rot_im),
                    Real(m.gamma), Real(m.accel_amp), Real(m.click_b0), Real(m.click_a1), Real(m.click_a2), Real(m.click_z1), Real(m.click_z2)};
     }
-    ensure(ctx, B.d_impacts, std::max<uint32_t>(n_impacts, 1));
+    HIP_CHECK(hipMemcpyAsync(A.dev, A.host, both_end, hipMemcpyHostToDevice, st));
+    // ---- device passes ----
+    Real *d_out_gain = A.d<Real>(o_out_gain), *d_listener = A.d<Real>(o_listener), *d_out = A.d<Real>(o_out);
+    ImpactDev<Real> *d_impacts = A.d<ImpactDev<Real>>(o_impacts);
     ensure(ctx, B.force, size_t(std::max<uint32_t>(n_impacts, 1)) * frames);
     ensure(ctx, B.click, size_t(std::max<uint32_t>(n_impacts, 1)) * frames);
     if (n_impacts) {
-        HIP_CHECK(hipMemcpyAsync(B.d_impacts.get(), himp.data(), n_impacts * sizeof(ImpactDev<Real>), hipMemcpyHostToDevice, st));
-        k_bank_forces<Real><<<div_up(n_impacts, 64), 64, 0, st>>>(B.d_impacts, n_impacts, B.d_listener_gain, Real(click_gain), frames, B.force, B.click);
+        k_bank_forces<Real><<<div_up(n_impacts, 64), 64, 0, st>>>(d_impacts, n_impacts, d_listener, Real(click_gain), frames, B.force, B.click);
         KERNEL_CHECK();
     }
     ensure(ctx, B.rout, size_t(std::max<uint32_t>(n_renderers, 1)) * frames);
     if (n_dealt) {
-        ensure(ctx, B.d_waves, n_waves + 1);
-        ensure(ctx, B.d_deal_objects, n_dealt);
-        ensure(ctx, B.d_render_count, n_dealt);
-        ensure(ctx, B.d_chunk_base, n_dealt + 1);
-        ensure(ctx, B.d_imp_ptr, n_dealt + 1);
-        ensure(ctx, B.d_imp_idx, imp_idx.size() + 1);
-        ensure(ctx, B.d_renderer_chunk_ptr, n_renderers + 1);
         ensure(ctx, B.partial, size_t(n_chunks + 1) * frames);
         ensure(ctx, B.chunk_energy, n_chunks + 1);
         ensure(ctx, B.gain_scratch, size_t(n_waves + 1) * max_imp * WAVE);
-        ensure(ctx, B.d_energy, n_dealt);
-        ensure(ctx, B.d_modal_energy, n_dealt);
-        ensure(ctx, B.d_tuned, n_dealt);
-        HIP_CHECK(hipMemcpyAsync(B.d_tuned.get(), tuned_count, n_dealt * 4, hipMemcpyHostToDevice, st));
-        ensure(ctx, B.d_live, n_dealt);
-        ensure(ctx, B.d_silenced, n_dealt);
-        if (n_waves) HIP_CHECK(hipMemcpyAsync(B.d_waves.get(), waves.data(), n_waves * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(B.d_deal_objects.get(), deal_objects, n_dealt * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(B.d_render_count.get(), render_count, n_dealt * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(B.d_chunk_base.get(), chunk_base.data(), (n_dealt + 1) * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(B.d_imp_ptr.get(), imp_ptr.data(), (n_dealt + 1) * 4, hipMemcpyHostToDevice, st));
-        if (!imp_idx.empty()) HIP_CHECK(hipMemcpyAsync(B.d_imp_idx.get(), imp_idx.data(), imp_idx.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(B.d_renderer_chunk_ptr.get(), renderer_chunk_ptr.data(), (n_renderers + 1) * 4, hipMemcpyHostToDevice, st));
+        const uint32_t *d_deal = A.d<uint32_t>(o_deal), *d_count = A.d<uint32_t>(o_count), *d_chunk_base = A.d<uint32_t>(o_chunk_base), *d_imp_ptr = A.d<uint32_t>(o_imp_ptr);
         if (n_waves) {
-            k_bank_modes<Real><<<n_waves, WAVE, 0, st>>>(B.cols(), B.d_waves, B.d_deal_objects, B.d_render_count, B.d_chunk_base, B.d_imp_ptr, B.d_imp_idx,
-                                                         B.d_impacts, B.force, B.d_out_gain, B.d_listener_gain, frames, B.partial, B.chunk_energy,
-                                                         B.gain_scratch, max_imp);
+            k_bank_modes<Real><<<n_waves, WAVE, 0, st>>>(B.cols(), A.d<WaveDesc>(o_waves), d_deal, d_count, d_chunk_base, d_imp_ptr, A.d<uint32_t>(o_imp_idx), d_impacts,
+                                                         B.force, d_out_gain, d_listener, frames, B.partial, B.chunk_energy, B.gain_scratch, max_imp);
             KERNEL_CHECK();
         }
-        k_bank_objects<Real><<<div_up(n_dealt, 64), 64, 0, st>>>(B.cols(), B.d_deal_objects, B.d_render_count, B.d_chunk_base, B.d_imp_ptr, B.d_out_gain,
-                                                                  B.chunk_energy, n_dealt, B.d_energy, B.d_live, B.d_silenced, B.d_tuned, B.d_modal_energy);
+        k_bank_objects<Real><<<n_dealt, WAVE, 0, st>>>(B.cols(), d_deal, d_count, d_chunk_base, d_imp_ptr, d_out_gain, B.chunk_energy, n_dealt, A.d<double>(o_energy),
+                                                        A.d<uint32_t>(o_live), A.d<uint8_t>(o_silenced), A.d<uint32_t>(o_tuned), A.d<double>(o_modal));
         KERNEL_CHECK();
-        dim3 grid(div_up(frames, 64), n_renderers);
-        k_bank_renderer_sum<Real><<<grid, 64, 0, st>>>(B.partial, B.d_renderer_chunk_ptr, frames, B.rout);
-        KERNEL_CHECK();
+        launch_renderer_sum<Real>(st, B.partial, A.d<uint32_t>(o_rcp), frames, n_renderers, B.rout);
     } else if (n_renderers) {
         HIP_CHECK(hipMemsetAsync(B.rout.get(), 0, size_t(n_renderers) * frames * sizeof(Real), st));
     }
-    k_bank_mix<Real><<<div_up(frames, 64), 64, 0, st>>>(B.click, n_impacts, B.rout, n_renderers, frames, B.d_out);
+    k_bank_mix<Real><<<div_up(frames, 64), 64, 0, st>>>(B.click, n_impacts, B.rout, n_renderers, frames, d_out);
     KERNEL_CHECK();
-    // downloads
-    HIP_CHECK(hipMemcpyAsync(out, B.d_out.get(), frames * sizeof(Real), hipMemcpyDeviceToHost, st));
-    if (n_impacts) HIP_CHECK(hipMemcpyAsync(himp.data(), B.d_impacts.get(), n_impacts * sizeof(ImpactDev<Real>), hipMemcpyDeviceToHost, st));
-    if (n_dealt) {
-        HIP_CHECK(hipMemcpyAsync(object_energy, B.d_energy.get(), n_dealt * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(object_live, B.d_live.get(), n_dealt * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(object_silenced, B.d_silenced.get(), n_dealt, hipMemcpyDeviceToHost, st));
-        if (object_modal_energy) HIP_CHECK(hipMemcpyAsync(object_modal_energy, B.d_modal_energy.get(), n_dealt * sizeof(double), hipMemcpyDeviceToHost, st));
-    }
+    // ---- one copy back ----
+    HIP_CHECK(hipMemcpyAsync(A.host + both_begin, A.dev + both_begin, (n_dealt ? total : both_end) - both_begin, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    std::copy(A.h<Real>(o_out), A.h<Real>(o_out) + frames, out);
+    if (n_dealt) {
+        std::copy(A.h<double>(o_energy), A.h<double>(o_energy) + n_dealt, object_energy);
+        std::copy(A.h<uint32_t>(o_live), A.h<uint32_t>(o_live) + n_dealt, object_live);
+        std::copy(A.h<uint8_t>(o_silenced), A.h<uint8_t>(o_silenced) + n_dealt, object_silenced);
+        if (object_modal_energy) std::copy(A.h<double>(o_modal), A.h<double>(o_modal) + n_dealt, object_modal_energy);
+    }
     for (uint32_t i = 0; i < n_impacts; ++i) {
         mh_impact &m = impacts[i];
         m.samples_left = himp[i].samples_left;
