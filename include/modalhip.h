@@ -103,6 +103,11 @@ int mh_system_matvec(mh_system *, int which, const double *x, double *y, uint32_
  * algorithmic bytes of one launch (76 B per node block + 4 B per row pointer + 16 B per panel entry). */
 int mh_system_bench_spmm(mh_system *, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes);
 
+/* Measurement aid for the dense tall-skinny kernels of the eigensolver: kind 0 = Gram G = X^T Y (X n x wa, Y n x wb),
+ * kind 1 = basis update Z = [X | W] C (n x wa and n x wb times (wa + wb) x wa).  Average device time of `reps` launches
+ * over resident random panels. */
+int mh_context_bench_dense(mh_context *, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms);
+
 /* The nearest tet point to each excitation position, first minimum wins (mesh2modes.cpp:626-636). */
 int mh_nearest_points(mh_context *, const mh_mesh *, uint32_t n, const float *positions_xyz, uint32_t *nearest);
 

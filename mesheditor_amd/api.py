@@ -56,6 +56,12 @@ class Context:
     def time_kernels(self, enable=True):
         self.check(self.L.mh_context_time_kernels(self.h, int(enable)))
 
+    def bench_dense(self, kind, n, wa, wb, reps=10):
+        """Average ms of the Gram (kind 0) or basis-update (kind 1) kernel on resident n x wa / n x wb panels."""
+        ms = C.c_double(0)
+        self.check(self.L.mh_context_bench_dense(self.h, kind, n, wa, wb, reps, C.byref(ms)))
+        return ms.value
+
     def kernel_stats(self):
         n, ms, by = C.c_uint64(0), C.c_double(0), C.c_double(0)
         self.check(self.L.mh_context_kernel_stats(self.h, C.byref(n), C.byref(ms), C.byref(by)))

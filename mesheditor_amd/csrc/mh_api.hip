@@ -271,6 +271,38 @@ int mh_system_bench_spmm(mh_system *s, uint32_t width, uint32_t reps, double *av
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+int mh_context_bench_dense(mh_context *ctx, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms) {
+    if (!ctx || !avg_ms || n == 0 || wa == 0 || wb == 0 || reps == 0 || kind < 0 || kind > 1) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        DevArray<double> x(ctx, n * wa), y(ctx, n * wb), g(ctx, size_t(wa + wb) * (wa + wb)), z(ctx, n * wa);
+        std::vector<double> h(n * std::max(wa, wb));
+        for (size_t i = 0; i < h.size(); ++i) h[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        x.upload(h.data(), n * wa);
+        y.upload(h.data(), n * wb);
+        g.upload(h.data(), g.count);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        auto run = [&]() {
+            if (kind == 0) mh_gram(ctx, n, x, wa, y, wb, g, wa);
+            else mh_combine(ctx, n, x, wa, y, wb, nullptr, 0, g, wa, z, wa, nullptr);
+        };
+        run();
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t r = 0; r < reps; ++r) run();
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 int mh_nearest_points(mh_context *ctx, const mh_mesh *mesh, uint32_t n, const float *positions_xyz, uint32_t *nearest) {
     if (!ctx || !mesh || (n && (!positions_xyz || !nearest))) return MH_EINVAL;
     if (n == 0) return MH_OK;

@@ -102,6 +102,143 @@ __global__ void __launch_bounds__(WAVES * 64) k_gram(const double *__restrict__ 
     }
 }
 
+// Register-blocked Gram: every wave keeps a TI x TJ block of 16x16 output tiles in accumulators and, per 4-row k-step,
+// reads TI + TJ operand fragments from LDS for TI*TJ MFMAs (0.4 LDS reads per MFMA at 5 x 5, against 2 when each tile
+// fetches its own operands).  The workgroup's W = GI*GJ*KS waves tile the output GI x GJ ways and split the staged
+// rows KS ways (wave ks takes the k-steps ks, ks+KS, ...); the KS partial blocks are folded through LDS in a fixed
+// order at the end, so the result stays bit-reproducible.  Tile loops are unrolled at compile time and skipped with
+// scalar branches on the kernel-argument widths: no exec-mask divergence around the MFMAs.
+template<int TI, int TJ, int GI, int GJ, int KS>
+__global__ void __launch_bounds__(GI * GJ * KS * 64) k_gram_blocked(const double *__restrict__ X, int wa, const double *__restrict__ Y, int wb, size_t n,
+                                                                  size_t rows_per_wg, double *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NTH = GI * GJ * KS * 64;
+    constexpr int CA = TI * GI, CB = TJ * GJ; // 16-column strips of the two panels (all staged; missing ones as zeros)
+    constexpr int PA = (CA * 16) % 32 == 16 ? CA * 16 : CA * 16 + 16, PB = (CB * 16) % 32 == 16 ? CB * 16 : CB * 16 + 16;
+    double *Xs = smem, *Ys = smem + KC * PA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wave % KS, gj = (wave / KS) % GJ, gi = wave / (KS * GJ);
+    const int ti0 = gi * TI, tj0 = gj * TJ; // this wave's first tile row / column
+    double4_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = double4_t{0, 0, 0, 0};
+    const size_t r_begin = size_t(blockIdx.x) * rows_per_wg;
+    const size_t r_end = min(n, r_begin + rows_per_wg);
+    const int kk_lane = lane >> 4, c_lane = lane & 15;
+    // staging map: 16 threads per row, NTH/16 rows per pass.  The hot loop has no branch: loads go to clamped
+    // addresses and out-of-range entries are zeroed by a 0/1 factor (a select would be turned back into a branch with
+    // a wait per load).
+    constexpr int RPP = NTH / 16;
+    static_assert(KC % RPP == 0 || RPP > KC, "staging passes");
+    constexpr int PASSES = RPP >= KC ? 1 : KC / RPP;
+    const int srow = tid >> 4, scol = tid & 15;
+    const bool stager = srow < KC; // RPP > KC: the extra threads carry nothing
+    int xcol[CA], ycol[CB];
+    uint32_t xbits = 0, ybits = 0; // strips of this thread's column that exist in the panels
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+        const int col = scol + 16 * c;
+        xcol[c] = min(col, wa - 1);
+        xbits |= (col < wa ? 1u : 0u) << c;
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int col = scol + 16 * c;
+        ycol[c] = min(col, wb - 1);
+        ybits |= (col < wb ? 1u : 0u) << c;
+    }
+    double px[PASSES][CA], py[PASSES][CB];
+    auto fetch = [&](size_t r0) { // raw loads from clamped addresses
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const size_t r = r0 + ps * RPP + srow;
+            const size_t rc = (r < r_end && stager) ? r : r_begin;
+            const double *xr = X + rc * wa, *yr = Y + rc * wb;
+#pragma unroll
+            for (int c = 0; c < CA; ++c) px[ps][c] = xr[xcol[c]];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) py[ps][c] = yr[ycol[c]];
+        }
+    };
+    auto commit = [&](size_t r0) { // registers -> LDS, entries outside the panels as zeros
+        if (!stager) return;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int k = ps * RPP + srow;
+            const bool rok = r0 + k < r_end;
+#pragma unroll
+            for (int c = 0; c < CA; ++c) Xs[k * PA + scol + 16 * c] = (rok && ((xbits >> c) & 1u)) ? px[ps][c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) Ys[k * PB + scol + 16 * c] = (rok && ((ybits >> c) & 1u)) ? py[ps][c] : 0.0;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (size_t r0 = r_begin; r0 < r_end; r0 += KC) {
+        commit(r0);
+        __syncthreads();
+        if (r0 + KC < r_end) fetch(r0 + KC); // in flight while the MFMAs below run
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int step = 0; step < KC / (4 * KS); ++step) {
+            const int kk = 4 * (ks + KS * step);
+            const double *xr = Xs + (kk + kk_lane) * PA + ti0 * 16 + c_lane;
+            const double *yr = Ys + (kk + kk_lane) * PB + tj0 * 16 + c_lane;
+            double af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = xr[i * 16];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = yr[j * 16];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // fold the KS row-splits of each output block through LDS (256 doubles per tile, lane-major), fixed order
+    if (KS > 1) {
+        double *fold = smem + size_t(gi * GJ + gj) * (TI * TJ * 256);
+        for (int src = 1; src < KS; ++src) {
+            if (ks == src) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) fold[((i * TJ + j) * 4 + reg) * 64 + lane] = acc[i][j][reg];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) acc[i][j][reg] += fold[((i * TJ + j) * 4 + reg) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (ks != 0) return;
+    double *out = partial + size_t(blockIdx.x) * wa * wb;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = (tj0 + j) * 16 + c_lane;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = (ti0 + i) * 16 + kk_lane + 4 * reg;
+                if (row < wa && col < wb) out[size_t(col) * wa + row] = acc[i][j][reg];
+            }
+        }
+    }
+}
+
 // 8 threads per output entry: each sums a strided eighth of the partial Grams, then a fixed-order combine
 __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int wa, int wb, double *__restrict__ g, int ld) {
     __shared__ double s[256];
@@ -215,10 +352,13 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
     if (!wa || !wb) return;
     const int ntiles = int((wa + 15) / 16) * int((wb + 15) / 16);
     if (ntiles > 256) mh_throw(MH_EINVAL, "gram: block width %u x %u exceeds 256 x 256", wa, wb);
-    // ~4 workgroups per CU for the 256-thread variant, fewer for the wide ones (their workgroups fill a CU alone)
+    const int ti_n = int((wa + 15) / 16), tj_n = int((wb + 15) / 16);
+    static const bool legacy = getenv("MH_GRAM_LEGACY") && atoi(getenv("MH_GRAM_LEGACY")) != 0;
+    // workgroups: enough to cover 256 CUs a few times; the blocked kernels run one workgroup per CU at a time
     const uint32_t wmax = std::max(wa, wb);
     const bool small = ntiles <= 32 && wmax <= 96;
-    const size_t target = small ? 1024 : (ntiles <= 64 && wmax <= 128 ? 512 : 256);
+    size_t target = small ? 1024 : (ntiles <= 64 && wmax <= 128 ? 512 : 256);
+    if (!legacy) target = 512;
     int nwg = int(std::min<size_t>(target, (n + KC - 1) / KC));
     size_t rows_per_wg = ((n + nwg - 1) / nwg + KC - 1) / KC * KC;
     nwg = int((n + rows_per_wg - 1) / rows_per_wg);
@@ -230,13 +370,36 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
     }
     double *workspace = static_cast<double *>(ctx->gram_ws);
     const size_t lds = size_t(KC) * (pad_pitch(int(wa)) + pad_pitch(int(wb))) * sizeof(double);
-    if (small) {
-        k_gram<4, 8, 6><<<nwg, 256, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-    } else if (ntiles <= 64 && wmax <= 128) {
-        k_gram<8, 8, 8><<<nwg, 512, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-    } else {
-        k_gram<16, 16, 16><<<nwg, 1024, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-    }
+    auto blocked = [&](auto ti, auto tj, auto gi, auto gj, auto ks) {
+        constexpr int TI = decltype(ti)::value, TJ = decltype(tj)::value, GI = decltype(gi)::value, GJ = decltype(gj)::value, KS = decltype(ks)::value;
+        constexpr int CA = TI * GI, CB = TJ * GJ;
+        constexpr int PA = (CA * 16) % 32 == 16 ? CA * 16 : CA * 16 + 16, PB = (CB * 16) % 32 == 16 ? CB * 16 : CB * 16 + 16;
+        const size_t fold = KS > 1 ? size_t(GI * GJ) * TI * TJ * 256 * sizeof(double) : 0;
+        const size_t bytes = std::max(size_t(KC) * (PA + PB) * sizeof(double), fold);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gram_blocked<TI, TJ, GI, GJ, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        k_gram_blocked<TI, TJ, GI, GJ, KS><<<nwg, GI * GJ * KS * 64, bytes, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+    };
+#define IC(v) std::integral_constant<int, v>{}
+    if (legacy) {
+        if (small) k_gram<4, 8, 6><<<nwg, 256, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+        else if (ntiles <= 64 && wmax <= 128) k_gram<8, 8, 8><<<nwg, 512, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+        else k_gram<16, 16, 16><<<nwg, 1024, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+    } else if (ti_n <= 1 && tj_n <= 1) blocked(IC(1), IC(1), IC(1), IC(1), IC(4));
+    else if (ti_n <= 2 && tj_n <= 2) blocked(IC(2), IC(2), IC(1), IC(1), IC(4));
+    else if (ti_n <= 3 && tj_n <= 3) blocked(IC(3), IC(3), IC(1), IC(1), IC(4));
+    else if (ti_n <= 4 && tj_n <= 4) blocked(IC(4), IC(4), IC(1), IC(1), IC(4));
+    else if (ti_n <= 5 && tj_n <= 3) blocked(IC(5), IC(3), IC(1), IC(1), IC(4));
+    else if (ti_n <= 3 && tj_n <= 5) blocked(IC(3), IC(5), IC(1), IC(1), IC(4));
+    else if (ti_n <= 5 && tj_n <= 5) blocked(IC(5), IC(5), IC(1), IC(1), IC(4));
+    else if (ti_n <= 10 && tj_n <= 5) blocked(IC(5), IC(5), IC(2), IC(1), IC(2));
+    else if (ti_n <= 5 && tj_n <= 10) blocked(IC(5), IC(5), IC(1), IC(2), IC(2));
+    else if (ti_n <= 10 && tj_n <= 10) blocked(IC(5), IC(5), IC(2), IC(2), IC(1));
+    else blocked(IC(4), IC(4), IC(4), IC(4), IC(1));
+#undef IC
     KERNEL_CHECK();
     k_gram_reduce<<<div_up(size_t(wa) * wb, 32), 256, 0, ctx->stream>>>(workspace, nwg, int(wa), int(wb), g, int(ld));
     KERNEL_CHECK();

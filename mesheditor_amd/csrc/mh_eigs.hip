@@ -12,7 +12,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <numeric>
+#include <type_traits>
 
 __global__ void k_shift_values(const double *kval, const double *mval, size_t nblocks, double sigma, double *aval);
 __global__ void k_diag_inverse(const uint32_t *row_ptr, const uint32_t *col, const double *aval, uint32_t nnodes, double *dinv);
@@ -59,30 +61,57 @@ __global__ void k_random_panel(double *__restrict__ x, size_t count, uint64_t se
 }
 
 // Chebyshev first step: r = b - t (t optional), d = dinv * r / theta, x = d or x += d.
-__global__ void k_cheb_init(const double *__restrict__ b, const double *__restrict__ t, const double *__restrict__ dinv, double inv_theta,
-                            double *__restrict__ r, double *__restrict__ d, double *__restrict__ x, int accumulate, size_t rows, uint32_t w) {
+template<typename T>
+__global__ void k_cheb_init(const T *__restrict__ b, const T *__restrict__ t, const T *__restrict__ dinv, T inv_theta, T *__restrict__ r, T *__restrict__ d,
+                            T *__restrict__ x, int accumulate, size_t rows, uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
-    const double rv = t ? b[i] - t[i] : b[i];
-    const double dv = dinv[i / w] * rv * inv_theta;
+    const T rv = t ? b[i] - t[i] : b[i];
+    const T dv = dinv[i / w] * rv * inv_theta;
     r[i] = rv;
     d[i] = dv;
     x[i] = accumulate ? x[i] + dv : dv;
 }
-__global__ void k_cheb_step(const double *__restrict__ t, const double *__restrict__ dinv, double c1, double c2, double *__restrict__ r,
-                            double *__restrict__ d, double *__restrict__ x, size_t rows, uint32_t w) {
+template<typename T>
+__global__ void k_cheb_step(const T *__restrict__ t, const T *__restrict__ dinv, T c1, T c2, T *__restrict__ r, T *__restrict__ d, T *__restrict__ x, size_t rows,
+                            uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
-    const double rv = r[i] - t[i];
-    const double dv = c1 * d[i] + c2 * dinv[i / w] * rv;
+    const T rv = r[i] - t[i];
+    const T dv = c1 * d[i] + c2 * dinv[i / w] * rv;
     r[i] = rv;
     d[i] = dv;
     x[i] += dv;
 }
+// Last Chebyshev step of the cycle: the iterate leaves in double, at the caller's (unpadded) pitch wo <= w.
+template<typename T>
+__global__ void k_cheb_last(const T *__restrict__ t, const T *__restrict__ dinv, T c1, T c2, const T *__restrict__ r, const T *__restrict__ d, const T *__restrict__ x,
+                            double *__restrict__ z, size_t rows, uint32_t w, uint32_t wo) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const size_t row = i / w;
+    const uint32_t c = uint32_t(i % w);
+    if (c >= wo) return;
+    const T rv = r[i] - t[i];
+    z[row * wo + c] = double(x[i] + (c1 * d[i] + c2 * dinv[row] * rv));
+}
+template<typename S, typename D> __global__ void k_convert(const S *__restrict__ src, D *__restrict__ dst, size_t count) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = D(src[i]);
+}
+// dst (rows x wd) <- src (rows x ws), converting; columns beyond the source's are zero, beyond the destination's dropped
+template<typename S, typename D> __global__ void k_convert_pitch(const S *__restrict__ src, uint32_t ws, D *__restrict__ dst, uint32_t wd, size_t rows) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * wd) return;
+    const size_t row = i / wd;
+    const uint32_t c = uint32_t(i % wd);
+    dst[i] = c < ws ? D(src[row * ws + c]) : D(0);
+}
 
 // r1 = P^T (b - t): corner value plus half of every incident edge's midside value.
-__global__ void k_restrict_p1(const double *__restrict__ b, const double *__restrict__ t, const uint32_t *__restrict__ p1_corner,
-                              const uint32_t *__restrict__ eptr, const uint32_t *__restrict__ emid, double *__restrict__ r1, uint32_t npts, uint32_t w) {
+template<typename T>
+__global__ void k_restrict_p1(const T *__restrict__ b, const T *__restrict__ t, const uint32_t *__restrict__ p1_corner, const uint32_t *__restrict__ eptr,
+                              const uint32_t *__restrict__ emid, T *__restrict__ r1, uint32_t npts, uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= size_t(npts) * 3 * w) return;
     const uint32_t c = uint32_t(i % w), comp = uint32_t((i / w) % 3), p = uint32_t(i / (size_t(3) * w));
@@ -90,24 +119,26 @@ __global__ void k_restrict_p1(const double *__restrict__ b, const double *__rest
         const size_t o = (size_t(3) * node + comp) * w + c;
         return b[o] - t[o];
     };
-    double s = res(p1_corner[p]);
-    double h = 0;
+    T s = res(p1_corner[p]);
+    T h = 0;
     for (uint32_t e = eptr[p]; e < eptr[p + 1]; ++e) h += res(emid[e]);
-    r1[i] = s + 0.5 * h;
+    r1[i] = s + T(0.5) * h;
 }
 // x2 += P x1
-__global__ void k_prolong_p1(const double *__restrict__ x1, const uint32_t *__restrict__ pa, const uint32_t *__restrict__ pb, double *__restrict__ x2,
-                             uint32_t nnodes, uint32_t w) {
+template<typename T>
+__global__ void k_prolong_p1(const T *__restrict__ x1, const uint32_t *__restrict__ pa, const uint32_t *__restrict__ pb, T *__restrict__ x2, uint32_t nnodes,
+                             uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= size_t(nnodes) * 3 * w) return;
     const uint32_t c = uint32_t(i % w), comp = uint32_t((i / w) % 3), node = uint32_t(i / (size_t(3) * w));
     const uint32_t a = pa[node], bb = pb[node];
-    const double va = x1[(size_t(3) * a + comp) * w + c];
-    x2[i] += a == bb ? va : 0.5 * (va + x1[(size_t(3) * bb + comp) * w + c]);
+    const T va = x1[(size_t(3) * a + comp) * w + c];
+    x2[i] += a == bb ? va : T(0.5) * (va + x1[(size_t(3) * bb + comp) * w + c]);
 }
-// r0 = T^T (b - t) per aggregate (6 rows each), one thread per (aggregate dof, column)
-__global__ void k_restrict_agg(const double *__restrict__ b, const double *__restrict__ t, const double *__restrict__ tmat, double *__restrict__ r0,
-                               uint32_t npts, uint32_t agg_size, uint32_t nagg, uint32_t w) {
+// r0 = T^T (b - t) per aggregate (6 rows each), one thread per (aggregate dof, column); the coarse level stays double
+template<typename T>
+__global__ void k_restrict_agg(const T *__restrict__ b, const T *__restrict__ t, const double *__restrict__ tmat, double *__restrict__ r0, uint32_t npts,
+                               uint32_t agg_size, uint32_t nagg, uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= size_t(nagg) * 6 * w) return;
     const uint32_t c = uint32_t(i % w), q = uint32_t((i / w) % 6), a = uint32_t(i / (size_t(6) * w));
@@ -117,14 +148,15 @@ __global__ void k_restrict_agg(const double *__restrict__ b, const double *__res
         const double *tm = tmat + 18 * size_t(nd);
         for (int p = 0; p < 3; ++p) {
             const size_t o = (size_t(3) * nd + p) * w + c;
-            s += tm[6 * p + q] * (b[o] - t[o]);
+            s += tm[6 * p + q] * double(b[o] - t[o]);
         }
     }
     r0[i] = s;
 }
 // x1 += T x0
-__global__ void k_prolong_agg(const double *__restrict__ x0, const double *__restrict__ tmat, double *__restrict__ x1, uint32_t npts, uint32_t agg_size,
-                              uint32_t nagg, uint32_t w) {
+template<typename T>
+__global__ void k_prolong_agg(const double *__restrict__ x0, const double *__restrict__ tmat, T *__restrict__ x1, uint32_t npts, uint32_t agg_size, uint32_t nagg,
+                              uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= size_t(npts) * 3 * w) return;
     const uint32_t c = uint32_t(i % w), p = uint32_t((i / w) % 3), nd = uint32_t(i / (size_t(3) * w));
@@ -132,7 +164,7 @@ __global__ void k_prolong_agg(const double *__restrict__ x0, const double *__res
     const double *tm = tmat + 18 * size_t(nd) + 6 * p;
     double s = 0;
     for (int q = 0; q < 6; ++q) s += tm[q] * x0[(size_t(6) * a + q) * w + c];
-    x1[i] += s;
+    x1[i] += T(s);
 }
 
 // R[:, k] = AX[:, idx[k]] - theta[idx[k]] * MX[:, idx[k]]
@@ -334,16 +366,24 @@ void colsumsq(mh_context *ctx, const double *x, size_t rows, uint32_t w, double 
 }
 
 // ---- multilevel preconditioner ---------------------------------------------------------------------------------
-struct Precond {
+// T = precision of the two smoothed levels (float by default: the smoothers are gather-bound, so halving the bytes
+// nearly halves their time, and the outer iteration -- residuals, Rayleigh-Ritz, convergence test -- stays double).
+// The aggregate level is always solved in double: it carries the near-null (rigid-body) components.
+template<typename T> struct Precond {
     mh_system *sys;
     mh_context *ctx;
     uint32_t wmax;
     int deg2{2}, deg1{3}, gamma{3};
     double ratio{8.0};
-    DevArray<double> d2, t2, r2, r1, x1, d1, t1, rr1, r0, x0;
-    Precond(mh_system *s, uint32_t w) : sys(s), ctx(s->ctx), wmax(w) {
+    DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
+    DevArray<double> r0, x0;
+    static constexpr bool kDouble = std::is_same<T, double>::value;
+    static uint32_t pitch(uint32_t w) { return kDouble ? w : (w + 3u) & ~3u; } // 16-byte panel rows for the wide-load SpMM
+    Precond(mh_system *s, uint32_t w_in) : sys(s), ctx(s->ctx), wmax(w_in) {
+        const uint32_t w = pitch(w_in);
         const size_t n2 = size_t(3) * s->n_nodes, n1 = size_t(3) * s->n_points, n0 = size_t(6) * s->n_agg;
-        d2.reset(ctx, n2 * w); t2.reset(ctx, n2 * w); r2.reset(ctx, n2 * w);
+        d2.reset(ctx, n2 * w); t2.reset(ctx, n2 * w); r2.reset(ctx, n2 * w); z2.reset(ctx, n2 * w);
+        if (!kDouble) rin.reset(ctx, n2 * w);
         r1.reset(ctx, n1 * w); x1.reset(ctx, n1 * w); d1.reset(ctx, n1 * w); t1.reset(ctx, n1 * w); rr1.reset(ctx, n1 * w);
         r0.reset(ctx, n0 * w);
         x0.reset(ctx, n0 * w);
@@ -351,45 +391,69 @@ struct Precond {
         if (const char *e = getenv("MH_DEG1")) deg1 = std::max(1, atoi(e));
         if (const char *e = getenv("MH_GAMMA")) gamma = std::max(1, atoi(e));
     }
-    void cheb(const BsrLevel &lvl, int deg, const double *b, double *x, bool zero_init, double *r, double *d, double *t, uint32_t w) {
+    void spmm(const BsrLevel &lvl, const T *x, T *y, uint32_t w) {
+        if constexpr (kDouble) mh_spmm(ctx, lvl, lvl.aval, x, y, nullptr, nullptr, w);
+        else mh_spmm_f32(ctx, lvl, x, y, w);
+    }
+    static const T *dinv_of(const BsrLevel &lvl) {
+        if constexpr (kDouble) return lvl.dinv.get();
+        else return lvl.dinv32.get();
+    }
+    // deg Chebyshev-Jacobi steps on lvl; when z_out is given the last step writes the iterate there (in double)
+    void cheb(const BsrLevel &lvl, int deg, const T *b, T *x, bool zero_init, T *r, T *d, T *t, uint32_t w, double *z_out = nullptr, uint32_t w_out = 0) {
         const size_t rows = size_t(3) * lvl.n_nodes;
         const double lmax = lvl.lmax, lmin = lvl.lmax / ratio;
         const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig = theta / delta;
         double rho = 1.0 / sig;
-        if (!zero_init) mh_spmm(ctx, lvl, lvl.aval, x, t, nullptr, nullptr, w);
-        k_cheb_init<<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, lvl.dinv, 1.0 / theta, r, d, x, zero_init ? 0 : 1, rows, w);
+        const T *dinv = dinv_of(lvl);
+        if (!zero_init) spmm(lvl, x, t, w);
+        k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
         KERNEL_CHECK();
         for (int k = 1; k < deg; ++k) {
-            mh_spmm(ctx, lvl, lvl.aval, d, t, nullptr, nullptr, w);
+            spmm(lvl, d, t, w);
             const double rho_new = 1.0 / (2 * sig - rho);
-            k_cheb_step<<<grid1(rows * w), TB, 0, ctx->stream>>>(t, lvl.dinv, rho_new * rho, 2 * rho_new / delta, r, d, x, rows, w);
+            if (z_out && k + 1 == deg) k_cheb_last<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(t, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, d, x, z_out, rows, w, w_out);
+            else k_cheb_step<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(t, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, d, x, rows, w);
             KERNEL_CHECK();
             rho = rho_new;
         }
+        if (z_out && deg == 1) {
+            k_convert_pitch<T, double><<<grid1(rows * w_out), TB, 0, ctx->stream>>>(x, w, z_out, w_out, rows);
+            KERNEL_CHECK();
+        }
     }
     // z = B r for an n2 x w panel
-    void apply(const double *r, double *z, uint32_t w) {
+    void apply(const double *r_in, double *z_out, uint32_t w_in) {
+        const uint32_t w = pitch(w_in);
         const uint32_t nn = sys->n_nodes, np = sys->n_points, na = sys->n_agg;
-        const size_t n1 = size_t(3) * np, n0 = size_t(6) * na;
+        const size_t n2 = size_t(3) * nn, n1 = size_t(3) * np, n0 = size_t(6) * na;
         const double one = 1, zero = 0;
+        const T *r;
+        if constexpr (kDouble) r = r_in;
+        else {
+            k_convert_pitch<double, T><<<grid1(n2 * w), TB, 0, ctx->stream>>>(r_in, w_in, rin.get(), w, n2);
+            KERNEL_CHECK();
+            r = rin.get();
+        }
+        T *z = z2.get();
         cheb(sys->L2, deg2, r, z, true, r2, d2, t2, w);
-        mh_spmm(ctx, sys->L2, sys->L2.aval, z, t2, nullptr, nullptr, w);
-        k_restrict_p1<<<grid1(n1 * w), TB, 0, ctx->stream>>>(r, t2, sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1, np, w);
+        spmm(sys->L2, z, t2, w);
+        k_restrict_p1<T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r, t2.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1.get(), np, w);
         KERNEL_CHECK();
         for (int g = 0; g < gamma; ++g) {
             cheb(sys->L1, deg1, r1, x1, g == 0, rr1, d1, t1, w);
-            mh_spmm(ctx, sys->L1, sys->L1.aval, x1, t1, nullptr, nullptr, w);
-            k_restrict_agg<<<grid1(n0 * w), TB, 0, ctx->stream>>>(r1, t1, sys->agg_t, r0, np, sys->agg_size, na, w);
+            spmm(sys->L1, x1, t1, w);
+            k_restrict_agg<T><<<grid1(n0 * w), TB, 0, ctx->stream>>>(r1.get(), t1.get(), sys->agg_t, r0, np, sys->agg_size, na, w);
             KERNEL_CHECK();
             // r0 is (6 na) x w row-major = w x (6 na) column-major: x0 = r0 * A0^-1 (A0^-1 symmetric, explicit)
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, rocblas_int(n0), rocblas_int(n0), &one, r0, w, sys->a0, rocblas_int(n0), &zero, x0, w));
-            k_prolong_agg<<<grid1(n1 * w), TB, 0, ctx->stream>>>(x0, sys->agg_t, x1, np, sys->agg_size, na, w);
+            k_prolong_agg<T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(x0, sys->agg_t, x1.get(), np, sys->agg_size, na, w);
             KERNEL_CHECK();
             cheb(sys->L1, deg1, r1, x1, false, rr1, d1, t1, w);
         }
-        k_prolong_p1<<<grid1(size_t(3) * nn * w), TB, 0, ctx->stream>>>(x1, sys->parent_a, sys->parent_b, z, nn, w);
+        k_prolong_p1<T><<<grid1(n2 * w), TB, 0, ctx->stream>>>(x1.get(), sys->parent_a, sys->parent_b, z, nn, w);
         KERNEL_CHECK();
-        cheb(sys->L2, deg2, r, z, false, r2, d2, t2, w);
+        cheb(sys->L2, deg2, r, z, false, r2, d2, t2, w, z_out, w_in);
     }
 };
 
@@ -430,6 +494,12 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
         k_diag_inverse<<<grid1(lvl->n_nodes), TB, 0, ctx->stream>>>(lvl->row_ptr, lvl->col, lvl->aval, lvl->n_nodes, lvl->dinv);
         KERNEL_CHECK();
         lvl->lmax = estimate_lmax(ctx, *lvl);
+        lvl->aval32.reset(ctx, lvl->n_blocks * 9);
+        lvl->dinv32.reset(ctx, size_t(3) * lvl->n_nodes);
+        k_convert<double, float><<<grid1(lvl->n_blocks * 9), TB, 0, ctx->stream>>>(lvl->aval.get(), lvl->aval32.get(), lvl->n_blocks * 9);
+        KERNEL_CHECK();
+        k_convert<double, float><<<grid1(size_t(3) * lvl->n_nodes), TB, 0, ctx->stream>>>(lvl->dinv.get(), lvl->dinv32.get(), size_t(3) * lvl->n_nodes);
+        KERNEL_CHECK();
     }
     const size_t n0 = size_t(6) * sys->n_agg;
     sys->a0.reset(ctx, n0 * n0);
@@ -527,7 +597,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
             DevArray<uint32_t> idx_d(ctx, b);
             DevArray<int> info(ctx, 1);
-            Precond prec(sys, b);
+            static const bool fp32_prec = !(getenv("MH_PRECOND_FP64") && atoi(getenv("MH_PRECOND_FP64")) != 0);
+            std::unique_ptr<Precond<float>> prec32;
+            std::unique_ptr<Precond<double>> prec64;
+            if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, b);
+            else prec64 = std::make_unique<Precond<double>>(sys, b);
 
             // --- initial block: seed columns (warm start), then Gaussian noise; M-orthonormalise; Rayleigh-Ritz
             k_random_panel<<<grid1(n * b), TB, 0, st>>>(X, n * b, 20260710ull);
@@ -633,7 +707,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 KERNEL_CHECK();
                 {
                     Timer tp(ctx);
-                    prec.apply(Rw, W, w);
+                    if (prec32) prec32->apply(Rw, W, w);
+                    else prec64->apply(Rw, W, w);
                     precond_seconds += tp.stop();
                     prof.op_applications += w;
                 }

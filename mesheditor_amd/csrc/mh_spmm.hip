@@ -10,10 +10,10 @@ namespace {
 constexpr int TB = 256;
 
 // CW = panel columns per row group (power of two <= 64); a wave covers 64/CW block rows.
-// NC = columns per lane (stride 64) so that panels up to 64*NC wide read the matrix once.
-template<int CW, int NC, bool WITH_M, bool WITH_A>
-__global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ vals9,
-                                            const double *__restrict__ mscal, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ y2,
+// NC = columns per lane (stride CW) so that panels up to CW*NC wide read the matrix once.
+template<typename T, int CW, int NC, bool WITH_M, bool WITH_A>
+__global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const T *__restrict__ vals9,
+                                            const T *__restrict__ mscal, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ y2,
                                             uint32_t nnodes, uint32_t w, int xcd_remap) {
     constexpr int RPW = 64 / CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -29,10 +29,10 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
     uint32_t cc[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        active[k] = c0 + 64 * k < w;
-        cc[k] = active[k] ? c0 + 64 * k : 0;
+        active[k] = c0 + CW * k < w;
+        cc[k] = active[k] ? c0 + CW * k : 0;
     }
-    double a0[NC], a1[NC], a2[NC], m0[NC], m1[NC], m2[NC];
+    T a0[NC], a1[NC], a2[NC], m0[NC], m1[NC], m2[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) a0[k] = a1[k] = a2[k] = m0[k] = m1[k] = m2[k] = 0;
     const uint32_t p1 = row_ptr[row + 1];
@@ -44,10 +44,10 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
         uint32_t j[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) j[u] = col[p + u];
-        double xv[U][NC][3];
+        T xv[U][NC][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const double *xr = x + size_t(3) * j[u] * w;
+            const T *xr = x + size_t(3) * j[u] * w;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 xv[u][k][0] = xr[cc[k]];
@@ -55,20 +55,20 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
                 xv[u][k][2] = xr[2 * size_t(w) + cc[k]];
             }
         }
-        double v[U][9], m[U];
+        T v[U][9], m[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (WITH_A) {
 #pragma unroll
                 for (int e = 0; e < 9; ++e) v[u][e] = vals9[size_t(9) * (p + u) + e];
             }
-            m[u] = WITH_M ? mscal[p + u] : 0.0;
+            m[u] = WITH_M ? mscal[p + u] : T(0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const double x0 = xv[u][k][0], x1 = xv[u][k][1], x2 = xv[u][k][2];
+                const T x0 = xv[u][k][0], x1 = xv[u][k][1], x2 = xv[u][k][2];
                 if (WITH_A) {
                     a0[k] += v[u][0] * x0 + v[u][1] * x1 + v[u][2] * x2;
                     a1[k] += v[u][3] * x0 + v[u][4] * x1 + v[u][5] * x2;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
         }
         p += U;
     };
-    constexpr int UMAX = NC >= 4 ? 2 : (NC == 2 ? 4 : 8);
+    constexpr int UMAX = NC >= 3 ? 2 : (NC == 2 ? 4 : 8);
     while (p + UMAX <= p1) step(std::integral_constant<int, UMAX>{});
     if (UMAX >= 8 && p + 4 <= p1) step(std::integral_constant<int, 4>{});
     if (UMAX >= 4 && p + 2 <= p1) step(std::integral_constant<int, 2>{});
@@ -91,14 +91,156 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         if (!active[k]) continue;
-        const size_t o = size_t(3) * row * w + c0 + 64 * k;
+        const size_t o = size_t(3) * row * w + c0 + CW * k;
         if (WITH_A) { y[o] = a0[k]; y[o + w] = a1[k]; y[o + 2 * size_t(w)] = a2[k]; }
         if (WITH_M) { y2[o] = m0[k]; y2[o + w] = m1[k]; y2[o + 2 * size_t(w)] = m2[k]; }
     }
 }
 
-template<bool WITH_M, bool WITH_A>
-void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
+// ---- wide-load variant -----------------------------------------------------------------------------------------
+// Measured on MI355X (S100k, tools/spmm_bench.py): the gather costs a fixed ~16-20 cycles of a CU's address path per
+// wave-level load INSTRUCTION almost regardless of the bytes it moves (w = 16 and w = 64 columns take 390 us and
+// 470 us for the same 12.6 M gathers), and the scalar path streams the block values at under 1.5 TB/s.  So this kernel
+//   * gathers with 16-byte loads: a lane owns V = 2 doubles / 4 floats of a panel row, CL lanes cover the row, and
+//     the wave's G = 64/CL lane groups work on G different node blocks of the row at once -- V*G times fewer gather
+//     instructions than one 8-byte column per lane;
+//   * brings the row's column indices and 9-value blocks in with coalesced vector loads (lane l takes elements
+//     l, l+64, ... of the row's contiguous slice of the BSR arrays) into a wave-private LDS slice, from which every
+//     lane group reads its own block's values;
+//   * folds the G partial rows with a fixed shuffle tree at the end of the row (deterministic).
+// The panel pitch w must be a multiple of V (16-byte rows).
+template<typename T, int CL, bool WITH_M, bool WITH_A>
+__global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const T *__restrict__ vals9,
+                                                 const T *__restrict__ mscal, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ y2, uint32_t nnodes,
+                                                 uint32_t w, int xcd_remap) {
+    constexpr int V = 16 / sizeof(T), G = 64 / CL, STRIP = 64, VP = sizeof(T) == 4 ? 12 : 10, U = 4;
+    typedef T Vec __attribute__((ext_vector_type(V)));
+    __shared__ __attribute__((aligned(16))) T sv[TB / 64][WITH_A ? STRIP * VP : 1];
+    __shared__ T sm[TB / 64][WITH_M ? STRIP : 1];
+    __shared__ uint32_t sc[TB / 64][STRIP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = lane % CL, g = lane / CL;
+    const uint32_t nb_grid = gridDim.x, per = (nb_grid + 7) / 8;
+    const uint32_t bid = xcd_remap ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    const uint32_t row = __builtin_amdgcn_readfirstlane(bid * (TB / 64) + wave);
+    if (row >= nnodes) return;
+    const bool act = V * c < w;
+    const uint32_t coff = act ? V * c : 0;
+    Vec acc[3], macc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = macc[i] = Vec(0);
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane(row_ptr[row]), p1 = __builtin_amdgcn_readfirstlane(row_ptr[row + 1]);
+    T *svw = sv[wave];
+    T *smw = sm[wave];
+    uint32_t *scw = sc[wave];
+    for (uint32_t base = p0; base < p1; base += STRIP) {
+        const uint32_t nb = min(uint32_t(STRIP), p1 - base);
+        if (base != p0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous strip fully consumed
+        scw[lane] = uint32_t(lane) < nb ? col[base + lane] : 0u;
+        if (WITH_A) {
+            const T *src = vals9 + size_t(9) * base;
+            T tmp[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const uint32_t f = lane + 64 * i;
+                tmp[i] = f < 9 * nb ? src[f] : T(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const uint32_t f = lane + 64 * i;
+                if (f < 9 * nb) svw[(f / 9) * VP + f % 9] = tmp[i];
+            }
+        }
+        if (WITH_M) smw[lane] = uint32_t(lane) < nb ? mscal[base + lane] : T(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // round t: lane group g takes block t*G + g of the strip
+        const uint32_t rounds = (nb + G - 1) / G;
+        for (uint32_t t0 = 0; t0 < rounds; t0 += U) {
+            Vec xv[U][3];
+            uint32_t bi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u < rounds) { // wave-uniform
+                    bi[u] = min((t0 + u) * G + g, nb - 1);
+                    const T *xr = x + size_t(3) * scw[bi[u]] * w + coff;
+                    xv[u][0] = *reinterpret_cast<const Vec *>(xr);
+                    xv[u][1] = *reinterpret_cast<const Vec *>(xr + w);
+                    xv[u][2] = *reinterpret_cast<const Vec *>(xr + 2 * size_t(w));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u < rounds) {
+                    const bool ok = (t0 + u) * G + g < nb;
+                    if (WITH_A) {
+                        T v[9];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) v[e] = ok ? svw[bi[u] * VP + e] : T(0);
+                        acc[0] += v[0] * xv[u][0] + v[1] * xv[u][1] + v[2] * xv[u][2];
+                        acc[1] += v[3] * xv[u][0] + v[4] * xv[u][1] + v[5] * xv[u][2];
+                        acc[2] += v[6] * xv[u][0] + v[7] * xv[u][1] + v[8] * xv[u][2];
+                    }
+                    if (WITH_M) {
+                        const T m = ok ? smw[bi[u]] : T(0);
+                        macc[0] += m * xv[u][0];
+                        macc[1] += m * xv[u][1];
+                        macc[2] += m * xv[u][2];
+                    }
+                }
+            }
+        }
+    }
+    // fold the G lane groups (fixed tree), group 0 stores
+#pragma unroll
+    for (int sft = G / 2; sft >= 1; sft >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (WITH_A) acc[i][e] += __shfl_down(acc[i][e], sft * CL, 64);
+                if (WITH_M) macc[i][e] += __shfl_down(macc[i][e], sft * CL, 64);
+            }
+        }
+    }
+    if (g == 0 && act) {
+        const size_t o = size_t(3) * row * w + coff;
+        if (WITH_A) {
+            *reinterpret_cast<Vec *>(y + o) = acc[0];
+            *reinterpret_cast<Vec *>(y + o + w) = acc[1];
+            *reinterpret_cast<Vec *>(y + o + 2 * size_t(w)) = acc[2];
+        }
+        if (WITH_M) {
+            *reinterpret_cast<Vec *>(y2 + o) = macc[0];
+            *reinterpret_cast<Vec *>(y2 + o + w) = macc[1];
+            *reinterpret_cast<Vec *>(y2 + o + 2 * size_t(w)) = macc[2];
+        }
+    }
+}
+
+template<typename T, bool WITH_M, bool WITH_A>
+bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const T *vals9, const T *x, T *y, const T *mscal, T *y2, uint32_t w) {
+    constexpr uint32_t V = 16 / sizeof(T);
+    static const bool legacy = getenv("MH_SPMM_LEGACY") && atoi(getenv("MH_SPMM_LEGACY")) != 0;
+    if (legacy || w % V != 0 || w > 64 * V) return false;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y2)) & 15) return false;
+    static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+    const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
+    auto go = [&](auto cl_tag) {
+        constexpr int CL = decltype(cl_tag)::value;
+        k_spmm_wide<T, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
+    };
+    const uint32_t lanes = div_up(w, V);
+    if (lanes <= 8) go(std::integral_constant<int, 8>{});
+    else if (lanes <= 16) go(std::integral_constant<int, 16>{});
+    else if (lanes <= 32) go(std::integral_constant<int, 32>{});
+    else go(std::integral_constant<int, 64>{});
+    KERNEL_CHECK();
+    return true;
+}
+
+template<typename T, bool WITH_M, bool WITH_A>
+void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const T *vals9, const T *x, T *y, const T *mscal, T *y2, uint32_t w) {
+    if (launch_spmm_wide<T, WITH_M, WITH_A>(ctx, lvl, vals9, x, y, mscal, y2, w)) return;
     const uint32_t n = lvl.n_nodes;
     auto go = [&](auto cw_tag, auto nc_tag) {
         constexpr int CW = decltype(cw_tag)::value, NC = decltype(nc_tag)::value;
@@ -106,16 +248,21 @@ void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, cons
         static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
         // grid.x padded to a multiple of 8 so the XCD remap is a bijection onto [0, 8*per)
         dim3 grid((div_up(n, (TB / 64) * RPW) + 7) / 8 * 8, div_up(w, CW * NC));
-        k_spmm<CW, NC, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, n, w, xcd);
+        k_spmm<T, CW, NC, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, n, w, xcd);
     };
     using I = std::integral_constant<int, 0>;
     (void)sizeof(I);
-    if (w <= 8) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
-    else if (w <= 16) go(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
-    else if (w <= 32) go(std::integral_constant<int, 32>{}, std::integral_constant<int, 1>{});
-    else if (w <= 64) go(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
-    else if (w <= 128) go(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
-    else go(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
+    auto ic = [](auto v) { return v; };
+    (void)ic;
+#define MH_GO(CWV, NCV) go(std::integral_constant<int, CWV>{}, std::integral_constant<int, NCV>{})
+    // One row per wave (wave-uniform block values through the scalar path) beats packing several rows into a wave
+    // even when most lanes idle: measured at S100k, w = 32 takes 1013 us with two rows per wave and 525 us with one.
+    if (w <= 8) MH_GO(8, 1);
+    else if (w <= 64) MH_GO(64, 1);
+    else if (w <= 128) MH_GO(64, 2);
+    else if (w <= 192) MH_GO(64, 3);
+    else MH_GO(64, 4);
+#undef MH_GO
     KERNEL_CHECK();
 }
 
@@ -301,12 +448,14 @@ void mh_timer_flush(mh_context *ctx) {
     ctx->timer_used = 0;
 }
 
-void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
-    if (w == 0) return;
-    // Timed launches: products with the P2 operator's 3x3 blocks (A-values only).
-    const bool timed = ctx->time_kernels && vals9 && !mscal && lvl.id == 2;
-    size_t slot = 0;
-    if (timed) {
+namespace {
+// HIP events around one launch on the context's stream; resolved lazily by mh_timer_flush.
+struct TimedLaunch {
+    mh_context *ctx;
+    bool on;
+    size_t slot{0};
+    TimedLaunch(mh_context *c, bool enable, double algorithmic_bytes) : ctx(c), on(enable) {
+        if (!on) return;
         if (ctx->timer_used == ctx->timer_events.size()) {
             hipEvent_t a, b;
             HIP_CHECK(hipEventCreate(&a));
@@ -315,17 +464,33 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
             ctx->timer_bytes.push_back(0);
         }
         slot = ctx->timer_used++;
-        // algorithmic bytes: 9 values + column index per node block, row pointers, x read once, y written once
-        ctx->timer_bytes[slot] = 76.0 * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + 2.0 * 8.0 * 3.0 * double(lvl.n_nodes) * w;
+        ctx->timer_bytes[slot] = algorithmic_bytes;
         HIP_CHECK(hipEventRecord(ctx->timer_events[slot].first, ctx->stream));
     }
-    struct Stop {
-        mh_context *c; bool on; size_t s;
-        ~Stop() { if (on) (void)hipEventRecord(c->timer_events[s].second, c->stream); }
-    } stop{ctx, timed, slot};
-    if (vals9 && mscal) launch_spmm<true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
-    else if (vals9) {
-        if (!launch_spmm_tiled(ctx, lvl, vals9, x, y, w)) launch_spmm<false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
+    ~TimedLaunch() {
+        if (on) (void)hipEventRecord(ctx->timer_events[slot].second, ctx->stream);
     }
-    else launch_spmm<true, false>(ctx, lvl, nullptr, x, nullptr, mscal, y2, w);
+};
+// algorithmic bytes of one product: 9 values + column index per node block, row pointers, x read once, y written once
+double spmm_bytes(const BsrLevel &lvl, uint32_t w, size_t scalar) {
+    return (9.0 * scalar + 4.0) * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + 2.0 * scalar * 3.0 * double(lvl.n_nodes) * w;
+}
+} // namespace
+
+void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
+    if (w == 0) return;
+    // Timed launches: products with the P2 operator's 3x3 blocks (A-values only).
+    TimedLaunch timed(ctx, ctx->time_kernels && vals9 && !mscal && lvl.id == 2, spmm_bytes(lvl, w, sizeof(double)));
+    if (vals9 && mscal) launch_spmm<double, true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
+    else if (vals9) {
+        if (!launch_spmm_tiled(ctx, lvl, vals9, x, y, w)) launch_spmm<double, false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
+    }
+    else launch_spmm<double, true, false>(ctx, lvl, nullptr, x, nullptr, mscal, y2, w);
+}
+
+// fp32 product with the level's single-precision copy of A (preconditioner only).
+void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w) {
+    if (w == 0) return;
+    TimedLaunch timed(ctx, ctx->time_kernels && lvl.id == 2, spmm_bytes(lvl, w, sizeof(float)));
+    launch_spmm<float, false, true>(ctx, lvl, lvl.aval32.get(), x, y, static_cast<const float *>(nullptr), static_cast<float *>(nullptr), w);
 }

@@ -74,7 +74,7 @@ def test_spmm_matches_oracle(api, ctx, oracle):
     sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
     syso = oracle.System(pts, tets, mo)
     rng = np.random.default_rng(3)
-    for width in (1, 5, 33, 70, 130):
+    for width in (1, 2, 5, 16, 33, 48, 64, 70, 76, 128, 130):
         x = rng.standard_normal((sysg.n, width))
         for which in (0, 1):
             y = sysg.matvec(which, x)

@@ -6,6 +6,6 @@ ctx = api.Context(0)
 for name in sys.argv[1:] or ["cube_s100k"]:
     p, t, m, kw = meshes.workload(name)
     s = api.System(ctx, api.Mesh(ctx, p, t), api.material(*m))
-    for w in (1, 8, 16, 32, 64, 75, 128, 230):
+    for w in [int(v) for v in os.environ.get('WIDTHS', '1,8,16,32,64,75,128,230').split(',')]:
         ms, by = s.bench_spmm(w, 20)
         print(f"{name} w={w:4d}  {ms*1e3:8.1f} us  {by/1e6:8.1f} MB  {by/ms/1e6:8.1f} GB/s  {100*by/ms/1e6/8000:5.1f}% of 8 TB/s", flush=True)
