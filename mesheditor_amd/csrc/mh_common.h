@@ -170,15 +170,7 @@ struct BsrLevel {
     DevArray<double> dinv; // 3*n_nodes: 1 / diag(A)
     DevArray<float> aval32, dinv32; // single-precision copies for the preconditioner's smoothers
     double lmax{0}; // spectral radius estimate of D^-1 A
-    // Row tiles of TILE_ROWS consecutive rows for the LDS-staged SpMM: the sorted union of each tile's column nodes
-    // and, per node block, its column's position in that union.
-    uint32_t n_tiles{0};
-    DevArray<uint32_t> tile_uptr; // n_tiles + 1
-    DevArray<uint32_t> tile_ucols; // tile_uptr[n_tiles]
-    DevArray<uint16_t> block_local; // n_blocks
-    bool tiled{false};
 };
-constexpr uint32_t MH_TILE_ROWS = 64;
 
 struct mh_system {
     mh_context *ctx;
@@ -239,4 +231,5 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip
+void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w); // double A x of a float panel
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

@@ -19,97 +19,14 @@ __host__ __device__ inline int pad_pitch(int w) { // smallest p >= w with p = 16
     return p;
 }
 
-template<int WAVES, int MAXT, int MAXC>
-__global__ void __launch_bounds__(WAVES * 64) k_gram(const double *__restrict__ X, int wa, const double *__restrict__ Y, int wb, size_t n, size_t rows_per_wg,
-                                                    double *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NTH = WAVES * 64;
-    const int pa = pad_pitch(wa), pb = pad_pitch(wb);
-    double *Xs = smem, *Ys = smem + KC * pa;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ti_n = (wa + 15) / 16, tj_n = (wb + 15) / 16, ntiles = ti_n * tj_n;
-    double4_t acc[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = double4_t{0, 0, 0, 0};
-    const size_t r_begin = size_t(blockIdx.x) * rows_per_wg;
-    const size_t r_end = min(n, r_begin + rows_per_wg);
-    const int kk_lane = lane >> 4, c_lane = lane & 15;
-    // staging map: 16 threads per row, NTH/16 rows per pass; elements a thread carries per chunk (registers)
-    constexpr int RPP = NTH / 16; // rows per pass
-    constexpr int PASSES = KC / RPP > 0 ? KC / RPP : 1;
-    const int srow = tid >> 4, scol = tid & 15;
-    double px[PASSES][MAXC], py[PASSES][MAXC];
-    const int nca = (wa + 15) / 16, ncb = (wb + 15) / 16; // column strips actually loaded
-    auto fetch = [&](size_t r0) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const size_t r = r0 + ps * RPP + srow;
-            const bool rok = r < r_end && ps * RPP + srow < KC;
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int col = scol + 16 * c;
-                if (c < nca) px[ps][c] = (rok && col < wa) ? X[r * wa + col] : 0.0;
-                if (c < ncb) py[ps][c] = (rok && col < wb) ? Y[r * wb + col] : 0.0;
-            }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int k = ps * RPP + srow;
-            if (k < KC) {
-#pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    const int col = scol + 16 * c;
-                    if (c < nca) Xs[k * pa + col] = px[ps][c];
-                    if (c < ncb) Ys[k * pb + col] = py[ps][c];
-                }
-            }
-        }
-    };
-    if (r_begin < r_end) fetch(r_begin);
-    for (size_t r0 = r_begin; r0 < r_end; r0 += KC) {
-        commit();
-        __syncthreads();
-        if (r0 + KC < r_end) fetch(r0 + KC); // in flight while the MFMAs below run
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 4) {
-            const double *xr = Xs + (kk + kk_lane) * pa + c_lane;
-            const double *yr = Ys + (kk + kk_lane) * pb + c_lane;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int tile = wave + t * WAVES;
-                if (tile < ntiles) {
-                    const int ti = tile / tj_n, tj = tile % tj_n;
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[ti * 16], yr[tj * 16], acc[t], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    double *out = partial + size_t(blockIdx.x) * wa * wb;
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int tile = wave + t * WAVES;
-        if (tile >= ntiles) continue;
-        const int ti = tile / tj_n, tj = tile % tj_n;
-        const int j = tj * 16 + c_lane;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int i = ti * 16 + kk_lane + 4 * reg;
-            if (i < wa && j < wb) out[size_t(j) * wa + i] = acc[t][reg];
-        }
-    }
-}
-
 // Register-blocked Gram: every wave keeps a TI x TJ block of 16x16 output tiles in accumulators and, per 4-row k-step,
 // reads TI + TJ operand fragments from LDS for TI*TJ MFMAs (0.4 LDS reads per MFMA at 5 x 5, against 2 when each tile
 // fetches its own operands).  The workgroup's W = GI*GJ*KS waves tile the output GI x GJ ways and split the staged
 // rows KS ways (wave ks takes the k-steps ks, ks+KS, ...); the KS partial blocks are folded through LDS in a fixed
 // order at the end, so the result stays bit-reproducible.  Tile loops are unrolled at compile time and skipped with
 // scalar branches on the kernel-argument widths: no exec-mask divergence around the MFMAs.
-template<int TI, int TJ, int GI, int GJ, int KS>
-__global__ void __launch_bounds__(GI * GJ * KS * 64) k_gram_blocked(const double *__restrict__ X, int wa, const double *__restrict__ Y, int wb, size_t n,
+template<int TI, int TJ, int GI, int GJ, int KS, int OCC>
+__global__ void __launch_bounds__(GI * GJ * KS * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) k_gram_blocked(const double *__restrict__ X, int ldx, int wa, const double *__restrict__ Y, int ldy, int wb, size_t n,
                                                                   size_t rows_per_wg, double *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NTH = GI * GJ * KS * 64;
@@ -156,7 +73,7 @@ __global__ void __launch_bounds__(GI * GJ * KS * 64) k_gram_blocked(const double
         for (int ps = 0; ps < PASSES; ++ps) {
             const size_t r = r0 + ps * RPP + srow;
             const size_t rc = (r < r_end && stager) ? r : r_begin;
-            const double *xr = X + rc * wa, *yr = Y + rc * wb;
+            const double *xr = X + rc * ldx, *yr = Y + rc * ldy;
 #pragma unroll
             for (int c = 0; c < CA; ++c) px[ps][c] = xr[xcol[c]];
 #pragma unroll
@@ -262,72 +179,77 @@ __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int w
 // directions from the same basis) and reads the basis once.  A workgroup owns 64 rows (16 per wave) and all nc <= 256
 // output columns; the basis rows and the matching coefficient rows are staged through LDS in K-chunks of 32 and
 // multiplied with v_mfma_f64_16x16x4_f64.  Bound: 2 n m nc flops on fp64 MFMA vs 8 n (m + nc) bytes of HBM.
-constexpr int CK = 16; // K chunk
+constexpr int CK = 32; // K chunk
 template<int NT, bool ACCUMULATE> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =
 __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, const double *__restrict__ W, int ww, const double *__restrict__ P, int wp,
                                                 const double *__restrict__ Ct, int nc, size_t n, double *__restrict__ out1, int n1, double *__restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = wx + ww + wp;
-    const int ncp = ((nc + 15) / 16) * 16;
-    const int cpitch = (ncp % 32 == 16) ? ncp : ncp + 16; // = 16 (mod 32): conflict-free B reads
+    constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16; // = 16 (mod 32): conflict-free B reads
     constexpr int SP = CK + 2; // A-tile pitch: rows 2 doubles apart mod 32 -> conflict-free ds_read_b64
     double *Ss = smem; // 64 rows x SP
-    double *Cs = smem + 64 * SP; // CK x cpitch
+    double *Cs = smem + 64 * SP; // CK x CP (all NT column strips staged; missing ones as zeros)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t r0 = size_t(blockIdx.x) * 64;
     double4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = double4_t{0, 0, 0, 0};
-    const int ntile = ncp / 16;
     // staging maps: S tile: thread -> (row = tid / 4, 4 consecutive k); C tile: NT strips of 16 columns per k row
-    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    constexpr int SJ = CK / 4, CPASS = CK / 16; // S: thread -> (row = tid / 4, SJ consecutive k); C: 16 k rows per pass
+    const int srow = tid >> 2, sk = (tid & 3) * SJ;
     const int ck = tid >> 4, cc = tid & 15; // 16 k rows x 16 threads, each thread NT columns (stride 16)
-    double ps[4], pc[NT];
+    double ps[SJ], pc[CPASS][NT];
+    // Branch-free staging: every load goes to a clamped, always-valid address (the panel is picked by pointer
+    // selects), and entries outside the operands are zeroed when the registers are written to LDS.
+    const size_t rs = min(r0 + srow, n - 1);
+    const bool row_ok = r0 + srow < n;
+    const double *xrow = X + rs * wx, *wrow = W ? W + rs * ww : X, *prow = P ? P + rs * wp : X;
     auto fetch = [&](int k0) {
-        const size_t r = r0 + srow;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + sk + j;
-            double v = 0.0;
-            if (r < n && k < m) {
-                if (k < wx) v = X[r * wx + k];
-                else if (k < wx + ww) v = W[r * ww + (k - wx)];
-                else v = P[r * wp + (k - wx - ww)];
-            }
-            ps[j] = v;
+        for (int j = 0; j < SJ; ++j) {
+            const int k = min(k0 + sk + j, m - 1);
+            const double *src = k < wx ? xrow + k : (k < wx + ww ? wrow + (k - wx) : prow + (k - wx - ww));
+            ps[j] = *src;
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = cc + 16 * t;
-            pc[t] = (t < ntile && k0 + ck < m && c < nc) ? Ct[size_t(k0 + ck) * nc + c] : 0.0;
+        for (int q = 0; q < CPASS; ++q) {
+            const double *crow = Ct + size_t(min(k0 + ck + 16 * q, m - 1)) * nc;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pc[q][t] = crow[min(cc + 16 * t, nc - 1)];
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Ss[srow * SP + sk + j] = ps[j];
+        for (int j = 0; j < SJ; ++j) Ss[srow * SP + sk + j] = (row_ok && k0 + sk + j < m) ? ps[j] : 0.0;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t < ntile) Cs[ck * cpitch + cc + 16 * t] = pc[t];
+        for (int q = 0; q < CPASS; ++q) {
+            const bool kok = k0 + ck + 16 * q < m;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Cs[(ck + 16 * q) * CP + cc + 16 * t] = (kok && cc + 16 * t < nc) ? pc[q][t] : 0.0;
+        }
     };
     fetch(0);
     for (int k0 = 0; k0 < m; k0 += CK) {
-        commit();
+        commit(k0);
         __syncthreads();
         if (k0 + CK < m) fetch(k0 + CK); // in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < CK; kk += 4) {
             const double a = Ss[(wave * 16 + (lane & 15)) * SP + kk + (lane >> 4)];
-            const double *brow = Cs + (kk + (lane >> 4)) * cpitch + (lane & 15);
+            const double *brow = Cs + (kk + (lane >> 4)) * CP + (lane & 15);
+            double bf[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[t * 16], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) bf[t] = brow[t * 16];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[t], acc[t], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (t >= ntile) continue;
         const int c = t * 16 + (lane & 15);
         if (c >= nc) continue;
 #pragma unroll
@@ -347,19 +269,12 @@ __global__ void k_transpose_small(const double *__restrict__ c, int rows, int co
 }
 } // namespace
 
-// G (wa x wb, column-major, leading dimension ld) = X^T Y
-void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld) {
-    if (!wa || !wb) return;
-    const int ntiles = int((wa + 15) / 16) * int((wb + 15) / 16);
-    if (ntiles > 256) mh_throw(MH_EINVAL, "gram: block width %u x %u exceeds 256 x 256", wa, wb);
+namespace {
+// One Gram block: G (wa x wb at leading dimension ld) = X[:, 0:wa]^T Y[:, 0:wb] for panels of row pitch ldx, ldy.
+void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32_t wa, const double *y, uint32_t ldy, uint32_t wb, double *g, uint32_t ld) {
     const int ti_n = int((wa + 15) / 16), tj_n = int((wb + 15) / 16);
-    static const bool legacy = getenv("MH_GRAM_LEGACY") && atoi(getenv("MH_GRAM_LEGACY")) != 0;
-    // workgroups: enough to cover 256 CUs a few times; the blocked kernels run one workgroup per CU at a time
-    const uint32_t wmax = std::max(wa, wb);
-    const bool small = ntiles <= 32 && wmax <= 96;
-    size_t target = small ? 1024 : (ntiles <= 64 && wmax <= 128 ? 512 : 256);
-    if (!legacy) target = 512;
-    int nwg = int(std::min<size_t>(target, (n + KC - 1) / KC));
+    // ~2 workgroups per CU; each stages KC rows per step and owns a contiguous row range
+    int nwg = int(std::min<size_t>(512, (n + KC - 1) / KC));
     size_t rows_per_wg = ((n + nwg - 1) / nwg + KC - 1) / KC * KC;
     nwg = int((n + rows_per_wg - 1) / rows_per_wg);
     const size_t need = size_t(nwg) * wa * wb * sizeof(double);
@@ -369,40 +284,50 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
         ctx->gram_ws_bytes = need + need / 4;
     }
     double *workspace = static_cast<double *>(ctx->gram_ws);
-    const size_t lds = size_t(KC) * (pad_pitch(int(wa)) + pad_pitch(int(wb))) * sizeof(double);
-    auto blocked = [&](auto ti, auto tj, auto gi, auto gj, auto ks) {
-        constexpr int TI = decltype(ti)::value, TJ = decltype(tj)::value, GI = decltype(gi)::value, GJ = decltype(gj)::value, KS = decltype(ks)::value;
+    auto blocked = [&](auto ti, auto tj, auto gi, auto gj, auto ks, auto occ) {
+        constexpr int TI = decltype(ti)::value, TJ = decltype(tj)::value, GI = decltype(gi)::value, GJ = decltype(gj)::value, KS = decltype(ks)::value, OCC = decltype(occ)::value;
         constexpr int CA = TI * GI, CB = TJ * GJ;
         constexpr int PA = (CA * 16) % 32 == 16 ? CA * 16 : CA * 16 + 16, PB = (CB * 16) % 32 == 16 ? CB * 16 : CB * 16 + 16;
         const size_t fold = KS > 1 ? size_t(GI * GJ) * TI * TJ * 256 * sizeof(double) : 0;
         const size_t bytes = std::max(size_t(KC) * (PA + PB) * sizeof(double), fold);
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gram_blocked<TI, TJ, GI, GJ, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gram_blocked<TI, TJ, GI, GJ, KS, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        k_gram_blocked<TI, TJ, GI, GJ, KS><<<nwg, GI * GJ * KS * 64, bytes, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
+        k_gram_blocked<TI, TJ, GI, GJ, KS, OCC><<<nwg, GI * GJ * KS * 64, bytes, ctx->stream>>>(x, int(ldx), int(wa), y, int(ldy), int(wb), n, rows_per_wg, workspace);
     };
 #define IC(v) std::integral_constant<int, v>{}
-    if (legacy) {
-        if (small) k_gram<4, 8, 6><<<nwg, 256, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-        else if (ntiles <= 64 && wmax <= 128) k_gram<8, 8, 8><<<nwg, 512, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-        else k_gram<16, 16, 16><<<nwg, 1024, lds, ctx->stream>>>(x, int(wa), y, int(wb), n, rows_per_wg, workspace);
-    } else if (ti_n <= 1 && tj_n <= 1) blocked(IC(1), IC(1), IC(1), IC(1), IC(4));
-    else if (ti_n <= 2 && tj_n <= 2) blocked(IC(2), IC(2), IC(1), IC(1), IC(4));
-    else if (ti_n <= 3 && tj_n <= 3) blocked(IC(3), IC(3), IC(1), IC(1), IC(4));
-    else if (ti_n <= 4 && tj_n <= 4) blocked(IC(4), IC(4), IC(1), IC(1), IC(4));
-    else if (ti_n <= 5 && tj_n <= 3) blocked(IC(5), IC(3), IC(1), IC(1), IC(4));
-    else if (ti_n <= 3 && tj_n <= 5) blocked(IC(3), IC(5), IC(1), IC(1), IC(4));
-    else if (ti_n <= 5 && tj_n <= 5) blocked(IC(5), IC(5), IC(1), IC(1), IC(4));
-    else if (ti_n <= 10 && tj_n <= 5) blocked(IC(5), IC(5), IC(2), IC(1), IC(2));
-    else if (ti_n <= 5 && tj_n <= 10) blocked(IC(5), IC(5), IC(1), IC(2), IC(2));
-    else if (ti_n <= 10 && tj_n <= 10) blocked(IC(5), IC(5), IC(2), IC(2), IC(1));
-    else blocked(IC(4), IC(4), IC(4), IC(4), IC(1));
+    if (ti_n <= 1 && tj_n <= 1) blocked(IC(1), IC(1), IC(1), IC(1), IC(4), IC(2));
+    else if (ti_n <= 2 && tj_n <= 2) blocked(IC(2), IC(2), IC(1), IC(1), IC(4), IC(2));
+    else if (ti_n <= 3 && tj_n <= 3) blocked(IC(3), IC(3), IC(1), IC(1), IC(4), IC(2));
+    else if (ti_n <= 4 && tj_n <= 4) blocked(IC(4), IC(4), IC(1), IC(1), IC(4), IC(2));
+    else if (ti_n <= 5 && tj_n <= 3) blocked(IC(5), IC(3), IC(1), IC(1), IC(4), IC(2));
+    else if (ti_n <= 3 && tj_n <= 5) blocked(IC(3), IC(5), IC(1), IC(1), IC(4), IC(2));
+    // wider blocks: at most 15 tiles per wave so that two waves share a SIMD (one hides the other's staging)
+    else if (ti_n <= 5 && tj_n <= 6) blocked(IC(5), IC(3), IC(1), IC(2), IC(2), IC(2));
+    else if (ti_n <= 6 && tj_n <= 5) blocked(IC(3), IC(5), IC(2), IC(1), IC(2), IC(2));
+    else if (ti_n <= 10 && tj_n <= 6) blocked(IC(5), IC(3), IC(2), IC(2), IC(1), IC(2));
+    else if (ti_n <= 6 && tj_n <= 10) blocked(IC(3), IC(5), IC(2), IC(2), IC(1), IC(2));
+    else mh_throw(MH_EINVAL, "gram block %u x %u too wide", wa, wb);
 #undef IC
     KERNEL_CHECK();
     k_gram_reduce<<<div_up(size_t(wa) * wb, 32), 256, 0, ctx->stream>>>(workspace, nwg, int(wa), int(wb), g, int(ld));
     KERNEL_CHECK();
+}
+} // namespace
+
+// G (wa x wb, column-major, leading dimension ld) = X^T Y.  Blocks wider than 160 x 96 columns are cut into a grid
+// of column blocks (each a launch of the register-blocked kernel over the same rows).
+void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld) {
+    if (!wa || !wb) return;
+    const bool a_long = wa >= wb;
+    const uint32_t cap_a = a_long ? 160 : 96, cap_b = a_long ? 96 : 160;
+    const uint32_t na = div_up(wa, cap_a), nbk = div_up(wb, cap_b);
+    const uint32_t step_a = (div_up(wa, na) + 15) / 16 * 16, step_b = (div_up(wb, nbk) + 15) / 16 * 16;
+    for (uint32_t i0 = 0; i0 < wa; i0 += step_a)
+        for (uint32_t j0 = 0; j0 < wb; j0 += step_b)
+            gram_block(ctx, n, x + i0, wa, std::min(step_a, wa - i0), y + j0, wb, std::min(step_b, wb - j0), g + size_t(j0) * ld + i0, ld);
 }
 
 // Row-major (k-major) packing of two column-major coefficient blocks side by side: ct[m][n1 + n2]
@@ -422,20 +347,25 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
                 double *out1, uint32_t n1, double *out2, bool accumulate) {
     if (!nc) return;
     if (nc > 256) mh_throw(MH_EINVAL, "combine: %u output columns exceed 256", nc);
-    const int ncp = int((nc + 15) / 16) * 16;
-    const int cpitch = (ncp % 32 == 16) ? ncp : ncp + 16;
-    const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * cpitch) * sizeof(double);
     const unsigned grid = div_up(n, 64);
     auto go = [&](auto nt_tag) {
         constexpr int NT = decltype(nt_tag)::value;
+        constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
+        const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
         if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
         else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
     };
-    const int ntile = ncp / 16;
-    if (ntile <= 4) go(std::integral_constant<int, 4>{});
-    else if (ntile <= 8) go(std::integral_constant<int, 8>{});
-    else if (ntile <= 12) go(std::integral_constant<int, 12>{});
-    else go(std::integral_constant<int, 16>{});
+    const int ntile = int((nc + 15) / 16);
+    switch ((ntile + 1) / 2) { // the kernel computes all NT column strips: pick the smallest even NT that covers nc
+        case 1: go(std::integral_constant<int, 2>{}); break;
+        case 2: go(std::integral_constant<int, 4>{}); break;
+        case 3: go(std::integral_constant<int, 6>{}); break;
+        case 4: go(std::integral_constant<int, 8>{}); break;
+        case 5: go(std::integral_constant<int, 10>{}); break;
+        case 6: go(std::integral_constant<int, 12>{}); break;
+        case 7: go(std::integral_constant<int, 14>{}); break;
+        default: go(std::integral_constant<int, 16>{}); break;
+    }
     KERNEL_CHECK();
 }
 

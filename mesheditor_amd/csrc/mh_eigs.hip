@@ -377,13 +377,18 @@ template<typename T> struct Precond {
     double ratio{8.0};
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
     DevArray<double> r0, x0;
+    DevArray<double> rin64, t2d, r1d, t1d; // single-precision smoothers: the residuals handed down a level stay double
     static constexpr bool kDouble = std::is_same<T, double>::value;
     static uint32_t pitch(uint32_t w) { return kDouble ? w : (w + 3u) & ~3u; } // 16-byte panel rows for the wide-load SpMM
     Precond(mh_system *s, uint32_t w_in) : sys(s), ctx(s->ctx), wmax(w_in) {
         const uint32_t w = pitch(w_in);
         const size_t n2 = size_t(3) * s->n_nodes, n1 = size_t(3) * s->n_points, n0 = size_t(6) * s->n_agg;
         d2.reset(ctx, n2 * w); t2.reset(ctx, n2 * w); r2.reset(ctx, n2 * w); z2.reset(ctx, n2 * w);
-        if (!kDouble) rin.reset(ctx, n2 * w);
+        if (!kDouble) {
+            rin.reset(ctx, n2 * w);
+            rin64.reset(ctx, n2 * w); t2d.reset(ctx, n2 * w);
+            r1d.reset(ctx, n1 * w); t1d.reset(ctx, n1 * w);
+        }
         r1.reset(ctx, n1 * w); x1.reset(ctx, n1 * w); d1.reset(ctx, n1 * w); t1.reset(ctx, n1 * w); rr1.reset(ctx, n1 * w);
         r0.reset(ctx, n0 * w);
         x0.reset(ctx, n0 * w);
@@ -437,13 +442,31 @@ template<typename T> struct Precond {
         }
         T *z = z2.get();
         cheb(sys->L2, deg2, r, z, true, r2, d2, t2, w);
-        spmm(sys->L2, z, t2, w);
-        k_restrict_p1<T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r, t2.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1.get(), np, w);
-        KERNEL_CHECK();
+        // Residual for the next level.  With single-precision smoothers it is formed in double (double A, double r,
+        // the float iterate): a float residual carries an error of 6e-8 ||A|| ||z|| that the coarse solves amplify by
+        // the condition number, which stalls the lowest modes of thin, ill-conditioned bodies at ~1e-4.
+        if constexpr (kDouble) {
+            spmm(sys->L2, z, t2, w);
+            k_restrict_p1<double><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r, t2.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1.get(), np, w);
+            KERNEL_CHECK();
+        } else {
+            k_convert_pitch<double, double><<<grid1(n2 * w), TB, 0, ctx->stream>>>(r_in, w_in, rin64.get(), w, n2);
+            KERNEL_CHECK();
+            mh_spmm_mixed(ctx, sys->L2, z, t2d, w);
+            k_restrict_p1<double><<<grid1(n1 * w), TB, 0, ctx->stream>>>(rin64.get(), t2d.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1d.get(), np, w);
+            KERNEL_CHECK();
+            k_convert<double, T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r1d.get(), r1.get(), n1 * w);
+            KERNEL_CHECK();
+        }
         for (int g = 0; g < gamma; ++g) {
             cheb(sys->L1, deg1, r1, x1, g == 0, rr1, d1, t1, w);
-            spmm(sys->L1, x1, t1, w);
-            k_restrict_agg<T><<<grid1(n0 * w), TB, 0, ctx->stream>>>(r1.get(), t1.get(), sys->agg_t, r0, np, sys->agg_size, na, w);
+            if constexpr (kDouble) {
+                spmm(sys->L1, x1, t1, w);
+                k_restrict_agg<double><<<grid1(n0 * w), TB, 0, ctx->stream>>>(r1.get(), t1.get(), sys->agg_t, r0, np, sys->agg_size, na, w);
+            } else {
+                mh_spmm_mixed(ctx, sys->L1, x1, t1d, w);
+                k_restrict_agg<double><<<grid1(n0 * w), TB, 0, ctx->stream>>>(r1d.get(), t1d.get(), sys->agg_t, r0, np, sys->agg_size, na, w);
+            }
             KERNEL_CHECK();
             // r0 is (6 na) x w row-major = w x (6 na) column-major: x0 = r0 * A0^-1 (A0^-1 symmetric, explicit)
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, rocblas_int(n0), rocblas_int(n0), &one, r0, w, sys->a0, rocblas_int(n0), &zero, x0, w));
@@ -696,7 +719,9 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 if (verbose) {
                     double worst = 0;
                     for (uint32_t i = 0; i < nev; ++i) worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
-                    fprintf(stderr, "[lobpcg] it %3u conv %3u/%u active %zu wp %u worst %.2e\n", it, nconv, nev, act.size(), wp, worst);
+                    fprintf(stderr, "[lobpcg] it %3u conv %3u/%u active %zu wp %u worst %.2e  floor-ratio[0..7]:", it, nconv, nev, act.size(), wp, worst);
+                    for (uint32_t i = 0; i < std::min(8u, b); ++i) fprintf(stderr, " %.1f", std::sqrt(rn[i]) / (2.2e-16 * anorm * std::sqrt(xn[i])));
+                    fprintf(stderr, "  theta0 %.6e\n", theta[0]);
                 }
                 iters = it;
                 if (nconv >= nev) { converged = true; break; }

@@ -329,70 +329,6 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
 }
 
 
-// ---- row tiles for the LDS-staged SpMM ---------------------------------------------------------------------
-// One workgroup per tile: bitonic-sort the tile's column ids in LDS, count / write the unique ones, and give every
-// node block the rank of its column among them.
-constexpr int TILE_CAP = 4096;
-template<bool FILL>
-__global__ void __launch_bounds__(256) k_tile_columns(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, uint32_t nnodes, uint32_t tile_rows,
-                                                     uint32_t *__restrict__ ucount, const uint32_t *__restrict__ uptr, uint32_t *__restrict__ ucols,
-                                                     uint16_t *__restrict__ local, uint32_t *__restrict__ overflow) {
-    __shared__ uint32_t s_key[TILE_CAP];
-    __shared__ uint32_t s_flag[TILE_CAP];
-    const uint32_t t = blockIdx.x;
-    const uint32_t r0 = t * tile_rows, r1 = min(nnodes, r0 + tile_rows);
-    const uint32_t p0 = row_ptr[r0], p1 = row_ptr[r1];
-    const uint32_t cnt = p1 - p0;
-    if (cnt > TILE_CAP) {
-        if (threadIdx.x == 0) { atomicAdd(overflow, 1u); if (!FILL) ucount[t] = 0; }
-        return;
-    }
-    for (uint32_t i = threadIdx.x; i < TILE_CAP; i += 256) s_key[i] = i < cnt ? col[p0 + i] : 0xffffffffu;
-    __syncthreads();
-    for (uint32_t k = 2; k <= TILE_CAP; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < TILE_CAP; i += 256) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = s_key[i], b = s_key[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // unique: flag heads, then a serial-free rank via block-wide inclusive scan over TILE_CAP entries
-    for (uint32_t i = threadIdx.x; i < TILE_CAP; i += 256) s_flag[i] = (i < cnt && (i == 0 || s_key[i] != s_key[i - 1])) ? 1u : 0u;
-    __syncthreads();
-    for (uint32_t off = 1; off < TILE_CAP; off <<= 1) { // Hillis-Steele inclusive scan, double pass per step
-        uint32_t v[TILE_CAP / 256];
-        for (uint32_t q = 0, i = threadIdx.x; i < TILE_CAP; i += 256, ++q) v[q] = s_flag[i] + (i >= off ? s_flag[i - off] : 0u);
-        __syncthreads();
-        for (uint32_t q = 0, i = threadIdx.x; i < TILE_CAP; i += 256, ++q) s_flag[i] = v[q];
-        __syncthreads();
-    }
-    const uint32_t nu = cnt ? s_flag[cnt - 1] : 0;
-    if (!FILL) {
-        if (threadIdx.x == 0) ucount[t] = nu;
-        return;
-    }
-    const uint32_t base = uptr[t];
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256)
-        if (i == 0 || s_key[i] != s_key[i - 1]) ucols[base + s_flag[i] - 1] = s_key[i];
-    __syncthreads();
-    // rank of every block's column: binary search in the sorted keys, then the scan gives its unique rank
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const uint32_t c = col[p0 + i];
-        uint32_t lo = 0, hi = cnt;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_key[mid] < c) lo = mid + 1; else hi = mid;
-        }
-        local[p0 + i] = uint16_t(s_flag[lo] - 1);
-    }
-}
-
 // ---- level 0: rigid-body aggregates ------------------------------------------------------------------------
 __global__ void k_aggregate_t(const double *__restrict__ p1_xyz, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ tmat) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,27 +444,6 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
     const double mu = mat.young_modulus / (2 * (1 + mat.poisson_ratio));
     k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
     KERNEL_CHECK();
-    // row tiles for the LDS-staged SpMM (skipped for small levels, where the plain kernel is latency-bound anyway)
-    lvl.tiled = false;
-    if (nb >= 200000 && getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) != 0) {
-        const uint32_t ntiles = div_up(nnodes, MH_TILE_ROWS);
-        DevArray<uint32_t> ucount(ctx, ntiles), overflow(ctx, 1);
-        overflow.zero();
-        lvl.tile_uptr.reset(ctx, size_t(ntiles) + 1);
-        k_tile_columns<false><<<ntiles, 256, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, nnodes, MH_TILE_ROWS, ucount, nullptr, nullptr, nullptr, overflow);
-        KERNEL_CHECK();
-        HIP_CHECK(hipMemsetAsync(lvl.tile_uptr.get(), 0, sizeof(uint32_t), ctx->stream));
-        inclusive_sum(ctx, tmp, ucount, lvl.tile_uptr.get() + 1, ntiles);
-        const uint32_t total = read_u32(ctx, lvl.tile_uptr.get() + ntiles);
-        if (read_u32(ctx, overflow) == 0 && total > 0) {
-            lvl.tile_ucols.reset(ctx, total);
-            lvl.block_local.reset(ctx, nb);
-            k_tile_columns<true><<<ntiles, 256, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, nnodes, MH_TILE_ROWS, nullptr, lvl.tile_uptr, lvl.tile_ucols, lvl.block_local, overflow);
-            KERNEL_CHECK();
-            lvl.n_tiles = ntiles;
-            lvl.tiled = true;
-        }
-    }
 }
 
 // Exact unit-volume integrals of the shape-function products (GetQuadBasis, mesh2modes.cpp:209-237), in closed form.

@@ -109,14 +109,17 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
 //     lane group reads its own block's values;
 //   * folds the G partial rows with a fixed shuffle tree at the end of the row (deterministic).
 // The panel pitch w must be a multiple of V (16-byte rows).
-template<typename T, int CL, bool WITH_M, bool WITH_A>
-__global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const T *__restrict__ vals9,
-                                                 const T *__restrict__ mscal, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ y2, uint32_t nnodes,
+// TV = matrix values, TX = panel read, TY = accumulators and panel written (TV = TY = double with TX = float gives the
+// double-precision residual of a single-precision iterate at single-precision gather cost).
+template<typename TV, typename TX, typename TY, int CL, bool WITH_M, bool WITH_A>
+__global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
+                                                 const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
                                                  uint32_t w, int xcd_remap) {
-    constexpr int V = 16 / sizeof(T), G = 64 / CL, STRIP = 64, VP = sizeof(T) == 4 ? 12 : 10, U = 4;
-    typedef T Vec __attribute__((ext_vector_type(V)));
-    __shared__ __attribute__((aligned(16))) T sv[TB / 64][WITH_A ? STRIP * VP : 1];
-    __shared__ T sm[TB / 64][WITH_M ? STRIP : 1];
+    constexpr int V = 16 / sizeof(TX), G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4;
+    typedef TX Vec __attribute__((ext_vector_type(V)));
+    typedef TY Acc __attribute__((ext_vector_type(V)));
+    __shared__ __attribute__((aligned(16))) TV sv[TB / 64][WITH_A ? STRIP * VP : 1];
+    __shared__ TV sm[TB / 64][WITH_M ? STRIP : 1];
     __shared__ uint32_t sc[TB / 64][STRIP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = lane % CL, g = lane / CL;
@@ -126,24 +129,24 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
     if (row >= nnodes) return;
     const bool act = V * c < w;
     const uint32_t coff = act ? V * c : 0;
-    Vec acc[3], macc[3];
+    Acc acc[3], macc[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) acc[i] = macc[i] = Vec(0);
+    for (int i = 0; i < 3; ++i) acc[i] = macc[i] = Acc(0);
     const uint32_t p0 = __builtin_amdgcn_readfirstlane(row_ptr[row]), p1 = __builtin_amdgcn_readfirstlane(row_ptr[row + 1]);
-    T *svw = sv[wave];
-    T *smw = sm[wave];
+    TV *svw = sv[wave];
+    TV *smw = sm[wave];
     uint32_t *scw = sc[wave];
     for (uint32_t base = p0; base < p1; base += STRIP) {
         const uint32_t nb = min(uint32_t(STRIP), p1 - base);
         if (base != p0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous strip fully consumed
         scw[lane] = uint32_t(lane) < nb ? col[base + lane] : 0u;
         if (WITH_A) {
-            const T *src = vals9 + size_t(9) * base;
-            T tmp[9];
+            const TV *src = vals9 + size_t(9) * base;
+            TV tmp[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const uint32_t f = lane + 64 * i;
-                tmp[i] = f < 9 * nb ? src[f] : T(0);
+                tmp[i] = f < 9 * nb ? src[f] : TV(0);
             }
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
                 if (f < 9 * nb) svw[(f / 9) * VP + f % 9] = tmp[i];
             }
         }
-        if (WITH_M) smw[lane] = uint32_t(lane) < nb ? mscal[base + lane] : T(0);
+        if (WITH_M) smw[lane] = uint32_t(lane) < nb ? mscal[base + lane] : TV(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // round t: lane group g takes block t*G + g of the strip
         const uint32_t rounds = (nb + G - 1) / G;
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < rounds) { // wave-uniform
                     bi[u] = min((t0 + u) * G + g, nb - 1);
-                    const T *xr = x + size_t(3) * scw[bi[u]] * w + coff;
+                    const TX *xr = x + size_t(3) * scw[bi[u]] * w + coff;
                     xv[u][0] = *reinterpret_cast<const Vec *>(xr);
                     xv[u][1] = *reinterpret_cast<const Vec *>(xr + w);
                     xv[u][2] = *reinterpret_cast<const Vec *>(xr + 2 * size_t(w));
@@ -172,19 +175,20 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < rounds) {
                     const bool ok = (t0 + u) * G + g < nb;
+                    const Acc x0 = __builtin_convertvector(xv[u][0], Acc), x1 = __builtin_convertvector(xv[u][1], Acc), x2 = __builtin_convertvector(xv[u][2], Acc);
                     if (WITH_A) {
-                        T v[9];
+                        TY v[9];
 #pragma unroll
-                        for (int e = 0; e < 9; ++e) v[e] = ok ? svw[bi[u] * VP + e] : T(0);
-                        acc[0] += v[0] * xv[u][0] + v[1] * xv[u][1] + v[2] * xv[u][2];
-                        acc[1] += v[3] * xv[u][0] + v[4] * xv[u][1] + v[5] * xv[u][2];
-                        acc[2] += v[6] * xv[u][0] + v[7] * xv[u][1] + v[8] * xv[u][2];
+                        for (int e = 0; e < 9; ++e) v[e] = ok ? TY(svw[bi[u] * VP + e]) : TY(0);
+                        acc[0] += v[0] * x0 + v[1] * x1 + v[2] * x2;
+                        acc[1] += v[3] * x0 + v[4] * x1 + v[5] * x2;
+                        acc[2] += v[6] * x0 + v[7] * x1 + v[8] * x2;
                     }
                     if (WITH_M) {
-                        const T m = ok ? smw[bi[u]] : T(0);
-                        macc[0] += m * xv[u][0];
-                        macc[1] += m * xv[u][1];
-                        macc[2] += m * xv[u][2];
+                        const TY m = ok ? TY(smw[bi[u]]) : TY(0);
+                        macc[0] += m * x0;
+                        macc[1] += m * x1;
+                        macc[2] += m * x2;
                     }
                 }
             }
@@ -205,29 +209,30 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
     if (g == 0 && act) {
         const size_t o = size_t(3) * row * w + coff;
         if (WITH_A) {
-            *reinterpret_cast<Vec *>(y + o) = acc[0];
-            *reinterpret_cast<Vec *>(y + o + w) = acc[1];
-            *reinterpret_cast<Vec *>(y + o + 2 * size_t(w)) = acc[2];
+            *reinterpret_cast<Acc *>(y + o) = acc[0];
+            *reinterpret_cast<Acc *>(y + o + w) = acc[1];
+            *reinterpret_cast<Acc *>(y + o + 2 * size_t(w)) = acc[2];
         }
         if (WITH_M) {
-            *reinterpret_cast<Vec *>(y2 + o) = macc[0];
-            *reinterpret_cast<Vec *>(y2 + o + w) = macc[1];
-            *reinterpret_cast<Vec *>(y2 + o + 2 * size_t(w)) = macc[2];
+            *reinterpret_cast<Acc *>(y2 + o) = macc[0];
+            *reinterpret_cast<Acc *>(y2 + o + w) = macc[1];
+            *reinterpret_cast<Acc *>(y2 + o + 2 * size_t(w)) = macc[2];
         }
     }
 }
 
-template<typename T, bool WITH_M, bool WITH_A>
-bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const T *vals9, const T *x, T *y, const T *mscal, T *y2, uint32_t w) {
-    constexpr uint32_t V = 16 / sizeof(T);
+template<typename TV, typename TX, typename TY, bool WITH_M, bool WITH_A>
+bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const TV *vals9, const TX *x, TY *y, const TV *mscal, TY *y2, uint32_t w) {
+    constexpr uint32_t V = 16 / sizeof(TX);
     static const bool legacy = getenv("MH_SPMM_LEGACY") && atoi(getenv("MH_SPMM_LEGACY")) != 0;
-    if (legacy || w % V != 0 || w > 64 * V) return false;
+    constexpr bool mixed = !std::is_same<TV, TX>::value || !std::is_same<TX, TY>::value;
+    if ((legacy && !mixed) || w % V != 0 || w > 64 * V) return false;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y2)) & 15) return false;
     static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
     auto go = [&](auto cl_tag) {
         constexpr int CL = decltype(cl_tag)::value;
-        k_spmm_wide<T, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
+        k_spmm_wide<TV, TX, TY, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
     };
     const uint32_t lanes = div_up(w, V);
     if (lanes <= 8) go(std::integral_constant<int, 8>{});
@@ -240,7 +245,7 @@ bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const T *vals9, cons
 
 template<typename T, bool WITH_M, bool WITH_A>
 void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const T *vals9, const T *x, T *y, const T *mscal, T *y2, uint32_t w) {
-    if (launch_spmm_wide<T, WITH_M, WITH_A>(ctx, lvl, vals9, x, y, mscal, y2, w)) return;
+    if (launch_spmm_wide<T, T, T, WITH_M, WITH_A>(ctx, lvl, vals9, x, y, mscal, y2, w)) return;
     const uint32_t n = lvl.n_nodes;
     auto go = [&](auto cw_tag, auto nc_tag) {
         constexpr int CW = decltype(cw_tag)::value, NC = decltype(nc_tag)::value;
@@ -266,173 +271,6 @@ void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const T *vals9, const T *
     KERNEL_CHECK();
 }
 
-// ---- LDS-staged variant ---------------------------------------------------------------------------------------
-// One 1024-thread workgroup per tile of 64 consecutive rows; wave v owns rows 4v..4v+3 and keeps their accumulators in
-// registers.  The tile's sorted unique column nodes are walked in segments of S nodes: the segment's x rows (3*w
-// doubles each, contiguous) are staged in LDS once and every node block of the tile that points into the segment
-// reads its x from there.  Each x row therefore leaves L2 once per tile instead of once per node block (~5x fewer
-// gathered bytes on P2 tetrahedral meshes in Morton order).  The next segment's rows are fetched into registers
-// before the current segment is consumed and written to LDS after it (issue-early / write-late), so the gather latency
-// hides under the FMAs; block values stream through scalar loads exactly once.
-template<int NC, int MAXR>
-__global__ void __launch_bounds__(1024) k_spmm_tiled(const uint32_t *__restrict__ row_ptr, const uint16_t *__restrict__ local, const double *__restrict__ vals9,
-                                                    const uint32_t *__restrict__ tile_uptr, const uint32_t *__restrict__ tile_ucols,
-                                                    const double *__restrict__ x, double *__restrict__ y, uint32_t nnodes, uint32_t w, uint32_t seg_nodes,
-                                                    uint32_t ntiles) {
-    extern __shared__ __attribute__((aligned(16))) double xs[];
-    constexpr int SI = 3 * NC; // 64-lane strips per staged x row (3*w <= 192*NC doubles)
-    const uint32_t per = (gridDim.x + 7) / 8;
-    const uint32_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8; // XCD-contiguous tiles
-    if (tile >= ntiles) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t w3 = 3 * w;
-    const uint32_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
-    uint32_t cc[NC];
-    bool active[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        active[k] = uint32_t(lane) + 64 * k < w;
-        cc[k] = active[k] ? lane + 64 * k : 0;
-    }
-    uint32_t pstart[4], pend[4], lv[4], used[4];
-    double acc[4][NC][3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t r = tile * MH_TILE_ROWS + wave * 4 + q;
-        pstart[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r] : 0);
-        pend[q] = __builtin_amdgcn_readfirstlane(r < nnodes ? row_ptr[r + 1] : 0);
-        lv[q] = pstart[q] + lane < pend[q] ? uint32_t(local[pstart[q] + lane]) : 0xffffu;
-        used[q] = 0;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) acc[q][k][0] = acc[q][k][1] = acc[q][k][2] = 0;
-    }
-    double pre[MAXR][SI];
-    auto fetch = [&](uint32_t base) { // this wave's rows of the segment starting at `base` -> registers
-        const uint32_t cnt = min(seg_nodes, nu - base);
-#pragma unroll
-        for (int j = 0; j < MAXR; ++j) {
-            const uint32_t k = wave + 16 * j;
-            if (k < cnt) {
-                const double *src = x + size_t(tile_ucols[u0 + base + k]) * w3;
-#pragma unroll
-                for (int i = 0; i < SI; ++i) {
-                    const uint32_t off = lane + 64 * i;
-                    pre[j][i] = off < w3 ? src[off] : 0.0;
-                }
-            }
-        }
-    };
-    auto commit = [&](uint32_t base) { // registers -> LDS
-        const uint32_t cnt = min(seg_nodes, nu - base);
-#pragma unroll
-        for (int j = 0; j < MAXR; ++j) {
-            const uint32_t k = wave + 16 * j;
-            if (k < cnt) {
-#pragma unroll
-                for (int i = 0; i < SI; ++i) {
-                    const uint32_t off = lane + 64 * i;
-                    if (off < w3) xs[size_t(k) * w3 + off] = pre[j][i];
-                }
-            }
-        }
-    };
-    if (nu) fetch(0);
-    if (nu) commit(0);
-    __syncthreads();
-    for (uint32_t base = 0; base < nu; base += seg_nodes) {
-        const uint32_t cnt = min(seg_nodes, nu - base);
-        const bool more = base + seg_nodes < nu;
-        if (more) fetch(base + seg_nodes);
-        const uint32_t lim = base + cnt;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            for (;;) {
-                const uint32_t avail = min(64u, pend[q] - pstart[q]);
-                const uint32_t n = __popcll(__ballot(uint32_t(lane) >= used[q] && uint32_t(lane) < avail && lv[q] < lim));
-                uint32_t p = pstart[q] + used[q];
-                uint32_t first = used[q];
-                auto step = [&](auto u_tag) {
-                    constexpr int U = decltype(u_tag)::value;
-                    double v[U][9];
-                    uint32_t li[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        li[u] = __builtin_amdgcn_readlane(int(lv[q]), int(first) + u) - base;
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) v[u][e] = vals9[size_t(9) * (p + u) + e];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const double *xr = xs + size_t(li[u]) * w3;
-#pragma unroll
-                        for (int k = 0; k < NC; ++k) {
-                            const double x0 = xr[cc[k]], x1 = xr[w + cc[k]], x2 = xr[2 * w + cc[k]];
-                            acc[q][k][0] += v[u][0] * x0 + v[u][1] * x1 + v[u][2] * x2;
-                            acc[q][k][1] += v[u][3] * x0 + v[u][4] * x1 + v[u][5] * x2;
-                            acc[q][k][2] += v[u][6] * x0 + v[u][7] * x1 + v[u][8] * x2;
-                        }
-                    }
-                    p += U;
-                    first += U;
-                };
-                uint32_t done = 0;
-                while (done + 4 <= n) { step(std::integral_constant<int, 4>{}); done += 4; }
-                while (done < n) { step(std::integral_constant<int, 1>{}); done += 1; }
-                used[q] += n;
-                // a row longer than 64 node blocks: move the 64-block window once it is used up
-                if (used[q] == 64 && pstart[q] + 64 < pend[q]) {
-                    pstart[q] += 64;
-                    lv[q] = pstart[q] + lane < pend[q] ? uint32_t(local[pstart[q] + lane]) : 0xffffu;
-                    used[q] = 0;
-                    continue;
-                }
-                break;
-            }
-        }
-        __syncthreads();
-        if (more) commit(base + seg_nodes);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t r = tile * MH_TILE_ROWS + wave * 4 + q;
-        if (r >= nnodes) continue;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            if (!active[k]) continue;
-            const size_t o = size_t(r) * w3 + lane + 64 * k;
-            y[o] = acc[q][k][0];
-            y[o + w] = acc[q][k][1];
-            y[o + 2 * size_t(w)] = acc[q][k][2];
-        }
-    }
-}
-
-bool launch_spmm_tiled(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, uint32_t w) {
-    // Off by default: correct, but its barriers and per-row serial phases make it slower than the plain kernel on
-    // MI355X (742 us vs 527 us at S100k, w = 64, even with the block values removed); kept for the next round.
-    static const bool enabled = getenv("MH_SPMM_TILED") && atoi(getenv("MH_SPMM_TILED")) != 0;
-    if (!enabled || !lvl.tiled || w < 24 || w > 256) return false; // narrow panels: the plain kernel packs several rows per wave
-    static const int lds_kb = getenv("MH_SPMM_LDS_KB") ? atoi(getenv("MH_SPMM_LDS_KB")) : 150;
-    const unsigned grid = (lvl.n_tiles + 7) / 8 * 8;
-    auto go = [&](auto nc_tag, auto maxr_tag) {
-        constexpr int NC = decltype(nc_tag)::value, MAXR = decltype(maxr_tag)::value;
-        uint32_t seg = uint32_t(size_t(lds_kb) * 1024 / (size_t(24) * w));
-        seg = std::max(4u, std::min(seg, uint32_t(16 * MAXR)));
-        const size_t lds = size_t(seg) * 3 * w * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_tiled<NC, MAXR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        k_spmm_tiled<NC, MAXR><<<grid, 1024, lds, ctx->stream>>>(lvl.row_ptr, lvl.block_local, vals9, lvl.tile_uptr, lvl.tile_ucols, x, y, lvl.n_nodes, w, seg, lvl.n_tiles);
-    };
-    if (w <= 64) go(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{});
-    else if (w <= 128) go(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
-    else go(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
-    KERNEL_CHECK();
-    return true;
-}
 } // namespace
 
 void mh_timer_flush(mh_context *ctx) {
@@ -483,7 +321,7 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
     TimedLaunch timed(ctx, ctx->time_kernels && vals9 && !mscal && lvl.id == 2, spmm_bytes(lvl, w, sizeof(double)));
     if (vals9 && mscal) launch_spmm<double, true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
     else if (vals9) {
-        if (!launch_spmm_tiled(ctx, lvl, vals9, x, y, w)) launch_spmm<double, false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
+        launch_spmm<double, false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
     }
     else launch_spmm<double, true, false>(ctx, lvl, nullptr, x, nullptr, mscal, y2, w);
 }
@@ -493,4 +331,13 @@ void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y,
     if (w == 0) return;
     TimedLaunch timed(ctx, ctx->time_kernels && lvl.id == 2, spmm_bytes(lvl, w, sizeof(float)));
     launch_spmm<float, false, true>(ctx, lvl, lvl.aval32.get(), x, y, static_cast<const float *>(nullptr), static_cast<float *>(nullptr), w);
+}
+
+// y (double) = A x for a single-precision panel x and the double-precision A: the residual path of the preconditioner.
+// The pitch w must be a multiple of 4 (16-byte single-precision rows).
+void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w) {
+    if (w == 0) return;
+    TimedLaunch timed(ctx, ctx->time_kernels && lvl.id == 2, (9.0 * 8 + 4.0) * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + (4.0 + 8.0) * 3.0 * double(lvl.n_nodes) * w);
+    if (!launch_spmm_wide<double, float, double, false, true>(ctx, lvl, lvl.aval.get(), x, y, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), w))
+        mh_throw(MH_EINVAL, "mixed-precision product needs a 16-byte aligned panel of pitch %% 4 == 0 (got %u)", w);
 }
