@@ -24,6 +24,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable with a streaming copy
 
 
+def pmc_traffic():
+    """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this command (profiles/, made by
+    tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 rule and checked on a kernel of known byte count) -- a
+    separate profiled run, never this one; None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["spmm_family"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def bank_metric(blocks=72):
+    """Secondary figure: the 1024 x 256 resonator bank at 48 kHz through the C++
+    mirror's RenderModal, as x real time."""
+    try:
+        from tools import bank_bench
+        return bank_bench.run(blocks=blocks)
+    except Exception as e:  # the headline line must not depend on it
+        return {"error": str(e)[:200]}
+
+
 def cpu_baseline(seconds_budget=60.0):
     """The CPU oracle (restated reference algorithm: multifrontal Cholesky shift-invert + Lanczos, one thread) on a
     bounded sample of the same workload: the 10k-tet cube with the same 65 requested eigenpairs."""
@@ -134,13 +156,16 @@ def main():
     }
     if stats["launches"]:
         achieved = stats["total_bytes"] / (stats["total_ms"] * 1e-3) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "k_spmm (BSR 3x3 fp64, P2 operator x n-by-w panel)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": stats["launches"],
-                            "avg_launch_us": 1e3 * stats["total_ms"] / stats["launches"],
+        line["roofline"] = {"bound": "hbm",
+                            "kernel": "k_spmm_wide / k_spmm: BSR 3x3 SpMM of the P2 and P1 operators over n-by-w panels "
+                                      "(every launch of the solve: fp32 smoother products, mixed fp64-A x fp32-panel residuals, fp64 operator products)",
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                            "launches": stats["launches"], "avg_launch_us": 1e3 * stats["total_ms"] / stats["launches"],
                             "algorithmic_bytes_per_launch": stats["total_bytes"] / stats["launches"]}
     line["profile"] = {k: last.profile.get(k) for k in ("assemble", "factorize", "iterate", "op_solve", "restarts", "op_applications")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
+        line["resonator_bank"] = bank_metric()
     if rank == 0:
         print(json.dumps(line), flush=True)
     mesh.close()

@@ -309,16 +309,18 @@ struct TimedLaunch {
         if (on) (void)hipEventRecord(ctx->timer_events[slot].second, ctx->stream);
     }
 };
-// algorithmic bytes of one product: 9 values + column index per node block, row pointers, x read once, y written once
-double spmm_bytes(const BsrLevel &lvl, uint32_t w, size_t scalar) {
-    return (9.0 * scalar + 4.0) * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + 2.0 * scalar * 3.0 * double(lvl.n_nodes) * w;
+// algorithmic bytes of one product: the block values read (9 per node block for A, 1 for M) + column index, the row
+// pointers, x read once, every output panel written once
+double spmm_bytes(const BsrLevel &lvl, uint32_t w, size_t value_bytes, size_t x_bytes, size_t y_bytes, bool with_a, bool with_m) {
+    const double per_block = (with_a ? 9.0 : 0.0) * value_bytes + (with_m ? 1.0 : 0.0) * value_bytes + 4.0;
+    const double panel = 3.0 * double(lvl.n_nodes) * w;
+    return per_block * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + panel * x_bytes + panel * y_bytes * ((with_a ? 1 : 0) + (with_m ? 1 : 0));
 }
 } // namespace
 
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
     if (w == 0) return;
-    // Timed launches: products with the P2 operator's 3x3 blocks (A-values only).
-    TimedLaunch timed(ctx, ctx->time_kernels && vals9 && !mscal && lvl.id == 2, spmm_bytes(lvl, w, sizeof(double)));
+    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 8, 8, 8, vals9 != nullptr, mscal != nullptr));
     if (vals9 && mscal) launch_spmm<double, true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
     else if (vals9) {
         launch_spmm<double, false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
@@ -329,7 +331,7 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
 // fp32 product with the level's single-precision copy of A (preconditioner only).
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w) {
     if (w == 0) return;
-    TimedLaunch timed(ctx, ctx->time_kernels && lvl.id == 2, spmm_bytes(lvl, w, sizeof(float)));
+    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 4, 4, 4, true, false));
     launch_spmm<float, false, true>(ctx, lvl, lvl.aval32.get(), x, y, static_cast<const float *>(nullptr), static_cast<float *>(nullptr), w);
 }
 
@@ -337,7 +339,7 @@ void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y,
 // The pitch w must be a multiple of 4 (16-byte single-precision rows).
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w) {
     if (w == 0) return;
-    TimedLaunch timed(ctx, ctx->time_kernels && lvl.id == 2, (9.0 * 8 + 4.0) * double(lvl.n_blocks) + 4.0 * (double(lvl.n_nodes) + 1) + (4.0 + 8.0) * 3.0 * double(lvl.n_nodes) * w);
+    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 8, 4, 8, true, false));
     if (!launch_spmm_wide<double, float, double, false, true>(ctx, lvl, lvl.aval.get(), x, y, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), w))
         mh_throw(MH_EINVAL, "mixed-precision product needs a 16-byte aligned panel of pitch %% 4 == 0 (got %u)", w);
 }

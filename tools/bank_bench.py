@@ -20,13 +20,8 @@ def modes_for(o, n_modes):
     return freqs, t60s, shapes
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--objects", type=int, default=1024)
-    ap.add_argument("--modes", type=int, default=256)
-    ap.add_argument("--blocks", type=int, default=192)
-    ap.add_argument("--renderers", type=int, default=4)
-    a = ap.parse_args()
+def run(objects=1024, modes=256, blocks=192, renderers=4):
+    a = argparse.Namespace(objects=objects, modes=modes, blocks=blocks, renderers=renderers)
     pos = np.array([[p * 0.01, 0.0, 0.02 if p % 2 else 0.0] for p in range(POINTS)], np.float32)
     idx = np.array([[p, p + 1, p + 2] for p in range(POINTS - 2)], np.uint32).reshape(-1)
     sc = hipbank.Scene(SR, 0)
@@ -60,10 +55,21 @@ def main():
     assert np.isfinite(peak) and peak > 0
     t = np.array(times[8:])
     ms = 1e3 * t.mean()
-    print(json.dumps({"workload": f"bank {a.objects}x{a.modes} @48k, {BLOCK}-frame blocks, {a.renderers} renderers", "blocks": len(t),
+    sc.close()
+    return ({"workload": f"bank {a.objects}x{a.modes} @48k, {BLOCK}-frame blocks, {a.renderers} renderers", "blocks": len(t),
                       "ms_per_block": ms, "ms_per_block_p99": 1e3 * float(np.quantile(t, 0.99)), "x_real_time": BLOCK / SR / t.mean(),
                       "mode_samples_per_s": a.objects * a.modes * BLOCK / t.mean(), "live_modes_mean": float(np.mean(live_modes[8:])),
-                      "live_mode_samples_per_s": float(np.mean(live_modes[8:])) * BLOCK / t.mean(), "peak": peak}))
+                      "live_mode_samples_per_s": float(np.mean(live_modes[8:])) * BLOCK / t.mean(), "peak": peak})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--objects", type=int, default=1024)
+    ap.add_argument("--modes", type=int, default=256)
+    ap.add_argument("--blocks", type=int, default=192)
+    ap.add_argument("--renderers", type=int, default=4)
+    a = ap.parse_args()
+    print(json.dumps(run(a.objects, a.modes, a.blocks, a.renderers)))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,66 @@
+"""Per-kernel HBM traffic from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KiB) of one bench.py run.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-byte requests at 64 bytes for wide
+coalesced reads, so it is doubled; WRITE_SIZE is exact for streaming stores.  The factor is CHECKED on this run's own
+access pattern: k_convert_pitch<double, float> reads and writes a byte count known from its grid (8-byte loads,
+4-byte stores), and the summary reports measured / known for it."""
+import csv, glob, json, re, sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    f = sorted(glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[-1]
+    per = defaultdict(lambda: [0, 0.0, 0])  # launches, sum KiB, sum grid
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        per[k][0] += 1
+        per[k][1] += float(r["Counter_Value"])
+        per[k][2] += int(r["Grid_Size"])
+    return per
+
+
+def short(name):
+    m = re.search(r"(k_\w+(<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        n = max(fetch[k][0], write[k][0])
+        rd = 2.0 * fetch[k][1] * 1024 / max(fetch[k][0], 1)  # gfx950: doubled
+        wr = write[k][1] * 1024 / max(write[k][0], 1)
+        rows.append({"kernel": short(k), "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                     "avg_grid": fetch[k][2] / max(fetch[k][0], 1)})
+    rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over the same bench.py command; reads doubled per the gfx950 rule",
+           "kernels": rows}
+    # calibration on a kernel with a known byte count: one thread per destination element, 8 B read + 4 B written
+    cal = [r for r in rows if r["kernel"].startswith("k_convert_pitch<double, float>")]
+    if cal:
+        c = cal[0]
+        elems = c["avg_grid"]  # grid covers rows * padded width (<= 255 idle threads)
+        out["calibration"] = {"kernel": c["kernel"], "known_read_bytes": 8.0 * elems, "measured_read_bytes": c["read_bytes_per_launch"],
+                              "read_ratio": c["read_bytes_per_launch"] / (8.0 * elems), "known_write_bytes": 4.0 * elems,
+                              "measured_write_bytes": c["write_bytes_per_launch"], "write_ratio": c["write_bytes_per_launch"] / (4.0 * elems),
+                              "note": "source pitch <= destination pitch, so the true read is up to 5 % below 8 B x grid"}
+    fam = [r for r in rows if r["kernel"].startswith("k_spmm")]
+    tot_l = sum(r["launches"] for r in fam)
+    if tot_l:
+        out["spmm_family"] = {"launches": tot_l, "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in fam) / tot_l}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for r in rows[:14]:
+        print(f"{r['kernel'][:60]:60s} x{r['launches']:5d}  read {r['read_bytes_per_launch']/1e6:9.1f} MB  write {r['write_bytes_per_launch']/1e6:9.1f} MB")
+    print(json.dumps(out.get("calibration"), indent=1))
+    print(json.dumps(out.get("spmm_family")))
+
+
+if __name__ == "__main__":
+    main()
