@@ -726,6 +726,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             }
             std::vector<uint32_t> act;
             bool converged = false;
+            uint32_t stall_nconv = 0, stall_count = 0;
+            double stall_worst = 1e300;
             for (uint32_t it = 0; it <= max_iters; ++it) {
                 if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
                 theta_d.upload(theta.data(), b);
@@ -759,6 +761,22 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 iters = it;
                 if (nconv >= nev) { converged = true; break; }
                 if (it == max_iters) break;
+                // Safety net of the single-precision smoothers: no newly converged pair and no 20 % drop of the worst
+                // residual for 6 iterations in a row switches the cycle to double precision for the rest of the solve.
+                {
+                    double worst = 0;
+                    for (uint32_t i = 0; i < nev; ++i) worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
+                    if (nconv > stall_nconv || worst < 0.8 * stall_worst) {
+                        stall_nconv = nconv;
+                        stall_worst = worst;
+                        stall_count = 0;
+                    } else if (++stall_count >= 6 && prec32) {
+                        if (verbose) fprintf(stderr, "[lobpcg] it %3u stagnation: switching the preconditioner to double precision\n", it);
+                        prec32.reset();
+                        prec64 = std::make_unique<Precond<double>>(sys, b);
+                        stall_count = 0;
+                    }
+                }
                 const uint32_t w = uint32_t(act.size());
                 idx_d.upload(act.data(), w);
                 k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);

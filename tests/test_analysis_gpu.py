@@ -225,3 +225,31 @@ def test_full_size_properties(api, ctx):
         assert np.allclose(rq[6:], ev[6:], rtol=1e-8)
         sysg.close()
         mesh.close()
+
+
+def test_thin_plate_converges_with_single_precision_smoothers(api, ctx):
+    """A thin, ill-conditioned body (BASELINE configs[2] geometry at a quarter of the size): the lowest elastic modes
+    sit 9 orders below ||A||.  The default cycle (fp32 smoothers, fp64 residuals between levels) must reach the same
+    eigenvalues and residuals as a dense-accuracy run would -- checked through size-independent properties -- and the
+    215-pair block (wider than the 256-column fused update) must go through."""
+    pts, tets = meshes.kuhn_box(46, 46, 2, 0.26, 0.26, 0.012)
+    m = meshes.MATERIALS["Iron"]
+    mesh = api.Mesh(ctx, pts, tets)
+    sysg = api.System(ctx, mesh, api.material(*m))
+    nev = 215
+    ev, prof = sysg.eigs(nev, SIGMA, 1e-5, max_iters=80)
+    assert prof["restarts"] <= 60, prof
+    assert (np.abs(ev[:6]) < 1e-6 * ev[6]).all() and ev[6] > 0 and np.all(np.diff(ev[6:]) >= 0)
+    V = sysg.eigenvectors(nev)
+    KV, MV = sysg.matvec(0, V), sysg.matvec(1, V)
+    res = np.linalg.norm(KV - MV * ev, axis=0) / (np.abs(ev - SIGMA) * np.linalg.norm(MV, axis=0))
+    assert res[6:].max() < 1.5e-5, res.max()
+    assert np.abs(V.T @ MV - np.eye(nev)).max() < 1e-7
+    # plate bending: the first elastic mode of a free square plate, f ~ 13.47/(2 pi a^2) sqrt(D / (rho h)) (Leissa)
+    E, nu, rho, a, h = m[1], m[2], m[0], 0.26, 0.012
+    D = E * h ** 3 / (12 * (1 - nu ** 2))
+    f_plate = 13.47 / (2 * np.pi * a * a) * np.sqrt(D / (rho * h))
+    f1 = np.sqrt(ev[6]) / (2 * np.pi)
+    assert abs(f1 / f_plate - 1) < 0.05, (f1, f_plate)
+    sysg.close()
+    mesh.close()
