@@ -182,7 +182,9 @@ __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int w
 constexpr int CK = 32; // K chunk
 template<int NT, bool ACCUMULATE> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =
 __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, const double *__restrict__ W, int ww, const double *__restrict__ P, int wp,
-                                                const double *__restrict__ Ct, int nc, size_t n, double *__restrict__ out1, int n1, double *__restrict__ out2) {
+                                                const double *__restrict__ Ct, int ldc, int c0, int nc, size_t n, double *__restrict__ out1, int n1,
+                                                double *__restrict__ out2) {
+    // this launch owns output columns c0 .. c0 + nc of the ldc the coefficient matrix has
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = wx + ww + wp;
     constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16; // = 16 (mod 32): conflict-free B reads
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
         }
 #pragma unroll
         for (int q = 0; q < CPASS; ++q) {
-            const double *crow = Ct + size_t(min(k0 + ck + 16 * q, m - 1)) * nc;
+            const double *crow = Ct + size_t(min(k0 + ck + 16 * q, m - 1)) * ldc + c0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) pc[q][t] = crow[min(cc + 16 * t, nc - 1)];
         }
@@ -250,13 +252,13 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int c = t * 16 + (lane & 15);
-        if (c >= nc) continue;
+        if (t * 16 + (lane & 15) >= nc) continue;
+        const int c = c0 + t * 16 + (lane & 15);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const size_t r = r0 + wave * 16 + (lane >> 4) + 4 * reg;
             if (r >= n) continue;
-            double *dst = c < n1 ? out1 + r * n1 + c : out2 + r * (nc - n1) + (c - n1);
+            double *dst = c < n1 ? out1 + r * n1 + c : out2 + r * (ldc - n1) + (c - n1);
             *dst = ACCUMULATE ? *dst + acc[t][reg] : acc[t][reg];
         }
     }
@@ -346,27 +348,31 @@ void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const 
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
                 double *out1, uint32_t n1, double *out2, bool accumulate) {
     if (!nc) return;
-    if (nc > 256) mh_throw(MH_EINVAL, "combine: %u output columns exceed 256", nc);
     const unsigned grid = div_up(n, 64);
-    auto go = [&](auto nt_tag) {
-        constexpr int NT = decltype(nt_tag)::value;
-        constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
-        const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
-        if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
-        else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), n, out1, int(n1), out2);
-    };
-    const int ntile = int((nc + 15) / 16);
-    switch ((ntile + 1) / 2) { // the kernel computes all NT column strips: pick the smallest even NT that covers nc
-        case 1: go(std::integral_constant<int, 2>{}); break;
-        case 2: go(std::integral_constant<int, 4>{}); break;
-        case 3: go(std::integral_constant<int, 6>{}); break;
-        case 4: go(std::integral_constant<int, 8>{}); break;
-        case 5: go(std::integral_constant<int, 10>{}); break;
-        case 6: go(std::integral_constant<int, 12>{}); break;
-        case 7: go(std::integral_constant<int, 14>{}); break;
-        default: go(std::integral_constant<int, 16>{}); break;
+    // more than 256 output columns: column chunks, each a launch over the same basis
+    const uint32_t chunks = div_up(nc, 256), step = (div_up(nc, chunks) + 15) / 16 * 16;
+    for (uint32_t c0 = 0; c0 < nc; c0 += step) {
+        const uint32_t ncc = std::min(step, nc - c0);
+        auto go = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
+            const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
+            if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2);
+            else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2);
+        };
+        const int ntile = int((ncc + 15) / 16);
+        switch ((ntile + 1) / 2) { // the kernel computes all NT column strips: pick the smallest even NT that covers the chunk
+            case 1: go(std::integral_constant<int, 2>{}); break;
+            case 2: go(std::integral_constant<int, 4>{}); break;
+            case 3: go(std::integral_constant<int, 6>{}); break;
+            case 4: go(std::integral_constant<int, 8>{}); break;
+            case 5: go(std::integral_constant<int, 10>{}); break;
+            case 6: go(std::integral_constant<int, 12>{}); break;
+            case 7: go(std::integral_constant<int, 14>{}); break;
+            default: go(std::integral_constant<int, 16>{}); break;
+        }
+        KERNEL_CHECK();
     }
-    KERNEL_CHECK();
 }
 
 // Row-major (k-major) packing of two column-major blocks stacked vertically, scaled: ct[(r1 + r2)][cols]

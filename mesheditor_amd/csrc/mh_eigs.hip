@@ -797,18 +797,10 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 for (int pass = 0; pass < ortho_passes && ok; ++pass) {
                     gram(ctx, n, MX, b, W, w, H, b); // b x w
                     if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
-                    if (w <= 256) { // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
-                        mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
-                        mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
-                        mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
-                    } else {
-                        panel_mul(ctx, n, X, b, H, b, W, w, -1.0, 1.0);
-                        panel_mul(ctx, n, MX, b, H, b, MW, w, -1.0, 1.0);
-                        if (wp) {
-                            panel_mul(ctx, n, P, wp, H2, wp, W, w, -1.0, 1.0);
-                            panel_mul(ctx, n, MP, wp, H2, wp, MW, w, -1.0, 1.0);
-                        }
-                    }
+                    // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
+                    mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
+                    mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
+                    mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
                     ok = chol_orthonormalise(W, MW, nullptr, w);
                 }
                 if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
@@ -883,26 +875,10 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
                 }
                 // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
-                if (b + wp_new <= 256) {
-                    mh_pack_coefficients(ctx, gA, b, Cp, wp_new, m, m, Ct);
-                    mh_combine(ctx, n, X, b, W, w, P, wp, Ct, b + wp_new, Xn, b, Pn);
-                    mh_combine(ctx, n, AX, b, AW, w, AP, wp, Ct, b + wp_new, AXn, b, APn);
-                    mh_combine(ctx, n, MX, b, MW, w, MP, wp, Ct, b + wp_new, MXn, b, MPn);
-                } else {
-                    auto combine = [&](const double *x, const double *wv, const double *pv, const double *c, uint32_t wout, double *out) {
-                        panel_mul(ctx, n, x, b, c, m, out, wout, 1.0, 0.0);
-                        panel_mul(ctx, n, wv, w, c + b, m, out, wout, 1.0, 1.0);
-                        if (wp) panel_mul(ctx, n, pv, wp, c + b + w, m, out, wout, 1.0, 1.0);
-                    };
-                    combine(X, W, P, gA, b, Xn);
-                    combine(AX, AW, AP, gA, b, AXn);
-                    combine(MX, MW, MP, gA, b, MXn);
-                    if (wp_new) {
-                        combine(X, W, P, Cp, wp_new, Pn);
-                        combine(AX, AW, AP, Cp, wp_new, APn);
-                        combine(MX, MW, MP, Cp, wp_new, MPn);
-                    }
-                }
+                mh_pack_coefficients(ctx, gA, b, Cp, wp_new, m, m, Ct);
+                mh_combine(ctx, n, X, b, W, w, P, wp, Ct, b + wp_new, Xn, b, Pn);
+                mh_combine(ctx, n, AX, b, AW, w, AP, wp, Ct, b + wp_new, AXn, b, APn);
+                mh_combine(ctx, n, MX, b, MW, w, MP, wp, Ct, b + wp_new, MXn, b, MPn);
                 std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
                 std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
                 wp = wp_new;
