@@ -1,0 +1,2 @@
+#pragma once
+#include "../modal/model_io.hpp"

@@ -1,0 +1,147 @@
+// The wire formats either side of the path: KHR_audio_rigid_bodies modal models (read rules of the reference's
+// src/gltf/GltfScene.cpp:2455-2508, export conventions of :4519-4562) and the content-addressed `.modal` store
+// (src/audio/ModalModelFile.h).  Host code only: runs without a GPU.  The golden document is the reference's committed
+// sample scene glTF_PhysicalAudio/samples/test/StrikeOne/a_ThreeInstances.gltf (a data file, kept under tests/golden/).
+#include "harness.hpp"
+
+#include <audio/ModalModelFile.h>
+
+#include <filesystem>
+#include <fstream>
+#include <limits>
+#include <sstream>
+
+namespace {
+namespace fs = std::filesystem;
+std::string Slurp(const fs::path &p) {
+    std::ifstream in{p, std::ios::binary};
+    std::stringstream ss;
+    ss << in.rdbuf();
+    return ss.str();
+}
+fs::path GoldenDir() { return fs::path{GOLDEN_DIR}; }
+
+ModalModes SmallModel() {
+    ModalModes m;
+    m.Freqs = {440.f, 1234.5f, 3001.25f};
+    m.T60s = {0.5f, 0.f, 0.125f}; // T60 == 0 is the undamped sentinel
+    m.Positions = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    m.Indices = {0, 1, 2, 0, 2, 3};
+    m.Shapes.assign(4, std::vector<vec3>(3));
+    for (uint32_t p = 0; p < 4; ++p)
+        for (uint32_t k = 0; k < 3; ++k) m.Shapes[p][k] = {0.1f * float(p + 1), -0.01f * float(k + 1), 0.5f * float(p) - float(k)};
+    m.OriginalFundamentalFreq = 440.f;
+    return m;
+}
+} // namespace
+
+CASE(the_reference_sample_scene_reads_back_its_solved_model) {
+    const auto text = Slurp(GoldenDir() / "StrikeOne_a_ThreeInstances.gltf");
+    EXPECT(!text.empty());
+    const auto doc = modal::io::ReadGltfModalModels(text);
+    EXPECT(doc.has_value());
+    if (!doc) return;
+    EXPECT(doc->Materials.size() == 2 && doc->Materials[0].Name == "Ceramic" && doc->Materials[1].Name == "Steel");
+    EXPECT(doc->Materials[0].Properties == materials::acoustic::Ceramic.Properties);
+    EXPECT(doc->Models.size() == 1);
+    if (doc->Models.empty()) return;
+    const auto &rec = doc->Models.front();
+    EXPECT(rec.Name == "Solved box");
+    EXPECT(rec.Modes.Freqs.size() == 10 && rec.Modes.Positions.size() == 104 && rec.Modes.Indices.size() == 3 * 204);
+    EXPECT(rec.Modes.Shapes.size() == 104 && rec.Modes.Shapes.front().size() == 10);
+    EXPECT(rec.Modes.Freqs.front() == 1806.7595f && rec.Modes.Freqs.back() == 14305.89f);
+    EXPECT(rec.Modes.OriginalFundamentalFreq == rec.Modes.Freqs.front());
+    // decay rate d = (alpha + beta omega^2) / 2 for the ceramic's Rayleigh damping; T60 = ln 1000 / d
+    const double omega = 2 * 3.141592653589793 * rec.Modes.Freqs.front(), d0 = (6 + 1e-7 * omega * omega) / 2;
+    EXPECT(check::near(rec.Modes.T60s.front(), 6.907755278982137 / d0, 1e-5));
+    EXPECT(rec.Material.value_or(9) == 0u);
+    EXPECT(rec.Mass.has_value() && check::near(rec.Mass->Mass, 0.7775999710321417, 1e-15));
+    EXPECT(rec.Mass && check::near(rec.Mass->InertiaDiagonal.y, 0.0038616334, 1e-7));
+}
+
+CASE(a_written_document_reads_back_the_same_model) {
+    modal::io::ModalModelDocument doc;
+    doc.Materials = {materials::acoustic::Glass, materials::acoustic::Iron};
+    MassProperties mass;
+    mass.Mass = 1.25;
+    mass.CenterOfMass = {0.1f, -0.2f, 0.3f};
+    mass.InertiaDiagonal = {1e-3f, 2e-3f, 3e-3f};
+    mass.InertiaOrientation = {0.5f, 0.5f, -0.5f, 0.5f};
+    doc.Models.push_back({"bell \"A\"", SmallModel(), mass, 1u});
+    doc.Models.push_back({"empty", {}, std::nullopt, std::nullopt}); // skipped on export
+    const auto text = modal::io::WriteGltfModalModels(doc);
+    const auto back = modal::io::ReadGltfModalModels(text);
+    EXPECT(back.has_value() && back->Warnings.empty());
+    if (!back) return;
+    EXPECT(back->Materials.size() == 2 && back->Materials[1] == materials::acoustic::Iron);
+    EXPECT(back->Models.size() == 1);
+    if (back->Models.empty()) return;
+    const auto &got = back->Models.front();
+    const auto want = SmallModel();
+    EXPECT(got.Name == "bell \"A\"" && got.Material.value_or(9) == 1u);
+    EXPECT(got.Modes.Freqs == want.Freqs && got.Modes.Positions == want.Positions && got.Modes.Indices == want.Indices && got.Modes.Shapes == want.Shapes);
+    EXPECT(got.Modes.T60s[1] == 0.f);
+    for (const int k : {0, 2}) EXPECT(check::near(got.Modes.T60s[k], want.T60s[k], 2e-7)); // through d = ln 1000 / T60 in float
+    EXPECT(got.Mass.has_value() && *got.Mass == mass);
+}
+
+CASE(malformed_models_read_back_empty_and_keep_their_slot) {
+    const auto with = [](auto &&edit) {
+        modal::io::ModalModelDocument doc;
+        auto m = SmallModel();
+        edit(m);
+        doc.Models.push_back({"m", m, std::nullopt, std::nullopt});
+        return modal::io::ReadGltfModalModels(modal::io::WriteGltfModalModels(doc));
+    };
+    const auto zero_freq = with([](ModalModes &m) { m.Freqs[1] = 0.f; });
+    EXPECT(zero_freq && zero_freq->Models.size() == 1 && zero_freq->Models[0].Modes.Freqs.empty() && !zero_freq->Warnings.empty());
+    const auto nan_shape = with([](ModalModes &m) { m.Shapes[2][1].y = std::numeric_limits<float>::quiet_NaN(); });
+    EXPECT(nan_shape && nan_shape->Models[0].Modes.Freqs.empty());
+    const auto negative_decay = with([](ModalModes &m) { m.T60s[0] = -1.f; }); // exported as d = 0 (undamped), which is valid
+    EXPECT(negative_decay && negative_decay->Models[0].Modes.T60s[0] == 0.f);
+    const auto bad_surface = with([](ModalModes &m) { m.Indices[4] = 17; });
+    EXPECT(bad_surface && !bad_surface->Models[0].Modes.Freqs.empty() && bad_surface->Models[0].Modes.Indices.empty() && bad_surface->Warnings.size() == 1);
+    // hand-written documents: a negative decay rate, a shape block of the wrong length, not JSON at all
+    EXPECT(!modal::io::ReadGltfModalModels("[1, 2").has_value());
+    const auto plain = modal::io::ReadGltfModalModels("{\"asset\":{\"version\":\"2.0\"}}");
+    EXPECT(plain && plain->Models.empty());
+    const auto dangling = modal::io::ReadGltfModalModels(
+        "{\"accessors\":[],\"extensions\":{\"KHR_audio_rigid_bodies\":{\"modalModels\":[{\"name\":\"x\",\"frequencies\":0,\"decayRates\":1,\"positions\":2,\"shapes\":3}]}}}");
+    EXPECT(dangling && dangling->Models.size() == 1 && dangling->Models[0].Modes.Freqs.empty());
+}
+
+CASE(the_modal_store_is_write_once_and_content_addressed) {
+    ModalModelData data;
+    data.Modes = SmallModel();
+    data.Modes.Vertices = {7, 8, 9, 10};
+    data.Mass.Mass = 2.5;
+    data.Mass.InertiaOrientation = {0.6f, 0.f, 0.8f, 0.f};
+    data.Tets.Positions = {{0, 0, 0}, {1, 2, 3}};
+    data.Tets.EdgeIndices = {0, 1};
+    data.Summary.Eigenvalues = {1.5e7, 2.5e8};
+    data.Summary.Shapes = {{{1, 2, 3}, {4, 5, 6}}};
+    data.Summary.SolvedMaterial = materials::acoustic::Wood.Properties;
+    data.Summary.TetInputsHash = 0x1234567890abcdefull;
+    data.Summary.SolvedVertices = {3, 1, 2};
+    const auto dir = fs::temp_directory_path() / ("modal_store_" + std::to_string(::getpid()));
+    fs::remove_all(dir);
+    const auto name = SaveModalModelFile(dir, data);
+    EXPECT(!name.empty() && name.extension() == ".modal" && name.stem().string().size() == 16);
+    EXPECT(SaveModalModelFile(dir, data) == name); // identical content reuses the file
+    size_t files = 0;
+    for (const auto &e : fs::directory_iterator(dir)) files += e.is_regular_file();
+    EXPECT(files == 1);
+    const auto back = LoadModalModelFile(dir / name);
+    EXPECT(back.has_value() && *back == data);
+    auto other = data;
+    other.Modes.Freqs[0] = 441.f;
+    EXPECT(SaveModalModelFile(dir, other) != name);
+    // a truncated image does not load
+    auto bytes = SerializeModalModel(data);
+    bytes.resize(bytes.size() - 3);
+    EXPECT(!DeserializeModalModel(bytes).has_value());
+    EXPECT(!LoadModalModelFile(dir / "absent.modal").has_value());
+    fs::remove_all(dir);
+}
+
+int main() { return check::run_all(); }

@@ -25,13 +25,65 @@ def _run(name, timeout=600):
 
 def test_cpp_tests_compile_against_the_mirror():
     _build()
-    for name in ("modal_solver_test", "modal_render_test", "contact_model_test"):
+    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test"):
         assert os.path.exists(os.path.join(CPP, "bin", name))
 
 
 def test_contact_model_known_answers():
     _build()
     assert "0 failure(s)" in _run("contact_model_test")
+
+
+def test_gltf_modal_models_and_modal_store():
+    """the KHR_audio_rigid_bodies reader/writer against the reference's committed sample
+    scene, and the content-addressed .modal store (host code, no GPU)."""
+    _build()
+    assert "0 failure(s)" in _run("model_io_test")
+
+
+@pytest.mark.gpu
+def test_solve_tool_reproduces_the_reference_sample_model(golden):
+    """The JSON solve tool (the reference's MeshEditorModalSolve, which its sample generator shells out to) on the
+    'Solved box' body of the reference's sample scene: same fields, frequencies within the tetrahedralisation tolerance
+    (SURVEY 8c, G3), exact decay law, mass; the --gltf output reads back as the same model."""
+    import base64, json, struct, tempfile
+    import numpy as np
+    _build()
+    model = golden["Solved box"]
+    lo, hi = np.array(model["positionMin"]), np.array(model["positionMax"])
+    ext = hi - lo
+    tool = os.path.join(ROOT, "mesheditor_amd", "cpp", "bin", "modal_solve")
+    with tempfile.TemporaryDirectory() as tmp:
+        gltf = os.path.join(tmp, "box.gltf")
+        args = [tool, "--kuhn", *(repr(float(v)) for v in ext), "12", "3", "1", "--origin", *(repr(float(v)) for v in lo), "--young", "7.2e10", "--poisson", "0.19",
+                "--density", "2700", "--alpha", "6", "--beta", "1e-7", "--modes", "10", "--gltf", gltf]
+        p = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = json.loads(p.stdout)
+        doc = json.load(open(gltf))
+    f = np.array(out["frequencies"])
+    ref = np.array(model["frequencies"])
+    assert len(f) == len(ref) == 10
+    assert np.abs(f[:4] / ref[:4] - 1).max() < 3.5e-4 and np.abs(f / ref - 1).max() < 3e-3, f / ref
+    # d = (alpha + beta omega^2) / 2 with omega the UNDAMPED rate; the model lists damped frequencies, omega_d^2 = omega^2 - d^2
+    wd = 2 * np.pi * f
+    d = np.zeros_like(wd)
+    for _ in range(8):
+        d = (6 + 1e-7 * (wd * wd + d * d)) / 2
+    assert np.allclose(out["decayRates"], d, rtol=2e-6)
+    assert abs(out["mass"] / model["massProperties"]["mass"] - 1) < 1e-6
+    # lumped vertex volumes depend on the tetrahedralisation (Kuhn here, the reference's generator there)
+    assert np.allclose(out["inertiaDiagonal"], model["massProperties"]["inertiaDiagonal"], rtol=0.1), out["inertiaDiagonal"]
+    npts = len(out["positions"])
+    assert npts == model["numPositions"] and len(out["shapes"]) == 10 * npts and len(out["indices"]) == 3 * model["numTriangles"]
+    assert max(out["indices"]) < npts
+    # the glTF written beside it carries the same numbers
+    mm = doc["extensions"]["KHR_audio_rigid_bodies"]["modalModels"][0]
+    blob = base64.b64decode(doc["buffers"][0]["uri"].split(",", 1)[1])
+    view = doc["bufferViews"][doc["accessors"][mm["frequencies"]]["bufferView"]]
+    got = struct.unpack_from("<10f", blob, view["byteOffset"])
+    assert np.allclose(got, f, rtol=1e-7)
+    assert abs(mm["massProperties"]["mass"] - out["mass"]) < 1e-12
 
 
 @pytest.mark.gpu
