@@ -275,6 +275,7 @@ int mh_context_bench_dense(mh_context *ctx, int kind, uint64_t n, uint32_t wa, u
     if (!ctx || !avg_ms || n == 0 || wa == 0 || wb == 0 || reps == 0 || kind < 0 || kind > 1) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
+        std::lock_guard<std::mutex> lock(mh_solve_mutex());
         DevArray<double> x(ctx, n * wa), y(ctx, n * wb), g(ctx, size_t(wa + wb) * (wa + wb)), z(ctx, n * wa);
         std::vector<double> h(n * std::max(wa, wb));
         for (size_t i = 0; i < h.size(); ++i) h[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -220,6 +221,7 @@ inline int mh_guard(mh_context *ctx, const std::exception &e) {
 inline unsigned div_up(size_t a, size_t b) { return unsigned((a + b - 1) / b); }
 
 // ---- stage entry points implemented across the .hip files ----
+std::mutex &mh_solve_mutex(); // mh_eigs.hip: one eigensolve (or Gram benchmark) at a time per process, see there
 void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &mat, mh_system *sys); // mh_pipeline.hip
 void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
 // y (n x w row-major, ld = w) = A x with A given by 9-value blocks; optionally y2 = M x from the scalar blocks.

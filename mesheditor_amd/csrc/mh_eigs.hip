@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <type_traits>
 
@@ -23,6 +24,18 @@ __global__ void k_fix_coarse_diag(double *a0, uint32_t n0, double rel);
 
 namespace {
 constexpr int TB = 256;
+
+// Concurrency contract of a solve.  Measured on this stack (ROCm 7.2, MI355X) with three host threads solving on their
+// own contexts: rocsolver_dpotrf of the SAME 3 690 x 3 690 coarse operator (identical input checksums) returned
+// info != 0 in ~10 % of the calls -- also when every rocSOLVER call ran under one lock, and specifically whenever
+// another stream was running the register-blocked Gram kernel (not the SpMM, basis-update or assembly kernels); the
+// operator buffer itself was never touched while idle.  The factorisation is disturbed by unrelated concurrent work, so
+// the whole eigensolve (hierarchy set-up + iteration) of a process runs under one lock: concurrent callers are safe and
+// their solves execute one after the other on the GPU.  g_rocsolver_mutex additionally keeps rocSOLVER calls apart
+// should other entry points ever use it.
+std::mutex g_solve_mutex;
+std::mutex g_rocsolver_mutex;
+using SolverLock = std::unique_lock<std::mutex>;
 
 struct Timer {
     mh_context *ctx;
@@ -372,6 +385,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         memcpy(&d, &bits, sizeof(d));
         identity = d < 1e-11;
     }
+    SolverLock solver_lock(g_rocsolver_mutex);
     if (!identity) {
         ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, m, gM, m, info));
         info.download(&hinfo, 1);
@@ -382,6 +396,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
     ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
     info.download(&hinfo, 1);
     if (hinfo != 0) return hinfo;
+    solver_lock.unlock();
     if (!identity)
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
     return 0;
@@ -565,6 +580,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), 1e-12);
     KERNEL_CHECK();
     DevArray<int> info(ctx, 1);
+    SolverLock solver_lock(g_rocsolver_mutex);
     ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
     int hinfo = 0;
     info.download(&hinfo, 1);
@@ -573,6 +589,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     // solves at these sizes, and free of their O(n0/128) dependent launches).
     ROCBLAS_CHECK(rocsolver_dpotri(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
     info.download(&hinfo, 1);
+    solver_lock.unlock();
     if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse inverse failed (potri info %d)", hinfo);
     k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
     KERNEL_CHECK();
@@ -595,6 +612,7 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues)
     KERNEL_CHECK();
     k_bsr_to_dense<<<grid1(lvl.n_nodes), TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, lvl.mval, lvl.n_nodes, a, m);
     KERNEL_CHECK();
+    SolverLock solver_lock(g_rocsolver_mutex);
     ROCBLAS_CHECK(rocsolver_dsygvd(ctx->blas, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_lower, rocblas_int(n), a, rocblas_int(n), m, rocblas_int(n), d, e, info));
     int hinfo = 0;
     info.download(&hinfo, 1);
@@ -687,9 +705,12 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
                 KERNEL_CHECK();
                 double *Gs = G.get() + size_t(w) * w;
-                ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
                 int hinfo = 0;
-                info.download(&hinfo, 1);
+                {
+                    SolverLock solver_lock(g_rocsolver_mutex);
+                    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                    info.download(&hinfo, 1);
+                }
                 if (hinfo != 0) return false;
                 k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
                 KERNEL_CHECK();
@@ -859,9 +880,12 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 KERNEL_CHECK();
                 {
                     double *Gs = G.get() + size_t(w) * w;
-                    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
                     int hinfo = 0;
-                    info.download(&hinfo, 1);
+                    {
+                        SolverLock solver_lock(g_rocsolver_mutex);
+                        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                        info.download(&hinfo, 1);
+                    }
                     if (hinfo != 0) {
                         wp_new = 0;
                     } else {
@@ -898,11 +922,15 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
     }
 }
 
+std::mutex &mh_solve_mutex() { return g_solve_mutex; }
+
 extern "C" int mh_eigs(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
                        uint32_t seed_cols, const volatile unsigned char *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
     if (!sys || !eigenvalues || nev == 0) return MH_EINVAL;
     try {
+        std::lock_guard<std::mutex> one_solve_at_a_time(g_solve_mutex);
         eigs_impl(sys, nev, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, eigenvalues, profile);
+        HIP_CHECK(hipStreamSynchronize(sys->ctx->stream)); // nothing of this solve is in flight when the next one starts
         return MH_OK;
     } catch (const std::exception &e) {
         return mh_guard(sys->ctx, e);

@@ -253,3 +253,36 @@ def test_thin_plate_converges_with_single_precision_smoothers(api, ctx):
     assert abs(f1 / f_plate - 1) < 0.05, (f1, f_plate)
     sysg.close()
     mesh.close()
+
+
+def test_concurrent_solves_from_several_threads(api):
+    """The reference runs one solve job per entity, several at a time (AudioSystem.cpp:812,865).  Three host threads with
+    their own contexts solve at once: every result must equal the single-threaded one."""
+    import threading
+    pts, tets, m, kw = meshes.workload("cube_s10k")
+    mat = api.material(*m)
+    ctxs = [api.Context(0) for _ in range(3)]
+    ms = [api.Mesh(c, pts, tets) for c in ctxs]
+    s0 = api.System(ctxs[0], ms[0], mat)
+    ref, _ = s0.eigs(40, SIGMA, 1e-6)
+    s0.close()
+    out, errs = {}, []
+
+    def work(i):
+        try:
+            for rep in range(3):
+                s = api.System(ctxs[i], ms[i], mat)
+                ev, _ = s.eigs(40, SIGMA, 1e-6)
+                out[(i, rep)] = ev
+                s.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert len(out) == 9
+    for ev in out.values():
+        assert np.allclose(ev[6:], ref[6:], rtol=1e-9)
+    for c in ctxs:
+        c.close()
