@@ -93,6 +93,7 @@ int mh_context_create(int device, mh_context **out) {
         ROCBLAS_CHECK(rocblas_create_handle(&ctx->blas));
         ROCBLAS_CHECK(rocblas_set_stream(ctx->blas, ctx->stream));
         ROCBLAS_CHECK(rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host));
+        ROCBLAS_CHECK(rocblas_set_atomics_mode(ctx->blas, rocblas_atomics_not_allowed)); // bit-reproducible library reductions
         *out = ctx;
         return MH_OK;
     } catch (const std::exception &e) {

@@ -575,7 +575,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     const size_t n0 = size_t(6) * sys->n_agg;
     sys->a0.reset(ctx, n0 * n0);
     sys->a0.zero();
-    k_coarse_matrix<<<grid1(sys->n_points), TB, 0, ctx->stream>>>(sys->L1.row_ptr, sys->L1.col, sys->L1.aval, sys->agg_t, sys->n_points, sys->agg_size, sys->n_agg, sys->a0);
+    k_coarse_matrix<<<sys->n_agg, 64, 0, ctx->stream>>>(sys->L1.row_ptr, sys->L1.col, sys->L1.aval, sys->agg_t, sys->n_points, sys->agg_size, sys->n_agg, sys->a0);
     KERNEL_CHECK();
     k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), 1e-12);
     KERNEL_CHECK();

@@ -383,27 +383,31 @@ __global__ void k_diag_inverse(const uint32_t *__restrict__ row_ptr, const uint3
     }
 }
 
-// A0 += T_i^T A_ij T_j for every P1 node block (i, j); A0 dense column-major of order 6*nagg.
-__global__ void k_coarse_matrix(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ aval,
-                                const double *__restrict__ tmat, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ a0) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npts) return;
-    const uint32_t ai = min(i / agg_size, nagg - 1);
+// A0 = sum over P1 node blocks (i, j) of T_i^T A_ij T_j; A0 dense column-major of order 6*nagg (zeroed by the caller).
+// One 64-thread workgroup per aggregate; its first 36 threads own the (r, c) entries of that aggregate's 6-row band
+// and walk the aggregate's node blocks in storage order, so every entry is summed in a fixed order by one thread: no
+// atomics, bit-reproducible.
+__global__ void __launch_bounds__(64) k_coarse_matrix(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ aval,
+                                                     const double *__restrict__ tmat, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ a0) {
+    const uint32_t ai = blockIdx.x, t = threadIdx.x;
+    if (t >= 36) return;
+    const uint32_t r = t / 6, c = t % 6;
     const size_t n0 = size_t(6) * nagg;
-    const double *ti = tmat + 18 * size_t(i);
-    for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p) {
-        const uint32_t j = col[p];
-        const uint32_t aj = min(j / agg_size, nagg - 1);
-        const double *a = aval + 9 * size_t(p);
-        const double *tj = tmat + 18 * size_t(j);
-        double at[3][6]; // A_ij T_j
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 6; ++c) at[r][c] = a[3 * r] * tj[c] + a[3 * r + 1] * tj[6 + c] + a[3 * r + 2] * tj[12 + c];
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 6; ++c) {
-                const double v = ti[r] * at[0][c] + ti[6 + r] * at[1][c] + ti[12 + r] * at[2][c];
-                if (v != 0.0) atomicAdd(&a0[(size_t(6) * aj + c) * n0 + size_t(6) * ai + r], v);
-            }
+    const uint32_t i0 = ai * agg_size, i1 = ai == nagg - 1 ? npts : (ai + 1) * agg_size;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const double *ti = tmat + 18 * size_t(i);
+        const double t0 = ti[r], t1 = ti[6 + r], t2 = ti[12 + r];
+        for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p) {
+            const uint32_t j = col[p];
+            const uint32_t aj = min(j / agg_size, nagg - 1);
+            const double *a = aval + 9 * size_t(p);
+            const double *tj = tmat + 18 * size_t(j);
+            // (T_i^T A_ij T_j)[r][c] = sum_k T_i[k][r] * (A_ij T_j)[k][c]
+            const double at0 = a[0] * tj[c] + a[1] * tj[6 + c] + a[2] * tj[12 + c];
+            const double at1 = a[3] * tj[c] + a[4] * tj[6 + c] + a[5] * tj[12 + c];
+            const double at2 = a[6] * tj[c] + a[7] * tj[6 + c] + a[8] * tj[12 + c];
+            a0[(size_t(6) * aj + c) * n0 + size_t(6) * ai + r] += t0 * at0 + t1 * at1 + t2 * at2;
+        }
     }
 }
 

@@ -286,3 +286,20 @@ def test_concurrent_solves_from_several_threads(api):
         assert np.allclose(ev[6:], ref[6:], rtol=1e-9)
     for c in ctxs:
         c.close()
+
+
+def test_solve_is_bit_reproducible(api, ctx):
+    """Fixed seeds, ordered reductions, no atomics (SURVEY 8b 'Determinism'): two solves of the same mesh give the same
+    bits -- eigenvalues and the gathered shapes."""
+    pts, tets, m, kw = meshes.workload("cube_s10k")
+    runs = []
+    for _ in range(2):
+        mesh = api.Mesh(ctx, pts, tets)
+        s = api.System(ctx, mesh, api.material(*m))
+        ev, prof = s.eigs(40, SIGMA, 1e-6)
+        runs.append((ev.copy(), s.gather_shapes(np.arange(0, 200, 7, dtype=np.uint32), 40).copy(), prof["restarts"]))
+        s.close()
+        mesh.close()
+    assert runs[0][2] == runs[1][2]
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][1], runs[1][1])
