@@ -191,6 +191,29 @@ __global__ void k_residual(const double *__restrict__ ax, const double *__restri
     r[i] = ax[row * b + src] - theta[src] * mx[row * b + src];
 }
 
+// Residuals of all b columns and the three column norms the convergence test needs, in one pass over the panels:
+// R = AX - theta MX, partial[blk][0..2][c] = sums of r^2, (Mx)^2, x^2 over the block's rows (fixed order).
+__global__ void k_residual_norms(const double *__restrict__ ax, const double *__restrict__ mx, const double *__restrict__ xx, const double *__restrict__ theta,
+                                 double *__restrict__ r, size_t rows, uint32_t b, uint32_t rows_per_block, double *__restrict__ partial) {
+    const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= b) return;
+    const size_t r0 = size_t(blockIdx.x) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const double th = theta[c];
+    double sr = 0, sm = 0, sx = 0;
+    for (size_t row = r0; row < r1; ++row) {
+        const size_t i = row * b + c;
+        const double m = mx[i], x = xx[i], res = ax[i] - th * m;
+        r[i] = res;
+        sr += res * res;
+        sm += m * m;
+        sx += x * x;
+    }
+    double *p = partial + size_t(blockIdx.x) * 3 * b;
+    p[c] = sr;
+    p[b + c] = sm;
+    p[2 * size_t(b) + c] = sx;
+}
+
 // Column sums of squares, two deterministic stages.
 __global__ void k_colsumsq_partial(const double *__restrict__ x, size_t rows, uint32_t w, double *__restrict__ partial, uint32_t rows_per_block) {
     const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
@@ -267,12 +290,18 @@ __global__ void k_build_cp(const double *__restrict__ c, const uint32_t *__restr
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m * w) return;
     const uint32_t r = i % m, k = i / m;
-    cp[size_t(k) * ldp + r] = r < b ? 0.0 : c[size_t(idx[k]) * ldc + r];
+    cp[size_t(k) * ldp + r] = r < b ? 0.0 : c[size_t(idx ? idx[k] : k) * ldc + r];
 }
 __global__ void k_gather_cols(const double *__restrict__ src, const uint32_t *__restrict__ idx, double *__restrict__ dst, size_t rows, uint32_t wsrc, uint32_t w) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
     dst[i] = src[(i / w) * wsrc + idx[i % w]];
+}
+// dst[:, idx[k]] = src[:, k]
+__global__ void k_scatter_cols(const double *__restrict__ src, const uint32_t *__restrict__ idx, double *__restrict__ dst, size_t rows, uint32_t wdst, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    dst[(i / w) * wdst + idx[i % w]] = src[i];
 }
 // seed basis (column-major float, reference DOF order) -> leading columns of a row-major internal-order panel
 __global__ void k_load_seed(const float *__restrict__ seed, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t ncols, uint32_t b, double *__restrict__ x) {
@@ -665,6 +694,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> X(ctx, n * b), AX(ctx, n * b), MX(ctx, n * b), Xn(ctx, n * b), AXn(ctx, n * b), MXn(ctx, n * b);
             DevArray<double> W(ctx, n * b), AW(ctx, n * b), MW(ctx, n * b), P(ctx, n * b), AP(ctx, n * b), MP(ctx, n * b);
             DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
+            DevArray<double> XA(ctx, n * b), AXA(ctx, n * b), MXA(ctx, n * b);
             DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), gA0(ctx, size_t(mmax) * mmax), App(ctx, size_t(b) * b), evals(ctx, mmax), ework(ctx, mmax);
             static const bool implicit_p = !(getenv("MH_IMPLICIT_P") && atoi(getenv("MH_IMPLICIT_P")) == 0);
             DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), H2(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
@@ -737,7 +767,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             uint32_t wp = 0; // width of P
             uint32_t iters = 0, nconv = 0;
             std::vector<double> rn(b), mn(b), xn(b);
-            DevArray<double> xn_d(ctx, b);
+            DevArray<double> norms_d(ctx, 3 * size_t(b));
+            std::vector<double> norms(3 * size_t(b));
             double anorm = 0;
             {
                 auto hd = sys->L2.dinv.to_host();
@@ -745,48 +776,60 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 for (double v : hd) dmin = std::min(dmin, v);
                 anorm = sys->L2.lmax / dmin; // lambda_max(A) <= lambda_max(D^-1 A) * max diag(A)
             }
-            std::vector<uint32_t> act;
+            std::vector<uint32_t> act, order(b);
+            std::vector<uint8_t> locked(b, 0); // hard locking: a converged column leaves the Rayleigh-Ritz basis for good
+            std::vector<double> theta_act(b);
+            DevArray<double> theta_act_d(ctx, b);
             bool converged = false;
             uint32_t stall_nconv = 0, stall_count = 0;
             double stall_worst = 1e300;
             for (uint32_t it = 0; it <= max_iters; ++it) {
                 if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
                 theta_d.upload(theta.data(), b);
-                k_residual<<<grid1(n * b), TB, 0, st>>>(AX, MX, theta_d, nullptr, R, n, b, b);
-                KERNEL_CHECK();
-                colsumsq(ctx, R, n, b, rn_d, scratch);
-                colsumsq(ctx, MX, n, b, mn_d, scratch);
-                colsumsq(ctx, X, n, b, xn_d, scratch);
-                rn_d.download(rn.data(), b);
-                mn_d.download(mn.data(), b);
-                xn_d.download(xn.data(), b);
+                {
+                    const uint32_t rpb = 256, nblk = div_up(n, rpb);
+                    if (scratch.count < size_t(nblk) * 3 * b) scratch.reset(ctx, size_t(nblk) * 3 * b);
+                    dim3 grid(nblk, div_up(b, 64));
+                    k_residual_norms<<<grid, 64, 0, st>>>(AX, MX, X, theta_d, R, n, b, rpb, scratch);
+                    KERNEL_CHECK();
+                    k_colsumsq_final<<<3 * b, 256, 0, st>>>(scratch, nblk, 3 * b, norms_d); // partial rows are 3b wide
+                    KERNEL_CHECK();
+                    norms_d.download(norms.data(), 3 * size_t(b));
+                    std::copy(norms.begin(), norms.begin() + b, rn.begin());
+                    std::copy(norms.begin() + b, norms.begin() + 2 * b, mn.begin());
+                    std::copy(norms.begin() + 2 * b, norms.end(), xn.begin());
+                }
                 act.clear();
-                nconv = 0;
                 for (uint32_t i = 0; i < b; ++i) {
                     // Converged: relative residual below tol, or at the rounding floor of forming A x (which is what
                     // limits the rigid-body pairs: theta = |sigma| sits 10-12 orders below ||A||).
                     const double rel = std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]));
                     const bool ok = rel < residual_tol || std::sqrt(rn[i]) < 50 * 2.2e-16 * anorm * std::sqrt(xn[i]);
-                    if (!ok) act.push_back(i);
-                    if (ok && i < nev) ++nconv;
+                    if (ok) locked[i] = 1;
+                    if (!locked[i]) act.push_back(i);
                 }
+                // the nev smallest Ritz values must all belong to converged columns
+                std::iota(order.begin(), order.end(), 0u);
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return theta[a] < theta[c]; });
+                nconv = 0;
+                for (uint32_t k = 0; k < nev; ++k) nconv += locked[order[k]];
                 if (progress) *progress = 0.3f + 0.65f * float(nconv) / float(nev);
                 static const bool verbose = getenv("MH_VERBOSE") != nullptr;
                 if (verbose) {
                     double worst = 0;
-                    for (uint32_t i = 0; i < nev; ++i) worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
+                    for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
                     fprintf(stderr, "[lobpcg] it %3u conv %3u/%u active %zu wp %u worst %.2e  floor-ratio[0..7]:", it, nconv, nev, act.size(), wp, worst);
                     for (uint32_t i = 0; i < std::min(8u, b); ++i) fprintf(stderr, " %.1f", std::sqrt(rn[i]) / (2.2e-16 * anorm * std::sqrt(xn[i])));
                     fprintf(stderr, "  theta0 %.6e\n", theta[0]);
                 }
                 iters = it;
-                if (nconv >= nev) { converged = true; break; }
+                if (nconv >= nev || act.empty()) { converged = nconv >= nev; break; }
                 if (it == max_iters) break;
                 // Safety net of the single-precision smoothers: no newly converged pair and no 20 % drop of the worst
                 // residual for 6 iterations in a row switches the cycle to double precision for the rest of the solve.
                 {
                     double worst = 0;
-                    for (uint32_t i = 0; i < nev; ++i) worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
+                    for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
                     if (nconv > stall_nconv || worst < 0.8 * stall_worst) {
                         stall_nconv = nconv;
                         stall_worst = worst;
@@ -801,7 +844,13 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 const uint32_t w = uint32_t(act.size());
                 idx_d.upload(act.data(), w);
                 k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
+                // the active Ritz vectors as contiguous panels (the Rayleigh-Ritz basis is [X_active W P])
+                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(X, idx_d, XA, n, b, w);
+                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(AX, idx_d, AXA, n, b, w);
+                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(MX, idx_d, MXA, n, b, w);
                 KERNEL_CHECK();
+                for (uint32_t k = 0; k < w; ++k) theta_act[k] = theta[act[k]];
+                theta_act_d.upload(theta_act.data(), w);
                 {
                     Timer tp(ctx);
                     if (prec32) prec32->apply(Rw, W, w);
@@ -826,32 +875,35 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 }
                 if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
                 mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
-                // Gram matrices of S = [X W P] (lower triangles), X block known: diag(theta) and I
-                uint32_t m = b + w + wp;
+                // Gram matrices of S = [X_active W P] (lower triangles), X block known: diag(theta) and I.  Locked columns are
+                // not part of the basis any more (W was projected against them above): the small problem has order
+                // 2w + wp instead of b + w + wp.
+                const uint32_t wa = w;
+                uint32_t m = wa + w + wp;
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     HIP_CHECK(hipMemsetAsync(gA, 0, size_t(m) * m * sizeof(double), st));
                     HIP_CHECK(hipMemsetAsync(gM, 0, size_t(m) * m * sizeof(double), st));
-                    k_set_identity_blocks<<<grid1(b), TB, 0, st>>>(gA, gM, theta_d, b, m);
+                    k_set_identity_blocks<<<grid1(wa), TB, 0, st>>>(gA, gM, theta_act_d, wa, m);
                     KERNEL_CHECK();
-                    gram(ctx, n, W, w, AX, b, gA.get() + b, m);
-                    gram(ctx, n, W, w, MX, b, gM.get() + b, m);
-                    gram(ctx, n, W, w, AW, w, gA.get() + size_t(b) * m + b, m);
-                    gram(ctx, n, W, w, MW, w, gM.get() + size_t(b) * m + b, m);
+                    gram(ctx, n, W, w, AXA, wa, gA.get() + wa, m);
+                    gram(ctx, n, W, w, MXA, wa, gM.get() + wa, m);
+                    gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
+                    gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
                     if (wp) {
-                        gram(ctx, n, P, wp, AW, w, gA.get() + size_t(b) * m + b + w, m);
-                        gram(ctx, n, P, wp, MW, w, gM.get() + size_t(b) * m + b + w, m);
+                        gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m);
+                        gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
                         if (implicit_p) {
                             // P = S_prev Cp with Cp gM-orthonormal and gM-orthogonal to the Ritz coefficients Cx, and
                             // gA Cx = gM Cx Theta: hence P^T M P = I, P^T M X = P^T A X = 0 and P^T A P = Cp^T gA_prev Cp
                             // (formed last iteration from the small matrices) -- four tall Gram products saved.
-                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gA.get() + size_t(b + w) * m + b + w, m, App, wp);
-                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(b + w) * m + b + w, m, nullptr, wp);
+                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gA.get() + size_t(wa + w) * m + wa + w, m, App, wp);
+                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(wa + w) * m + wa + w, m, nullptr, wp);
                             KERNEL_CHECK();
                         } else {
-                            gram(ctx, n, P, wp, AX, b, gA.get() + b + w, m);
-                            gram(ctx, n, P, wp, MX, b, gM.get() + b + w, m);
-                            gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(b + w) * m + b + w, m);
-                            gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(b + w) * m + b + w, m);
+                            gram(ctx, n, P, wp, AXA, wa, gA.get() + wa + w, m);
+                            gram(ctx, n, P, wp, MXA, wa, gM.get() + wa + w, m);
+                            gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(wa + w) * m + wa + w, m);
+                            gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(wa + w) * m + wa + w, m);
                         }
                     }
                     k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, st>>>(gA, m, m);
@@ -862,18 +914,19 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     if (hinfo == 0) break;
                     if (attempt == 1 || wp == 0) mh_throw(MH_ENOTCONVERGED, "Rayleigh-Ritz failed at iteration %u (info %d)", it, hinfo);
                     wp = 0; // drop the previous directions and retry on [X W]
-                    m = b + w;
+                    m = wa + w;
                 }
-                evals.download(theta.data(), b);
+                evals.download(theta_act.data(), wa); // ascending Ritz values into the (ascending) active slots
+                for (uint32_t k = 0; k < wa; ++k) theta[act[k]] = theta_act[k];
                 // New directions in coefficient space: the [W P] part of the active Ritz vectors, made
                 // gM-orthonormal against the new X coefficients and among themselves.
                 const double one = 1, zero = 0, mone = -1;
                 uint32_t wp_new = w;
-                k_build_cp<<<grid1(size_t(m) * w), TB, 0, st>>>(gA, idx_d, b, m, w, m, Cp, m);
+                k_build_cp<<<grid1(size_t(m) * w), TB, 0, st>>>(gA, nullptr, wa, m, w, m, Cp, m);
                 KERNEL_CHECK();
                 ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, b, w, m, &one, gA, m, T1, m, &zero, H, b));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, b, &mone, gA, m, H, b, &one, Cp, m));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, T1, m, &zero, H, wa));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, wa, &mone, gA, m, H, wa, &one, Cp, m));
                 ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
                 ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, T1, m, &zero, G, w));
                 k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
@@ -899,22 +952,27 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
                 }
                 // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
-                mh_pack_coefficients(ctx, gA, b, Cp, wp_new, m, m, Ct);
-                mh_combine(ctx, n, X, b, W, w, P, wp, Ct, b + wp_new, Xn, b, Pn);
-                mh_combine(ctx, n, AX, b, AW, w, AP, wp, Ct, b + wp_new, AXn, b, APn);
-                mh_combine(ctx, n, MX, b, MW, w, MP, wp, Ct, b + wp_new, MXn, b, MPn);
-                std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
+                mh_pack_coefficients(ctx, gA, wa, Cp, wp_new, m, m, Ct);
+                mh_combine(ctx, n, XA, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn);
+                mh_combine(ctx, n, AXA, wa, AW, w, AP, wp, Ct, wa + wp_new, AXn, wa, APn);
+                mh_combine(ctx, n, MXA, wa, MW, w, MP, wp, Ct, wa + wp_new, MXn, wa, MPn);
+                k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
+                k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
+                k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
+                KERNEL_CHECK();
                 std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
                 wp = wp_new;
             }
             prof.restarts = iters;
             prof.op_solve = precond_seconds;
             if (!converged) mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged in %u iterations", nconv, nev, iters);
-            for (uint32_t i = 0; i < nev; ++i) eigenvalues[i] = theta[i] + sigma;
+            for (uint32_t k = 0; k < nev; ++k) eigenvalues[k] = theta[order[k]] + sigma;
             sys->evecs.reset(ctx, n * nev);
             sys->evec_cols = nev;
-            k_copy_cols<<<grid1(n * nev), TB, 0, st>>>(X, b, sys->evecs, nev, n, nev);
+            idx_d.upload(order.data(), nev);
+            k_gather_cols<<<grid1(n * nev), TB, 0, st>>>(X, idx_d, sys->evecs, n, b, nev);
             KERNEL_CHECK();
+            HIP_CHECK(hipStreamSynchronize(st));
             prof.iterate = t_iter.stop();
             sys->profile = prof;
             if (profile) *profile = prof;
