@@ -781,8 +781,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             std::vector<double> theta_act(b);
             DevArray<double> theta_act_d(ctx, b);
             bool converged = false;
-            uint32_t stall_nconv = 0, stall_count = 0;
-            double stall_worst = 1e300;
+            std::vector<double> hist_worst;
+            std::vector<uint32_t> hist_nconv;
             for (uint32_t it = 0; it <= max_iters; ++it) {
                 if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
                 theta_d.upload(theta.data(), b);
@@ -826,19 +826,19 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 if (nconv >= nev || act.empty()) { converged = nconv >= nev; break; }
                 if (it == max_iters) break;
                 // Safety net of the single-precision smoothers: no newly converged pair and no 20 % drop of the worst
-                // residual for 6 iterations in a row switches the cycle to double precision for the rest of the solve.
+                // residual over 6 iterations switches the cycle to double precision for the rest of the solve.
                 {
                     double worst = 0;
                     for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
-                    if (nconv > stall_nconv || worst < 0.8 * stall_worst) {
-                        stall_nconv = nconv;
-                        stall_worst = worst;
-                        stall_count = 0;
-                    } else if (++stall_count >= 6 && prec32) {
+                    hist_worst.push_back(worst);
+                    hist_nconv.push_back(nconv);
+                    const size_t h = hist_worst.size();
+                    // against the state six iterations ago (the first iterations are not monotone: the residuals of a
+                    // random block first rise)
+                    if (prec32 && it >= 10 && h > 6 && hist_nconv[h - 7] == nconv && worst > 0.5 * hist_worst[h - 7]) {
                         if (verbose) fprintf(stderr, "[lobpcg] it %3u stagnation: switching the preconditioner to double precision\n", it);
                         prec32.reset();
                         prec64 = std::make_unique<Precond<double>>(sys, b);
-                        stall_count = 0;
                     }
                 }
                 const uint32_t w = uint32_t(act.size());
