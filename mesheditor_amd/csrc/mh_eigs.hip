@@ -671,7 +671,10 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         prof.stiffness_nonzeros = uint32_t((sys->L2.n_blocks - sys->n_nodes) / 2 * 9 + uint64_t(6) * sys->n_nodes);
         if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
         static const int guard_pct = getenv("MH_GUARD_PCT") ? atoi(getenv("MH_GUARD_PCT")) : 10;
-        uint32_t b = nev + std::max(10u, nev * guard_pct / 100);
+        // guard vectors: at least 15 (measured at S100k, nev = 65: 10 -> 23 iterations / 338 ms, 15 -> 19 / 317 ms,
+        // 31 -> 15 / 338 ms), block rounded up to whole 16-column MFMA tiles
+        uint32_t b = (nev + std::max(15u, nev * guard_pct / 100) + 15u) / 16u * 16u;
+        if (const char *e = getenv("MH_GUARD_ABS")) b = nev + uint32_t(std::max(1, atoi(e)));
         if (n <= 768 || n < size_t(5) * b) {
             Timer t(ctx);
             dense_eigs(sys, nev, sigma, eigenvalues);
