@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -129,6 +130,10 @@ template<typename T> struct DevArray {
         ctx = c;
         count = n;
         ptr = n ? static_cast<T *>(c->pool.alloc(n * sizeof(T))) : nullptr;
+        // MH_POISON=1 (test mode): every fresh array starts as all-ones bits (NaN for floating point), so a read of
+        // memory the code never wrote shows up as a wrong result instead of depending on what the pool handed back
+        static const bool poison = getenv("MH_POISON") && atoi(getenv("MH_POISON")) != 0;
+        if (poison && ptr) (void)hipMemsetAsync(ptr, 0xff, n * sizeof(T), c->stream);
     }
     void free() {
         if (ptr && ctx) ctx->pool.release(ptr);
@@ -230,6 +235,7 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
 // [X | W | P] * Ct -> out1 (first n1 columns), out2 (the rest); Ct row-major m x nc.  mh_dense.hip
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
                 double *out1, uint32_t n1, double *out2, bool accumulate = false);
+void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices);
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip

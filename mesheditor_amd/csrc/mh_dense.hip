@@ -179,14 +179,18 @@ __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int w
 // directions from the same basis) and reads the basis once.  A workgroup owns 64 rows (16 per wave) and all nc <= 256
 // output columns; the basis rows and the matching coefficient rows are staged through LDS in K-chunks of 32 and
 // multiplied with v_mfma_f64_16x16x4_f64.  Bound: 2 n m nc flops on fp64 MFMA vs 8 n (m + nc) bytes of HBM.
-constexpr int CK = 32; // K chunk
+constexpr int CK = 16; // K chunk (32 measured slower: 475 vs 427 us at 75 + 75 -> 75)
 template<int NT, bool ACCUMULATE> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =
 __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, const double *__restrict__ W, int ww, const double *__restrict__ P, int wp,
                                                 const double *__restrict__ Ct, int ldc, int c0, int nc, size_t n, double *__restrict__ out1, int n1,
-                                                double *__restrict__ out2) {
-    // this launch owns output columns c0 .. c0 + nc of the ldc the coefficient matrix has
+                                                double *__restrict__ out2, size_t split_stride) {
+    // this launch owns output columns c0 .. c0 + nc of the ldc the coefficient matrix has; with gridDim.y > 1 the K range
+    // is cut into gridDim.y slices and slice s writes its partial product to out1 + s * split_stride
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = wx + ww + wp;
+    const int kslice = (((m + int(gridDim.y) - 1) / int(gridDim.y)) + CK - 1) / CK * CK;
+    const int kb = int(blockIdx.y) * kslice, ke = min(m, kb + kslice);
+    if (gridDim.y > 1) out1 += size_t(blockIdx.y) * split_stride;
     constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16; // = 16 (mod 32): conflict-free B reads
     constexpr int SP = CK + 2; // A-tile pitch: rows 2 doubles apart mod 32 -> conflict-free ds_read_b64
     double *Ss = smem; // 64 rows x SP
@@ -222,19 +226,19 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
     };
     auto commit = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < SJ; ++j) Ss[srow * SP + sk + j] = (row_ok && k0 + sk + j < m) ? ps[j] : 0.0;
+        for (int j = 0; j < SJ; ++j) Ss[srow * SP + sk + j] = (row_ok && k0 + sk + j < ke) ? ps[j] : 0.0;
 #pragma unroll
         for (int q = 0; q < CPASS; ++q) {
-            const bool kok = k0 + ck + 16 * q < m;
+            const bool kok = k0 + ck + 16 * q < ke;
 #pragma unroll
             for (int t = 0; t < NT; ++t) Cs[(ck + 16 * q) * CP + cc + 16 * t] = (kok && cc + 16 * t < nc) ? pc[q][t] : 0.0;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < m; k0 += CK) {
+    fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += CK) {
         commit(k0);
         __syncthreads();
-        if (k0 + CK < m) fetch(k0 + CK); // in flight under the MFMAs
+        if (k0 + CK < ke) fetch(k0 + CK); // in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < CK; kk += 4) {
@@ -357,8 +361,8 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
             constexpr int NT = decltype(nt_tag)::value;
             constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
             const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
-            if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2);
-            else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2);
+            if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2, 0);
+            else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2, 0);
         };
         const int ntile = int((ncc + 15) / 16);
         switch ((ntile + 1) / 2) { // the kernel computes all NT column strips: pick the smallest even NT that covers the chunk
@@ -371,6 +375,48 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
             case 7: go(std::integral_constant<int, 14>{}); break;
             default: go(std::integral_constant<int, 16>{}); break;
         }
+        KERNEL_CHECK();
+    }
+}
+
+namespace {
+__global__ void k_sum_slices(const double *__restrict__ partial, int slices, size_t count, double *__restrict__ out) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0;
+    for (int q = 0; q < slices; ++q) s += partial[size_t(q) * count + i]; // fixed order
+    out[i] = s;
+}
+} // namespace
+
+// out (n x nc, row-major) = A (n x m, row-major) * Ct (m x nc, row-major) for a SHORT A (n of a few thousand rows, m
+// comparable): the rows alone give too few workgroups, so the K range is cut into `slices` and the partial products
+// are added in a fixed order.  Used for the coarse solve x0 = A0^-1 r0 of the preconditioner (n = m = 6 * aggregates).
+void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices) {
+    if (!nc || !n) return;
+    if (nc > 256) mh_throw(MH_EINVAL, "short product: %u columns exceed 256", nc);
+    const dim3 grid(div_up(n, 64), slices);
+    const size_t stride = n * nc;
+    auto go = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
+        const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
+        k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(a, int(m), nullptr, 0, nullptr, 0, ct, int(nc), 0, int(nc), n, slices > 1 ? partial : out, int(nc), nullptr, stride);
+    };
+    const int ntile = int((nc + 15) / 16);
+    switch ((ntile + 1) / 2) {
+        case 1: go(std::integral_constant<int, 2>{}); break;
+        case 2: go(std::integral_constant<int, 4>{}); break;
+        case 3: go(std::integral_constant<int, 6>{}); break;
+        case 4: go(std::integral_constant<int, 8>{}); break;
+        case 5: go(std::integral_constant<int, 10>{}); break;
+        case 6: go(std::integral_constant<int, 12>{}); break;
+        case 7: go(std::integral_constant<int, 14>{}); break;
+        default: go(std::integral_constant<int, 16>{}); break;
+    }
+    KERNEL_CHECK();
+    if (slices > 1) {
+        k_sum_slices<<<div_up(stride, 256), 256, 0, ctx->stream>>>(partial, int(slices), stride, out);
         KERNEL_CHECK();
     }
 }

@@ -453,7 +453,9 @@ template<typename T> struct Precond {
     int deg2{2}, deg1{3}, gamma{3};
     double ratio{8.0};
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
-    DevArray<double> r0, x0;
+    DevArray<double> r0, x0, x0_partial;
+    static constexpr uint32_t COARSE_SLICES = 8;
+    bool coarse_mfma{true};
     DevArray<double> rin64, t2d, r1d, t1d; // single-precision smoothers: the residuals handed down a level stay double
     static constexpr bool kDouble = std::is_same<T, double>::value;
     static uint32_t pitch(uint32_t w) { return kDouble ? w : (w + 3u) & ~3u; } // 16-byte panel rows for the wide-load SpMM
@@ -469,6 +471,8 @@ template<typename T> struct Precond {
         r1.reset(ctx, n1 * w); x1.reset(ctx, n1 * w); d1.reset(ctx, n1 * w); t1.reset(ctx, n1 * w); rr1.reset(ctx, n1 * w);
         r0.reset(ctx, n0 * w);
         x0.reset(ctx, n0 * w);
+        x0_partial.reset(ctx, n0 * w * COARSE_SLICES);
+        if (const char *e = getenv("MH_COARSE_ROCBLAS")) coarse_mfma = atoi(e) == 0;
         if (const char *e = getenv("MH_DEG2")) deg2 = std::max(1, atoi(e));
         if (const char *e = getenv("MH_DEG1")) deg1 = std::max(1, atoi(e));
         if (const char *e = getenv("MH_GAMMA")) gamma = std::max(1, atoi(e));
@@ -546,7 +550,8 @@ template<typename T> struct Precond {
             }
             KERNEL_CHECK();
             // r0 is (6 na) x w row-major = w x (6 na) column-major: x0 = r0 * A0^-1 (A0^-1 symmetric, explicit)
-            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, rocblas_int(n0), rocblas_int(n0), &one, r0, w, sys->a0, rocblas_int(n0), &zero, x0, w));
+            if (coarse_mfma) mh_short_product(ctx, n0, sys->a0, uint32_t(n0), r0, w, x0, x0_partial, COARSE_SLICES);
+            else ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, rocblas_int(n0), rocblas_int(n0), &one, r0, w, sys->a0, rocblas_int(n0), &zero, x0, w));
             k_prolong_agg<T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(x0, sys->agg_t, x1.get(), np, sys->agg_size, na, w);
             KERNEL_CHECK();
             cheb(sys->L1, deg1, r1, x1, false, rr1, d1, t1, w);
@@ -722,8 +727,10 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 KERNEL_CHECK();
                 HIP_CHECK(hipStreamSynchronize(st));
             }
-            if (!warm && b >= 12) {
-                // A free body's six rigid-body modes are exact eigenvectors (lambda = 0): start from them.
+            if (b >= 12) {
+                // A free body's six rigid-body modes are exact eigenvectors (lambda = 0): start from them -- also on a warm
+                // start, where they replace the six seeded (single-precision) copies: a rigid mode known only to 1e-7
+                // leaves A x = |sigma| M x as the difference of terms 12 orders larger, and its Ritz value is then noise.
                 auto hx = sys->node_xyz.to_host();
                 double c[3] = {0, 0, 0};
                 for (uint32_t i = 0; i < sys->n_nodes; ++i)
@@ -959,6 +966,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 mh_combine(ctx, n, XA, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn);
                 mh_combine(ctx, n, AXA, wa, AW, w, AP, wp, Ct, wa + wp_new, AXn, wa, APn);
                 mh_combine(ctx, n, MXA, wa, MW, w, MP, wp, Ct, wa + wp_new, MXn, wa, MPn);
+                if ((it + 1) % 8 == 0) {
+                    // every eighth iteration the images of the new Ritz vectors are recomputed from the vectors instead of
+                    // recombined: A X and M X otherwise inherit eight generations of rounding from the updates
+                    mh_spmm(ctx, sys->L2, sys->L2.aval, Xn, AXn, sys->L2.mval, MXn, wa);
+                }
                 k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
                 k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
                 k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
