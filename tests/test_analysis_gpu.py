@@ -303,3 +303,40 @@ def test_solve_is_bit_reproducible(api, ctx):
     assert runs[0][2] == runs[1][2]
     assert np.array_equal(runs[0][0], runs[1][0])
     assert np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_results_do_not_depend_on_recycled_device_memory(api, ctx):
+    """MH_POISON=1 makes every array taken from the device pool start as NaN bit patterns: a solve and a bank block in
+    that mode (a fresh process, the switch is read once) must reproduce the normal run bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import json, numpy as np\n"
+        "from mesheditor_amd import api, meshes, bank as hipbank\n"
+        "from tests import bank_harness as bh\n"
+        "ctx = api.Context(0)\n"
+        "out = {}\n"
+        "for rep in range(2):\n"  # the second pass runs on recycled blocks
+        "    pts, tets, m, kw = meshes.workload('cube_s10k')\n"
+        "    mesh = api.Mesh(ctx, pts, tets)\n"
+        "    s = api.System(ctx, mesh, api.material(*m))\n"
+        "    ev, prof = s.eigs(40, -(2 * np.pi * 20.0) ** 2, 1e-6)\n"
+        "    out['ev%d' % rep] = [float(v).hex() for v in ev]\n"
+        "    s.close(); mesh.close()\n"
+        "sc = bh.DeviceScene(8, 64, 0.5, 2)\n"
+        "class O:  # the event type of the harness without the oracle\n"
+        "    Event = lambda *a: hipbank.Event(*a)\n"
+        "for o in sc.objects: sc.enqueue(bh.impact_event(O, o, 1.0))\n"
+        "out['sig'] = [float(v).hex() for v in sc.render(2, bh.BLOCK)]\n"
+        "print(json.dumps(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for poison in ("0", "1"):
+        env = dict(os.environ, MH_POISON=poison, PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert runs[0]["ev0"] == runs[0]["ev1"] == runs[1]["ev0"] == runs[1]["ev1"]
+    assert runs[0]["sig"] == runs[1]["sig"] and any(float.fromhex(v) != 0 for v in runs[0]["sig"])
