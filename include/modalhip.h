@@ -95,7 +95,7 @@ int mh_system_element_nodes(const mh_system *, uint32_t *out_kept_tets_x10);
 /* Every stored node block as (row node, col node, 9 row-major K entries, M scalar), reference numbering, full
  * (both triangles).  Arrays sized by mh_system_dims' node_blocks. */
 int mh_system_export_blocks(const mh_system *, uint32_t *row_node, uint32_t *col_node, double *k_blocks, double *m_blocks);
-/* y = K x (which = 0) or M x (which = 1) for `width` vectors, x and y column-major n x width in the reference's
+/* y = K x (which = 0), M x (which = 1) or (K - sigma M) x at the reference's shift (which = 2) for `width` vectors, x and y column-major n x width in the reference's
  * DOF order (3*node + component).  The SpMM kernel of the eigensolver, exposed for parity and roofline measurement. */
 int mh_system_matvec(mh_system *, int which, const double *x, double *y, uint32_t width);
 

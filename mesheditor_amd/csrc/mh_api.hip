@@ -235,7 +235,12 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
         k_ref_to_panel<<<div_up(n * width, TB), TB, 0, ctx->stream>>>(xr, s->perm, s->n_nodes, width, xp);
         KERNEL_CHECK();
         if (which == 0) mh_spmm(ctx, s->L2, s->L2.kval, xp, yp, nullptr, nullptr, width);
-        else mh_spmm(ctx, s->L2, nullptr, xp, nullptr, s->L2.mval, yp, width);
+        else if (which == 1) mh_spmm(ctx, s->L2, nullptr, xp, nullptr, s->L2.mval, yp, width);
+        else { // which == 2: the shifted operator A = K - sigma M of the eigensolver at the reference's shift
+            std::lock_guard<std::mutex> lock(mh_solve_mutex());
+            mh_build_hierarchy(s, -15791.367041742974);
+            mh_spmm(ctx, s->L2, s->L2.aval, xp, yp, nullptr, nullptr, width);
+        }
         k_panel_to_ref<double><<<div_up(n * width, TB), TB, 0, ctx->stream>>>(yp, s->perm, s->n_nodes, width, width, xr.get());
         KERNEL_CHECK();
         xr.download(y, n * width);

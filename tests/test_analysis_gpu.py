@@ -80,6 +80,10 @@ def test_spmm_matches_oracle(api, ctx, oracle):
             y = sysg.matvec(which, x)
             ref = np.stack([syso.matvec(which, x[:, j]) for j in range(width)], 1)
             assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max() * 10
+        # the shifted operator the eigensolver multiplies with
+        a = sysg.matvec(2, x)
+        ref = sysg.matvec(0, x) - SIGMA * sysg.matvec(1, x)
+        assert np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max(), (width, np.abs(a - ref).max() / np.abs(ref).max())
 
 
 @pytest.mark.parametrize("name,nev", [("cube_small", 45), ("bar_square", 45), ("bar_thin", 30)])
