@@ -180,9 +180,10 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
                         TY v[9];
 #pragma unroll
                         for (int e = 0; e < 9; ++e) v[e] = ok ? TY(svw[bi[u] * VP + e]) : TY(0);
-                        acc[0] += v[0] * x0 + v[1] * x1 + v[2] * x2;
-                        acc[1] += v[3] * x0 + v[4] * x1 + v[5] * x2;
-                        acc[2] += v[6] * x0 + v[7] * x1 + v[8] * x2;
+                        // one fused multiply-add per term (a sum of three products first costs a fourth instruction)
+                        acc[0] += v[0] * x0; acc[0] += v[1] * x1; acc[0] += v[2] * x2;
+                        acc[1] += v[3] * x0; acc[1] += v[4] * x1; acc[1] += v[5] * x2;
+                        acc[2] += v[6] * x0; acc[2] += v[7] * x1; acc[2] += v[8] * x2;
                     }
                     if (WITH_M) {
                         const TY m = ok ? TY(smw[bi[u]]) : TY(0);
