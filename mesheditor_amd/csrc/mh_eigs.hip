@@ -422,9 +422,23 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
     }
-    ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
-    info.download(&hinfo, 1);
-    if (hinfo != 0) return hinfo;
+    static const bool own_sytrd = !(getenv("MH_RR_SYEVD") && atoi(getenv("MH_RR_SYEVD")) != 0);
+    if (own_sytrd && m >= 8 && m <= 256) {
+        // syevd by parts: the tridiagonalisation (70 % of rocSOLVER's syevd at this order) in one workgroup of ours, then
+        // rocSOLVER's divide and conquer on T and the back-transformation Z <- Q Z
+        DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
+        mh_sytrd_small(ctx, gA, m, evals, ework, tau); // gA is fully symmetric here (k_symmetrize_lower above / the reduction)
+        ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
+        info.download(&hinfo, 1);
+        if (hinfo != 0) return hinfo;
+        ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, m, gA, m, tau, z, m));
+        HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } else {
+        ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
+        info.download(&hinfo, 1);
+        if (hinfo != 0) return hinfo;
+    }
     solver_lock.unlock();
     if (!identity)
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));

@@ -1,5 +1,6 @@
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_stats.csv'))[-1]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 tot = sum(int(r['TotalDurationNs']) for r in rows)
 print("total kernel ms %.1f" % (tot / 1e6))
