@@ -438,86 +438,92 @@ void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const doubl
 // storage convention on output: D, E, tau and the reflector tails below the subdiagonal of A, as rocsolver_dormtr
 // expects).  rocSOLVER's sytrd spends 3.5 ms of a 5.0 ms syevd at m = 222 in ~170 tiny launches; here the 400 KB matrix
 // stays in L2 and the 1 024 threads of one workgroup sweep it three times per column (matvec, rank-2 update), with the
-// small vectors in LDS: 1.25 ms at m = 222, bound by the ~9 barriers and three dependent sweeps of each of the m steps
-// (running the last 128 columns out of an LDS image changed nothing).  The full symmetric matrix is kept up to date (both triangles), so every pass is column-major
+// small vectors in LDS.  Bound by the barriers and the dependent sweeps of each of the m steps (running the last 128
+// columns out of an LDS image changed nothing): the reflector scalars and the two dot products are therefore computed
+// redundantly by every wave from LDS -- six barriers per step, no serial section.  The full symmetric matrix is kept up to date (both triangles), so every pass is column-major
 // coalesced.  All reductions run in a fixed order: bit-reproducible.
 namespace {
-__device__ inline double block_sum_256(double val, double *red, int tid) { // sum over threads 0..255 (others pass 0), fixed tree
-    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
-    if (tid < 256 && (tid & 63) == 0) red[tid >> 6] = val;
-    __syncthreads();
-    const double total = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    return total;
+// Sum of buf[0 .. count) computed by every wave for itself (count <= 256, fixed order): no barrier, no broadcast.
+__device__ inline double wave_sum_lds(const double *buf, int count, int lane) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        s += i < count ? buf[i] : 0.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
 }
 
 __global__ void __launch_bounds__(1024) k_sytrd_small(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
-    __shared__ double v[256], wv[256], part[1024], red[4];
-    __shared__ double s_tau, s_scale, s_beta;
-    const int tid = threadIdx.x;
-    double *const M = A;
-    const int ld = m, base = 0;
+    // per step: x (raw column), v (reflector), w, squares / products for the wave-local reductions, matvec partials
+    __shared__ double xs[256], v[256], wv[256], sq[256], part[1024];
+    const int tid = threadIdx.x, lane = tid & 63;
     for (int k = 0; k + 1 < m; ++k) {
         const int l = m - k - 1; // order of the trailing block, rows/cols k+1 .. m-1
         // thread map of the two sweeps: RB row slots (power of two >= l) x NG column groups, all 1 024 threads busy
         int rb = 32;
         while (rb < l) rb <<= 1;
         const int ng = 1024 / rb, rr = tid & (rb - 1), cq = tid / rb;
-        double *col = M + size_t(k - base) * ld + (k + 1 - base);
-        double *gcol = A + size_t(k) * m + (k + 1); // the reflector also goes to the global matrix (for ormtr)
-        if (tid < l) v[tid] = col[tid];
-        __syncthreads();
-        const double tail = (tid >= 1 && tid < l) ? v[tid] * v[tid] : 0.0;
-        const double xnorm2 = block_sum_256(tid < 256 ? tail : 0.0, red, tid);
+        double *col = A + size_t(k) * m + (k + 1);
+        if (tid < l) {
+            const double x = col[tid];
+            xs[tid] = x;
+            sq[tid] = tid >= 1 ? x * x : 0.0;
+        }
+        __syncthreads(); // (1) column published
+        // every thread derives the reflector scalars itself: no serial section, no broadcast
+        const double xnorm2 = wave_sum_lds(sq, l, lane);
+        const double alpha = xs[0];
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (xnorm2 > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
         if (tid == 0) {
-            const double alpha = v[0];
-            double tau = 0.0, beta = alpha, scale = 0.0;
-            if (xnorm2 > 0.0) {
-                beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-                tau = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
-            s_tau = tau; s_scale = scale; s_beta = beta;
-            D[k] = M[size_t(k - base) * ld + (k - base)];
+            D[k] = A[size_t(k) * m + k];
             E[k] = beta;
             TAU[k] = tau;
         }
-        __syncthreads();
-        const double tau = s_tau;
-        if (tau == 0.0) continue; // H = I (uniform)
-        if (tid < l) {
-            const double vi = tid == 0 ? 1.0 : v[tid] * s_scale;
-            v[tid] = vi;
-            gcol[tid] = tid == 0 ? s_beta : vi; // subdiagonal entry, then the reflector tail
+        if (tau == 0.0) { // H = I (uniform: every thread computed the same bits)
+            __syncthreads();
+            continue;
         }
-        __syncthreads();
+        if (tid < l) {
+            const double vi = tid == 0 ? 1.0 : xs[tid] * scale;
+            v[tid] = vi;
+            col[tid] = tid == 0 ? beta : vi; // subdiagonal entry, then the reflector tail
+        }
+        __syncthreads(); // (2) reflector published
         // p = tau * A22 v: each column group sums its columns, the groups are added in order
-        double *a22 = M + size_t(k + 1 - base) * ld + (k + 1 - base);
+        double *a22 = A + size_t(k + 1) * m + (k + 1);
         double acc = 0.0;
         if (rr < l)
-            for (int c = cq; c < l; c += ng) acc += a22[size_t(c) * ld + rr] * v[c];
+            for (int c = cq; c < l; c += ng) acc += a22[size_t(c) * m + rr] * v[c];
         part[cq * rb + rr] = acc;
-        __syncthreads();
+        __syncthreads(); // (3) partial products published
         double p = 0.0;
         if (tid < l) {
             double sum = 0.0;
             for (int g = 0; g < ng; ++g) sum += part[g * rb + tid];
             p = tau * sum;
-            wv[tid] = p;
+            sq[tid] = p * v[tid];
         }
-        const double pv = block_sum_256(tid < l ? p * v[tid] : 0.0, red, tid);
+        __syncthreads(); // (4) p . v terms published
+        const double pv = wave_sum_lds(sq, l, lane);
         if (tid < l) wv[tid] = p - 0.5 * tau * pv * v[tid];
-        __syncthreads();
+        __syncthreads(); // (5) w published
         // A22 -= v w^T + w v^T
         if (rr < l) {
             const double vr = v[rr], wr = wv[rr];
             double *arow = a22 + rr;
-            for (int c = cq; c < l; c += ng) arow[size_t(c) * ld] -= vr * wv[c] + wr * v[c];
+            for (int c = cq; c < l; c += ng) arow[size_t(c) * m] -= vr * wv[c] + wr * v[c];
         }
-        __syncthreads();
+        __syncthreads(); // (6) trailing block updated
     }
     if (tid == 0) {
-        D[m - 1] = M[size_t(m - 1 - base) * ld + (m - 1 - base)];
+        D[m - 1] = A[size_t(m - 1) * m + (m - 1)];
         TAU[m - 1] = 0.0;
     }
 }
