@@ -344,3 +344,25 @@ def test_results_do_not_depend_on_recycled_device_memory(api, ctx):
         runs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert runs[0]["ev0"] == runs[0]["ev1"] == runs[1]["ev0"] == runs[1]["ev1"]
     assert runs[0]["sig"] == runs[1]["sig"] and any(float.fromhex(v) != 0 for v in runs[0]["sig"])
+
+
+def test_batch_of_meshes_through_the_sharding_path(api, ctx):
+    """BASELINE configs[3] in miniature on one rank: jittered boxes of the batch family, dealt, solved, packed into
+    fixed-size records and unpacked; each record equals the direct solve of that mesh."""
+    from mesheditor_amd import sharding
+    batch = []
+    for i in range(3):
+        p, t = meshes.jittered_box(6, 1000 + i)
+        batch.append((p, t, meshes.MATERIALS[meshes.MATERIAL_ORDER[i % 7]], {"num_modes": 10, "num_fem_modes": 25}))
+
+    def solve(i, m):
+        p, t, mat, kw = m
+        cfg = api.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"], max_mode_freq=1e6)
+        return api.mesh2modes(ctx, p, t, api.material(*mat), p[::20].astype(np.float32), config=cfg)
+    recs = sharding.solve_batch(batch, solve, 25)
+    assert [r["index"] for r in recs] == [0, 1, 2]
+    for i, r in enumerate(recs):
+        direct = solve(i, batch[i])
+        assert len(r["eigenvalues"]) == 25 and np.array_equal(r["eigenvalues"], direct.eigenvalues)
+        assert np.allclose(r["freqs"], direct.freqs, rtol=1e-6) and r["dofs"] == direct.profile["dofs"]
+        assert abs(r["mass"] - direct.mass) <= 1e-12 * direct.mass
