@@ -111,11 +111,11 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
 // The panel pitch w must be a multiple of V (16-byte rows).
 // TV = matrix values, TX = panel read, TY = accumulators and panel written (TV = TY = double with TX = float gives the
 // double-precision residual of a single-precision iterate at single-precision gather cost).
-template<typename TV, typename TX, typename TY, int CL, bool WITH_M, bool WITH_A>
+template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A>
 __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
                                                  uint32_t w, int xcd_remap) {
-    constexpr int V = 16 / sizeof(TX), G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4;
+    constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
     __shared__ __attribute__((aligned(16))) TV sv[TB / 64][WITH_A ? STRIP * VP : 1];
@@ -224,22 +224,29 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
 
 template<typename TV, typename TX, typename TY, bool WITH_M, bool WITH_A>
 bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const TV *vals9, const TX *x, TY *y, const TV *mscal, TY *y2, uint32_t w) {
-    constexpr uint32_t V = 16 / sizeof(TX);
+    constexpr uint32_t VFULL = 16 / sizeof(TX);
     static const bool legacy = getenv("MH_SPMM_LEGACY") && atoi(getenv("MH_SPMM_LEGACY")) != 0;
     constexpr bool mixed = !std::is_same<TV, TX>::value || !std::is_same<TX, TY>::value;
-    if ((legacy && !mixed) || w % V != 0 || w > 64 * V) return false;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y2)) & 15) return false;
+    if (legacy && !mixed) return false;
     static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
-    auto go = [&](auto cl_tag) {
-        constexpr int CL = decltype(cl_tag)::value;
-        k_spmm_wide<TV, TX, TY, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
+    auto run = [&](auto v_tag) {
+        constexpr int V = decltype(v_tag)::value;
+        auto go = [&](auto cl_tag) {
+            constexpr int CL = decltype(cl_tag)::value;
+            k_spmm_wide<TV, TX, TY, V, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
+        };
+        const uint32_t lanes = div_up(w, uint32_t(V));
+        if (lanes <= 8) go(std::integral_constant<int, 8>{});
+        else if (lanes <= 16) go(std::integral_constant<int, 16>{});
+        else if (lanes <= 32) go(std::integral_constant<int, 32>{});
+        else go(std::integral_constant<int, 64>{});
     };
-    const uint32_t lanes = div_up(w, V);
-    if (lanes <= 8) go(std::integral_constant<int, 8>{});
-    else if (lanes <= 16) go(std::integral_constant<int, 16>{});
-    else if (lanes <= 32) go(std::integral_constant<int, 32>{});
-    else go(std::integral_constant<int, 64>{});
+    const bool aligned16 = !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y2)) & 15);
+    if (w % VFULL == 0 && w <= 64 * VFULL && aligned16) run(std::integral_constant<int, int(VFULL)>{});
+    else if (!mixed && w <= 16) run(std::integral_constant<int, 1>{}); // narrow odd pitch (SpMV: w = 1): one entry per lane, 4-8 node blocks per
+                                                                       // wave at once: 184 us against 417 us at w = 1; above 16 columns k_spmm is faster
+    else return false;
     KERNEL_CHECK();
     return true;
 }
