@@ -95,6 +95,7 @@ struct mh_context {
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     void *gram_ws{nullptr}; // partial-Gram workspace of mh_gram, grown on demand
     size_t gram_ws_bytes{0};
+    uint32_t *iota{nullptr}; // 0, 1, 2, ... (1 024 entries): the identity column map, created on first use
     // Optional per-launch timing of the level-2 SpMM (the path's dominant kernel): HIP events on this stream around
     // every launch, resolved lazily.  Totals feed bench.py's roofline object.
     bool time_kernels{false};
@@ -231,10 +232,12 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
 void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
 // y (n x w row-major, ld = w) = A x with A given by 9-value blocks; optionally y2 = M x from the scalar blocks.
 // G (wa x wb, column-major, ld) = X^T Y for row-major panels (fp64 MFMA, deterministic two-stage reduction).  mh_dense.hip
-void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld);
+// Optional column map on Y: logical column j of Y is physical column ymap[j] of a panel of pitch ldy (0 = wb, no map).
+void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld, uint32_t ldy = 0, const uint32_t *ymap = nullptr);
 // [X | W | P] * Ct -> out1 (first n1 columns), out2 (the rest); Ct row-major m x nc.  mh_dense.hip
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
-                double *out1, uint32_t n1, double *out2, bool accumulate = false);
+                double *out1, uint32_t n1, double *out2, bool accumulate = false, uint32_t ldx = 0, const uint32_t *xmap = nullptr, uint32_t ld1 = 0,
+                const uint32_t *omap = nullptr); // optional column maps on X (read) and out1 (write), pitches ldx / ld1
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau); // mh_dense.hip: A (column-major, ld m, symmetric, full) -> D, E, tau, reflectors
 void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices);
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);

@@ -26,8 +26,8 @@ __host__ __device__ inline int pad_pitch(int w) { // smallest p >= w with p = 16
 // order at the end, so the result stays bit-reproducible.  Tile loops are unrolled at compile time and skipped with
 // scalar branches on the kernel-argument widths: no exec-mask divergence around the MFMAs.
 template<int TI, int TJ, int GI, int GJ, int KS, int OCC>
-__global__ void __launch_bounds__(GI * GJ * KS * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) k_gram_blocked(const double *__restrict__ X, int ldx, int wa, const double *__restrict__ Y, int ldy, int wb, size_t n,
-                                                                  size_t rows_per_wg, double *__restrict__ partial) {
+__global__ void __launch_bounds__(GI * GJ * KS * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) k_gram_blocked(const double *__restrict__ X, int ldx, int wa, const double *__restrict__ Y, int ldy, const uint32_t *__restrict__ ymap, int wb,
+                                                                  size_t n, size_t rows_per_wg, double *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NTH = GI * GJ * KS * 64;
     constexpr int CA = TI * GI, CB = TJ * GJ; // 16-column strips of the two panels (all staged; missing ones as zeros)
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(GI * GJ * KS * 64) __attribute__((amdgpu_waves
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
         const int col = scol + 16 * c;
-        ycol[c] = min(col, wb - 1);
+        ycol[c] = ymap ? int(ymap[min(col, wb - 1)]) : min(col, wb - 1); // optional column map: Y's logical column -> physical column
         ybits |= (col < wb ? 1u : 0u) << c;
     }
     double px[PASSES][CA], py[PASSES][CB];
@@ -180,10 +180,14 @@ __global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int w
 // output columns; the basis rows and the matching coefficient rows are staged through LDS in K-chunks of 32 and
 // multiplied with v_mfma_f64_16x16x4_f64.  Bound: 2 n m nc flops on fp64 MFMA vs 8 n (m + nc) bytes of HBM.
 constexpr int CK = 16; // K chunk (32 measured slower: 475 vs 427 us at 75 + 75 -> 75)
-template<int NT, bool ACCUMULATE> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =
-__global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, const double *__restrict__ W, int ww, const double *__restrict__ P, int wp,
+template<int NT, bool ACCUMULATE, bool MAPPED> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =; MAPPED: column maps on X / out1
+__global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, int ldx, const uint32_t *__restrict__ xmap, const double *__restrict__ W, int ww,
+                                                const double *__restrict__ P, int wp,
                                                 const double *__restrict__ Ct, int ldc, int c0, int nc, size_t n, double *__restrict__ out1, int n1,
-                                                double *__restrict__ out2, size_t split_stride) {
+                                                double *__restrict__ out2, size_t split_stride, int ld1, const uint32_t *__restrict__ omap) {
+    // X's logical column k lives at physical column xmap[k] of a panel of pitch ldx (xmap null: identity); out1's logical
+    // column c goes to physical column omap[c] of a panel of pitch ld1 (in place over X is safe: a workgroup reads all of its
+    // 64 rows before it writes them)
     // this launch owns output columns c0 .. c0 + nc of the ldc the coefficient matrix has; with gridDim.y > 1 the K range
     // is cut into gridDim.y slices and slice s writes its partial product to out1 + s * split_stride
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -195,6 +199,11 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
     constexpr int SP = CK + 2; // A-tile pitch: rows 2 doubles apart mod 32 -> conflict-free ds_read_b64
     double *Ss = smem; // 64 rows x SP
     double *Cs = smem + 64 * SP; // CK x CP (all NT column strips staged; missing ones as zeros)
+    int *xm = reinterpret_cast<int *>(Cs + CK * CP); // MAPPED: physical column of each logical X column
+    if (MAPPED) {
+        for (int k = threadIdx.x; k < wx; k += 256) xm[k] = int(xmap[k]);
+        __syncthreads();
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t r0 = size_t(blockIdx.x) * 64;
     double4_t acc[NT];
@@ -209,12 +218,12 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
     // selects), and entries outside the operands are zeroed when the registers are written to LDS.
     const size_t rs = min(r0 + srow, n - 1);
     const bool row_ok = r0 + srow < n;
-    const double *xrow = X + rs * wx, *wrow = W ? W + rs * ww : X, *prow = P ? P + rs * wp : X;
+    const double *xrow = X + rs * ldx, *wrow = W ? W + rs * ww : X, *prow = P ? P + rs * wp : X;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < SJ; ++j) {
             const int k = min(k0 + sk + j, m - 1);
-            const double *src = k < wx ? xrow + k : (k < wx + ww ? wrow + (k - wx) : prow + (k - wx - ww));
+            const double *src = k < wx ? xrow + (MAPPED ? xm[k] : k) : (k < wx + ww ? wrow + (k - wx) : prow + (k - wx - ww));
             ps[j] = *src;
         }
 #pragma unroll
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
         for (int reg = 0; reg < 4; ++reg) {
             const size_t r = r0 + wave * 16 + (lane >> 4) + 4 * reg;
             if (r >= n) continue;
-            double *dst = c < n1 ? out1 + r * n1 + c : out2 + r * (ldc - n1) + (c - n1);
+            double *dst = c < n1 ? out1 + r * ld1 + (MAPPED ? int(omap[c]) : c) : out2 + r * (ldc - n1) + (c - n1);
             *dst = ACCUMULATE ? *dst + acc[t][reg] : acc[t][reg];
         }
     }
@@ -277,7 +286,8 @@ __global__ void k_transpose_small(const double *__restrict__ c, int rows, int co
 
 namespace {
 // One Gram block: G (wa x wb at leading dimension ld) = X[:, 0:wa]^T Y[:, 0:wb] for panels of row pitch ldx, ldy.
-void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32_t wa, const double *y, uint32_t ldy, uint32_t wb, double *g, uint32_t ld) {
+void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32_t wa, const double *y, uint32_t ldy, const uint32_t *ymap, uint32_t wb, double *g,
+                uint32_t ld) {
     const int ti_n = int((wa + 15) / 16), tj_n = int((wb + 15) / 16);
     // ~2 workgroups per CU; each stages KC rows per step and owns a contiguous row range
     int nwg = int(std::min<size_t>(512, (n + KC - 1) / KC));
@@ -301,7 +311,7 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gram_blocked<TI, TJ, GI, GJ, KS, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        k_gram_blocked<TI, TJ, GI, GJ, KS, OCC><<<nwg, GI * GJ * KS * 64, bytes, ctx->stream>>>(x, int(ldx), int(wa), y, int(ldy), int(wb), n, rows_per_wg, workspace);
+        k_gram_blocked<TI, TJ, GI, GJ, KS, OCC><<<nwg, GI * GJ * KS * 64, bytes, ctx->stream>>>(x, int(ldx), int(wa), y, int(ldy), ymap, int(wb), n, rows_per_wg, workspace);
     };
 #define IC(v) std::integral_constant<int, v>{}
     if (ti_n <= 1 && tj_n <= 1) blocked(IC(1), IC(1), IC(1), IC(1), IC(4), IC(2));
@@ -325,15 +335,17 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
 
 // G (wa x wb, column-major, leading dimension ld) = X^T Y.  Blocks wider than 160 x 96 columns are cut into a grid
 // of column blocks (each a launch of the register-blocked kernel over the same rows).
-void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld) {
+void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld, uint32_t ldy, const uint32_t *ymap) {
     if (!wa || !wb) return;
+    if (!ldy) ldy = wb;
     const bool a_long = wa >= wb;
     const uint32_t cap_a = a_long ? 160 : 96, cap_b = a_long ? 96 : 160;
     const uint32_t na = div_up(wa, cap_a), nbk = div_up(wb, cap_b);
     const uint32_t step_a = (div_up(wa, na) + 15) / 16 * 16, step_b = (div_up(wb, nbk) + 15) / 16 * 16;
     for (uint32_t i0 = 0; i0 < wa; i0 += step_a)
         for (uint32_t j0 = 0; j0 < wb; j0 += step_b)
-            gram_block(ctx, n, x + i0, wa, std::min(step_a, wa - i0), y + j0, wb, std::min(step_b, wb - j0), g + size_t(j0) * ld + i0, ld);
+            gram_block(ctx, n, x + i0, wa, std::min(step_a, wa - i0), ymap ? y : y + j0, ldy, ymap ? ymap + j0 : nullptr, std::min(step_b, wb - j0),
+                       g + size_t(j0) * ld + i0, ld);
 }
 
 // Row-major (k-major) packing of two column-major coefficient blocks side by side: ct[m][n1 + n2]
@@ -348,10 +360,28 @@ void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const 
     }
 }
 
+namespace {
+__global__ void k_iota(uint32_t *p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+} // namespace
+
 // out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct  (+= when accumulate)
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
-                double *out1, uint32_t n1, double *out2, bool accumulate) {
+                double *out1, uint32_t n1, double *out2, bool accumulate, uint32_t ldx, const uint32_t *xmap, uint32_t ld1, const uint32_t *omap) {
     if (!nc) return;
+    const bool mapped = xmap != nullptr;
+    if (mapped && accumulate) mh_throw(MH_EINVAL, "combine: column maps are not supported with accumulate");
+    if (mapped && !omap) { // the mapped kernel writes out1 through a map: identity when the caller has none
+        if (!ctx->iota) {
+            ctx->iota = static_cast<uint32_t *>(ctx->pool.alloc(1024 * sizeof(uint32_t)));
+            k_iota<<<4, 256, 0, ctx->stream>>>(ctx->iota, 1024);
+            KERNEL_CHECK();
+        }
+        if (n1 > 1024) mh_throw(MH_EINVAL, "combine: %u mapped output columns exceed 1024", n1);
+        omap = ctx->iota;
+    }
     const unsigned grid = div_up(n, 64);
     // more than 256 output columns: column chunks, each a launch over the same basis
     const uint32_t chunks = div_up(nc, 256), step = (div_up(nc, chunks) + 15) / 16 * 16;
@@ -361,8 +391,12 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
             constexpr int NT = decltype(nt_tag)::value;
             constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
             const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
-            if (accumulate) k_combine<NT, true><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2, 0);
-            else k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(x, int(wx), w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2, 0);
+            const size_t lds_m = lds + (mapped ? size_t(wx) * sizeof(int) : 0);
+#define MH_COMBINE_ARGS x, int(wx), int(ldx ? ldx : wx), xmap, w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2, 0, int(ld1 ? ld1 : n1), omap
+            if (accumulate) k_combine<NT, true, false><<<grid, 256, lds, ctx->stream>>>(MH_COMBINE_ARGS);
+            else if (mapped) k_combine<NT, false, true><<<grid, 256, lds_m, ctx->stream>>>(MH_COMBINE_ARGS);
+            else k_combine<NT, false, false><<<grid, 256, lds, ctx->stream>>>(MH_COMBINE_ARGS);
+#undef MH_COMBINE_ARGS
         };
         const int ntile = int((ncc + 15) / 16);
         switch ((ntile + 1) / 2) { // the kernel computes all NT column strips: pick the smallest even NT that covers the chunk
@@ -401,7 +435,8 @@ void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, co
         constexpr int NT = decltype(nt_tag)::value;
         constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
         const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
-        k_combine<NT, false><<<grid, 256, lds, ctx->stream>>>(a, int(m), nullptr, 0, nullptr, 0, ct, int(nc), 0, int(nc), n, slices > 1 ? partial : out, int(nc), nullptr, stride);
+        k_combine<NT, false, false><<<grid, 256, lds, ctx->stream>>>(a, int(m), int(m), nullptr, nullptr, 0, nullptr, 0, ct, int(nc), 0, int(nc), n, slices > 1 ? partial : out, int(nc), nullptr, stride,
+                                                             int(nc), nullptr);
     };
     const int ntile = int((nc + 15) / 16);
     switch ((ntile + 1) / 2) {

@@ -716,7 +716,6 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> X(ctx, n * b), AX(ctx, n * b), MX(ctx, n * b), Xn(ctx, n * b), AXn(ctx, n * b), MXn(ctx, n * b);
             DevArray<double> W(ctx, n * b), AW(ctx, n * b), MW(ctx, n * b), P(ctx, n * b), AP(ctx, n * b), MP(ctx, n * b);
             DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
-            DevArray<double> XA(ctx, n * b), AXA(ctx, n * b), MXA(ctx, n * b);
             DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), gA0(ctx, size_t(mmax) * mmax), App(ctx, size_t(b) * b), evals(ctx, mmax), ework(ctx, mmax);
             static const bool implicit_p = !(getenv("MH_IMPLICIT_P") && atoi(getenv("MH_IMPLICIT_P")) == 0);
             DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), H2(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
@@ -868,11 +867,9 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 const uint32_t w = uint32_t(act.size());
                 idx_d.upload(act.data(), w);
                 k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
-                // the active Ritz vectors as contiguous panels (the Rayleigh-Ritz basis is [X_active W P])
-                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(X, idx_d, XA, n, b, w);
-                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(AX, idx_d, AXA, n, b, w);
-                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(MX, idx_d, MXA, n, b, w);
                 KERNEL_CHECK();
+                // The Rayleigh-Ritz basis is [X_active W P]; the active columns of X, A X, M X are addressed in place through
+                // the index list idx_d (column maps of the Gram and basis-update kernels), never copied out.
                 for (uint32_t k = 0; k < w; ++k) theta_act[k] = theta[act[k]];
                 theta_act_d.upload(theta_act.data(), w);
                 {
@@ -909,8 +906,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     HIP_CHECK(hipMemsetAsync(gM, 0, size_t(m) * m * sizeof(double), st));
                     k_set_identity_blocks<<<grid1(wa), TB, 0, st>>>(gA, gM, theta_act_d, wa, m);
                     KERNEL_CHECK();
-                    gram(ctx, n, W, w, AXA, wa, gA.get() + wa, m);
-                    gram(ctx, n, W, w, MXA, wa, gM.get() + wa, m);
+                    mh_gram(ctx, n, W, w, AX, wa, gA.get() + wa, m, b, idx_d);
+                    mh_gram(ctx, n, W, w, MX, wa, gM.get() + wa, m, b, idx_d);
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
                     gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
                     if (wp) {
@@ -924,8 +921,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                             k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(wa + w) * m + wa + w, m, nullptr, wp);
                             KERNEL_CHECK();
                         } else {
-                            gram(ctx, n, P, wp, AXA, wa, gA.get() + wa + w, m);
-                            gram(ctx, n, P, wp, MXA, wa, gM.get() + wa + w, m);
+                            mh_gram(ctx, n, P, wp, AX, wa, gA.get() + wa + w, m, b, idx_d);
+                            mh_gram(ctx, n, P, wp, MX, wa, gM.get() + wa + w, m, b, idx_d);
                             gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(wa + w) * m + wa + w, m);
                             gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(wa + w) * m + wa + w, m);
                         }
@@ -977,18 +974,33 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 }
                 // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
                 mh_pack_coefficients(ctx, gA, wa, Cp, wp_new, m, m, Ct);
-                mh_combine(ctx, n, XA, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn);
-                mh_combine(ctx, n, AXA, wa, AW, w, AP, wp, Ct, wa + wp_new, AXn, wa, APn);
-                mh_combine(ctx, n, MXA, wa, MW, w, MP, wp, Ct, wa + wp_new, MXn, wa, MPn);
-                if ((it + 1) % 8 == 0) {
-                    // every eighth iteration the images of the new Ritz vectors are recomputed from the vectors instead of
-                    // recombined: A X and M X otherwise inherit eight generations of rounding from the updates
+                // X_active <- S Cx (mapped columns of X), P <- S Cp.  One launch per image works in place (a workgroup reads its 64
+                // rows completely before writing them); more than 256 output columns take several launches over the same
+                // inputs, so those go through a contiguous copy and a scatter.
+                const bool refresh = (it + 1) % 8 == 0; // images of the new Ritz vectors recomputed instead of recombined: A X and
+                                                        // M X otherwise inherit eight generations of rounding from the updates
+                const bool in_place = wa + wp_new <= 256;
+                auto update = [&](DevArray<double> &x_all, const double *wpanel, const double *ppanel, DevArray<double> &x_new, double *p_new, bool keep_contiguous) {
+                    if (in_place && !keep_contiguous) {
+                        mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_all, wa, p_new, false, b, idx_d, b, idx_d);
+                    } else {
+                        mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_new, wa, p_new, false, b, idx_d);
+                        if (!keep_contiguous) {
+                            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(x_new.get(), idx_d, x_all.get(), n, b, wa);
+                            KERNEL_CHECK();
+                        }
+                    }
+                };
+                update(X, W, P, Xn, Pn, refresh); // on a refresh Xn keeps the new vectors contiguously for the products below
+                update(AX, AW, AP, AXn, APn, refresh);
+                update(MX, MW, MP, MXn, MPn, refresh);
+                if (refresh) {
                     mh_spmm(ctx, sys->L2, sys->L2.aval, Xn, AXn, sys->L2.mval, MXn, wa);
+                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
+                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
+                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
+                    KERNEL_CHECK();
                 }
-                k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
-                k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
-                k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
-                KERNEL_CHECK();
                 std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
                 wp = wp_new;
             }
