@@ -719,6 +719,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), gA0(ctx, size_t(mmax) * mmax), App(ctx, size_t(b) * b), evals(ctx, mmax), ework(ctx, mmax);
             static const bool implicit_p = !(getenv("MH_IMPLICIT_P") && atoi(getenv("MH_IMPLICIT_P")) == 0);
             DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), H2(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
+            DevArray<double> Linv(ctx, size_t(b) * b);
             DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
             DevArray<uint32_t> idx_d(ctx, b);
             DevArray<int> info(ctx, 1);
@@ -767,9 +768,20 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 if (hinfo != 0) return false;
                 k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
                 KERNEL_CHECK();
-                panel_trsm(ctx, n, V, w, Gs, w);
-                if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
-                if (AV) panel_trsm(ctx, n, AV, w, Gs, w);
+                static const bool trsm_rocblas = getenv("MH_TRSM_ROCBLAS") && atoi(getenv("MH_TRSM_ROCBLAS")) != 0;
+                if (trsm_rocblas || w > 256) {
+                    panel_trsm(ctx, n, V, w, Gs, w);
+                    if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
+                    if (AV) panel_trsm(ctx, n, AV, w, Gs, w);
+                } else {
+                    // V <- V L^-T through the explicit small inverse and the MFMA basis-update kernel (in place: a workgroup
+                    // reads its rows before it writes them): L^-1 column-major IS the k-major coefficient matrix of V L^-T
+                    HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
+                    ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
+                    mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
+                    if (MV) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);
+                    if (AV) mh_combine(ctx, n, AV, w, nullptr, 0, nullptr, 0, Linv, w, AV, w, nullptr);
+                }
                 return true;
             };
             mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
