@@ -569,3 +569,53 @@ void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e
     k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
     KERNEL_CHECK();
 }
+
+// ---- small Cholesky --------------------------------------------------------------------------------------------------
+// Lower Cholesky factor of a symmetric positive definite matrix of order w <= 128 (column-major, ld w) by ONE workgroup
+// with the matrix in LDS: the Gram matrices of the Cholesky-QR steps.  info = 0, or k + 1 when the pivot of column k is not
+// positive (as LAPACK's potrf).  rocSOLVER's potf2 takes ~100 us at these orders; this runs ~3 barriers per column.
+namespace {
+__global__ void __launch_bounds__(256) k_potrf_small(double *__restrict__ A, int w, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double L[]; // w x w, column-major, pitch w + 1 (bank spread)
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, pitch = w + 1;
+    for (int idx = tid; idx < w * w; idx += 256) L[(idx / w) * pitch + idx % w] = A[idx];
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int k = 0; k < w; ++k) {
+        const double akk = L[k * pitch + k];
+        if (!(akk > 0.0)) { // uniform: every thread reads the same value
+            if (tid == 0) s_fail = k + 1;
+            break;
+        }
+        const double d = sqrt(akk), inv = 1.0 / d;
+        __syncthreads(); // everyone has read the pivot
+        for (int i = k + tid; i < w; i += 256) L[k * pitch + i] = i == k ? d : L[k * pitch + i] * inv;
+        __syncthreads();
+        // trailing update of the lower triangle: columns j > k, rows i >= j
+        const int rem = w - k - 1;
+        for (int idx = tid; idx < rem * rem; idx += 256) {
+            const int j = k + 1 + idx / rem, i = k + 1 + idx % rem;
+            if (i >= j) L[j * pitch + i] -= L[k * pitch + i] * L[k * pitch + j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int j = idx / w, i = idx % w;
+        if (i >= j) A[idx] = L[j * pitch + i]; // the strictly upper part keeps the input, as potrf
+    }
+    if (tid == 0) *info = s_fail;
+}
+} // namespace
+
+void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
+    if (w < 1 || w > 128) mh_throw(MH_EINVAL, "potrf_small: order %u outside 1..128", w);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        attr_set = true;
+    }
+    k_potrf_small<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
+    KERNEL_CHECK();
+}

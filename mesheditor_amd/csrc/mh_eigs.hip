@@ -761,9 +761,14 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 double *Gs = G.get() + size_t(w) * w;
                 int hinfo = 0;
                 {
-                    SolverLock solver_lock(g_rocsolver_mutex);
-                    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
-                    info.download(&hinfo, 1);
+                    if (w <= 128) {
+                        mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
+                        info.download(&hinfo, 1);
+                    } else {
+                        SolverLock solver_lock(g_rocsolver_mutex);
+                        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                        info.download(&hinfo, 1);
+                    }
                 }
                 if (hinfo != 0) return false;
                 k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
@@ -968,9 +973,14 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     double *Gs = G.get() + size_t(w) * w;
                     int hinfo = 0;
                     {
-                        SolverLock solver_lock(g_rocsolver_mutex);
-                        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
-                        info.download(&hinfo, 1);
+                        if (w <= 128) {
+                            mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
+                            info.download(&hinfo, 1);
+                        } else {
+                            SolverLock solver_lock(g_rocsolver_mutex);
+                            ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                            info.download(&hinfo, 1);
+                        }
                     }
                     if (hinfo != 0) {
                         wp_new = 0;
