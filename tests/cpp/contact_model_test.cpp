@@ -3,6 +3,7 @@
 #include "harness.hpp"
 
 #include <audio/ContactModel.h>
+#include <modal/strike.hpp>
 
 #include <numbers>
 
@@ -110,6 +111,62 @@ CASE(a_lighter_striker_shortens_the_contact) {
     heavy.Length = 5.f;
     EXPECT(ContactTime(d, Ceramic, 5, 0, 1, 1, light) < ContactTime(d, Ceramic, 5, 0, 1, 1, heavy));
     EXPECT(StrikerMass(heavy) > StrikerMass(light));
+}
+
+// ---- strike translation (the reference's TriggerModalStrike, src/audio/AudioSystem.cpp:400-465) ------------
+namespace {
+ModalModes TwoPointModes() {
+    ModalModes m;
+    m.Freqs = {440.f, 880.f};
+    m.T60s = {0.5f, 0.25f};
+    m.Positions = {{0, 0, 0}, {0.1f, 0, 0}, {0, 0.1f, 0}};
+    m.Vertices = {0, 1, 2};
+    m.Indices = {0, 1, 2};
+    m.Shapes = {{{1, 0, 0}, {0, 2, 0}}, {{0, 1, 0}, {3, 0, 0}}, {{0, 0, 1}, {0, 0, 1}}};
+    return m;
+}
+} // namespace
+
+CASE(a_strike_becomes_the_event_the_bank_consumes) {
+    const auto modes = TwoPointModes();
+    ModalAudio audio; // bank bookkeeping only: nothing is rendered, so no device is touched
+    ModalBank &bank = LiveBank(audio);
+    bank.SampleRate = 48'000.f;
+    const auto slot = AddModalObject(bank, entt::entity{7}, modes);
+    // helpers of the scene look-ups
+    EXPECT(NearestSamplePoint(modes.Positions, vec3{0.09f, 0.01f, 0}) == 1u);
+    EXPECT(check::near(PeakModalDrive(modes, 1, vec3{2.f, 0, 0}), 6.0, 1e-6)); // mode 1 at point 1: (3,0,0) . (2,0,0)
+    EXPECT(length(UnitOrZero(vec3{0.f})) == 0.f && check::near(length(UnitOrZero(vec3{3, 4, 0})), 1.0, 1e-6));
+    EXPECT(check::near(VolumeEquivalentRadius(4.0 / 3.0 * std::numbers::pi * 0.027), 0.3, 1e-12));
+    // without dynamics or material: the default 0.1 ms contact, no click
+    StrikeContext bare;
+    const auto plain = MakeStrikeEvent(bank, slot, 1, vec3{0, 0, 1}, 2.f, 1.f, bare);
+    EXPECT(plain.Object == slot && plain.ExPos == 1u && plain.Jz == 2.f && plain.Jx == 0.f);
+    EXPECT(check::near(plain.PulseStep, 1.0 / (1e-4 * 48000.0), 1e-6) && plain.PulseGamma == 2 * plain.PulseStep && plain.AccelAmp == 0.f && plain.ClickB0 == 0.f);
+    // with them: the contact time of the model, the recoil click of the displaced volume, a nominal impulse for a mallet
+    ContactDynamics dyn = Body(0.5, Scaled(0.f));
+    dyn.ContactArm = {vec3{0.f}, vec3{0.f}, vec3{0.f}};
+    const AcousticMaterial ceramic{"c", Ceramic};
+    StrikeContext sc{.Dynamics = &dyn, .Material = &ceramic, .Elastic = Ceramic, .Curvature = 10, .EnclosedVolume = 0, .ScaleRatio = 1.f, .Roughness = 0};
+    const Striker mallet{};
+    const auto hit = MakeStrikeEvent(bank, slot, 1, vec3{0, 0, 1}, 1.f, 2.f, sc, std::nullopt, mallet);
+    const double tau = EstimateContactTime(dyn, 1, vec3{0, 0, 1}, 2.0, Ceramic, 10, 0, StrikerImpactor(mallet), 1.0, 0.0);
+    EXPECT(check::near(hit.PulseStep, 1.0 / (tau * 48000.0), 1e-6));
+    const double volume = 0.5 / 2700.0;
+    const auto click = RecoilClickFilter(VolumeEquivalentRadius(volume), volume, 0.5, 48000.0);
+    EXPECT(hit.ClickB0 == click.B0 && hit.ClickA1 == click.A1 && hit.ClickA2 == click.A2);
+    EXPECT(check::near(hit.AccelAmp, ReducedContactMass(dyn, 1, vec3{0, 0, 1}, StrikerImpactor(mallet)) * 2.0 * 48000.0, 1e-6));
+    // a collision carries its own impactor and a true impulse
+    PhysicsStrike phys{.Direction = vec3{0, 0, 2}, .Impactor = Impactor{Polymer, 5.0, 1.0}, .NominalArea = 1e-5f, .ResultantIndex = 2};
+    const auto crash = MakeStrikeEvent(bank, slot, 1, vec3{0, 0, 1}, 0.03f, 1.5f, sc, phys);
+    EXPECT(check::near(crash.AccelAmp, 0.03 * 48000.0, 1e-6));
+    const double tau_c = EstimateContactTime(dyn, 2, vec3{0, 0, 1}, 1.5, Ceramic, 10, 1e-5f, phys.Impactor, 1.0, 0.0);
+    EXPECT(check::near(crash.PulseStep, 1.0 / (tau_c * 48000.0), 1e-6));
+    // queued through the entity look-up; unknown entities and out-of-range points are ignored
+    EXPECT(TriggerModalStrike(audio, entt::entity{7}, modes, 1, vec3{0, 0, 1}, 1.f, 1.f, sc));
+    EXPECT(!TriggerModalStrike(audio, entt::entity{8}, modes, 1, vec3{0, 0, 1}, 1.f, 1.f, sc));
+    EXPECT(!TriggerModalStrike(audio, entt::entity{7}, modes, 5, vec3{0, 0, 1}, 1.f, 1.f, sc));
+    EXPECT(audio.EventWrite.load() - audio.EventRead.load() == 1u);
 }
 
 int main() { return check::run_all(); }
