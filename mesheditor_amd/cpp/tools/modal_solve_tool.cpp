@@ -1,7 +1,9 @@
 // Solve a tetrahedral mesh's modal model on the MI355X and print it as JSON on stdout: the fields of the reference's
 // MeshEditorModalSolve (tests/ModalSolveTool.cpp:101-123 -- frequencies, decayRates, positions, mode-major shapes,
 // indices, mass, centerOfMass, inertiaDiagonal), which its sample generator shells out to.  The reference tool starts
-// from a surface .obj and tetrahedralises it; tet generation is outside this build, so the input here is the tet mesh:
+// from a surface .obj and tetrahedralises it; here an .obj is filled by tetra::FillStarShaped (star-shaped solids only,
+// modal/tets.hpp) and its vertices are the excitation positions, or the tet mesh is given directly:
+//   modal_solve <mesh.obj> [--layers k] [options]
 //   modal_solve <mesh.tet> [options]        text file: "V T", V lines "x y z", T lines "a b c d" (positively oriented)
 //   modal_solve --kuhn lx ly lz nx ny nz [--origin x y z] [options]
 //   --young E --poisson v --density rho --alpha a --beta b   material (SI)
@@ -11,6 +13,7 @@
 // the sample points those vertices became.
 #include "modal/model_io.hpp"
 #include "modal/solver.hpp"
+#include "modal/tets.hpp"
 
 #include <algorithm>
 #include <array>
@@ -96,15 +99,28 @@ void PrintScalars(const char *key, const auto &values) {
 
 int main(int argc, char **argv) {
     std::optional<TetMesh> mesh;
+    std::optional<ObjSurface> surface;
     if (const auto k = ArgIndex(argc, argv, "--kuhn"); k && *k + 6 < size_t(argc)) {
         const dvec3 origin{ArgValue(argc, argv, "--origin", 0, 1), ArgValue(argc, argv, "--origin", 0, 2), ArgValue(argc, argv, "--origin", 0, 3)};
         mesh = KuhnBox(ArgValue(argc, argv, "--kuhn", 1, 1), ArgValue(argc, argv, "--kuhn", 1, 2), ArgValue(argc, argv, "--kuhn", 1, 3), int(ArgValue(argc, argv, "--kuhn", 1, 4)),
                        int(ArgValue(argc, argv, "--kuhn", 1, 5)), int(ArgValue(argc, argv, "--kuhn", 1, 6)), origin);
+    } else if (argc >= 2 && std::string_view{argv[1]}.ends_with(".obj")) {
+        surface = LoadObj(argv[1]);
+        if (!surface) {
+            std::fprintf(stderr, "Failed to load mesh: %s\n", argv[1]);
+            return 1;
+        }
+        auto tets = GenerateTets(surface->Positions, surface->TriangleIndices, uint32_t(ArgValue(argc, argv, "--layers", 2)));
+        if (!tets) {
+            std::fprintf(stderr, "Tetrahedralization failed: %s\n", tets.Error.c_str());
+            return 1;
+        }
+        mesh = std::move(tets.Mesh);
     } else if (argc >= 2 && argv[1][0] != '-') {
         mesh = LoadTetFile(argv[1]);
     }
     if (!mesh || mesh->Tets.empty()) {
-        std::fprintf(stderr, "Usage: %s <mesh.tet> | --kuhn lx ly lz nx ny nz [--origin x y z]  [--young E] [--poisson v] [--density rho] [--alpha a] [--beta b] "
+        std::fprintf(stderr, "Usage: %s <mesh.obj> [--layers k] | <mesh.tet> | --kuhn lx ly lz nx ny nz [--origin x y z]  [--young E] [--poisson v] [--density rho] [--alpha a] [--beta b] "
                              "[--min-freq f] [--max-freq f] [--modes n] [--gltf out.gltf]\n", argv[0]);
         return 1;
     }
@@ -123,9 +139,15 @@ int main(int argc, char **argv) {
     };
 
     // the surface: boundary faces, their vertices in first-use order as excitation positions
-    const auto faces = BoundaryFaces(*mesh);
     std::vector<uint32_t> surface_of_point(mesh->Points.size(), UINT32_MAX), triangles;
     std::vector<vec3> excite;
+    std::vector<std::array<uint32_t, 3>> faces;
+    if (surface) { // as the reference tool: the .obj's own vertices and triangles
+        excite = surface->Positions;
+        triangles = surface->TriangleIndices;
+    } else {
+        faces = BoundaryFaces(*mesh);
+    }
     for (const auto &f : faces)
         for (const auto v : f) {
             if (surface_of_point[v] == UINT32_MAX) {

@@ -25,7 +25,7 @@ def _run(name, timeout=600):
 
 def test_cpp_tests_compile_against_the_mirror():
     _build()
-    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test"):
+    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test", "tets_test"):
         assert os.path.exists(os.path.join(CPP, "bin", name))
 
 
@@ -39,6 +39,59 @@ def test_gltf_modal_models_and_modal_store():
     scene, and the content-addressed .modal store (host code, no GPU)."""
     _build()
     assert "0 failure(s)" in _run("model_io_test")
+
+
+def test_star_shaped_tet_fill_and_obj_loader():
+    """the tet-generation front end against the validity properties of the reference's
+    tests/ValidateTetMesh.h (host code, no GPU)."""
+    _build()
+    assert "0 failure(s)" in _run("tets_test")
+
+
+@pytest.mark.gpu
+def test_solve_tool_takes_a_surface_obj(tmp_path):
+    """The reference tool's own input: a surface .obj, filled with tets and solved with the .obj's vertices as the
+    excitation positions.  A cube's first elastic modes must agree with the same cube meshed as a Kuhn grid (two
+    different quadratic-tet discretisations of one solid) and the mass must be exact."""
+    import json
+    import numpy as np
+    _build()
+    n, side = 4, 0.1
+    ids, pts, tris = {}, [], []
+    def vid(c):
+        if c not in ids:
+            ids[c] = len(pts)
+            pts.append([side * v / n for v in c])
+        return ids[c]
+    for axis in range(3):
+        for s in (0, n):
+            for u in range(n):
+                for v in range(n):
+                    def at(uu, vv):
+                        c = [0, 0, 0]
+                        c[axis], c[(axis + 1) % 3], c[(axis + 2) % 3] = s, uu, vv
+                        return vid(tuple(c))
+                    a, b, c, d = at(u, v), at(u + 1, v), at(u + 1, v + 1), at(u, v + 1)
+                    tris += [(a, b, c), (a, c, d)]
+    obj = tmp_path / "cube.obj"
+    obj.write_text("".join(f"v {x!r} {y!r} {z!r}\n" for x, y, z in pts) + "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in tris))
+    tool = os.path.join(ROOT, "mesheditor_amd", "cpp", "bin", "modal_solve")
+    common = ["--young", "7.2e10", "--poisson", "0.19", "--density", "2700", "--modes", "8"]
+    p = subprocess.run([tool, str(obj), "--layers", "2", *common], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout)
+    q = subprocess.run([tool, "--kuhn", repr(side), repr(side), repr(side), "4", "4", "4", *common], capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    ref = json.loads(q.stdout)
+    assert abs(out["mass"] / (2700 * side ** 3) - 1) < 1e-6
+    assert len(out["positions"]) == len(pts) and len(out["indices"]) == 3 * len(tris)
+    assert np.allclose(np.array(out["positions"]), np.array(pts, dtype=np.float32), atol=1e-7)
+    f, g = np.array(out["frequencies"]), np.array(ref["frequencies"])
+    assert len(f) == len(g) == 8 and np.abs(f / g - 1).max() < 0.03, (f, g)
+    bad = tmp_path / "open.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\nf 1 2 4\nf 1 3 4\n")
+    r = subprocess.run([tool, str(bad)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Tetrahedralization failed" in r.stderr
 
 
 @pytest.mark.gpu
