@@ -76,7 +76,7 @@ def test_solve_tool_takes_a_surface_obj(tmp_path):
     obj = tmp_path / "cube.obj"
     obj.write_text("".join(f"v {x!r} {y!r} {z!r}\n" for x, y, z in pts) + "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in tris))
     tool = os.path.join(ROOT, "mesheditor_amd", "cpp", "bin", "modal_solve")
-    common = ["--young", "7.2e10", "--poisson", "0.19", "--density", "2700", "--modes", "8"]
+    common = ["--young", "7.2e10", "--poisson", "0.19", "--density", "2700", "--modes", "8", "--max-freq", "60000"]
     p = subprocess.run([tool, str(obj), "--layers", "2", *common], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout)
