@@ -96,7 +96,9 @@ int mh_system_element_nodes(const mh_system *, uint32_t *out_kept_tets_x10);
  * (both triangles).  Arrays sized by mh_system_dims' node_blocks. */
 int mh_system_export_blocks(const mh_system *, uint32_t *row_node, uint32_t *col_node, double *k_blocks, double *m_blocks);
 /* y = K x (which = 0), M x (which = 1) or (K - sigma M) x at the reference's shift (which = 2) for `width` vectors, x and y column-major n x width in the reference's
- * DOF order (3*node + component).  The SpMM kernel of the eigensolver, exposed for parity and roofline measurement. */
+ * DOF order (3*node + component).  The SpMM kernel of the eigensolver, exposed for parity and roofline measurement.
+ * which = 3 / 4: the same shifted product as the preconditioner's smoothers form it -- single-precision values and panel
+ * (3), double-precision values over a single-precision panel (4, width % 4 == 0) -- so those kernels can be checked too. */
 int mh_system_matvec(mh_system *, int which, const double *x, double *y, uint32_t width);
 
 /* Measurement aid: average device time of `reps` back-to-back K x products over a resident n x width panel, and the

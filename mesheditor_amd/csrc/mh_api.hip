@@ -25,6 +25,10 @@ __global__ void k_ref_to_panel(const double *__restrict__ xref, const uint32_t *
     const uint32_t c = uint32_t(i % w), comp = uint32_t((i / w) % 3), node = uint32_t(i / (size_t(3) * w));
     panel[i] = xref[size_t(c) * (size_t(3) * nnodes) + size_t(3) * perm[node] + comp];
 }
+template<typename S, typename D> __global__ void k_cast(const S *__restrict__ src, D *__restrict__ dst, size_t count) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = D(src[i]);
+}
 template<typename T>
 __global__ void k_panel_to_ref(const double *__restrict__ panel, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t wsrc, uint32_t w, T *__restrict__ xref) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -236,7 +240,21 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
         KERNEL_CHECK();
         if (which == 0) mh_spmm(ctx, s->L2, s->L2.kval, xp, yp, nullptr, nullptr, width);
         else if (which == 1) mh_spmm(ctx, s->L2, nullptr, xp, nullptr, s->L2.mval, yp, width);
-        else { // which == 2: the shifted operator A = K - sigma M of the eigensolver at the reference's shift
+        else if (which == 3 || which == 4) { // the preconditioner's products of the shifted operator: single precision / double A x single panel
+            std::lock_guard<std::mutex> lock(mh_solve_mutex());
+            mh_build_hierarchy(s, -15791.367041742974);
+            DevArray<float> xf(ctx, n * width), yf(ctx, n * width);
+            k_cast<double, float><<<div_up(n * width, TB), TB, 0, ctx->stream>>>(xp.get(), xf.get(), n * width);
+            KERNEL_CHECK();
+            if (which == 3) {
+                mh_spmm_f32(ctx, s->L2, xf, yf, width);
+                k_cast<float, double><<<div_up(n * width, TB), TB, 0, ctx->stream>>>(yf.get(), yp.get(), n * width);
+                KERNEL_CHECK();
+            } else {
+                mh_spmm_mixed(ctx, s->L2, xf, yp, width);
+            }
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else { // which == 2: the shifted operator A = K - sigma M of the eigensolver at the reference's shift
             std::lock_guard<std::mutex> lock(mh_solve_mutex());
             mh_build_hierarchy(s, -15791.367041742974);
             mh_spmm(ctx, s->L2, s->L2.aval, xp, yp, nullptr, nullptr, width);

@@ -391,8 +391,22 @@ __global__ void k_identity_defect(const double *__restrict__ g, uint32_t m, unsi
     if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
 }
 
+// E = gM - I as a full symmetric matrix from gM's lower triangle
+__global__ void k_defect_matrix(const double *__restrict__ g, uint32_t m, double *__restrict__ e) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * m) return;
+    const uint32_t r = i % m, c = i / m;
+    e[i] = (r >= c ? g[i] : g[size_t(r) * m + c]) - (r == c ? 1.0 : 0.0);
+}
+// S = I - E/2 + 3/8 E^2: the inverse square root of I + E to second order
+__global__ void k_inverse_sqrt_series(const double *__restrict__ e, const double *__restrict__ e2, uint32_t m, double *__restrict__ s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * m) return;
+    s[i] = (i % m == i / m ? 1.0 : 0.0) - 0.5 * e[i] + 0.375 * e2[i];
+}
+
 int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info) {
-    const double one = 1;
+    const double one = 1, zero = 0;
     int hinfo = 0;
     k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gA, m, m);
     KERNEL_CHECK();
@@ -400,7 +414,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
     // up to the orthogonalisation error.  When that error is below 1e-11 the pencil is solved as a standard problem:
     // no Cholesky reduction (potrf + three trsm, ~1.2 ms of a ~4 ms solve at order 225).  Otherwise the full reduction.
     static const bool always_reduce = getenv("MH_RR_REDUCE") && atoi(getenv("MH_RR_REDUCE")) != 0;
-    bool identity = false;
+    bool identity = false, series = false;
     if (!always_reduce) {
         static_assert(sizeof(unsigned long long) == sizeof(double), "defect word");
         unsigned long long *defect = reinterpret_cast<unsigned long long *>(ework);
@@ -413,6 +427,29 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         double d;
         memcpy(&d, &bits, sizeof(d));
         identity = d < 1e-11;
+        static const bool verbose = getenv("MH_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[rr] m %u identity defect %.2e\n", m, d);
+        // A small defect (one Cholesky-QR pass of an ill-conditioned W leaves 1e-10 .. 1e-8) is absorbed by the series
+        // S = (I + E)^(-1/2) = I - E/2 + 3/8 E^2 + O(E^3): S gA S z = theta z, c = S z.  Four order-m products instead of the
+        // Cholesky reduction's factorisation and three triangular solves (~1.2 ms of single-workgroup kernels).
+        static const bool use_series = !(getenv("MH_RR_SERIES") && atoi(getenv("MH_RR_SERIES")) == 0);
+        series = use_series && !identity && d < 1e-7;
+    }
+    DevArray<double> sroot, stmp;
+    if (series) {
+        sroot.reset(ctx, size_t(m) * m);
+        stmp.reset(ctx, size_t(m) * m * 2);
+        double *e = stmp.get(), *e2 = stmp.get() + size_t(m) * m;
+        k_defect_matrix<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gM, m, e);
+        KERNEL_CHECK();
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, e, m, e, m, &zero, e2, m));
+        k_inverse_sqrt_series<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(e, e2, m, sroot);
+        KERNEL_CHECK();
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, e, m));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, e, m, sroot, m, &zero, gA, m));
+        k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gA, m, m);
+        KERNEL_CHECK();
+        identity = true;
     }
     SolverLock solver_lock(g_rocsolver_mutex);
     if (!identity) {
@@ -440,7 +477,11 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         if (hinfo != 0) return hinfo;
     }
     solver_lock.unlock();
-    if (!identity)
+    if (series) { // c = S z
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, stmp, m));
+        HIP_CHECK(hipMemcpyAsync(gA, stmp.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the workspaces go back to the pool on return
+    } else if (!identity)
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
     return 0;
 }
@@ -464,7 +505,7 @@ template<typename T> struct Precond {
     mh_system *sys;
     mh_context *ctx;
     uint32_t wmax;
-    int deg2{2}, deg1{3}, gamma{3};
+    int deg2{2}, deg1{4}, gamma{3}; // measured at S100k (tools/precond_scan.sh): deg1 3 -> 4 saves one to two iterations for 1 ms of P1-level work
     double ratio{8.0};
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
     DevArray<double> r0, x0, x0_partial;
@@ -490,6 +531,7 @@ template<typename T> struct Precond {
         if (const char *e = getenv("MH_DEG2")) deg2 = std::max(1, atoi(e));
         if (const char *e = getenv("MH_DEG1")) deg1 = std::max(1, atoi(e));
         if (const char *e = getenv("MH_GAMMA")) gamma = std::max(1, atoi(e));
+        if (const char *e = getenv("MH_CHEB_RATIO")) ratio = std::max(1.5, atof(e));
     }
     void spmm(const BsrLevel &lvl, const T *x, T *y, uint32_t w) {
         if constexpr (kDouble) mh_spmm(ctx, lvl, lvl.aval, x, y, nullptr, nullptr, w);
@@ -896,23 +938,36 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     precond_seconds += tp.stop();
                     prof.op_applications += w;
                 }
-                // W <- (I - X X^T M - P P^T M) W, twice, keeping M W alongside; then M-orthonormalise.
-                mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
+                // W <- (I - X X^T M - P P^T M) W (the coefficients come from M X and M P: no M W needed yet), then A W and M W in
+                // one fused product, then M-orthonormalise W carrying both images along.  Against "M W first, project W and
+                // M W, orthonormalise, then A W" this is one basis-update launch and one pass over the matrix fewer per iteration.
                 bool ok = true;
                 // One projection + Cholesky-QR pass suffices: the Rayleigh-Ritz step solves the full pencil (gA, gM), so the
                 // basis only has to be well conditioned, not orthonormal to working precision.
                 static const int ortho_passes = getenv("MH_ORTHO_PASSES") ? std::max(1, atoi(getenv("MH_ORTHO_PASSES"))) : 1;
-                for (int pass = 0; pass < ortho_passes && ok; ++pass) {
+                static const bool fused_images = !(getenv("MH_FUSED_IMAGES") && atoi(getenv("MH_FUSED_IMAGES")) == 0);
+                if (fused_images && ortho_passes == 1) {
                     gram(ctx, n, MX, b, W, w, H, b); // b x w
                     if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
-                    // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
                     mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
                     mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
-                    mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
-                    ok = chol_orthonormalise(W, MW, nullptr, w);
+                    mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
+                    ok = chol_orthonormalise(W, MW, AW, w);
+                    if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+                } else {
+                    mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
+                    for (int pass = 0; pass < ortho_passes && ok; ++pass) {
+                        gram(ctx, n, MX, b, W, w, H, b); // b x w
+                        if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
+                        // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
+                        mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
+                        mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
+                        mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
+                        ok = chol_orthonormalise(W, MW, nullptr, w);
+                    }
+                    if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+                    mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
                 }
-                if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-                mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
                 // Gram matrices of S = [X_active W P] (lower triangles), X block known: diag(theta) and I.  Locked columns are
                 // not part of the basis any more (W was projected against them above): the small problem has order
                 // 2w + wp instead of b + w + wp.

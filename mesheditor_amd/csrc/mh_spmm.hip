@@ -122,12 +122,12 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
     __shared__ TV sm[TB / 64][WITH_M ? STRIP : 1];
     __shared__ uint32_t sc[TB / 64][STRIP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t c = lane % CL, g = lane / CL;
+    const uint32_t c = lane % CL, g = lane / CL; // CL need not divide 64 (20 lanes x 3 groups for 80 floats): lanes past G * CL idle
     const uint32_t nb_grid = gridDim.x, per = (nb_grid + 7) / 8;
     const uint32_t bid = xcd_remap ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
     const uint32_t row = __builtin_amdgcn_readfirstlane(bid * (TB / 64) + wave);
     if (row >= nnodes) return;
-    const bool act = V * c < w;
+    const bool act = V * c < w && g < G;
     const uint32_t coff = act ? V * c : 0;
     Acc acc[3], macc[3];
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < rounds) {
-                    const bool ok = (t0 + u) * G + g < nb;
+                    const bool ok = (t0 + u) * G + g < nb && (G * CL == 64 || g < G);
                     const Acc x0 = __builtin_convertvector(xv[u][0], Acc), x1 = __builtin_convertvector(xv[u][1], Acc), x2 = __builtin_convertvector(xv[u][2], Acc);
                     if (WITH_A) {
                         TY v[9];
@@ -195,15 +195,32 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
             }
         }
     }
-    // fold the G lane groups (fixed tree), group 0 stores
+    // fold the G lane groups (fixed tree; fixed chain when G is not a power of two), group 0 stores
+    if constexpr ((G & (G - 1)) == 0) {
 #pragma unroll
-    for (int sft = G / 2; sft >= 1; sft >>= 1) {
+        for (int sft = G / 2; sft >= 1; sft >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    if (WITH_A) acc[i][e] += __shfl_down(acc[i][e], sft * CL, 64);
+                    if (WITH_M) macc[i][e] += __shfl_down(macc[i][e], sft * CL, 64);
+                }
+            }
+        }
+    } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                if (WITH_A) acc[i][e] += __shfl_down(acc[i][e], sft * CL, 64);
-                if (WITH_M) macc[i][e] += __shfl_down(macc[i][e], sft * CL, 64);
+                TY sa = acc[i][e], sm_ = macc[i][e];
+#pragma unroll
+                for (int j = 1; j < G; ++j) {
+                    if (WITH_A) sa += __shfl_down(acc[i][e], j * CL, 64);
+                    if (WITH_M) sm_ += __shfl_down(macc[i][e], j * CL, 64);
+                }
+                acc[i][e] = sa;
+                macc[i][e] = sm_;
             }
         }
     }
@@ -239,6 +256,7 @@ bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const TV *vals9, con
         const uint32_t lanes = div_up(w, uint32_t(V));
         if (lanes <= 8) go(std::integral_constant<int, 8>{});
         else if (lanes <= 16) go(std::integral_constant<int, 16>{});
+        else if (lanes <= 20 && V == 4) go(std::integral_constant<int, 20>{}); // the 80-column block in single precision: 3 node blocks per round
         else if (lanes <= 32) go(std::integral_constant<int, 32>{});
         else go(std::integral_constant<int, 64>{});
     };

@@ -86,6 +86,24 @@ def test_spmm_matches_oracle(api, ctx, oracle):
         assert np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max(), (width, np.abs(a - ref).max() / np.abs(ref).max())
 
 
+def test_preconditioner_products_match_the_double_precision_operator(api, ctx):
+    """The smoothers' single-precision SpMM (every lane grouping of the wide-load kernel, incl. the 20-lane x 3-group
+    form the 80-column block uses) and the mixed double-A x single-panel product, against the fp64 product of the same
+    (float-rounded) panel: fp32 tolerance for the first, fp64 tolerance for the second."""
+    pts, tets, m, _ = meshes.workload("cube_small")
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), api.material(*m))
+    rng = np.random.default_rng(5)
+    for width in (4, 8, 20, 32, 36, 40, 48, 64, 72, 76, 80, 84, 96, 128, 200, 256, 7, 30):
+        x = rng.standard_normal((sysg.n, width)).astype(np.float32).astype(np.float64)
+        ref = sysg.matvec(2, x)
+        scale = np.abs(ref).max()
+        y32 = sysg.matvec(3, x)
+        assert np.abs(y32 - ref).max() <= 2e-5 * scale, (width, np.abs(y32 - ref).max() / scale)
+        if width % 4 == 0:
+            ymix = sysg.matvec(4, x)
+            assert np.abs(ymix - ref).max() <= 1e-12 * scale, (width, np.abs(ymix - ref).max() / scale)
+
+
 @pytest.mark.parametrize("name,nev", [("cube_small", 45), ("bar_square", 45), ("bar_thin", 30)])
 def test_eigenvalues_match_oracle(api, ctx, oracle, name, nev):
     """BASELINE north star: eigenvalues within 1e-6 relative of the shift-invert reference algorithm (fp64)."""
