@@ -227,6 +227,14 @@ inline int mh_guard(mh_context *ctx, const std::exception &e) {
 inline unsigned div_up(size_t a, size_t b) { return unsigned((a + b - 1) / b); }
 
 // ---- stage entry points implemented across the .hip files ----
+void mh_phase_shared_lock();   // mh_eigs.hip: MH_CONCURRENT_SOLVES -- device work of other entry points keeps out of an exclusive
+void mh_phase_shared_unlock(); // factorisation phase (no-ops in the default, serialised mode)
+struct MhSharedPhase {
+    MhSharedPhase() { mh_phase_shared_lock(); }
+    ~MhSharedPhase() { mh_phase_shared_unlock(); }
+    MhSharedPhase(const MhSharedPhase &) = delete;
+    MhSharedPhase &operator=(const MhSharedPhase &) = delete;
+};
 std::mutex &mh_solve_mutex(); // mh_eigs.hip: one eigensolve (or Gram benchmark) at a time per process, see there
 void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &mat, mh_system *sys); // mh_pipeline.hip
 void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor

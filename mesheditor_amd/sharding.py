@@ -75,19 +75,43 @@ def gather_records(local_records, n_items, dist=None, device="cpu"):
     return [records[i] for i in sorted(records)]
 
 
-def solve_batch(meshes, solve_fn, nev_max, dist=None, device="cpu"):
-    """meshes: list of (points, tets, material tuple, config kwargs).  solve_fn(index, mesh tuple) -> ModalResult-like.
-    Deals the batch over the ranks by cost, solves the local share, gathers every record to every rank."""
+def solve_batch(meshes, solve_fn, nev_max, dist=None, device="cpu", threads=1):
+    """meshes: list of (points, tets, material tuple, config kwargs).  solve_fn(index, mesh tuple) -> ModalResult-like
+    (with threads > 1: solve_fn(index, mesh tuple, worker) and `threads` host threads per rank, worker = 0 .. threads - 1,
+    each meant to use its own context: solves of different contexts iterate side by side on one GPU, the reference's
+    "one job per entity, several at a time").  Deals the batch over the ranks by cost, solves the local share, gathers
+    every record to every rank."""
     import time
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     costs = [mesh_cost(len(m[1]), m[3].get("num_fem_modes", 45)) for m in meshes]
     mine = lpt_deal(costs, world)[rank]
     local = {}
-    for i in mine:
-        t0 = time.perf_counter()
-        res = solve_fn(i, meshes[i])
-        local[i] = pack_record(i, res, nev_max, time.perf_counter() - t0)
+    if threads <= 1:
+        for i in mine:
+            t0 = time.perf_counter()
+            res = solve_fn(i, meshes[i])
+            local[i] = pack_record(i, res, nev_max, time.perf_counter() - t0)
+    else:
+        import threading
+        # the rank's share is dealt again over its workers by the same rule (largest first)
+        shares = lpt_deal([costs[i] for i in mine], threads)
+        errors = []
+
+        def work(worker):
+            try:
+                for j in shares[worker]:
+                    i = mine[j]
+                    t0 = time.perf_counter()
+                    res = solve_fn(i, meshes[i], worker)
+                    local[i] = pack_record(i, res, nev_max, time.perf_counter() - t0)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        pool = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+        [t.start() for t in pool]
+        [t.join() for t in pool]
+        if errors:
+            raise errors[0]
     return [unpack_record(r, nev_max) for r in gather_records(local, len(meshes), dist, device)]
 
 

@@ -76,6 +76,31 @@ def test_two_rank_batch_gather():
         assert dofs == 3000 + i and abs(evsum - ref.eigenvalues.sum()) < 1e-6 * evsum and k == 30
 
 
+def test_threaded_share_solves_every_mesh_once():
+    """Several host threads per rank (concurrent solves on one GPU): the rank's share is dealt over the workers by the same
+    rule, every mesh is solved exactly once, records come back in index order, a worker's failure is raised."""
+    n = 11
+    meshes = [(None, np.zeros((900 + 211 * (i % 5), 4)), None, {"num_fem_modes": 45}) for i in range(n)]
+    seen = []
+
+    def solve(i, m, worker):
+        seen.append((worker, i))
+        return _FakeResult(i, 45)
+    recs = sharding.solve_batch(meshes, solve, 45, None, threads=3)
+    assert [r["index"] for r in recs] == list(range(n))
+    assert sorted(i for _, i in seen) == list(range(n)) and {w for w, _ in seen} == {0, 1, 2}
+    for r in recs:
+        assert np.array_equal(r["eigenvalues"], _FakeResult(r["index"], 45).eigenvalues)
+
+    def failing(i, m, worker):
+        if i == 4:
+            raise RuntimeError("solve 4 failed")
+        return _FakeResult(i, 45)
+    import pytest
+    with pytest.raises(RuntimeError, match="solve 4 failed"):
+        sharding.solve_batch(meshes, failing, 45, None, threads=2)
+
+
 def test_record_round_trip_and_rank_order_mix():
     r = _FakeResult(3, 45)
     rec = sharding.pack_record(3, r, 65, 0.25)
