@@ -609,6 +609,76 @@ __global__ void __launch_bounds__(256) k_potrf_small(double *__restrict__ A, int
 }
 } // namespace
 
+// Inverse of a symmetric positive definite block of order w <= 128 (column-major, leading dimension lda) into out (w x w,
+// leading dimension ldo): in-place Gauss-Jordan without pivoting in registers, one workgroup.  Every pivot of an SPD matrix is
+// positive; a pivot that is not sets *info = its index + 1 (info is only ever raised: clear it before a sequence of calls).
+namespace {
+template<int NQ> // columns per thread: 128 * 128 / NQ threads
+__global__ void __launch_bounds__(128 * 128 / NQ) k_spd_inverse_small(const double *__restrict__ A, int lda, int w, double *__restrict__ out, int ldo, int *__restrict__ info) {
+    // Thread t owns row i = t & 127 and the NQ columns j = (t >> 7) + NG q of the (padded) 128 x 128 block, in registers for the
+    // whole elimination.  Step p needs row p and column p of the current matrix.  Between a processed and an unprocessed index
+    // the in-place Gauss-Jordan iterate is antisymmetric (rows were scaled by +1/pivot, columns by -1/pivot) and symmetric
+    // otherwise, so column p is row p with the sign of the processed entries flipped: only the NG owners of row p publish
+    // it (LDS, two alternating buffers), one barrier per step.
+    __shared__ double rowbuf[2][128];
+    const int tid = threadIdx.x, i = tid & 127, jg = tid >> 7;
+    constexpr int NG = 128 / NQ; // column groups
+    double val[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = jg + NG * q;
+        val[q] = (i < w && j < w) ? A[size_t(j) * lda + i] : (i == j ? 1.0 : 0.0); // identity padding: inert
+    }
+    for (int p = 0; p < w; ++p) {
+        double *rb = rowbuf[p & 1];
+        if (i == p) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rb[jg + NG * q] = val[q];
+        }
+        __syncthreads();
+        const double piv = rb[p];
+        if (!(piv > 0.0)) { // uniform
+            if (tid == 0) atomicMax(info, p + 1);
+            break;
+        }
+        const double inv = 1.0 / piv;
+        const double f = i < p ? -rb[i] : rb[i]; // element (i, p)
+        // generic entries first, without selects (the fp64 ALU work of the step is what bounds it) ...
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double t = f * rb[jg + NG * q];
+            val[q] = fma(-t, inv, val[q]);
+        }
+        // ... then row p (its owners' waves only) and column p (one register per owner, selected by a uniform switch)
+        if (i == p) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) val[q] = rb[jg + NG * q] * inv;
+        }
+        const int qp = p / NG;
+        const double cp = (i == p) ? inv : -f * inv; // element (i, p) of the result
+        if (jg == p % NG) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q == qp) val[q] = cp; // qp is uniform: a scalar compare per q, no per-lane select chains
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = jg + NG * q;
+        if (i < w && j < w) out[size_t(j) * ldo + i] = val[q];
+    }
+}
+} // namespace
+
+void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info) {
+    if (w < 1 || w > 128) mh_throw(MH_EINVAL, "spd_inverse_small: order %u outside 1..128", w);
+    static const int nq = getenv("MH_GJ_NQ") ? atoi(getenv("MH_GJ_NQ")) : 16;
+    if (nq == 16) k_spd_inverse_small<16><<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
+    else if (nq == 32) k_spd_inverse_small<32><<<1, 512, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
+    else k_spd_inverse_small<64><<<1, 256, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
+    KERNEL_CHECK();
+}
+
 void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "potrf_small: order %u outside 1..128", w);
     static bool attr_set = false;

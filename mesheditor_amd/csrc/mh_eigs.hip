@@ -30,14 +30,16 @@ constexpr int TB = 256;
 // own contexts: rocsolver_dpotrf of the SAME 3 690 x 3 690 coarse operator (identical input checksums) returned
 // info != 0 in ~10 % of the calls -- also when every rocSOLVER call ran under one lock, and specifically whenever
 // another stream was running the register-blocked Gram kernel (not the SpMM, basis-update or assembly kernels); the
-// operator buffer itself was never touched while idle.  The dense factorisation is disturbed by unrelated concurrent
-// work; nothing else of the solve is (tools/concurrent_solves.py: ~500 concurrent solves from 2-8 threads, every
+// operator buffer itself was never touched while idle.  rocSOLVER's dense factorisation is disturbed by unrelated
+// concurrent work; nothing else of the solve is (tools/concurrent_solves.py: ~500 concurrent solves from 2-8 threads, every
 // eigenvalue bit-identical to the serial run).  So:
-//   * solves of different contexts iterate side by side -- each iteration holds the device phase lock SHARED, as do the
-//     other entry points that launch work (assembly, nearest points, shape gathers);
-//   * the dense coarse factorisation (and the tiny-system dense eigensolve) takes it EXCLUSIVELY, after a device-wide
-//     synchronisation: it runs alone on the GPU (~17 ms of a 100k-tet solve).
-// 1.9x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
+//   * the coarse operator is inverted by our own block Gauss-Jordan elimination (mh_build_hierarchy: one-workgroup
+//     diagonal-block inverses + rocBLAS dgemm), which needs no isolation -- and is faster than potrf + potri;
+//   * solves of different contexts iterate side by side.  Each iteration holds the device phase lock SHARED, as do the other
+//     entry points that launch work (assembly, nearest points, shape gathers, bank rendering);
+//   * what still goes through a rocSOLVER factorisation -- the tiny-system dense eigensolve (sygvd), and the coarse
+//     operator under MH_COARSE_ROCSOLVER=1 -- takes the lock EXCLUSIVELY after a device-wide synchronisation: it runs alone.
+// 2.0x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
 // MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex); MH_ROCSOLVER_LOCK=1 additionally serialises the
 // rocSOLVER calls of the Rayleigh-Ritz step (not needed by any measurement).
 std::mutex g_solve_mutex;
@@ -731,19 +733,54 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), 1e-12);
     KERNEL_CHECK();
     DevArray<int> info(ctx, 1);
+    int hinfo = 0;
+    static const bool coarse_rocsolver = getenv("MH_COARSE_ROCSOLVER") && atoi(getenv("MH_COARSE_ROCSOLVER")) != 0;
+    if (!coarse_rocsolver) {
+        // Explicit inverse by block Gauss-Jordan elimination (no pivoting: the matrix is SPD), 128 columns per step:
+        //   P = A_kk^-1 (one workgroup, in LDS);  C = A(:, k);  R = P A(k, :);  A -= C R;  A(k, :) = R;  A(:, k) = -C P;  A_kk = P.
+        // 2 n0^3 flops in n0 / 128 rank-128 updates of the whole matrix (rocBLAS dgemm) instead of potrf + potri's chains of
+        // panel kernels: 17 ms -> 8 ms at n0 = 3 690 -- and, unlike rocsolver_dpotrf, undisturbed by concurrent streams, so a
+        // solve needs no exclusive phase on the device.  The coarse solve becomes one dense product per application (2.5x
+        // faster than two triangular solves at these sizes, and free of their O(n0 / 128) dependent launches).
+        const uint32_t nb = 128;
+        DevArray<double> cblk(ctx, n0 * nb), rblk(ctx, n0 * nb), pinv(ctx, size_t(nb) * nb);
+        info.zero();
+        const double one = 1, zero = 0, mone = -1;
+        const rocblas_int ld = rocblas_int(n0);
+        double *a = sys->a0.get();
+        for (size_t k0 = 0; k0 < n0; k0 += nb) {
+            const rocblas_int w = rocblas_int(std::min<size_t>(nb, n0 - k0));
+            mh_spd_inverse_small(ctx, a + k0 * n0 + k0, uint32_t(n0), uint32_t(w), pinv, uint32_t(w), info);
+            HIP_CHECK(hipMemcpyAsync(cblk, a + k0 * n0, n0 * size_t(w) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, ld, w, &one, pinv, w, a + k0, ld, &zero, rblk, w));
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, ld, w, &mone, cblk, ld, rblk, w, &one, a, ld));
+            HIP_CHECK(hipMemcpy2DAsync(a + k0, n0 * sizeof(double), rblk.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), n0, hipMemcpyDeviceToDevice, ctx->stream));
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, w, w, &mone, cblk, ld, pinv, w, &zero, a + k0 * n0, ld));
+            HIP_CHECK(hipMemcpy2DAsync(a + k0 * n0 + k0, n0 * sizeof(double), pinv.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), size_t(w), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        info.download(&hinfo, 1);
+        if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
+        static const bool check = getenv("MH_CHECK_COARSE") != nullptr;
+        if (check) { // || A0 A0^-1 - I ||_max against a copy taken before the elimination is not kept: check symmetry instead
+            std::vector<double> h(n0 * n0);
+            sys->a0.download(h.data(), n0 * n0);
+            double asym = 0, amax = 0;
+            for (size_t i = 0; i < n0; ++i)
+                for (size_t j = 0; j < i; ++j) { asym = std::max(asym, std::abs(h[i * n0 + j] - h[j * n0 + i])); amax = std::max(amax, std::abs(h[i * n0 + j])); }
+            fprintf(stderr, "[coarse] n0 %zu inverse asymmetry %.3e of max %.3e\n", n0, asym, amax);
+        }
+    } else {
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ExclusivePhase alone_on_the_device; // MH_CONCURRENT_SOLVES: nothing else runs beside the factorisation (see the top of the file)
+    ExclusivePhase alone_on_the_device; // rocsolver_dpotrf must not run beside other streams' kernels (see the top of the file)
     SolverLock solver_lock(g_rocsolver_mutex);
     ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
-    int hinfo = 0;
     info.download(&hinfo, 1);
     if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (potrf info %d): shift must be negative", hinfo);
-    // Explicit inverse: the coarse solve becomes one dense product per application (2.5x faster than two triangular
-    // solves at these sizes, and free of their O(n0/128) dependent launches).
     ROCBLAS_CHECK(rocsolver_dpotri(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
     info.download(&hinfo, 1);
     solver_lock.unlock();
     if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse inverse failed (potri info %d)", hinfo);
+    }
     k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -6,6 +6,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "skillet_s100k"
 nev = int(sys.argv[2]) if len(sys.argv) > 2 else 215
 p, t, m, kw = meshes.workload(name)
 mesh = api.Mesh(ctx, p, t)
+api.System(ctx, mesh, api.material(*m)).eigs(min(nev, 20), residual_tol=1e-3, max_iters=60)  # warm-up (code objects)
 t0 = time.perf_counter()
 s = api.System(ctx, mesh, api.material(*m))
 try:
