@@ -245,13 +245,16 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
 // [X | W | P] * Ct -> out1 (first n1 columns), out2 (the rest); Ct row-major m x nc.  mh_dense.hip
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
                 double *out1, uint32_t n1, double *out2, bool accumulate = false, uint32_t ldx = 0, const uint32_t *xmap = nullptr, uint32_t ld1 = 0,
-                const uint32_t *omap = nullptr); // optional column maps on X (read) and out1 (write), pitches ldx / ld1
+                const uint32_t *omap = nullptr, uint32_t col_begin = 0, uint32_t col_count = 0); // optional column maps on X (read) and out1 (write), pitches
+                                                                                                // ldx / ld1; col_count > 0: only columns [col_begin, +col_count) of Ct
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info); // mh_dense.hip
 void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info); // mh_dense.hip: lower Cholesky, order <= 128, one workgroup
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau); // mh_dense.hip: A (column-major, ld m, symmetric, full) -> D, E, tau, reflectors
 void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices);
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);
+void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w, uint32_t ldy,
+                    uint32_t wreal, const uint32_t *omap); // mh_spmm.hip: results into mapped columns of wider panels
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w); // double A x of a float panel
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

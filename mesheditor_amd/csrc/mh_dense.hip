@@ -369,8 +369,11 @@ __global__ void k_iota(uint32_t *p, uint32_t n) {
 
 // out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct  (+= when accumulate)
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
-                double *out1, uint32_t n1, double *out2, bool accumulate, uint32_t ldx, const uint32_t *xmap, uint32_t ld1, const uint32_t *omap) {
+                double *out1, uint32_t n1, double *out2, bool accumulate, uint32_t ldx, const uint32_t *xmap, uint32_t ld1, const uint32_t *omap, uint32_t col_begin,
+                uint32_t col_count) {
     if (!nc) return;
+    if (!col_count) { col_begin = 0; col_count = nc; }
+    if (col_begin + col_count > nc) mh_throw(MH_EINVAL, "combine: columns %u + %u exceed %u", col_begin, col_count, nc);
     const bool mapped = xmap != nullptr;
     if (mapped && accumulate) mh_throw(MH_EINVAL, "combine: column maps are not supported with accumulate");
     if (mapped && !omap) { // the mapped kernel writes out1 through a map: identity when the caller has none
@@ -384,9 +387,9 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     }
     const unsigned grid = div_up(n, 64);
     // more than 256 output columns: column chunks, each a launch over the same basis
-    const uint32_t chunks = div_up(nc, 256), step = (div_up(nc, chunks) + 15) / 16 * 16;
-    for (uint32_t c0 = 0; c0 < nc; c0 += step) {
-        const uint32_t ncc = std::min(step, nc - c0);
+    const uint32_t chunks = div_up(col_count, 256), step = (div_up(col_count, chunks) + 15) / 16 * 16;
+    for (uint32_t c0 = col_begin; c0 < col_begin + col_count; c0 += step) {
+        const uint32_t ncc = std::min(step, col_begin + col_count - c0);
         auto go = [&](auto nt_tag) {
             constexpr int NT = decltype(nt_tag)::value;
             constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;

@@ -148,6 +148,21 @@ __global__ void k_cheb_init(const T *__restrict__ b, const T *__restrict__ t, co
     d[i] = dv;
     x[i] = accumulate ? x[i] + dv : dv;
 }
+// The same with zero initial iterate, reading the double-precision right-hand side at its own pitch ws and leaving its
+// single-precision copy b32 (pitch w, zero padded) for the later steps: conversion and first step in one pass.
+__global__ void k_cheb_init_convert(const double *__restrict__ src, uint32_t ws, const float *__restrict__ dinv, float inv_theta, float *__restrict__ b32,
+                                    float *__restrict__ r, float *__restrict__ d, float *__restrict__ x, size_t rows, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const size_t row = i / w;
+    const uint32_t c = uint32_t(i % w);
+    const float rv = c < ws ? float(src[row * ws + c]) : 0.f;
+    const float dv = dinv[row] * rv * inv_theta;
+    b32[i] = rv;
+    r[i] = rv;
+    d[i] = dv;
+    x[i] = dv;
+}
 template<typename T>
 __global__ void k_cheb_step(const T *__restrict__ t, const T *__restrict__ dinv, T c1, T c2, T *__restrict__ r, T *__restrict__ d, T *__restrict__ x, size_t rows,
                             uint32_t w) {
@@ -187,13 +202,15 @@ template<typename S, typename D> __global__ void k_convert_pitch(const S *__rest
 // r1 = P^T (b - t): corner value plus half of every incident edge's midside value.
 template<typename T>
 __global__ void k_restrict_p1(const T *__restrict__ b, const T *__restrict__ t, const uint32_t *__restrict__ p1_corner, const uint32_t *__restrict__ eptr,
-                              const uint32_t *__restrict__ emid, T *__restrict__ r1, uint32_t npts, uint32_t w) {
+                              const uint32_t *__restrict__ emid, T *__restrict__ r1, uint32_t npts, uint32_t w, uint32_t wb = 0) {
+    // wb: pitch of b when it differs from the pitch w of t and r1 (columns >= wb of b read as zero)
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= size_t(npts) * 3 * w) return;
     const uint32_t c = uint32_t(i % w), comp = uint32_t((i / w) % 3), p = uint32_t(i / (size_t(3) * w));
+    const uint32_t pb = wb ? wb : w;
     auto res = [&](uint32_t node) {
-        const size_t o = (size_t(3) * node + comp) * w + c;
-        return b[o] - t[o];
+        const size_t row = size_t(3) * node + comp;
+        return (c < pb ? b[row * pb + c] : T(0)) - t[row * w + c];
     };
     T s = res(p1_corner[p]);
     T h = 0;
@@ -365,6 +382,13 @@ __global__ void k_scatter_cols(const double *__restrict__ src, const uint32_t *_
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
     dst[(i / w) * wdst + idx[i % w]] = src[i];
+}
+// dst[:, idx[k]] = src[:, k] for a source of pitch wsrc
+__global__ void k_scatter_cols_pitch(const double *__restrict__ src, uint32_t wsrc, const uint32_t *__restrict__ idx, double *__restrict__ dst, size_t rows, uint32_t wdst,
+                                     uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    dst[(i / w) * wdst + idx[i % w]] = src[(i / w) * wsrc + i % w];
 }
 // seed basis (column-major float, reference DOF order) -> leading columns of a row-major internal-order panel
 __global__ void k_load_seed(const float *__restrict__ seed, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t ncols, uint32_t b, double *__restrict__ x) {
@@ -574,7 +598,7 @@ template<typename T> struct Precond {
     DevArray<double> r0, x0, x0_partial;
     static constexpr uint32_t COARSE_SLICES = 8;
     bool coarse_mfma{true};
-    DevArray<double> rin64, t2d, r1d, t1d; // single-precision smoothers: the residuals handed down a level stay double
+    DevArray<double> t2d, r1d, t1d; // single-precision smoothers: the residuals handed down a level stay double
     static constexpr bool kDouble = std::is_same<T, double>::value;
     static uint32_t pitch(uint32_t w) { return kDouble ? w : (w + 3u) & ~3u; } // 16-byte panel rows for the wide-load SpMM
     Precond(mh_system *s, uint32_t w_in) : sys(s), ctx(s->ctx), wmax(w_in) {
@@ -583,7 +607,7 @@ template<typename T> struct Precond {
         d2.reset(ctx, n2 * w); t2.reset(ctx, n2 * w); r2.reset(ctx, n2 * w); z2.reset(ctx, n2 * w);
         if (!kDouble) {
             rin.reset(ctx, n2 * w);
-            rin64.reset(ctx, n2 * w); t2d.reset(ctx, n2 * w);
+            t2d.reset(ctx, n2 * w);
             r1d.reset(ctx, n1 * w); t1d.reset(ctx, n1 * w);
         }
         r1.reset(ctx, n1 * w); x1.reset(ctx, n1 * w); d1.reset(ctx, n1 * w); t1.reset(ctx, n1 * w); rr1.reset(ctx, n1 * w);
@@ -605,14 +629,20 @@ template<typename T> struct Precond {
         else return lvl.dinv32.get();
     }
     // deg Chebyshev-Jacobi steps on lvl; when z_out is given the last step writes the iterate there (in double)
-    void cheb(const BsrLevel &lvl, int deg, const T *b, T *x, bool zero_init, T *r, T *d, T *t, uint32_t w, double *z_out = nullptr, uint32_t w_out = 0) {
+    void cheb(const BsrLevel &lvl, int deg, const T *b, T *x, bool zero_init, T *r, T *d, T *t, uint32_t w, double *z_out = nullptr, uint32_t w_out = 0,
+              const double *b_src = nullptr, uint32_t w_src = 0, T *b_copy = nullptr) { // b_src: (single-precision cycle) convert the right-hand side on the way
         const size_t rows = size_t(3) * lvl.n_nodes;
         const double lmax = lvl.lmax, lmin = lvl.lmax / ratio;
         const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig = theta / delta;
         double rho = 1.0 / sig;
         const T *dinv = dinv_of(lvl);
         if (!zero_init) spmm(lvl, x, t, w);
-        k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
+        if constexpr (!kDouble) {
+            if (b_src && zero_init) k_cheb_init_convert<<<grid1(rows * w), TB, 0, ctx->stream>>>(b_src, w_src, dinv, float(1.0 / theta), b_copy, r, d, x, rows, w);
+            else k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
+        } else {
+            k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
+        }
         KERNEL_CHECK();
         for (int k = 1; k < deg; ++k) {
             spmm(lvl, d, t, w);
@@ -635,13 +665,10 @@ template<typename T> struct Precond {
         const double one = 1, zero = 0;
         const T *r;
         if constexpr (kDouble) r = r_in;
-        else {
-            k_convert_pitch<double, T><<<grid1(n2 * w), TB, 0, ctx->stream>>>(r_in, w_in, rin.get(), w, n2);
-            KERNEL_CHECK();
-            r = rin.get();
-        }
+        else r = rin.get(); // filled by the first smoothing step below
         T *z = z2.get();
-        cheb(sys->L2, deg2, r, z, true, r2, d2, t2, w);
+        if constexpr (kDouble) cheb(sys->L2, deg2, r, z, true, r2, d2, t2, w);
+        else cheb(sys->L2, deg2, r, z, true, r2, d2, t2, w, nullptr, 0, r_in, w_in, rin.get());
         // Residual for the next level.  With single-precision smoothers it is formed in double (double A, double r,
         // the float iterate): a float residual carries an error of 6e-8 ||A|| ||z|| that the coarse solves amplify by
         // the condition number, which stalls the lowest modes of thin, ill-conditioned bodies at ~1e-4.
@@ -650,10 +677,8 @@ template<typename T> struct Precond {
             k_restrict_p1<double><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r, t2.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1.get(), np, w);
             KERNEL_CHECK();
         } else {
-            k_convert_pitch<double, double><<<grid1(n2 * w), TB, 0, ctx->stream>>>(r_in, w_in, rin64.get(), w, n2);
-            KERNEL_CHECK();
             mh_spmm_mixed(ctx, sys->L2, z, t2d, w);
-            k_restrict_p1<double><<<grid1(n1 * w), TB, 0, ctx->stream>>>(rin64.get(), t2d.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1d.get(), np, w);
+            k_restrict_p1<double><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r_in, t2d.get(), sys->p1_corner, sys->p1_edge_ptr, sys->p1_edge_mid, r1d.get(), np, w, w_in); // r_in at its own pitch
             KERNEL_CHECK();
             k_convert<double, T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(r1d.get(), r1.get(), n1 * w);
             KERNEL_CHECK();
@@ -690,12 +715,13 @@ double estimate_lmax(mh_context *ctx, BsrLevel &lvl) {
     colsumsq(ctx, v, rows, w, nrm, scratch);
     k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
     KERNEL_CHECK();
-    for (int it = 0; it < 12; ++it) {
+    static const int power_its = getenv("MH_LMAX_ITS") ? std::max(2, atoi(getenv("MH_LMAX_ITS"))) : 12;
+    for (int it = 0; it < power_its; ++it) {
         mh_spmm(ctx, lvl, lvl.aval, v, t, nullptr, nullptr, w);
         k_dinv_mul<<<grid1(rows * w), TB, 0, ctx->stream>>>(t, lvl.dinv, v, rows, w);
         KERNEL_CHECK();
         colsumsq(ctx, v, rows, w, nrm, scratch);
-        if (it + 1 < 12) {
+        if (it + 1 < power_its) {
             k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
             KERNEL_CHECK();
         }
@@ -1163,9 +1189,24 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // X_active <- S Cx (mapped columns of X), P <- S Cp.  One launch per image works in place (a workgroup reads its 64
                 // rows completely before writing them); more than 256 output columns take several launches over the same
                 // inputs, so those go through a contiguous copy and a scatter.
+                // Images of the new block.  A X and M X are formed from the new Ritz vectors by one fused product (written straight into
+                // the active columns) instead of being recombined from [A X, A W, A P] and [M X, M W, M P]: one pass over the matrix
+                // costs less than two passes over three tall panels each, the images carry no accumulated rounding, and A P is
+                // not needed at all (P^T A P comes from the small matrices, above).  M P, which the next projection needs, is
+                // still recombined -- before M X is overwritten.
+                static const bool fresh_images = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
+                const bool in_place = wa + wp_new <= 256;
+                if (fresh_images && implicit_p && wa <= 128) {
+                    const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
+                    mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
+                    if (wp_new) mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);
+                    if (pitch == wa) k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), idx_d, X.get(), n, b, wa);
+                    else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
+                    KERNEL_CHECK();
+                    mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d);
+                } else {
                 const bool refresh = (it + 1) % 8 == 0; // images of the new Ritz vectors recomputed instead of recombined: A X and
                                                         // M X otherwise inherit eight generations of rounding from the updates
-                const bool in_place = wa + wp_new <= 256;
                 auto update = [&](DevArray<double> &x_all, const double *wpanel, const double *ppanel, DevArray<double> &x_new, double *p_new, bool keep_contiguous) {
                     if (in_place && !keep_contiguous) {
                         mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_all, wa, p_new, false, b, idx_d, b, idx_d);
@@ -1186,6 +1227,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
                     k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
                     KERNEL_CHECK();
+                }
                 }
                 std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
                 wp = wp_new;

@@ -111,10 +111,12 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
 // The panel pitch w must be a multiple of V (16-byte rows).
 // TV = matrix values, TX = panel read, TY = accumulators and panel written (TV = TY = double with TX = float gives the
 // double-precision residual of a single-precision iterate at single-precision gather cost).
-template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A>
+// MAPOUT: the results go to columns omap[c] (c < wreal) of panels of pitch ldy instead of a panel shaped like x -- the images
+// A X, M X of the new Ritz vectors written straight into the active columns of the block.
+template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false>
 __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
-                                                 uint32_t w, int xcd_remap) {
+                                                 uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr) {
     constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
@@ -223,6 +225,18 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
                 macc[i][e] = sm_;
             }
         }
+    }
+    if (MAPOUT) {
+        if (g == 0 && act) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (coff + e >= wreal) continue;
+                const size_t o = size_t(3) * row * ldy + omap[coff + e];
+                if (WITH_A) { y[o] = acc[0][e]; y[o + ldy] = acc[1][e]; y[o + 2 * size_t(ldy)] = acc[2][e]; }
+                if (WITH_M) { y2[o] = macc[0][e]; y2[o + ldy] = macc[1][e]; y2[o + 2 * size_t(ldy)] = macc[2][e]; }
+            }
+        }
+        return;
     }
     if (g == 0 && act) {
         const size_t o = size_t(3) * row * w + coff;
@@ -352,6 +366,26 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
         launch_spmm<double, false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
     }
     else launch_spmm<double, true, false>(ctx, lvl, nullptr, x, nullptr, mscal, y2, w);
+}
+
+// A x and M x of an n x w panel (w even, 16-byte aligned) written to columns omap[c], c < wreal, of panels of pitch ldy.
+void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w, uint32_t ldy,
+                    uint32_t wreal, const uint32_t *omap) {
+    if (w == 0 || wreal == 0) return;
+    if (w % 2 || w > 128 || (reinterpret_cast<uintptr_t>(x) & 15)) mh_throw(MH_EINVAL, "mapped product needs an even pitch <= 128 and an aligned panel (got %u)", w);
+    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, wreal, 8, 8, 8, true, true));
+    static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+    const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
+    auto go = [&](auto cl_tag) {
+        constexpr int CL = decltype(cl_tag)::value;
+        k_spmm_wide<double, double, double, 2, CL, true, true, true><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd, ldy, wreal, omap);
+    };
+    const uint32_t lanes = w / 2;
+    if (lanes <= 8) go(std::integral_constant<int, 8>{});
+    else if (lanes <= 16) go(std::integral_constant<int, 16>{});
+    else if (lanes <= 32) go(std::integral_constant<int, 32>{});
+    else go(std::integral_constant<int, 64>{});
+    KERNEL_CHECK();
 }
 
 // fp32 product with the level's single-precision copy of A (preconditioner only).
