@@ -255,6 +255,8 @@ void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const doubl
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);
 void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w, uint32_t ldy,
                     uint32_t wreal, const uint32_t *omap); // mh_spmm.hip: results into mapped columns of wider panels
+bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_in, float *d_out, float *r, float *x, const float *dinv, float c1, float c2,
+                           uint32_t w); // mh_spmm.hip: product + Chebyshev step in one launch
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w); // double A x of a float panel
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

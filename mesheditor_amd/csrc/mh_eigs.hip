@@ -644,12 +644,23 @@ template<typename T> struct Precond {
             k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
         }
         KERNEL_CHECK();
+        static const bool fuse_steps = !(getenv("MH_CHEB_FUSED") && atoi(getenv("MH_CHEB_FUSED")) == 0);
+        T *cur = d, *alt = t; // the direction lives in `cur`; `alt` takes the product, or (fused step) the next direction
         for (int k = 1; k < deg; ++k) {
-            spmm(lvl, d, t, w);
             const double rho_new = 1.0 / (2 * sig - rho);
-            if (z_out && k + 1 == deg) k_cheb_last<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(t, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, d, x, z_out, rows, w, w_out);
-            else k_cheb_step<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(t, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, d, x, rows, w);
-            KERNEL_CHECK();
+            const bool last = z_out && k + 1 == deg;
+            bool fused = false;
+            if constexpr (!kDouble) {
+                if (fuse_steps && !last) fused = mh_spmm_f32_cheb_step(ctx, lvl, cur, alt, r, x, dinv, float(rho_new * rho), float(2 * rho_new / delta), w);
+            }
+            if (fused) {
+                std::swap(cur, alt);
+            } else {
+                spmm(lvl, cur, alt, w);
+                if (last) k_cheb_last<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(alt, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, cur, x, z_out, rows, w, w_out);
+                else k_cheb_step<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(alt, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, cur, x, rows, w);
+                KERNEL_CHECK();
+            }
             rho = rho_new;
         }
         if (z_out && deg == 1) {

@@ -113,10 +113,20 @@ __global__ void __launch_bounds__(TB) k_spmm(const uint32_t *__restrict__ row_pt
 // double-precision residual of a single-precision iterate at single-precision gather cost).
 // MAPOUT: the results go to columns omap[c] (c < wreal) of panels of pitch ldy instead of a panel shaped like x -- the images
 // A X, M X of the new Ritz vectors written straight into the active columns of the block.
-template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false>
+// EPI = 1: instead of storing t = A d, the Chebyshev step that consumes it runs on the rows while they are in registers:
+// r -= t, d' = c1 d + c2 D^-1 r, x += d'.  d' goes to a second buffer (other rows are still gathering d).  One launch and one
+// pass over t less per smoothing step.
+struct ChebStep {
+    float *r = nullptr;
+    const float *dinv = nullptr;
+    float *d_out = nullptr;
+    float *x = nullptr;
+    float c1 = 0.f, c2 = 0.f;
+};
+template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false, int EPI = 0>
 __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
-                                                 uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr) {
+                                                 uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{}) {
     constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
@@ -134,6 +144,21 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
     Acc acc[3], macc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = macc[i] = Acc(0);
+    // EPI: the rows the step updates are requested now, so they arrive while the products are formed
+    Acc er[3], ed[3], ex[3];
+    TY edinv[3];
+    if constexpr (EPI == 1) {
+        if (g == 0 && act) {
+            const size_t o = size_t(3) * row * w + coff;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                er[i] = *reinterpret_cast<const Acc *>(epi.r + o + size_t(i) * w);
+                ed[i] = __builtin_convertvector(*reinterpret_cast<const Vec *>(x + o + size_t(i) * w), Acc);
+                ex[i] = *reinterpret_cast<const Acc *>(epi.x + o + size_t(i) * w);
+                edinv[i] = epi.dinv[size_t(3) * row + i];
+            }
+        }
+    }
     const uint32_t p0 = __builtin_amdgcn_readfirstlane(row_ptr[row]), p1 = __builtin_amdgcn_readfirstlane(row_ptr[row + 1]);
     TV *svw = sv[wave];
     TV *smw = sm[wave];
@@ -225,6 +250,21 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
                 macc[i][e] = sm_;
             }
         }
+    }
+    if constexpr (EPI == 1) {
+        if (g == 0 && act) {
+            const size_t o = size_t(3) * row * w + coff;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const size_t oi = o + size_t(i) * w;
+                const Acc rv = er[i] - acc[i];
+                const Acc dv = epi.c1 * ed[i] + (epi.c2 * edinv[i]) * rv;
+                *reinterpret_cast<Acc *>(epi.r + oi) = rv;
+                *reinterpret_cast<Acc *>(epi.d_out + oi) = dv;
+                *reinterpret_cast<Acc *>(epi.x + oi) = ex[i] + dv;
+            }
+        }
+        return;
     }
     if (MAPOUT) {
         if (g == 0 && act) {
@@ -386,6 +426,33 @@ void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, c
     else if (lanes <= 32) go(std::integral_constant<int, 32>{});
     else go(std::integral_constant<int, 64>{});
     KERNEL_CHECK();
+}
+
+// One Chebyshev-Jacobi step of the single-precision smoother with the product fused in (see ChebStep): t = A d never reaches
+// memory.  false when the panel does not qualify for the wide-load kernel (the caller then runs product and step apart).
+bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_in, float *d_out, float *r, float *x, const float *dinv, float c1, float c2, uint32_t w) {
+    if (w == 0) return true;
+    const bool aligned16 = !((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x)) & 15);
+    if (w % 4 || w > 256 || !aligned16) return false;
+    // algorithmic bytes: the product's (d read, no t written) plus the step's own passes: r and x read and written, d' written
+    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 4, 4, 0, true, false) + 5.0 * 4.0 * 3.0 * double(lvl.n_nodes) * w);
+    static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+    const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
+    ChebStep epi;
+    epi.r = r; epi.dinv = dinv; epi.d_out = d_out; epi.x = x; epi.c1 = c1; epi.c2 = c2;
+    auto go = [&](auto cl_tag) {
+        constexpr int CL = decltype(cl_tag)::value;
+        k_spmm_wide<float, float, float, 4, CL, false, true, false, 1><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval32.get(), static_cast<const float *>(nullptr), d_in,
+                                                                                                   static_cast<float *>(nullptr), static_cast<float *>(nullptr), lvl.n_nodes, w, xcd, 0, 0, nullptr, epi);
+    };
+    const uint32_t lanes = w / 4;
+    if (lanes <= 8) go(std::integral_constant<int, 8>{});
+    else if (lanes <= 16) go(std::integral_constant<int, 16>{});
+    else if (lanes <= 20) go(std::integral_constant<int, 20>{});
+    else if (lanes <= 32) go(std::integral_constant<int, 32>{});
+    else go(std::integral_constant<int, 64>{});
+    KERNEL_CHECK();
+    return true;
 }
 
 // fp32 product with the level's single-precision copy of A (preconditioner only).
