@@ -1207,7 +1207,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // still recombined -- before M X is overwritten.
                 static const bool fresh_images = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
                 const bool in_place = wa + wp_new <= 256;
-                if (fresh_images && implicit_p && wa <= 128) {
+                if (fresh_images && implicit_p) {
                     const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
                     mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
                     if (wp_new) mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);

@@ -126,7 +126,8 @@ struct ChebStep {
 template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false, int EPI = 0>
 __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
-                                                 uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{}) {
+                                                 uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{},
+                                                 uint32_t xpitch = 0) { // xpitch (MAPOUT): row pitch of x when the launch covers a column range of a wider panel
     constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
@@ -192,10 +193,11 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < rounds) { // wave-uniform
                     bi[u] = min((t0 + u) * G + g, nb - 1);
-                    const TX *xr = x + size_t(3) * scw[bi[u]] * w + coff;
+                    const uint32_t xp = MAPOUT ? xpitch : w;
+                    const TX *xr = x + size_t(3) * scw[bi[u]] * xp + coff;
                     xv[u][0] = *reinterpret_cast<const Vec *>(xr);
-                    xv[u][1] = *reinterpret_cast<const Vec *>(xr + w);
-                    xv[u][2] = *reinterpret_cast<const Vec *>(xr + 2 * size_t(w));
+                    xv[u][1] = *reinterpret_cast<const Vec *>(xr + xp);
+                    xv[u][2] = *reinterpret_cast<const Vec *>(xr + 2 * size_t(xp));
                 }
             }
 #pragma unroll
@@ -412,20 +414,26 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
 void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w, uint32_t ldy,
                     uint32_t wreal, const uint32_t *omap) {
     if (w == 0 || wreal == 0) return;
-    if (w % 2 || w > 128 || (reinterpret_cast<uintptr_t>(x) & 15)) mh_throw(MH_EINVAL, "mapped product needs an even pitch <= 128 and an aligned panel (got %u)", w);
-    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, wreal, 8, 8, 8, true, true));
+    if (w % 2 || (reinterpret_cast<uintptr_t>(x) & 15)) mh_throw(MH_EINVAL, "mapped product needs an even pitch and an aligned panel (got %u)", w);
     static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
-    auto go = [&](auto cl_tag) {
-        constexpr int CL = decltype(cl_tag)::value;
-        k_spmm_wide<double, double, double, 2, CL, true, true, true><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd, ldy, wreal, omap);
-    };
-    const uint32_t lanes = w / 2;
-    if (lanes <= 8) go(std::integral_constant<int, 8>{});
-    else if (lanes <= 16) go(std::integral_constant<int, 16>{});
-    else if (lanes <= 32) go(std::integral_constant<int, 32>{});
-    else go(std::integral_constant<int, 64>{});
-    KERNEL_CHECK();
+    // panels wider than the 128 columns one wave covers go in column ranges of the same pitch
+    const uint32_t ranges = div_up(w, 128u), step = (div_up(w, ranges) + 1u) & ~1u;
+    for (uint32_t c0 = 0; c0 < wreal; c0 += step) {
+        const uint32_t wc = std::min(step, w - c0), wr = std::min(wc, wreal - c0);
+        TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, wr, 8, 8, 8, true, true));
+        auto go = [&](auto cl_tag) {
+            constexpr int CL = decltype(cl_tag)::value;
+            k_spmm_wide<double, double, double, 2, CL, true, true, true><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x + c0, y, y2, lvl.n_nodes, wc, xcd, ldy, wr, omap + c0,
+                                                                                                  ChebStep{}, w);
+        };
+        const uint32_t lanes = wc / 2;
+        if (lanes <= 8) go(std::integral_constant<int, 8>{});
+        else if (lanes <= 16) go(std::integral_constant<int, 16>{});
+        else if (lanes <= 32) go(std::integral_constant<int, 32>{});
+        else go(std::integral_constant<int, 64>{});
+        KERNEL_CHECK();
+    }
 }
 
 // One Chebyshev-Jacobi step of the single-precision smoother with the product fused in (see ChebStep): t = A d never reaches
