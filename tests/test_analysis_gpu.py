@@ -68,6 +68,37 @@ def test_degenerate_and_ragged_inputs(api, ctx, oracle):
     assert e.value.code == 1
 
 
+def test_tiny_systems_and_solver_argument_errors(api, ctx, oracle):
+    """A system of a few hundred unknowns takes the dense path (one generalised eigensolve on the device): same eigenvalues
+    as the oracle.  Bad arguments come back as the documented codes: nev >= n (EINVAL), a non-negative shift (EFACTOR, the
+    reference's 'factorization failed'), an iteration limit that cannot be met (ENOTCONVERGED -> empty result upstream)."""
+    pts, tets = meshes.kuhn_box(2, 2, 2, 0.2, 0.15, 0.1)
+    m = meshes.MATERIALS["Glass"]
+    mg, mo = _mats(api, oracle, m)
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
+    syso = oracle.System(pts, tets, mo)
+    assert sysg.n == 375 == syso.n
+    ev, prof = sysg.eigs(20, SIGMA, 1e-6)
+    evo, _, _ = syso.eigs(20)
+    elastic = evo > 1e-6 * evo[-1]
+    assert elastic.sum() == 14
+    assert (np.abs(ev[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    assert np.abs(ev[~elastic]).max() < 1e-6 * evo[6]
+    with pytest.raises(api.ModalHipError) as e:
+        sysg.eigs(375, SIGMA)
+    assert e.value.code == 1
+    with pytest.raises(api.ModalHipError) as e:
+        sysg.eigs(20, +1.0)
+    assert e.value.code == 5
+    pts, tets, m, _ = meshes.workload("cube_small")
+    big = api.System(ctx, api.Mesh(ctx, pts, tets), api.material(*m))
+    with pytest.raises(api.ModalHipError) as e:
+        big.eigs(30, SIGMA, 1e-10, max_iters=2)
+    assert e.value.code == 4
+    ev, _ = big.eigs(30, SIGMA, 1e-6)  # the system is still usable after a failed solve
+    assert np.all(np.isfinite(ev))
+
+
 def test_spmm_matches_oracle(api, ctx, oracle):
     pts, tets, m, _ = meshes.workload("cube_small")
     mg, mo = _mats(api, oracle, m)
