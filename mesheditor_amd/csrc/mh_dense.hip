@@ -361,6 +361,12 @@ void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const 
 }
 
 namespace {
+// full[xmap[k]][:] = ct[k][:] for the wx mapped rows (k-major coefficient matrices of pitch nc)
+__global__ void k_spread_rows(const double *__restrict__ ct, const uint32_t *__restrict__ xmap, uint32_t wx, uint32_t nc, double *__restrict__ full) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(wx) * nc) return;
+    full[size_t(xmap[i / nc]) * nc + i % nc] = ct[i];
+}
 __global__ void k_iota(uint32_t *p, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
@@ -373,6 +379,7 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
                 uint32_t col_count) {
     if (!nc) return;
     if (!col_count) { col_begin = 0; col_count = nc; }
+    const bool caller_omap = omap != nullptr;
     if (col_begin + col_count > nc) mh_throw(MH_EINVAL, "combine: columns %u + %u exceed %u", col_begin, col_count, nc);
     const bool mapped = xmap != nullptr;
     if (mapped && accumulate) mh_throw(MH_EINVAL, "combine: column maps are not supported with accumulate");
@@ -384,6 +391,42 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
         }
         if (n1 > 1024) mh_throw(MH_EINVAL, "combine: %u mapped output columns exceed 1024", n1);
         omap = ctx->iota;
+    }
+    // Wide blocks (the 200-mode configuration: several hundred basis and output columns): the vendor dgemm reaches 50-65 TF/s
+    // on these tall-skinny shapes where our 256-column chunks stay at 36 (tools/probe/gemm_probe.py).  Row-major panels are
+    // column-major transposes, so out^T (cols x n) = Ct^T-block (cols x k) * panel^T (k x n), one call per panel and output;
+    // a column map on X becomes zero coefficient rows for the columns left out.
+    static const bool wide_blas = !(getenv("MH_COMBINE_BLAS") && atoi(getenv("MH_COMBINE_BLAS")) == 0);
+    const uint32_t m_total = wx + ww + wp;
+    if (wide_blas && m_total >= 400 && col_count >= 128 && !caller_omap && out1 != x && out2 != x && n >= 65536) {
+        const uint32_t px = ldx ? ldx : wx; // physical columns of the X panel
+        const double *cx = ct; // coefficient rows of the X part, k-major with pitch nc
+        DevArray<double> ct_full;
+        if (mapped) { // rows of Ct spread to the mapped columns of X, zeros elsewhere
+            ct_full.reset(ctx, size_t(px) * nc);
+            ct_full.zero();
+            k_spread_rows<<<div_up(size_t(wx) * nc, 256), 256, 0, ctx->stream>>>(ct, xmap, wx, nc, ct_full.get());
+            KERNEL_CHECK();
+            cx = ct_full.get();
+        }
+        const double one = 1, zero = 0;
+        struct Part { const double *panel; uint32_t width, pitch; const double *coeff; };
+        const Part parts[3] = {{x, mapped ? px : wx, px, cx}, {w, ww, ww, ct + size_t(wx) * nc}, {p, wp, wp, ct + size_t(wx + ww) * nc}};
+        auto emit = [&](double *out, uint32_t pitch, uint32_t c_begin, uint32_t c_count) {
+            if (!c_count) return;
+            bool first = true;
+            for (const Part &part : parts) {
+                if (!part.panel || !part.width) continue;
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(c_count), rocblas_int(n), rocblas_int(part.width), &one,
+                                            part.coeff + c_begin, rocblas_int(nc), part.panel, rocblas_int(part.pitch), (first && !accumulate) ? &zero : &one, out, rocblas_int(pitch)));
+                first = false;
+            }
+        };
+        const uint32_t c_end = col_begin + col_count;
+        if (col_begin < n1) emit(out1 + col_begin, ld1 ? ld1 : n1, col_begin, std::min(c_end, n1) - col_begin);
+        if (c_end > n1) emit(out2 + (std::max(col_begin, n1) - n1), nc - n1, std::max(col_begin, n1), c_end - std::max(col_begin, n1));
+        if (mapped) HIP_CHECK(hipStreamSynchronize(ctx->stream)); // ct_full returns to the pool
+        return;
     }
     const unsigned grid = div_up(n, 64);
     // more than 256 output columns: column chunks, each a launch over the same basis
