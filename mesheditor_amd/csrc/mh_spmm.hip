@@ -7,7 +7,10 @@
 #include "mh_common.h"
 
 namespace {
-constexpr int TB = 256;
+#ifndef MH_SPMM_TB
+#define MH_SPMM_TB 64
+#endif
+constexpr int TB = MH_SPMM_TB;
 
 // CW = panel columns per row group (power of two <= 64); a wave covers 64/CW block rows.
 // NC = columns per lane (stride CW) so that panels up to CW*NC wide read the matrix once.
