@@ -11,6 +11,9 @@ namespace {
 #define MH_SPMM_TB 64
 #endif
 constexpr int TB = MH_SPMM_TB;
+#ifndef MH_SPMM_U
+#define MH_SPMM_U 1 // node-block rounds whose gathers are in flight together: 1 keeps the registers low (occupancy 7-8 waves per SIMD beats deeper unrolling)
+#endif
 
 // CW = panel columns per row group (power of two <= 64); a wave covers 64/CW block rows.
 // NC = columns per lane (stride CW) so that panels up to CW*NC wide read the matrix once.
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
                                                  uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{},
                                                  uint32_t xpitch = 0) { // xpitch (MAPOUT): row pitch of x when the launch covers a column range of a wider panel
-    constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = 4; // V = panel entries per lane (16 bytes; 1 for odd pitches)
+    constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = MH_SPMM_U; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
     __shared__ __attribute__((aligned(16))) TV sv[TB / 64][WITH_A ? STRIP * VP : 1];
@@ -148,6 +151,7 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
     Acc acc[3], macc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = macc[i] = Acc(0);
+#ifdef MH_SPMM_EPI_PREFETCH
     // EPI: the rows the step updates are requested now, so they arrive while the products are formed
     Acc er[3], ed[3], ex[3];
     TY edinv[3];
@@ -163,6 +167,7 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
             }
         }
     }
+#endif
     const uint32_t p0 = __builtin_amdgcn_readfirstlane(row_ptr[row]), p1 = __builtin_amdgcn_readfirstlane(row_ptr[row + 1]);
     TV *svw = sv[wave];
     TV *smw = sm[wave];
@@ -262,11 +267,20 @@ __global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ r
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const size_t oi = o + size_t(i) * w;
+#ifdef MH_SPMM_EPI_PREFETCH
                 const Acc rv = er[i] - acc[i];
                 const Acc dv = epi.c1 * ed[i] + (epi.c2 * edinv[i]) * rv;
+                const Acc xn = ex[i] + dv;
+#else
+                // loaded here rather than up front: nine more vector registers per lane would cost two waves of occupancy,
+                // and occupancy is what hides the gathers
+                const Acc rv = *reinterpret_cast<const Acc *>(epi.r + oi) - acc[i];
+                const Acc dv = epi.c1 * __builtin_convertvector(*reinterpret_cast<const Vec *>(x + oi), Acc) + (epi.c2 * epi.dinv[size_t(3) * row + i]) * rv;
+                const Acc xn = *reinterpret_cast<const Acc *>(epi.x + oi) + dv;
+#endif
                 *reinterpret_cast<Acc *>(epi.r + oi) = rv;
                 *reinterpret_cast<Acc *>(epi.d_out + oi) = dv;
-                *reinterpret_cast<Acc *>(epi.x + oi) = ex[i] + dv;
+                *reinterpret_cast<Acc *>(epi.x + oi) = xn;
             }
         }
         return;
