@@ -129,8 +129,13 @@ struct ChebStep {
     float *x = nullptr;
     float c1 = 0.f, c2 = 0.f;
 };
+#ifdef MH_SPMM_WAVES
+#define MH_SPMM_OCC __attribute__((amdgpu_waves_per_eu(MH_SPMM_WAVES, 8)))
+#else
+#define MH_SPMM_OCC
+#endif
 template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false, int EPI = 0>
-__global__ void __launch_bounds__(TB) k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
+__global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
                                                  uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{},
                                                  uint32_t xpitch = 0) { // xpitch (MAPOUT): row pitch of x when the launch covers a column range of a wider panel
