@@ -148,6 +148,39 @@ __global__ void k_cheb_init(const T *__restrict__ b, const T *__restrict__ t, co
     d[i] = dv;
     x[i] = accumulate ? x[i] + dv : dv;
 }
+// Single-precision panels have pitches that are multiples of 4: the smoother's elementwise steps move 16 bytes per lane.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__global__ void k_cheb_init_v4(const f4_t *__restrict__ b, const f4_t *__restrict__ t, const float *__restrict__ dinv, float inv_theta, f4_t *__restrict__ r,
+                               f4_t *__restrict__ d, f4_t *__restrict__ x, int accumulate, size_t rows, uint32_t w4) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w4) return;
+    const f4_t rv = t ? b[i] - t[i] : b[i];
+    const f4_t dv = (dinv[i / w4] * inv_theta) * rv;
+    r[i] = rv;
+    d[i] = dv;
+    x[i] = accumulate ? x[i] + dv : dv;
+}
+__global__ void k_cheb_last_v4(const f4_t *__restrict__ t, const float *__restrict__ dinv, float c1, float c2, const f4_t *__restrict__ r, const f4_t *__restrict__ d,
+                               const f4_t *__restrict__ x, double *__restrict__ z, size_t rows, uint32_t w4, uint32_t wo) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * w4) return;
+    const size_t row = i / w4;
+    const uint32_t c = uint32_t(i % w4) * 4;
+    const f4_t rv = r[i] - t[i];
+    const f4_t zv = x[i] + (c1 * d[i] + (c2 * dinv[row]) * rv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c + e < wo) z[row * wo + c + e] = double(zv[e]);
+}
+__global__ void k_prolong_p1_v4(const f4_t *__restrict__ x1, const uint32_t *__restrict__ pa, const uint32_t *__restrict__ pb, f4_t *__restrict__ x2, uint32_t nnodes,
+                                uint32_t w4) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nnodes) * 3 * w4) return;
+    const uint32_t c = uint32_t(i % w4), comp = uint32_t((i / w4) % 3), node = uint32_t(i / (size_t(3) * w4));
+    const uint32_t a = pa[node], bb = pb[node];
+    const f4_t va = x1[(size_t(3) * a + comp) * w4 + c];
+    x2[i] += a == bb ? va : 0.5f * (va + x1[(size_t(3) * bb + comp) * w4 + c]);
+}
 // The same with zero initial iterate, reading the double-precision right-hand side at its own pitch ws and leaving its
 // single-precision copy b32 (pitch w, zero padded) for the later steps: conversion and first step in one pass.
 __global__ void k_cheb_init_convert(const double *__restrict__ src, uint32_t ws, const float *__restrict__ dinv, float inv_theta, float *__restrict__ b32,
@@ -639,7 +672,9 @@ template<typename T> struct Precond {
         if (!zero_init) spmm(lvl, x, t, w);
         if constexpr (!kDouble) {
             if (b_src && zero_init) k_cheb_init_convert<<<grid1(rows * w), TB, 0, ctx->stream>>>(b_src, w_src, dinv, float(1.0 / theta), b_copy, r, d, x, rows, w);
-            else k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
+            else k_cheb_init_v4<<<grid1(rows * (w / 4)), TB, 0, ctx->stream>>>(reinterpret_cast<const f4_t *>(b), zero_init ? nullptr : reinterpret_cast<const f4_t *>(t), dinv,
+                                                                               float(1.0 / theta), reinterpret_cast<f4_t *>(r), reinterpret_cast<f4_t *>(d),
+                                                                               reinterpret_cast<f4_t *>(x), zero_init ? 0 : 1, rows, w / 4);
         } else {
             k_cheb_init<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(b, zero_init ? nullptr : t, dinv, T(1.0 / theta), r, d, x, zero_init ? 0 : 1, rows, w);
         }
@@ -657,8 +692,15 @@ template<typename T> struct Precond {
                 std::swap(cur, alt);
             } else {
                 spmm(lvl, cur, alt, w);
-                if (last) k_cheb_last<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(alt, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, cur, x, z_out, rows, w, w_out);
-                else k_cheb_step<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(alt, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, cur, x, rows, w);
+                if (!last) {
+                    k_cheb_step<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(alt, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, cur, x, rows, w);
+                } else if constexpr (kDouble) {
+                    k_cheb_last<T><<<grid1(rows * w), TB, 0, ctx->stream>>>(alt, dinv, T(rho_new * rho), T(2 * rho_new / delta), r, cur, x, z_out, rows, w, w_out);
+                } else {
+                    k_cheb_last_v4<<<grid1(rows * (w / 4)), TB, 0, ctx->stream>>>(reinterpret_cast<const f4_t *>(alt), dinv, float(rho_new * rho), float(2 * rho_new / delta),
+                                                                             reinterpret_cast<const f4_t *>(r), reinterpret_cast<const f4_t *>(cur),
+                                                                             reinterpret_cast<const f4_t *>(x), z_out, rows, w / 4, w_out);
+                }
                 KERNEL_CHECK();
             }
             rho = rho_new;
@@ -711,7 +753,8 @@ template<typename T> struct Precond {
             KERNEL_CHECK();
             cheb(sys->L1, deg1, r1, x1, false, rr1, d1, t1, w);
         }
-        k_prolong_p1<T><<<grid1(n2 * w), TB, 0, ctx->stream>>>(x1.get(), sys->parent_a, sys->parent_b, z, nn, w);
+        if constexpr (kDouble) k_prolong_p1<T><<<grid1(n2 * w), TB, 0, ctx->stream>>>(x1.get(), sys->parent_a, sys->parent_b, z, nn, w);
+        else k_prolong_p1_v4<<<grid1(n2 * (w / 4)), TB, 0, ctx->stream>>>(reinterpret_cast<const f4_t *>(x1.get()), sys->parent_a, sys->parent_b, reinterpret_cast<f4_t *>(z), nn, w / 4);
         KERNEL_CHECK();
         cheb(sys->L2, deg2, r, z, false, r2, d2, t2, w, z_out, w_in);
     }
