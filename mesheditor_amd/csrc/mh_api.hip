@@ -64,6 +64,33 @@ __global__ void k_nearest(const double *__restrict__ pts, uint32_t npts, const f
     }
     if (i < n) nearest[i] = arg;
 }
+// The same for a handful of positions (the app and the bench use P = 10): one workgroup per position, the points dealt over
+// its threads, then an ordered reduction -- smallest distance, ties to the smallest index, i.e. the same first minimum.
+__global__ void k_nearest_few(const double *__restrict__ pts, uint32_t npts, const float *__restrict__ pos, uint32_t *__restrict__ nearest) {
+    __shared__ double s_d[TB];
+    __shared__ uint32_t s_i[TB];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const double px = double(pos[3 * size_t(q)]), py = double(pos[3 * size_t(q) + 1]), pz = double(pos[3 * size_t(q) + 2]);
+    double best = 1.7976931348623157e308;
+    uint32_t arg = 0xffffffffu;
+    for (uint32_t k = tid; k < npts; k += TB) {
+        const double dx = px - pts[3 * size_t(k)], dy = py - pts[3 * size_t(k) + 1], dz = pz - pts[3 * size_t(k) + 2];
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; arg = k; }
+    }
+    s_d[tid] = best;
+    s_i[tid] = arg;
+    __syncthreads();
+    for (uint32_t half = TB / 2; half > 0; half >>= 1) {
+        if (tid < half) {
+            const double od = s_d[tid + half];
+            const uint32_t oi = s_i[tid + half];
+            if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) nearest[q] = s_i[0] == 0xffffffffu ? 0u : s_i[0];
+}
 } // namespace
 
 template<typename T> static int export_vectors(const mh_system *s, uint32_t n_cols, T *out) {
@@ -339,7 +366,8 @@ int mh_nearest_points(mh_context *ctx, const mh_mesh *mesh, uint32_t n, const fl
         DevArray<float> pos(ctx, size_t(n) * 3);
         DevArray<uint32_t> out(ctx, n);
         pos.upload(positions_xyz, size_t(n) * 3);
-        k_nearest<<<div_up(n, TB), TB, 0, ctx->stream>>>(mesh->points, mesh->n_points, pos, n, out);
+        if (n <= 64) k_nearest_few<<<n, TB, 0, ctx->stream>>>(mesh->points, mesh->n_points, pos, out);
+        else k_nearest<<<div_up(n, TB), TB, 0, ctx->stream>>>(mesh->points, mesh->n_points, pos, n, out);
         KERNEL_CHECK();
         out.download(nearest, n);
         return MH_OK;

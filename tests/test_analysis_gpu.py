@@ -255,6 +255,9 @@ def test_nearest_points_first_minimum(api, ctx):
     got = mesh.nearest_points(q)
     d = ((q[:, None, :].astype(np.float64) - pts[None, :, :]) ** 2).sum(-1)
     assert np.array_equal(got, d.argmin(1).astype(np.uint32))
+    # a handful of positions takes the one-workgroup-per-position kernel: same first minimum, ties included
+    for count in (1, 10, 50, 64):
+        assert np.array_equal(mesh.nearest_points(q[:count]), d[:count].argmin(1).astype(np.uint32))
 
 
 def test_full_size_properties(api, ctx):
