@@ -1234,6 +1234,12 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, w, &one, Gs, w, Cp, m));
                     }
                 }
+                // No conjugate directions in the first iterations of a cold start, while the block is far from the invariant
+                // subspace: with residuals of order one the previous step carries no usable curvature information -- the iteration
+                // count is the same without it (18 and 18 at S100k) -- and an iteration on [X W] costs a third less
+                // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
+                static const uint32_t skip_p = getenv("MH_SKIP_P") ? uint32_t(atoi(getenv("MH_SKIP_P"))) : 4u;
+                if (!warm && it < skip_p && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
                 if (wp_new && implicit_p) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
                     ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m));
                     ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
