@@ -616,6 +616,283 @@ void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e
     KERNEL_CHECK();
 }
 
+// ---- lowest eigenpairs of a symmetric tridiagonal matrix, one workgroup ---------------------------------------------------
+// The Rayleigh-Ritz step needs only the k lowest of the m eigenpairs (the active Ritz vectors), and it needs them as an
+// orthonormal basis of the right invariant subspace, not as exactly diagonalising vectors (a rotation inside the wanted
+// subspace of size 1e-10 changes nothing the iteration can see).  rocSOLVER's divide and conquer computes all m pairs through
+// ~20 small launches (1.1 ms at m = 222).  Here, in one launch:
+//   1. multisection (Sturm counts, LAPACK dlaebz pivot handling) for the k lowest eigenvalues, all in parallel, 1024 / k points
+//      per eigenvalue and step;
+//   2. two steps of inverse iteration per eigenvalue from a pseudo-random start, each by Gaussian elimination with partial
+//      pivoting on T - lambda I (LAPACK dlagtf / dlagts), one thread per eigenvalue, vectors in LDS ([row][vector]: conflict
+//      free), the U factor in a global scratch of the same layout;
+//   3. classical Gram-Schmidt with reorthogonalisation over the k vectors (exact multiplets give independent vectors of the same
+//      eigenspace from their different starts; close pairs come out of step 2 orthogonal to eps ||T|| / gap, which this repairs);
+//   4. the residual max_j ||T x_j - lambda_j x_j||_inf / ||T|| goes to *quality for the caller to judge (fallback: divide and conquer).
+// z (m x k, column-major, leading dimension ldz) receives the vectors, w the eigenvalues in ascending order.
+#ifndef MH_TRIDIAG_ROUNDS
+#define MH_TRIDIAG_ROUNDS 1 // one step from a random start leaves neighbours at eps ||T|| / gap ~ 1e-10, which is all the Rayleigh-Ritz step needs
+#endif
+namespace {
+__global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restrict__ D, const double *__restrict__ E, int m, int k, double *__restrict__ w,
+                                                        double *__restrict__ z, int ldz, double *__restrict__ ufac, double *__restrict__ quality) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *d = sm, *e = d + 256, *e2 = e + 256, *lam = e2 + 256, *lo = lam + 256, *hi = lo + 256, *coef = hi + 256, *red = coef + 256; // red: 1024
+    int *cnt = reinterpret_cast<int *>(red + 1024); // 1024 ints
+    double *X = red + 1024 + 512; // m x k, [row][vector]
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 256) {
+        d[tid] = tid < m ? D[tid] : 0.0;
+        const double ev = tid + 1 < m ? E[tid] : 0.0;
+        e[tid] = ev;
+        e2[tid] = ev * ev;
+    }
+    __syncthreads();
+    // Gershgorin interval and the scale of T
+    {
+        double gl = 1.7976931348623157e308, gh = -1.7976931348623157e308;
+        for (int i = tid; i < m; i += 1024) {
+            const double r = (i ? fabs(e[i - 1]) : 0.0) + fabs(e[i]);
+            gl = fmin(gl, d[i] - r);
+            gh = fmax(gh, d[i] + r);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            gl = fmin(gl, __shfl_xor(gl, off, 64));
+            gh = fmax(gh, __shfl_xor(gh, off, 64));
+        }
+        if (lane == 0) { red[tid >> 6] = gl; red[16 + (tid >> 6)] = gh; }
+    }
+    __syncthreads();
+    double glo = red[0], ghi = red[16];
+    for (int q = 1; q < 16; ++q) { glo = fmin(glo, red[q]); ghi = fmax(ghi, red[16 + q]); }
+    const double tnorm = fmax(fabs(glo), fabs(ghi));
+    const double eps = 2.220446049250313e-16;
+    double e2max = 0;
+    for (int i = 0; i < m; ++i) e2max = fmax(e2max, e2[i]); // uniform, 222 LDS reads
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max);
+    glo -= 2.0 * tnorm * eps * m + 2.0 * pivmin;
+    ghi += 2.0 * tnorm * eps * m + 2.0 * pivmin;
+    __syncthreads();
+    // number of eigenvalues <= x (dlaebz)
+    auto count = [&](double x) {
+        int c = 0;
+        double q = d[0] - x;
+        if (q <= pivmin) { ++c; q = fmin(q, -pivmin); }
+        for (int i = 1; i < m; ++i) {
+            // reciprocal by the hardware estimate and one Newton step (the IEEE division sequence is 3x the instructions, and
+            // this loop is what the phase costs; a count only needs the sign of q, and |q| is kept away from 0 by pivmin)
+            double r = __builtin_amdgcn_rcp(q);
+            r = fma(fma(-q, r, 1.0), r, r);
+            q = fma(-e2[i - 1], r, d[i]) - x;
+            if (q <= pivmin) { ++c; q = fmin(q, -pivmin); }
+        }
+        return c;
+    };
+    const long long t_start = wall_clock64();
+    // 1. multisection: eigenvalue j (0-based) is the smallest x with count(x) >= j + 1
+    const int tpe = min(16, 1024 / k); // points per eigenvalue and step
+    const int grp = tid / tpe, sub = tid % tpe;
+    if (tid < k) { lo[tid] = glo; hi[tid] = ghi; }
+    __syncthreads();
+    const int steps = int(ceil(58.0 / log2(double(tpe + 1)))) + 1;
+    for (int s = 0; s < steps; ++s) {
+        double a = 0, b = 0;
+        if (grp < k) {
+            a = lo[grp];
+            b = hi[grp];
+            const double x = a + (b - a) * (double(sub + 1) / double(tpe + 1));
+            cnt[tid] = count(x);
+        }
+        __syncthreads();
+        if (grp < k && sub == 0) {
+            // first point whose count reaches j + 1 bounds the eigenvalue from above, its predecessor from below
+            double na = a, nb = b;
+            for (int t = 0; t < tpe; ++t) {
+                const double x = a + (b - a) * (double(t + 1) / double(tpe + 1));
+                if (cnt[grp * tpe + t] >= grp + 1) { nb = x; break; }
+                na = x;
+            }
+            lo[grp] = na;
+            hi[grp] = nb;
+        }
+        __syncthreads();
+    }
+    if (tid < k) lam[tid] = 0.5 * (lo[tid] + hi[tid]);
+    __syncthreads();
+    const long long t_bisect = wall_clock64();
+    // 2. inverse iteration, one thread per eigenvalue; U factor rows in ufac[(3 i + q) * k + j]
+    const double tiny = fmax(eps * tnorm, pivmin);
+    if (tid < k) {
+        const int j = tid;
+        const double lj = lam[j];
+        // pseudo-random start, different per vector (splitmix-style), entries in (-1, 1)
+        unsigned long long st = 0x9e3779b97f4a7c15ull * (unsigned long long)(j + 1);
+        for (int i = 0; i < m; ++i) {
+            st += 0x9e3779b97f4a7c15ull;
+            unsigned long long zz = st;
+            zz = (zz ^ (zz >> 30)) * 0xbf58476d1ce4e5b9ull;
+            zz = (zz ^ (zz >> 27)) * 0x94d049bb133111ebull;
+            zz ^= zz >> 31;
+            X[i * k + j] = double(zz >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        }
+        for (int round = 0; round < MH_TRIDIAG_ROUNDS; ++round) {
+            // forward elimination with row interchanges, applied to the right-hand side on the way
+            double cd = d[0] - lj, cs = m > 1 ? e[0] : 0.0; // current row: diagonal, superdiagonal (second superdiagonal is 0 before a swap)
+            double ri = X[j];
+            for (int i = 0; i + 1 < m; ++i) {
+                const double sb = e[i], nd = d[i + 1] - lj, ns = i + 2 < m ? e[i + 1] : 0.0;
+                double rn = X[(i + 1) * k + j];
+                double u0, u1, u2;
+                if (fabs(cd) >= fabs(sb)) {
+                    if (fabs(cd) < tiny) cd = copysign(tiny, cd);
+                    const double mult = sb / cd;
+                    u0 = cd; u1 = cs; u2 = 0.0;
+                    cd = nd - mult * cs;
+                    cs = ns;
+                    rn -= mult * ri;
+                    X[i * k + j] = ri;
+                } else {
+                    const double mult = cd / sb;
+                    u0 = sb; u1 = nd; u2 = ns;
+                    cd = cs - mult * nd;
+                    cs = -mult * ns;
+                    const double t = ri;
+                    X[i * k + j] = rn;
+                    rn = t - mult * rn;
+                }
+                ufac[(size_t(3) * i) * k + j] = u0;
+                ufac[(size_t(3) * i + 1) * k + j] = u1;
+                ufac[(size_t(3) * i + 2) * k + j] = u2;
+                ri = rn;
+            }
+            if (fabs(cd) < tiny) cd = copysign(tiny, cd);
+            // back substitution, overwriting the right-hand side; then normalise
+            double y1 = ri / cd, y2 = 0.0, nrm = y1 * y1;
+            X[(m - 1) * k + j] = y1;
+            // the factor rows come back from global memory eight at a time (one L2 round trip per eight dependent steps)
+            for (int i0 = m - 2; i0 >= 0; i0 -= 8) {
+                double u[8][3];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = max(i0 - q, 0);
+                    u[q][0] = ufac[(size_t(3) * i) * k + j];
+                    u[q][1] = ufac[(size_t(3) * i + 1) * k + j];
+                    u[q][2] = ufac[(size_t(3) * i + 2) * k + j];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 - q;
+                    if (i < 0) break;
+                    const double y = (X[i * k + j] - u[q][1] * y1 - u[q][2] * y2) / u[q][0];
+                    X[i * k + j] = y;
+                    nrm += y * y;
+                    y2 = y1;
+                    y1 = y;
+                }
+            }
+            // guard against overflow of the squared norm: rescale by the largest entry first when needed
+            if (!(nrm < 1e300)) {
+                double big = 0;
+                for (int i = 0; i < m; ++i) big = fmax(big, fabs(X[i * k + j]));
+                nrm = 0;
+                for (int i = 0; i < m; ++i) { const double v = X[i * k + j] / big; X[i * k + j] = v; nrm += v * v; }
+            }
+            const double inv = 1.0 / sqrt(nrm);
+            for (int i = 0; i < m; ++i) X[i * k + j] *= inv;
+        }
+    }
+    __syncthreads();
+    const long long t_invit = wall_clock64();
+    // 3. classical Gram-Schmidt, left-looking over the vectors; a second pass only when the first cancelled more than half of
+    //    the (unit) vector ("twice is enough")
+    for (int j = 0; j < k; ++j) {
+        double left = 1.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            // coefficient of vector a in vector j: eight threads per a, each a strided eighth of the rows, added in a fixed order
+            {
+                const int a = tid >> 3, part = tid & 7;
+                if (a < j) {
+                    double s = 0;
+                    for (int i = part; i < m; i += 8) s += X[i * k + a] * X[i * k + j];
+                    red[tid] = s;
+                }
+            }
+            __syncthreads();
+            if (tid < j) {
+                double s = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += red[tid * 8 + q];
+                coef[tid] = s;
+            }
+            __syncthreads();
+            // x_j -= X[:, :j] c: four threads per row; the squares of the new entries go out for the norm
+            {
+                const int i = tid >> 2, part = tid & 3;
+                double s = 0;
+                if (i < m)
+                    for (int a = part; a < j; a += 4) s += coef[a] * X[i * k + a];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0) {
+                    double v = 0.0;
+                    if (i < m) {
+                        v = X[i * k + j] - s;
+                        X[i * k + j] = v;
+                    }
+                    red[i] = v * v; // i < 256
+                }
+            }
+            __syncthreads();
+            left = wave_sum_lds(red, m, lane); // every wave the same bits
+            __syncthreads();
+            if (left > 0.5 || j == 0) break; // uniform
+        }
+        const double inv = 1.0 / sqrt(left);
+        if (tid < m) X[tid * k + j] *= inv;
+        __syncthreads();
+    }
+    const long long t_gs = wall_clock64();
+    // 4. residual of the finished pairs, and output
+    double worst = 0;
+    for (int idx = tid; idx < m * k; idx += 1024) {
+        const int i = idx / k, j = idx % k;
+        const double x = X[idx];
+        const double r = (d[i] - lam[j]) * x + (i ? e[i - 1] * X[idx - k] : 0.0) + (i + 1 < m ? e[i] * X[idx + k] : 0.0);
+        worst = fmax(worst, fabs(r));
+        z[size_t(j) * ldz + i] = x;
+    }
+    for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off, 64));
+    __syncthreads();
+    if (lane == 0) red[tid >> 6] = worst;
+    __syncthreads();
+    if (tid == 0) {
+        double q = 0;
+        for (int a = 0; a < 16; ++a) q = fmax(q, red[a]);
+        *quality = q / fmax(tnorm, 2.2250738585072014e-308);
+        quality[1] = double(t_bisect - t_start); // phase durations in 100 MHz ticks (diagnostics, MH_VERBOSE)
+        quality[2] = double(t_invit - t_bisect);
+        quality[3] = double(t_gs - t_invit);
+        quality[4] = double(wall_clock64() - t_gs);
+    }
+    if (tid < k) w[tid] = lam[tid];
+}
+} // namespace
+
+// false when the problem does not fit the one-workgroup kernel (the vectors must fit in LDS)
+bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *ufac, double *quality) {
+    if (m < 2 || m > 256 || k < 1 || k > m || k > 128) return false;
+    const size_t lds = (size_t(7) * 256 + 1024 + 512 + size_t(m) * k) * sizeof(double);
+    if (lds > 158 * 1024) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tridiag_lowest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    k_tridiag_lowest<<<1, 1024, lds, ctx->stream>>>(d, e, int(m), int(k), w, z, int(ldz), ufac, quality);
+    KERNEL_CHECK();
+    return true;
+}
+
 // ---- small Cholesky --------------------------------------------------------------------------------------------------
 // Lower Cholesky factor of a symmetric positive definite matrix of order w <= 128 (column-major, ld w) by ONE workgroup
 // with the matrix in LDS: the Gram matrices of the Cholesky-QR steps.  info = 0, or k + 1 when the pivot of column k is not

@@ -525,7 +525,8 @@ __global__ void k_inverse_sqrt_series(const double *__restrict__ e, const double
     s[i] = (i % m == i / m ? 1.0 : 0.0) - 0.5 * e[i] + 0.375 * e2[i];
 }
 
-int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info) {
+int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info, uint32_t nwant = 0) {
+    // nwant: only the nwant lowest pairs are needed (the active Ritz vectors): lets the tridiagonal stage compute a partial spectrum
     const double one = 1, zero = 0;
     int hinfo = 0;
     k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gA, m, m);
@@ -585,11 +586,36 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         // rocSOLVER's divide and conquer on T and the back-transformation Z <- Q Z
         DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
         mh_sytrd_small(ctx, gA, m, evals, ework, tau); // gA is fully symmetric here (k_symmetrize_lower above / the reduction)
-        ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
-        info.download(&hinfo, 1);
-        if (hinfo != 0) return hinfo;
-        ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, m, gA, m, tau, z, m));
-        HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        // only the nwant lowest pairs are needed: our one-launch multisection + inverse iteration (mh_tridiag_lowest) instead of
+        // the full divide and conquer, accepted when its residual check passes
+        static const bool own_tridiag = !(getenv("MH_RR_TRIDIAG") && atoi(getenv("MH_RR_TRIDIAG")) == 0);
+        uint32_t ncols = m;
+        bool done = false;
+        if (own_tridiag && nwant && nwant < m) {
+            DevArray<double> wv(ctx, m + 8), ufac(ctx, size_t(3) * m * nwant);
+            if (mh_tridiag_lowest(ctx, evals, ework, m, nwant, wv, z, m, ufac, wv.get() + m)) {
+                double qv[5] = {1, 0, 0, 0, 0};
+                HIP_CHECK(hipMemcpyAsync(qv, wv.get() + m, sizeof(qv), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                const double quality = qv[0];
+                static const bool verbose = getenv("MH_VERBOSE") != nullptr;
+                if (verbose)
+                    fprintf(stderr, "[rr] tridiagonal m %u lowest %u: residual / ||T|| %.2e; us: multisection %.0f, inverse iteration %.0f, Gram-Schmidt %.0f, output %.0f\n", m,
+                            nwant, quality, qv[1] * 0.01, qv[2] * 0.01, qv[3] * 0.01, qv[4] * 0.01);
+                if (quality < 1e-10) {
+                    HIP_CHECK(hipMemcpyAsync(evals, wv.get(), size_t(nwant) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                    ncols = nwant;
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
+            info.download(&hinfo, 1);
+            if (hinfo != 0) return hinfo;
+        }
+        ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, ncols, gA, m, tau, z, m));
+        HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     } else {
         ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
@@ -1216,7 +1242,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     KERNEL_CHECK();
                     HIP_CHECK(hipMemcpyAsync(gA0, gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
                     HIP_CHECK(hipMemcpyAsync(gM0, gM, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
-                    const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info);
+                    const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info, wa);
                     if (hinfo == 0) break;
                     if (attempt == 1 || wp == 0) mh_throw(MH_ENOTCONVERGED, "Rayleigh-Ritz failed at iteration %u (info %d)", it, hinfo);
                     wp = 0; // drop the previous directions and retry on [X W]
