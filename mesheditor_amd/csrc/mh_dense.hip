@@ -634,8 +634,66 @@ void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e
 #define MH_TRIDIAG_ROUNDS 1 // one step from a random start leaves neighbours at eps ||T|| / gap ~ 1e-10, which is all the Rayleigh-Ritz step needs
 #endif
 namespace {
+// Eigenvalue j of the tridiagonal matrix by 255-way multisection, one workgroup per eigenvalue (the counts are independent, and
+// one CU alone is throughput-bound on the k * m * evaluations divisions): 8 steps instead of the 17 thirteen-way steps the
+// single-workgroup kernel needs.  lam[j] = j-th smallest eigenvalue.
+__global__ void __launch_bounds__(256) k_tridiag_values(const double *__restrict__ D, const double *__restrict__ E, int m, double *__restrict__ lam) {
+    __shared__ double d[256], e2[256], bnd[2];
+    __shared__ int cnt[256];
+    const int tid = threadIdx.x, j = blockIdx.x;
+    double ea = 0;
+    if (tid < m) d[tid] = D[tid];
+    if (tid + 1 < m) ea = E[tid];
+    e2[tid] = ea * ea;
+    __shared__ double sabs[256];
+    sabs[tid] = fabs(ea);
+    __syncthreads();
+    double gl = 1.7976931348623157e308, gh = -1.7976931348623157e308, emax = e2[tid];
+    if (tid < m) {
+        const double r = (tid ? sabs[tid - 1] : 0.0) + sabs[tid];
+        gl = d[tid] - r;
+        gh = d[tid] + r;
+    }
+    __shared__ double rl[256], rh[256], rm[256];
+    rl[tid] = gl; rh[tid] = gh; rm[tid] = emax;
+    __syncthreads();
+    for (int half = 128; half > 0; half >>= 1) {
+        if (tid < half) { rl[tid] = fmin(rl[tid], rl[tid + half]); rh[tid] = fmax(rh[tid], rh[tid + half]); rm[tid] = fmax(rm[tid], rm[tid + half]); }
+        __syncthreads();
+    }
+    const double eps = 2.220446049250313e-16;
+    const double tnorm = fmax(fabs(rl[0]), fabs(rh[0]));
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, rm[0]);
+    if (tid == 0) {
+        bnd[0] = rl[0] - (2.0 * tnorm * eps * m + 2.0 * pivmin);
+        bnd[1] = rh[0] + (2.0 * tnorm * eps * m + 2.0 * pivmin);
+    }
+    __syncthreads();
+    for (int s = 0; s < 8; ++s) {
+        const double a = bnd[0], b = bnd[1];
+        const double x = a + (b - a) * (double(tid + 1) / 256.0); // tid = 255 evaluates b itself: count(b) >= j + 1 by construction
+        int c = 0;
+        double q = d[0] - x;
+        if (q <= pivmin) { ++c; q = fmin(q, -pivmin); }
+        for (int i = 1; i < m; ++i) {
+            double r = __builtin_amdgcn_rcp(q);
+            r = fma(fma(-q, r, 1.0), r, r);
+            q = fma(-e2[i - 1], r, d[i]) - x;
+            if (q <= pivmin) { ++c; q = fmin(q, -pivmin); }
+        }
+        cnt[tid] = c;
+        __syncthreads();
+        // the first point whose count reaches j + 1 bounds the eigenvalue from above, its predecessor from below
+        if (c >= j + 1 && (tid == 0 || cnt[tid - 1] < j + 1)) {
+            bnd[1] = x;
+            bnd[0] = tid == 0 ? a : a + (b - a) * (double(tid) / 256.0);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) lam[j] = 0.5 * (bnd[0] + bnd[1]);
+}
 __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restrict__ D, const double *__restrict__ E, int m, int k, double *__restrict__ w,
-                                                        double *__restrict__ z, int ldz, double *__restrict__ ufac, double *__restrict__ quality) {
+                                                        double *__restrict__ z, int ldz, double *__restrict__ ufac, double *__restrict__ quality, const double *__restrict__ lam_in) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *d = sm, *e = d + 256, *e2 = e + 256, *lam = e2 + 256, *lo = lam + 256, *hi = lo + 256, *coef = hi + 256, *red = coef + 256; // red: 1024
     int *cnt = reinterpret_cast<int *>(red + 1024); // 1024 ints
@@ -692,9 +750,9 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
     // 1. multisection: eigenvalue j (0-based) is the smallest x with count(x) >= j + 1
     const int tpe = min(16, 1024 / k); // points per eigenvalue and step
     const int grp = tid / tpe, sub = tid % tpe;
-    if (tid < k) { lo[tid] = glo; hi[tid] = ghi; }
+    if (tid < k) { lo[tid] = lam_in ? lam_in[tid] : glo; hi[tid] = lam_in ? lam_in[tid] : ghi; }
     __syncthreads();
-    const int steps = int(ceil(58.0 / log2(double(tpe + 1)))) + 1;
+    const int steps = lam_in ? 0 : int(ceil(58.0 / log2(double(tpe + 1)))) + 1; // eigenvalues given: k_tridiag_values ran before
     for (int s = 0; s < steps; ++s) {
         double a = 0, b = 0;
         if (grp < k) {
@@ -879,7 +937,8 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
 } // namespace
 
 // false when the problem does not fit the one-workgroup kernel (the vectors must fit in LDS)
-bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *ufac, double *quality) {
+bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *ufac, double *quality,
+                       double *lam_scratch) {
     if (m < 2 || m > 256 || k < 1 || k > m || k > 128) return false;
     const size_t lds = (size_t(7) * 256 + 1024 + 512 + size_t(m) * k) * sizeof(double);
     if (lds > 158 * 1024) return false;
@@ -888,7 +947,12 @@ bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tridiag_lowest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    k_tridiag_lowest<<<1, 1024, lds, ctx->stream>>>(d, e, int(m), int(k), w, z, int(ldz), ufac, quality);
+    static const bool spread = !(getenv("MH_TRIDIAG_SPREAD") && atoi(getenv("MH_TRIDIAG_SPREAD")) == 0);
+    if (spread) {
+        k_tridiag_values<<<k, 256, 0, ctx->stream>>>(d, e, int(m), lam_scratch);
+        KERNEL_CHECK();
+    }
+    k_tridiag_lowest<<<1, 1024, lds, ctx->stream>>>(d, e, int(m), int(k), w, z, int(ldz), ufac, quality, spread ? lam_scratch : nullptr);
     KERNEL_CHECK();
     return true;
 }

@@ -592,8 +592,8 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         uint32_t ncols = m;
         bool done = false;
         if (own_tridiag && nwant && nwant < m) {
-            DevArray<double> wv(ctx, m + 8), ufac(ctx, size_t(3) * m * nwant);
-            if (mh_tridiag_lowest(ctx, evals, ework, m, nwant, wv, z, m, ufac, wv.get() + m)) {
+            DevArray<double> wv(ctx, 2 * m + 8), ufac(ctx, size_t(3) * m * nwant);
+            if (mh_tridiag_lowest(ctx, evals, ework, m, nwant, wv, z, m, ufac, wv.get() + m, wv.get() + m + 8)) {
                 double qv[5] = {1, 0, 0, 0, 0};
                 HIP_CHECK(hipMemcpyAsync(qv, wv.get() + m, sizeof(qv), hipMemcpyDeviceToHost, ctx->stream));
                 HIP_CHECK(hipStreamSynchronize(ctx->stream));
