@@ -1005,7 +1005,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
                 KERNEL_CHECK();
             }
-            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w) -> bool {
+            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true) -> bool {
+                // transform_images = false: M V is only read (for the Gram matrix); the caller keeps the images untransformed
                 // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
                 gram(ctx, n, V, w, MV, w, G, w);
                 k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
@@ -1036,8 +1037,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
                     ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
                     mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
-                    if (MV) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);
-                    if (AV) mh_combine(ctx, n, AV, w, nullptr, 0, nullptr, 0, Linv, w, AV, w, nullptr);
+                    if (MV && transform_images) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);
+                    if (AV && transform_images) mh_combine(ctx, n, AV, w, nullptr, 0, nullptr, 0, Linv, w, AV, w, nullptr);
                 }
                 return true;
             };
@@ -1099,6 +1100,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             bool converged = false;
             std::vector<double> hist_worst;
             std::vector<uint32_t> hist_nconv;
+            static const bool lazy_env = !(getenv("MH_LAZY_IMAGES") && atoi(getenv("MH_LAZY_IMAGES")) == 0);
+            static const bool fresh_env = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
+            static const bool trsm_env = getenv("MH_TRSM_ROCBLAS") && atoi(getenv("MH_TRSM_ROCBLAS")) != 0;
+            const bool lazy_images_ok = lazy_env && fresh_env && implicit_p && !trsm_env;
+            bool lazy_images = false;
             for (uint32_t it = 0; it <= max_iters; ++it) {
                 if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
                 if (g_concurrent) {
@@ -1191,7 +1197,12 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
                     mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
                     mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
-                    ok = chol_orthonormalise(W, MW, AW, w);
+                    // Only W itself is multiplied by L^-T.  Its images keep their pre-orthonormalisation form (A W L^T, M W L^T): the
+                    // Gram blocks that involve them are corrected on the small matrices (B <- B L^-T), the recombination of M P folds
+                    // L^-T into its coefficient rows, and A X, M X are recomputed from the new Ritz vectors anyway -- two tall
+                    // basis-update launches fewer per iteration.
+                    lazy_images = lazy_images_ok && w <= 256;
+                    ok = chol_orthonormalise(W, MW, AW, w, !lazy_images);
                     if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
                 } else {
                     mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
@@ -1222,11 +1233,23 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     static const bool verify_cross = getenv("MH_VERIFY_CROSS") && atoi(getenv("MH_VERIFY_CROSS")) != 0;
                     mh_gram(ctx, n, W, w, AX, wa, gA.get() + wa, m, b, idx_d);
                     if (verify_cross) mh_gram(ctx, n, W, w, MX, wa, gM.get() + wa, m, b, idx_d);
+                    const double unit = 1;
+                    auto untransformed = [&](double *block, uint32_t rows) { // block (rows x w at leading dimension m) <- block L^-T
+                        if (lazy_images)
+                            ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, rocblas_int(rows),
+                                                        rocblas_int(w), &unit, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
+                    };
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
+                    untransformed(gA.get() + size_t(wa) * m + wa, w);
                     gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
+                    untransformed(gM.get() + size_t(wa) * m + wa, w);
                     if (wp) {
                         gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m);
-                        if (verify_cross || !implicit_p) gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
+                        untransformed(gA.get() + size_t(wa) * m + wa + w, wp);
+                        if (verify_cross || !implicit_p) {
+                            gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
+                            untransformed(gM.get() + size_t(wa) * m + wa + w, wp);
+                        }
                         if (implicit_p) {
                             // P = S_prev Cp with Cp gM-orthonormal and gM-orthogonal to the Ritz coefficients Cx, and
                             // gA Cx = gM Cx Theta: hence P^T M P = I, P^T M X = P^T A X = 0 and P^T A P = Cp^T gA_prev Cp
@@ -1307,12 +1330,20 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // costs less than two passes over three tall panels each, the images carry no accumulated rounding, and A P is
                 // not needed at all (P^T A P comes from the small matrices, above).  M P, which the next projection needs, is
                 // still recombined -- before M X is overwritten.
-                static const bool fresh_images = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
+                const bool fresh_images = fresh_env;
                 const bool in_place = wa + wp_new <= 256;
                 if (fresh_images && implicit_p) {
                     const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
                     mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
-                    if (wp_new) mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);
+                    if (wp_new) {
+                        if (lazy_images) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
+                            const double unit = 1;
+                            double *rows = Ct.get() + size_t(wa) * (wa + wp_new) + wa;
+                            ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wp_new),
+                                                        rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
+                        }
+                        mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);
+                    }
                     if (pitch == wa) k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), idx_d, X.get(), n, b, wa);
                     else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
                     KERNEL_CHECK();
