@@ -290,7 +290,8 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
                 uint32_t ld) {
     const int ti_n = int((wa + 15) / 16), tj_n = int((wb + 15) / 16);
     // ~2 workgroups per CU; each stages KC rows per step and owns a contiguous row range
-    int nwg = int(std::min<size_t>(512, (n + KC - 1) / KC));
+    static const size_t nwg_cap = getenv("MH_GRAM_WGS") ? size_t(atoi(getenv("MH_GRAM_WGS"))) : 512;
+    int nwg = int(std::min<size_t>(nwg_cap, (n + KC - 1) / KC));
     size_t rows_per_wg = ((n + nwg - 1) / nwg + KC - 1) / KC * KC;
     nwg = int((n + rows_per_wg - 1) / rows_per_wg);
     const size_t need = size_t(nwg) * wa * wb * sizeof(double);
