@@ -993,7 +993,14 @@ __global__ void __launch_bounds__(256) k_potrf_small(double *__restrict__ A, int
         const int j = idx / w, i = idx % w;
         if (i >= j) A[idx] = L[j * pitch + i]; // the strictly upper part keeps the input, as potrf
     }
-    if (tid == 0) *info = s_fail;
+    if (tid == 0) {
+        info[0] = s_fail;
+        // info[1]: 16 * log2(largest / smallest diagonal entry of L) -- for a Gram matrix scaled to unit diagonal the square of
+        // that ratio estimates its condition number, which is what the caller's Cholesky-QR loses in orthogonality
+        double lo = 1.7976931348623157e308, hi = 0;
+        for (int k = 0; k < w; ++k) { const double v = L[k * pitch + k]; lo = fmin(lo, v); hi = fmax(hi, v); }
+        info[1] = s_fail || !(lo > 0) ? 1 << 20 : int(16.0 * log2(hi / lo));
+    }
 }
 } // namespace
 

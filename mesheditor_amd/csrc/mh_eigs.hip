@@ -974,7 +974,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             DevArray<double> Linv(ctx, size_t(b) * b);
             DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
             DevArray<uint32_t> idx_d(ctx, b);
-            DevArray<int> info(ctx, 1);
+            DevArray<int> info(ctx, 2); // [1]: conditioning report of mh_potrf_small
             static const bool fp32_prec = !(getenv("MH_PRECOND_FP64") && atoi(getenv("MH_PRECOND_FP64")) != 0);
             std::unique_ptr<Precond<float>> prec32;
             std::unique_ptr<Precond<double>> prec64;
@@ -1005,6 +1005,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
                 KERNEL_CHECK();
             }
+            int last_spread = 1 << 20; // 16 log2(max / min diagonal of the last Cholesky factor of a unit-diagonal Gram matrix)
             auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true) -> bool {
                 // transform_images = false: M V is only read (for the Gram matrix); the caller keeps the images untransformed
                 // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
@@ -1014,9 +1015,13 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 double *Gs = G.get() + size_t(w) * w;
                 int hinfo = 0;
                 {
+                    last_spread = 1 << 20;
                     if (w <= 128) {
                         mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
-                        info.download(&hinfo, 1);
+                        int both[2] = {0, 0};
+                        info.download(both, 2);
+                        hinfo = both[0];
+                        last_spread = both[1];
                     } else {
                         SolverLock solver_lock(g_rocsolver_mutex);
                         ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
@@ -1241,8 +1246,17 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     };
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
                     untransformed(gA.get() + size_t(wa) * m + wa, w);
-                    gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
-                    untransformed(gM.get() + size_t(wa) * m + wa, w);
+                    // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
+                    // says cond(G) < 2^16 (deviation ~1e-11)
+                    const bool w_block_trusted = !verify_cross && last_spread < 16 * 8;
+                    if (w_block_trusted) {
+                        k_place_block<<<grid1(size_t(w) * w), TB, 0, st>>>(gM.get() + size_t(wa) * m + wa, m, nullptr, w);
+                        KERNEL_CHECK();
+                    } else {
+                        gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
+                        untransformed(gM.get() + size_t(wa) * m + wa, w);
+                    }
+                    if (verbose) fprintf(stderr, "[lobpcg] it %3u Cholesky-QR diagonal spread 2^%.1f%s\n", it, last_spread / 16.0, w_block_trusted ? "" : " (W block measured)");
                     if (wp) {
                         gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m);
                         untransformed(gA.get() + size_t(wa) * m + wa + w, wp);
