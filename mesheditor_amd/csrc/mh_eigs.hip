@@ -1005,8 +1005,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
                 KERNEL_CHECK();
             }
+            bool w_implicit = false; // W itself left untransformed this iteration (see chol_orthonormalise)
             int last_spread = 1 << 20; // 16 log2(max / min diagonal of the last Cholesky factor of a unit-diagonal Gram matrix)
-            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true) -> bool {
+            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true, bool allow_implicit = false) -> bool {
+                // allow_implicit: with a well-conditioned Gram matrix not even V is transformed (w_implicit is set): the caller works
+                // with V L^-T through L^-1 on the small matrices
                 // transform_images = false: M V is only read (for the Gram matrix); the caller keeps the images untransformed
                 // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
                 gram(ctx, n, V, w, MV, w, G, w);
@@ -1041,7 +1044,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     // reads its rows before it writes them): L^-1 column-major IS the k-major coefficient matrix of V L^-T
                     HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
                     ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
-                    mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
+                    w_implicit = allow_implicit && !transform_images && last_spread < 16 * 8;
+                    if (!w_implicit) mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
                     if (MV && transform_images) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);
                     if (AV && transform_images) mh_combine(ctx, n, AV, w, nullptr, 0, nullptr, 0, Linv, w, AV, w, nullptr);
                 }
@@ -1105,6 +1109,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             bool converged = false;
             std::vector<double> hist_worst;
             std::vector<uint32_t> hist_nconv;
+            static const bool implicit_w_env = !(getenv("MH_IMPLICIT_W") && atoi(getenv("MH_IMPLICIT_W")) == 0) && !(getenv("MH_VERIFY_CROSS") && atoi(getenv("MH_VERIFY_CROSS")) != 0);
             static const bool lazy_env = !(getenv("MH_LAZY_IMAGES") && atoi(getenv("MH_LAZY_IMAGES")) == 0);
             static const bool fresh_env = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
             static const bool trsm_env = getenv("MH_TRSM_ROCBLAS") && atoi(getenv("MH_TRSM_ROCBLAS")) != 0;
@@ -1207,7 +1212,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     // L^-T into its coefficient rows, and A X, M X are recomputed from the new Ritz vectors anyway -- two tall
                     // basis-update launches fewer per iteration.
                     lazy_images = lazy_images_ok && w <= 256;
-                    ok = chol_orthonormalise(W, MW, AW, w, !lazy_images);
+                    w_implicit = false;
+                    ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
                     if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
                 } else {
                     mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
@@ -1236,7 +1242,14 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     // W^T M X and P^T M W are zero by the projection that W just went through (measured 1e-14 .. 1e-12 in every run); they
                     // are formed only on request (MH_VERIFY_CROSS=1).  W^T M W, which carries the Cholesky-QR's error, is always measured.
                     static const bool verify_cross = getenv("MH_VERIFY_CROSS") && atoi(getenv("MH_VERIFY_CROSS")) != 0;
+                    const double unit_one = 1;
+                    auto left_corrected = [&](double *block, uint32_t cols) { // block (w x cols at leading dimension m) <- L^-1 block: W was not transformed
+                        if (w_implicit)
+                            ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(w),
+                                                        rocblas_int(cols), &unit_one, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
+                    };
                     mh_gram(ctx, n, W, w, AX, wa, gA.get() + wa, m, b, idx_d);
+                    left_corrected(gA.get() + wa, wa);
                     if (verify_cross) mh_gram(ctx, n, W, w, MX, wa, gM.get() + wa, m, b, idx_d);
                     const double unit = 1;
                     auto untransformed = [&](double *block, uint32_t rows) { // block (rows x w at leading dimension m) <- block L^-T
@@ -1246,6 +1259,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     };
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
                     untransformed(gA.get() + size_t(wa) * m + wa, w);
+                    left_corrected(gA.get() + size_t(wa) * m + wa, w);
                     // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
                     // says cond(G) < 2^16 (deviation ~1e-11)
                     const bool w_block_trusted = !verify_cross && last_spread < 16 * 8;
@@ -1348,9 +1362,15 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 const bool in_place = wa + wp_new <= 256;
                 if (fresh_images && implicit_p) {
                     const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
+                    if (w_implicit) { // the basis holds W, not W L^-T: every coefficient row of the W part <- L^-T row (all columns)
+                        const double unit = 1;
+                        double *rows = Ct.get() + size_t(wa) * (wa + wp_new);
+                        ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wa + wp_new),
+                                                    rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
+                    }
                     mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
                     if (wp_new) {
-                        if (lazy_images) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
+                        if (lazy_images && !w_implicit) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
                             const double unit = 1;
                             double *rows = Ct.get() + size_t(wa) * (wa + wp_new) + wa;
                             ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wp_new),
