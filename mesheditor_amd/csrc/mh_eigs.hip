@@ -616,7 +616,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         }
         ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, ncols, gA, m, tau, z, m));
         HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // no synchronisation: the workspaces return to the context's pool, whose blocks are only ever used on this same stream
     } else {
         ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
         info.download(&hinfo, 1);
@@ -1117,8 +1117,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             bool lazy_images = false;
             for (uint32_t it = 0; it <= max_iters; ++it) {
                 if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
-                if (g_concurrent) {
-                    HIP_CHECK(hipStreamSynchronize(st));
+                if (g_concurrent) { // an exclusive holder synchronises the device itself: no need to drain our queue first
                     iterating.release();
                     iterating.acquire();
                 }
