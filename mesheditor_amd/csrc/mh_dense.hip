@@ -611,9 +611,93 @@ __global__ void __launch_bounds__(1024) k_sytrd_small(double *__restrict__ A, in
 }
 } // namespace
 
+// The same reduction with the rank-2 update of step k - 1 deferred into the product pass of step k: the trailing block is
+// read, updated, written back and multiplied by the new reflector in ONE sweep (two sweeps per column instead of three, one
+// barrier fewer).  Column k of the logically updated matrix is formed first, from the stored column and the pending pair.
+__global__ void __launch_bounds__(1024) k_sytrd_small_fused(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
+    __shared__ double xs[256], v[256], wv[256], vp[256], wp[256], sq[256], part[1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    bool pending = false; // (vp, wp): reflector and w of the previous step, indexed over ITS trailing block (this step's index + 1)
+    for (int k = 0; k + 1 < m; ++k) {
+        const int l = m - k - 1; // order of the trailing block, rows/cols k+1 .. m-1
+        int rb = 32;
+        while (rb < l) rb <<= 1;
+        const int ng = 1024 / rb, rr = tid & (rb - 1), cq = tid / rb;
+        double *col = A + size_t(k) * m + (k + 1);
+        // column k of the updated matrix: index 0 of the previous trailing block is this column, index i + 1 is row k + 1 + i
+        if (tid < l) {
+            double x = col[tid];
+            if (pending) x -= vp[tid + 1] * wp[0] + wp[tid + 1] * vp[0];
+            xs[tid] = x;
+            sq[tid] = tid >= 1 ? x * x : 0.0;
+        }
+        double dk = A[size_t(k) * m + k];
+        if (pending) dk -= 2.0 * vp[0] * wp[0];
+        __syncthreads(); // (1) column published
+        const double xnorm2 = wave_sum_lds(sq, l, lane);
+        const double alpha = xs[0];
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (xnorm2 > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (tid == 0) {
+            D[k] = dk;
+            E[k] = beta;
+            TAU[k] = tau;
+        }
+        if (tid < l) {
+            const double vi = tau == 0.0 ? 0.0 : (tid == 0 ? 1.0 : xs[tid] * scale);
+            v[tid] = vi;
+            col[tid] = tid == 0 ? beta : (tau == 0.0 ? xs[tid] : vi); // subdiagonal entry, then the reflector tail (H = I: the column itself, all zeros below)
+        }
+        __syncthreads(); // (2) reflector published
+        // one sweep over the trailing block: apply the pending pair, write back, multiply by v
+        double *a22 = A + size_t(k + 1) * m + (k + 1);
+        double acc = 0.0;
+        if (rr < l) {
+            const double vpr = pending ? vp[rr + 1] : 0.0, wpr = pending ? wp[rr + 1] : 0.0;
+            for (int c = cq; c < l; c += ng) {
+                double a = a22[size_t(c) * m + rr];
+                if (pending) {
+                    a -= vpr * wp[c + 1] + wpr * vp[c + 1];
+                    a22[size_t(c) * m + rr] = a;
+                }
+                acc += a * v[c];
+            }
+        }
+        part[cq * rb + rr] = acc;
+        __syncthreads(); // (3) partial products published
+        double p = 0.0;
+        if (tid < l) {
+            double sum = 0.0;
+            for (int g = 0; g < ng; ++g) sum += part[g * rb + tid];
+            p = tau * sum;
+            sq[tid] = p * v[tid];
+        }
+        __syncthreads(); // (4) p . v terms published
+        const double pv = wave_sum_lds(sq, l, lane);
+        if (tid < l) {
+            vp[tid] = v[tid]; // becomes the pending pair of the next step (tau = 0: v = 0, w = 0, a no-op)
+            wp[tid] = p - 0.5 * tau * pv * v[tid];
+        }
+        pending = true;
+        __syncthreads(); // (5) pending pair published
+    }
+    if (tid == 0) {
+        double dl = A[size_t(m - 1) * m + (m - 1)];
+        if (pending && m >= 2) dl -= 2.0 * vp[0] * wp[0]; // the last pending pair lives on the 1 x 1 trailing block
+        D[m - 1] = dl;
+        TAU[m - 1] = 0.0;
+    }
+}
+
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau) {
     if (m < 1 || m > 256) mh_throw(MH_EINVAL, "sytrd_small: order %u outside 1..256", m);
-    k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
+    static const bool fused = !(getenv("MH_SYTRD_FUSED") && atoi(getenv("MH_SYTRD_FUSED")) == 0);
+    if (fused) k_sytrd_small_fused<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
+    else k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
     KERNEL_CHECK();
 }
 
