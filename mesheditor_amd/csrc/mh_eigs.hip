@@ -423,6 +423,20 @@ __global__ void k_scatter_cols_pitch(const double *__restrict__ src, uint32_t ws
     if (i >= rows * w) return;
     dst[(i / w) * wdst + idx[i % w]] = src[(i / w) * wsrc + i % w];
 }
+// dst (rows x cols at leading dimension ld) -= src (leading dimension lds)
+__global__ void k_sub_block(double *__restrict__ dst, uint32_t ld, const double *__restrict__ src, uint32_t lds, uint32_t rows, uint32_t cols) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const uint32_t r = i % rows, c = i / rows;
+    dst[size_t(c) * ld + r] -= src[size_t(c) * lds + r];
+}
+// bw (w x w at leading dimension ld) += -u - u^T + v  (u, v: w x w, leading dimension w)
+__global__ void k_wblock_fix(double *__restrict__ bw, uint32_t ld, const double *__restrict__ u, const double *__restrict__ v, uint32_t w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * w) return;
+    const uint32_t r = i % w, c = i / w;
+    bw[size_t(c) * ld + r] += v[size_t(c) * w + r] - u[size_t(c) * w + r] - u[size_t(r) * w + c];
+}
 // seed basis (column-major float, reference DOF order) -> leading columns of a row-major internal-order panel
 __global__ void k_load_seed(const float *__restrict__ seed, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t ncols, uint32_t b, double *__restrict__ x) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1007,12 +1021,21 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             }
             bool w_implicit = false; // W itself left untransformed this iteration (see chol_orthonormalise)
             int last_spread = 1 << 20; // 16 log2(max / min diagonal of the last Cholesky factor of a unit-diagonal Gram matrix)
-            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true, bool allow_implicit = false) -> bool {
+            bool p_needs_explicit = false; // the implicit projection against P was refused (ill-conditioned Gram matrix): caller redoes it explicitly
+            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true, bool allow_implicit = false,
+                                           const double *hp = nullptr, uint32_t hp_rows = 0) -> bool {
+                // hp (hp_rows x w, = P^T M V): V is to be taken as V - P hp without forming it: G -= hp^T hp (P is M-orthonormal).  Only
+                // valid together with the implicit treatment of V; when that is refused nothing is transformed and p_needs_explicit is set.
                 // allow_implicit: with a well-conditioned Gram matrix not even V is transformed (w_implicit is set): the caller works
                 // with V L^-T through L^-1 on the small matrices
                 // transform_images = false: M V is only read (for the Gram matrix); the caller keeps the images untransformed
                 // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
                 gram(ctx, n, V, w, MV, w, G, w);
+                if (hp) {
+                    const double minus = -1, plus = 1;
+                    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(hp_rows), &minus, hp,
+                                                rocblas_int(hp_rows), hp, rocblas_int(hp_rows), &plus, G, rocblas_int(w)));
+                }
                 k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
                 KERNEL_CHECK();
                 double *Gs = G.get() + size_t(w) * w;
@@ -1030,6 +1053,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
                         info.download(&hinfo, 1);
                     }
+                }
+                p_needs_explicit = false;
+                if (hp && (hinfo != 0 || last_spread >= 16 * 8)) { // V - P hp is nearly dependent: project in the tall space instead
+                    p_needs_explicit = true;
+                    return true;
                 }
                 if (hinfo != 0) return false;
                 k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
@@ -1114,6 +1142,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             static const bool fresh_env = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
             static const bool trsm_env = getenv("MH_TRSM_ROCBLAS") && atoi(getenv("MH_TRSM_ROCBLAS")) != 0;
             const bool lazy_images_ok = lazy_env && fresh_env && implicit_p && !trsm_env;
+            // W is orthogonalised against P in coefficient space (no M P panel, no tall projection against P): MH_IMPLICIT_PPROJ=0 disables
+            static const bool pproj_env = !(getenv("MH_IMPLICIT_PPROJ") && atoi(getenv("MH_IMPLICIT_PPROJ")) == 0);
+            const bool pproj_ok = pproj_env && lazy_images_ok && implicit_w_env && b <= 128;
+            DevArray<double> Hp(ctx, size_t(b) * b), Up(ctx, size_t(b) * b), Vp(ctx, size_t(b) * b), T1p(ctx, size_t(b) * b);
+            bool p_implicit = false; // this iteration: the basis is [X, (W - P Hp) L^-T, P] with W, P stored
             bool lazy_images = false;
             for (uint32_t it = 0; it <= max_iters; ++it) {
                 if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
@@ -1200,9 +1233,34 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // basis only has to be well conditioned, not orthonormal to working precision.
                 static const int ortho_passes = getenv("MH_ORTHO_PASSES") ? std::max(1, atoi(getenv("MH_ORTHO_PASSES"))) : 1;
                 static const bool fused_images = !(getenv("MH_FUSED_IMAGES") && atoi(getenv("MH_FUSED_IMAGES")) == 0);
-                if (fused_images && ortho_passes == 1) {
+                p_implicit = false;
+                if (fused_images && ortho_passes == 1 && pproj_ok && wp && w <= 128) {
+                    // project against X in the tall space, against P in coefficient space
                     gram(ctx, n, MX, b, W, w, H, b); // b x w
-                    if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
+                    mh_pack_stacked(ctx, H, b, nullptr, 0, w, -1.0, Ct);
+                    mh_combine(ctx, n, X, b, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
+                    mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
+                    gram(ctx, n, P, wp, MW, w, Hp, wp); // Hp = P^T M W, wp x w
+                    lazy_images = true;
+                    w_implicit = false;
+                    ok = chol_orthonormalise(W, MW, AW, w, false, true, Hp, wp);
+                    if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+                    if (p_needs_explicit) { // rare: W - P Hp nearly dependent -> explicit projection, images again, ordinary Cholesky-QR
+                        mh_pack_stacked(ctx, Hp, wp, nullptr, 0, w, -1.0, Ct);
+                        mh_combine(ctx, n, P, wp, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
+                        mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
+                        lazy_images = lazy_images_ok && w <= 256;
+                        ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
+                        if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+                    } else {
+                        p_implicit = true;
+                    }
+                } else if (fused_images && ortho_passes == 1) {
+                    gram(ctx, n, MX, b, W, w, H, b); // b x w
+                    if (wp) {
+                        if (pproj_ok) mh_spmm(ctx, sys->L2, nullptr, P, nullptr, sys->L2.mval, MP, wp); // M P is not maintained in this mode: form it (wide block)
+                        gram(ctx, n, MP, wp, W, w, H2, wp);
+                    }
                     mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
                     mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
                     mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
@@ -1257,11 +1315,26 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                                                         rocblas_int(w), &unit, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
                     };
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
+                    if (p_implicit && wp) {
+                        // W' = W - P Hp:  P^T A W' = Bp - App Hp,  W'^T A W' = Bw - U - U^T + Hp^T App Hp with U = Hp^T Bp  (P^T A P = App, X^T A P = 0)
+                        const double minus = -1, plus = 1, nil = 0;
+                        double *bw = gA.get() + size_t(wa) * m + wa, *bp = gA.get() + size_t(wa) * m + wa + w;
+                        gram(ctx, n, P, wp, AW, w, bp, m);
+                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), bp,
+                                                    rocblas_int(m), &nil, Up, rocblas_int(w)));
+                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(wp), rocblas_int(w), rocblas_int(wp), &plus, App, rocblas_int(wp), Hp,
+                                                    rocblas_int(wp), &nil, T1p, rocblas_int(wp)));
+                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), T1p,
+                                                    rocblas_int(wp), &nil, Vp, rocblas_int(w)));
+                        k_sub_block<<<grid1(size_t(wp) * w), TB, 0, st>>>(bp, m, T1p, wp, wp, w); // Bp -= App Hp
+                        k_wblock_fix<<<grid1(size_t(w) * w), TB, 0, st>>>(bw, m, Up, Vp, w);
+                        KERNEL_CHECK();
+                    }
                     untransformed(gA.get() + size_t(wa) * m + wa, w);
                     left_corrected(gA.get() + size_t(wa) * m + wa, w);
                     // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
                     // says cond(G) < 2^16 (deviation ~1e-11)
-                    const bool w_block_trusted = !verify_cross && last_spread < 16 * 8;
+                    const bool w_block_trusted = !verify_cross && last_spread < 16 * 8 && !(p_implicit && wp == 0); // (a retry without P after an implicit P-projection: measure)
                     if (w_block_trusted) {
                         k_place_block<<<grid1(size_t(w) * w), TB, 0, st>>>(gM.get() + size_t(wa) * m + wa, m, nullptr, w);
                         KERNEL_CHECK();
@@ -1271,7 +1344,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     }
                     if (verbose) fprintf(stderr, "[lobpcg] it %3u Cholesky-QR diagonal spread 2^%.1f%s\n", it, last_spread / 16.0, w_block_trusted ? "" : " (W block measured)");
                     if (wp) {
-                        gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m);
+                        if (!p_implicit) gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m); // (already formed and corrected above otherwise)
                         untransformed(gA.get() + size_t(wa) * m + wa + w, wp);
                         if (verify_cross || !implicit_p) {
                             gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
@@ -1367,8 +1440,15 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wa + wp_new),
                                                     rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
                     }
+                    if (p_implicit && wp) { // ... and it holds W, not W - P Hp: the P rows take the difference, rows_P -= Hp rows_W (all columns)
+                        const double minus = -1, plus = 1;
+                        const rocblas_int pitchc = rocblas_int(wa + wp_new);
+                        double *rows_w = Ct.get() + size_t(wa) * (wa + wp_new), *rows_p = Ct.get() + size_t(wa + w) * (wa + wp_new);
+                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, pitchc, rocblas_int(wp), rocblas_int(w), &minus, rows_w, pitchc, Hp,
+                                                    rocblas_int(wp), &plus, rows_p, pitchc));
+                    }
                     mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
-                    if (wp_new) {
+                    if (wp_new && !pproj_ok) {
                         if (lazy_images && !w_implicit) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
                             const double unit = 1;
                             double *rows = Ct.get() + size_t(wa) * (wa + wp_new) + wa;
