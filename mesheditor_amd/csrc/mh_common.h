@@ -247,6 +247,7 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
                 double *out1, uint32_t n1, double *out2, bool accumulate = false, uint32_t ldx = 0, const uint32_t *xmap = nullptr, uint32_t ld1 = 0,
                 const uint32_t *omap = nullptr, uint32_t col_begin = 0, uint32_t col_count = 0); // optional column maps on X (read) and out1 (write), pitches
                                                                                                 // ldx / ld1; col_count > 0: only columns [col_begin, +col_count) of Ct
+void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols); // mh_dense.hip: Z <- Q Z after mh_sytrd_small
 bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *ufac,
                        double *quality, double *lam_scratch); // mh_dense.hip: k lowest eigenpairs of a tridiagonal matrix (quality: 8 doubles, lam_scratch: k)
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info); // mh_dense.hip

@@ -701,6 +701,69 @@ void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e
     KERNEL_CHECK();
 }
 
+// Z <- Q Z for the orthogonal factor of mh_sytrd_small (LAPACK's lower storage: reflector k has v[k+1] = 1 and its tail in
+// A(k+2:, k)), one wave per column of Z: the column lives in registers (4 entries per lane, m <= 256), each reflector costs one
+// wave reduction, the next reflector's entries are requested before the current one is applied.  Replaces rocSOLVER's blocked
+// ormtr (~35 launches of larft/larfb pieces per call at these orders) by one launch.
+namespace {
+__global__ void __launch_bounds__(64) k_apply_q(const double *__restrict__ A, const double *__restrict__ tau, int m, double *__restrict__ Z, int ldz) {
+    const int lane = threadIdx.x;
+    double *zc = Z + size_t(blockIdx.x) * ldz;
+    double z[4], v[4], vn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = lane + 64 * q < m ? zc[lane + 64 * q] : 0.0;
+    auto load = [&](int k, double (&dst)[4]) { // reflector k on rows k + 1 .. m - 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            dst[q] = (k >= 0 && i < m && i > k + 1) ? A[size_t(k) * m + i] : (i == k + 1 ? 1.0 : 0.0);
+        }
+    };
+    load(m - 2, v);
+    for (int k = m - 2; k >= 0; --k) {
+        load(k - 1, vn);
+        double dot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dot += v[q] * z[q];
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const double t = tau[k] * dot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            z[q] -= t * v[q];
+            v[q] = vn[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < m) zc[lane + 64 * q] = z[q];
+}
+// inv = L^-1 for a lower-triangular L of order w <= 128 (column-major, leading dimensions ldl / ldi; the strict upper triangle of
+// inv is zeroed): one thread per column, forward substitution with L in LDS.  Replaces rocblas_dtrtri (~9 launches per call).
+__global__ void __launch_bounds__(128) k_trtri_small(const double *__restrict__ L, int ldl, int w, double *__restrict__ inv, int ldi) {
+    extern __shared__ __attribute__((aligned(16))) double sl[]; // w x w, pitch w + 1
+    const int tid = threadIdx.x, pitch = w + 1;
+    for (int idx = tid; idx < w * w; idx += 128) sl[(idx / w) * pitch + idx % w] = L[size_t(idx / w) * ldl + idx % w];
+    __syncthreads();
+    if (tid >= w) return;
+    // column j of the inverse: x[i] = (delta_ij - sum_{k = j}^{i - 1} L[i][k] x[k]) / L[i][i], i >= j; kept in the output column itself
+    const int j = tid;
+    double *x = inv + size_t(j) * ldi;
+    for (int i = 0; i < j; ++i) x[i] = 0.0;
+    for (int i = j; i < w; ++i) {
+        double s = i == j ? 1.0 : 0.0;
+        for (int k = j; k < i; ++k) s -= sl[k * pitch + i] * x[k];
+        x[i] = s / sl[i * pitch + i];
+    }
+}
+} // namespace
+
+void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols) {
+    if (m > 256) mh_throw(MH_EINVAL, "apply_q: order %u above 256", m);
+    if (!ncols || m < 2) return;
+    k_apply_q<<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
+    KERNEL_CHECK();
+}
+
 // ---- lowest eigenpairs of a symmetric tridiagonal matrix, one workgroup ---------------------------------------------------
 // The Rayleigh-Ritz step needs only the k lowest of the m eigenpairs (the active Ritz vectors), and it needs them as an
 // orthonormal basis of the right invariant subspace, not as exactly diagonalising vectors (a rotation inside the wanted

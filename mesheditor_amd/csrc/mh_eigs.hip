@@ -628,7 +628,9 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
             info.download(&hinfo, 1);
             if (hinfo != 0) return hinfo;
         }
-        ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, ncols, gA, m, tau, z, m));
+        static const bool own_ormtr = !(getenv("MH_RR_ORMTR") && atoi(getenv("MH_RR_ORMTR")) != 0);
+        if (own_ormtr) mh_apply_q(ctx, gA, tau, m, z, m, ncols);
+        else ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, ncols, gA, m, tau, z, m));
         HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         // no synchronisation: the workspaces return to the context's pool, whose blocks are only ever used on this same stream
     } else {
