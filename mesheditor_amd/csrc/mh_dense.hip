@@ -737,24 +737,6 @@ __global__ void __launch_bounds__(64) k_apply_q(const double *__restrict__ A, co
     for (int q = 0; q < 4; ++q)
         if (lane + 64 * q < m) zc[lane + 64 * q] = z[q];
 }
-// inv = L^-1 for a lower-triangular L of order w <= 128 (column-major, leading dimensions ldl / ldi; the strict upper triangle of
-// inv is zeroed): one thread per column, forward substitution with L in LDS.  Replaces rocblas_dtrtri (~9 launches per call).
-__global__ void __launch_bounds__(128) k_trtri_small(const double *__restrict__ L, int ldl, int w, double *__restrict__ inv, int ldi) {
-    extern __shared__ __attribute__((aligned(16))) double sl[]; // w x w, pitch w + 1
-    const int tid = threadIdx.x, pitch = w + 1;
-    for (int idx = tid; idx < w * w; idx += 128) sl[(idx / w) * pitch + idx % w] = L[size_t(idx / w) * ldl + idx % w];
-    __syncthreads();
-    if (tid >= w) return;
-    // column j of the inverse: x[i] = (delta_ij - sum_{k = j}^{i - 1} L[i][k] x[k]) / L[i][i], i >= j; kept in the output column itself
-    const int j = tid;
-    double *x = inv + size_t(j) * ldi;
-    for (int i = 0; i < j; ++i) x[i] = 0.0;
-    for (int i = j; i < w; ++i) {
-        double s = i == j ? 1.0 : 0.0;
-        for (int k = j; k < i; ++k) s -= sl[k * pitch + i] * x[k];
-        x[i] = s / sl[i * pitch + i];
-    }
-}
 } // namespace
 
 void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols) {
