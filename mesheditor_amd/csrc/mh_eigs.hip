@@ -1148,6 +1148,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             static const bool pproj_env = !(getenv("MH_IMPLICIT_PPROJ") && atoi(getenv("MH_IMPLICIT_PPROJ")) == 0);
             const bool pproj_ok = pproj_env && lazy_images_ok && implicit_w_env && b <= 128;
             DevArray<double> Hp(ctx, size_t(b) * b), Up(ctx, size_t(b) * b), Vp(ctx, size_t(b) * b), T1p(ctx, size_t(b) * b);
+            bool gm_identity = false; // this iteration's gM0 is exactly I (all blocks placed, none measured)
             bool p_implicit = false; // this iteration: the basis is [X, (W - P Hp) L^-T, P] with W, P stored
             bool lazy_images = false;
             for (uint32_t it = 0; it <= max_iters; ++it) {
@@ -1337,6 +1338,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
                     // says cond(G) < 2^16 (deviation ~1e-11)
                     const bool w_block_trusted = !verify_cross && last_spread < 16 * 8 && !(p_implicit && wp == 0); // (a retry without P after an implicit P-projection: measure)
+                    gm_identity = w_block_trusted && implicit_p; // every block of gM was set, not measured: gM0 is the identity exactly
                     if (w_block_trusted) {
                         k_place_block<<<grid1(size_t(w) * w), TB, 0, st>>>(gM.get() + size_t(wa) * m + wa, m, nullptr, w);
                         KERNEL_CHECK();
@@ -1384,11 +1386,13 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 uint32_t wp_new = w;
                 k_build_cp<<<grid1(size_t(m) * w), TB, 0, st>>>(gA, nullptr, wa, m, w, m, Cp, m);
                 KERNEL_CHECK();
-                ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, T1, m, &zero, H, wa));
+                // (gM0 Cp is Cp itself when gM0 is the identity by construction: the two symmetric products are skipped)
+                const double *mcp = gm_identity ? Cp.get() : T1.get();
+                if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, mcp, m, &zero, H, wa));
                 ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, wa, &mone, gA, m, H, wa, &one, Cp, m));
-                ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, T1, m, &zero, G, w));
+                if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, mcp, m, &zero, G, w));
                 k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
                 KERNEL_CHECK();
                 {
