@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_small(double *__restrict__ A, in
 // read, updated, written back and multiplied by the new reflector in ONE sweep (two sweeps per column instead of three, one
 // barrier fewer).  Column k of the logically updated matrix is formed first, from the stored column and the pending pair.
 __global__ void __launch_bounds__(1024) k_sytrd_small_fused(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
-    __shared__ double xs[256], v[256], wv[256], vp[256], wp[256], sq[256], part[1024];
+    __shared__ double xs[256], v[256], wv[256], vp[256], wp[256], sq[256], xnext[256], part[1024];
     const int tid = threadIdx.x, lane = tid & 63;
     bool pending = false; // (vp, wp): reflector and w of the previous step, indexed over ITS trailing block (this step's index + 1)
     for (int k = 0; k + 1 < m; ++k) {
@@ -625,13 +625,15 @@ __global__ void __launch_bounds__(1024) k_sytrd_small_fused(double *__restrict__
         const int ng = 1024 / rb, rr = tid & (rb - 1), cq = tid / rb;
         double *col = A + size_t(k) * m + (k + 1);
         // column k of the updated matrix: index 0 of the previous trailing block is this column, index i + 1 is row k + 1 + i
+        // (after the first step the stored values come from xnext, where the previous sweep left the first column of its block:
+        // no global round trip at the head of the step)
         if (tid < l) {
-            double x = col[tid];
+            double x = pending ? xnext[tid + 1] : col[tid];
             if (pending) x -= vp[tid + 1] * wp[0] + wp[tid + 1] * vp[0];
             xs[tid] = x;
             sq[tid] = tid >= 1 ? x * x : 0.0;
         }
-        double dk = A[size_t(k) * m + k];
+        double dk = pending ? xnext[0] : A[size_t(k) * m + k];
         if (pending) dk -= 2.0 * vp[0] * wp[0];
         __syncthreads(); // (1) column published
         const double xnorm2 = wave_sum_lds(sq, l, lane);
@@ -664,6 +666,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_small_fused(double *__restrict__
                     a -= vpr * wp[c + 1] + wpr * vp[c + 1];
                     a22[size_t(c) * m + rr] = a;
                 }
+                if (c == 0) xnext[rr] = a; // first column of this block = column k + 1 (and its diagonal entry) for the next step
                 acc += a * v[c];
             }
         }
