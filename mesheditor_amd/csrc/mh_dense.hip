@@ -614,15 +614,18 @@ __global__ void __launch_bounds__(1024) k_sytrd_small(double *__restrict__ A, in
 // The same reduction with the rank-2 update of step k - 1 deferred into the product pass of step k: the trailing block is
 // read, updated, written back and multiplied by the new reflector in ONE sweep (two sweeps per column instead of three, one
 // barrier fewer).  Column k of the logically updated matrix is formed first, from the stored column and the pending pair.
-__global__ void __launch_bounds__(1024) k_sytrd_small_fused(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
-    __shared__ double xs[256], v[256], wv[256], vp[256], wp[256], sq[256], xnext[256], part[1024];
+#ifndef MH_SYTRD_THREADS
+#define MH_SYTRD_THREADS 1024
+#endif
+__global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
+    __shared__ double xs[256], v[256], wv[256], vp[256], wp[256], sq[256], xnext[256], part[MH_SYTRD_THREADS];
     const int tid = threadIdx.x, lane = tid & 63;
     bool pending = false; // (vp, wp): reflector and w of the previous step, indexed over ITS trailing block (this step's index + 1)
     for (int k = 0; k + 1 < m; ++k) {
         const int l = m - k - 1; // order of the trailing block, rows/cols k+1 .. m-1
         int rb = 32;
         while (rb < l) rb <<= 1;
-        const int ng = 1024 / rb, rr = tid & (rb - 1), cq = tid / rb;
+        const int ng = max(1, MH_SYTRD_THREADS / rb), rr = tid & (rb - 1), cq = tid / rb;
         double *col = A + size_t(k) * m + (k + 1);
         // column k of the updated matrix: index 0 of the previous trailing block is this column, index i + 1 is row k + 1 + i
         // (after the first step the stored values come from xnext, where the previous sweep left the first column of its block:
@@ -699,7 +702,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_small_fused(double *__restrict__
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau) {
     if (m < 1 || m > 256) mh_throw(MH_EINVAL, "sytrd_small: order %u outside 1..256", m);
     static const bool fused = !(getenv("MH_SYTRD_FUSED") && atoi(getenv("MH_SYTRD_FUSED")) == 0);
-    if (fused) k_sytrd_small_fused<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
+    if (fused) k_sytrd_small_fused<<<1, MH_SYTRD_THREADS, 0, ctx->stream>>>(a, int(m), d, e, tau);
     else k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
     KERNEL_CHECK();
 }
