@@ -131,7 +131,9 @@ int mh_context_create(int device, mh_context **out) {
         const int code = mh_guard(ctx, e);
         fprintf(stderr, "modalhip: %s\n", e.what());
         if (ctx->blas) rocblas_destroy_handle(ctx->blas);
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+        if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return code;
     }
@@ -141,6 +143,7 @@ void mh_context_destroy(mh_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->blas) rocblas_destroy_handle(ctx->blas);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -89,6 +89,11 @@ struct DevicePool {
 struct mh_context {
     int device{0};
     hipStream_t stream{nullptr};
+    hipStream_t aux_stream{nullptr}; // second stream of the context: the coarse elimination beside the smoothers' set-up (created on first use)
+    bool aux_stream_ready() {
+        if (!aux_stream && hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) aux_stream = nullptr;
+        return aux_stream != nullptr;
+    }
     rocblas_handle blas{nullptr};
     DevicePool pool;
     std::string last_error;

@@ -832,19 +832,13 @@ double estimate_lmax(mh_context *ctx, BsrLevel &lvl) {
 void mh_build_hierarchy(mh_system *sys, double sigma) {
     mh_context *ctx = sys->ctx;
     if (sys->hierarchy_ready && sys->sigma_built == sigma) return;
+    hipStream_t main_stream = ctx->stream;
     for (BsrLevel *lvl : {&sys->L2, &sys->L1}) {
         lvl->aval.reset(ctx, lvl->n_blocks * 9);
         lvl->dinv.reset(ctx, size_t(3) * lvl->n_nodes);
         k_shift_values<<<grid1(lvl->n_blocks * 9), TB, 0, ctx->stream>>>(lvl->kval, lvl->mval, lvl->n_blocks, sigma, lvl->aval);
         KERNEL_CHECK();
         k_diag_inverse<<<grid1(lvl->n_nodes), TB, 0, ctx->stream>>>(lvl->row_ptr, lvl->col, lvl->aval, lvl->n_nodes, lvl->dinv);
-        KERNEL_CHECK();
-        lvl->lmax = estimate_lmax(ctx, *lvl);
-        lvl->aval32.reset(ctx, lvl->n_blocks * 9);
-        lvl->dinv32.reset(ctx, size_t(3) * lvl->n_nodes);
-        k_convert<double, float><<<grid1(lvl->n_blocks * 9), TB, 0, ctx->stream>>>(lvl->aval.get(), lvl->aval32.get(), lvl->n_blocks * 9);
-        KERNEL_CHECK();
-        k_convert<double, float><<<grid1(size_t(3) * lvl->n_nodes), TB, 0, ctx->stream>>>(lvl->dinv.get(), lvl->dinv32.get(), size_t(3) * lvl->n_nodes);
         KERNEL_CHECK();
     }
     const size_t n0 = size_t(6) * sys->n_agg;
@@ -857,9 +851,24 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     DevArray<int> info(ctx, 1);
     int hinfo = 0;
     static const bool coarse_rocsolver = getenv("MH_COARSE_ROCSOLVER") && atoi(getenv("MH_COARSE_ROCSOLVER")) != 0;
+    // The rest of the set-up -- the spectral bounds of both smoothers (power iterations: SpMMs that fill the GPU, with host
+    // round trips) and the single-precision copies -- does not depend on the coarse inverse, whose elimination is a chain of
+    // one-workgroup kernels and small products: the two run side by side on two streams (MH_HIERARCHY_OVERLAP=0: one after the other).
+    static const bool overlap = !(getenv("MH_HIERARCHY_OVERLAP") && atoi(getenv("MH_HIERARCHY_OVERLAP")) == 0);
+    auto smoother_setup = [&] {
+        for (BsrLevel *lvl : {&sys->L2, &sys->L1}) {
+            lvl->lmax = estimate_lmax(ctx, *lvl);
+            lvl->aval32.reset(ctx, lvl->n_blocks * 9);
+            lvl->dinv32.reset(ctx, size_t(3) * lvl->n_nodes);
+            k_convert<double, float><<<grid1(lvl->n_blocks * 9), TB, 0, ctx->stream>>>(lvl->aval.get(), lvl->aval32.get(), lvl->n_blocks * 9);
+            KERNEL_CHECK();
+            k_convert<double, float><<<grid1(size_t(3) * lvl->n_nodes), TB, 0, ctx->stream>>>(lvl->dinv.get(), lvl->dinv32.get(), size_t(3) * lvl->n_nodes);
+            KERNEL_CHECK();
+        }
+    };
     if (!coarse_rocsolver) {
         // Explicit inverse by block Gauss-Jordan elimination (no pivoting: the matrix is SPD), 128 columns per step:
-        //   P = A_kk^-1 (one workgroup, in LDS);  C = A(:, k);  R = P A(k, :);  A -= C R;  A(k, :) = R;  A(:, k) = -C P;  A_kk = P.
+        //   P = A_kk^-1 (one workgroup, in registers);  C = A(:, k);  R = P A(k, :);  A -= C R;  A(k, :) = R;  A(:, k) = -C P;  A_kk = P.
         // 2 n0^3 flops in n0 / 128 rank-128 updates of the whole matrix (rocBLAS dgemm) instead of potrf + potri's chains of
         // panel kernels: 17 ms -> 8 ms at n0 = 3 690 -- and, unlike rocsolver_dpotrf, undisturbed by concurrent streams, so a
         // solve needs no exclusive phase on the device.  The coarse solve becomes one dense product per application (2.5x
@@ -867,6 +876,26 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
         const uint32_t nb = 128;
         DevArray<double> cblk(ctx, n0 * nb), rblk(ctx, n0 * nb), pinv(ctx, size_t(nb) * nb);
         info.zero();
+        const bool side = overlap && ctx->aux_stream_ready();
+        struct StreamGuard { // whatever happens below, the context leaves on its own stream
+            mh_context *c;
+            hipStream_t s;
+            ~StreamGuard() {
+                if (c->stream != s) {
+                    c->stream = s;
+                    (void)rocblas_set_stream(c->blas, s);
+                    (void)hipStreamSynchronize(c->aux_stream);
+                }
+            }
+        } guard{ctx, main_stream};
+        hipEvent_t forked = nullptr;
+        if (side) { // everything queued so far precedes the elimination
+            HIP_CHECK(hipEventCreateWithFlags(&forked, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(forked, main_stream));
+            HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, forked, 0));
+            ctx->stream = ctx->aux_stream;
+            ROCBLAS_CHECK(rocblas_set_stream(ctx->blas, ctx->aux_stream));
+        }
         const double one = 1, zero = 0, mone = -1;
         const rocblas_int ld = rocblas_int(n0);
         double *a = sys->a0.get();
@@ -880,31 +909,42 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, w, w, &mone, cblk, ld, pinv, w, &zero, a + k0 * n0, ld));
             HIP_CHECK(hipMemcpy2DAsync(a + k0 * n0 + k0, n0 * sizeof(double), pinv.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), size_t(w), hipMemcpyDeviceToDevice, ctx->stream));
         }
+        k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
+        KERNEL_CHECK();
+        if (side) { // back to the main stream for the smoothers' set-up while the elimination runs
+            ctx->stream = main_stream;
+            ROCBLAS_CHECK(rocblas_set_stream(ctx->blas, main_stream));
+        }
+        smoother_setup();
+        if (side) {
+            HIP_CHECK(hipStreamSynchronize(ctx->aux_stream)); // (the workspaces above live until here)
+            (void)hipEventDestroy(forked);
+        }
         info.download(&hinfo, 1);
         if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
         static const bool check = getenv("MH_CHECK_COARSE") != nullptr;
-        if (check) { // || A0 A0^-1 - I ||_max against a copy taken before the elimination is not kept: check symmetry instead
+        if (check) { // symmetry of the computed inverse before it was symmetrised is gone by now: report its scale only
             std::vector<double> h(n0 * n0);
             sys->a0.download(h.data(), n0 * n0);
-            double asym = 0, amax = 0;
-            for (size_t i = 0; i < n0; ++i)
-                for (size_t j = 0; j < i; ++j) { asym = std::max(asym, std::abs(h[i * n0 + j] - h[j * n0 + i])); amax = std::max(amax, std::abs(h[i * n0 + j])); }
-            fprintf(stderr, "[coarse] n0 %zu inverse asymmetry %.3e of max %.3e\n", n0, asym, amax);
+            double amax = 0;
+            for (double v : h) amax = std::max(amax, std::abs(v));
+            fprintf(stderr, "[coarse] n0 %zu inverse, largest entry %.3e\n", n0, amax);
         }
     } else {
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ExclusivePhase alone_on_the_device; // rocsolver_dpotrf must not run beside other streams' kernels (see the top of the file)
-    SolverLock solver_lock(g_rocsolver_mutex);
-    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
-    info.download(&hinfo, 1);
-    if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (potrf info %d): shift must be negative", hinfo);
-    ROCBLAS_CHECK(rocsolver_dpotri(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
-    info.download(&hinfo, 1);
-    solver_lock.unlock();
-    if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse inverse failed (potri info %d)", hinfo);
+        smoother_setup();
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ExclusivePhase alone_on_the_device; // rocsolver_dpotrf must not run beside other streams' kernels (see the top of the file)
+        SolverLock solver_lock(g_rocsolver_mutex);
+        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
+        info.download(&hinfo, 1);
+        if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (potrf info %d): shift must be negative", hinfo);
+        ROCBLAS_CHECK(rocsolver_dpotri(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
+        info.download(&hinfo, 1);
+        solver_lock.unlock();
+        if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse inverse failed (potri info %d)", hinfo);
+        k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
+        KERNEL_CHECK();
     }
-    k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
-    KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     sys->sigma_built = sigma;
     sys->hierarchy_ready = true;
