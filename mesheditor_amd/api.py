@@ -283,21 +283,24 @@ def mesh2modes(ctx, points, tets, mat, excite_positions, baked_scale=(1.0, 1.0, 
     sigma = -float(np.float64(2 * np.pi * np.float64(cfg.min_mode_freq)) ** 2)
     empty = ModalResult(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros((len(pts), 0, 3), np.float32), positions, 0.0, np.zeros(0),
                         np.zeros((len(pts), 0, 3), np.float32), mass, com, inertia, quat, {}, remap)
+    keep = False
     try:
         warm = seed_basis is not None and seed_basis.shape[0] == n and seed_basis.shape[1] >= nev
         tol = float(min(1e-2, max(1e-9, np.sqrt(cfg.warm_tolerance) * 1e-2))) if warm else residual_tolerance(cfg)
-        ev, prof = system.eigs(nev, sigma, tol, max(cfg.max_restarts, 1) * 3, seed_basis if warm else None)
-    except ModalHipError as e:
-        if e.code == _lib.MH_EFACTOR:
-            raise RuntimeError("Modal shift-invert factorization failed.") from e
-        empty.profile = {"error": str(e)}
-        return empty
-    sshapes = system.gather_shapes(pts, nev)
-    freqs, t60s, shapes, orig = postprocess_modes(ev, sshapes, 1.0, mat, cfg)
-    basis = system.basis(nev) if keep_basis else None
-    res = ModalResult(freqs, t60s, shapes, positions, orig, ev, sshapes, mass, com, inertia, quat, prof, remap, basis, system if keep_system else None)
-    if not keep_system:
-        system.close()
-    if own_mesh:
-        mesh.close()
-    return res
+        try:
+            ev, prof = system.eigs(nev, sigma, tol, max(cfg.max_restarts, 1) * 3, seed_basis if warm else None)
+        except ModalHipError as e:
+            if e.code == _lib.MH_EFACTOR:
+                raise RuntimeError("Modal shift-invert factorization failed.") from e
+            empty.profile = {"error": str(e)}
+            return empty  # empty Modes; mass properties and the excitation map stay (mesh2modes.cpp:657)
+        sshapes = system.gather_shapes(pts, nev)
+        freqs, t60s, shapes, orig = postprocess_modes(ev, sshapes, 1.0, mat, cfg)
+        basis = system.basis(nev) if keep_basis else None
+        keep = keep_system
+        return ModalResult(freqs, t60s, shapes, positions, orig, ev, sshapes, mass, com, inertia, quat, prof, remap, basis, system if keep_system else None)
+    finally:  # handles are released on every path, the error ones included
+        if not keep:
+            system.close()
+        if own_mesh:
+            mesh.close()

@@ -31,7 +31,7 @@ def lib():
     L = C.CDLL(SO_PATH)
     vp, u32, i32, f32, f64 = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_double
     sig = {
-        "mhx_last_error": (C.c_char_p, []), "mhx_scene_create": (vp, [f32, i32]), "mhx_scene_destroy": (None, [vp]),
+        "mhx_last_error": (C.c_char_p, []), "mhx_scene_create": (vp, [f32, i32]), "mhx_scene_create_f64": (vp, [f32, i32]), "mhx_scene_destroy": (None, [vp]),
         "mhx_add_object": (u32, [vp, u32, u32, u32, vp, vp, u32, vp]), "mhx_tune_object": (None, [vp, i32, u32, u32, vp, vp, f32]),
         "mhx_set_shapes": (i32, [vp, i32, u32, u32, u32, vp]), "mhx_set_gains": (None, [vp, i32, u32, f32, f32]), "mhx_install": (i32, [vp]),
         "mhx_set_renderers": (None, [vp, u32]), "mhx_set_click_gain": (None, [vp, f32]), "mhx_set_max_impacts": (None, [vp, u32]),
@@ -57,9 +57,11 @@ def _p(a):
 class Scene:
     """ModalAudio + the bank under construction, as the reference's test harness drives them (tests/ModalBench.h:47-81)."""
 
-    def __init__(self, sample_rate=48000.0, device=0):
+    def __init__(self, sample_rate=48000.0, device=0, use_double=False):
+        """use_double: the fp64 bank (ModalBank64 / ModalAudio64) -- columns, impacts and output samples in double."""
         self.L = lib()
-        self.h = self.L.mhx_scene_create(sample_rate, device)
+        self.dtype = np.float64 if use_double else np.float32
+        self.h = (self.L.mhx_scene_create_f64 if use_double else self.L.mhx_scene_create)(sample_rate, device)
 
     def close(self):
         if self.h:
@@ -102,7 +104,7 @@ class Scene:
         return bool(self.L.mhx_enqueue(self.h, C.byref(e)))
 
     def render(self, out):
-        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+        assert out.dtype == self.dtype and out.flags["C_CONTIGUOUS"]
         if self.L.mhx_render(self.h, _p(out), len(out)):
             raise RuntimeError(self.L.mhx_last_error().decode())
 
@@ -130,18 +132,3 @@ class Scene:
     @property
     def render_share(self):
         return self.L.mhx_render_share(self.h)
-
-
-def smoke(ctx, po):
-    """One struck object through the device bank, sample-exact against the CPU oracle."""
-    import sys
-    sys.path.insert(0, os.path.dirname(_HERE))
-    from tests import bank_harness as bh
-    modes = bh.make_modes(32, 0.2)
-    signals = []
-    for make in (lambda: bh.OracleScene(po, 2, 32, 0.2, 1, modes=modes), lambda: bh.DeviceScene(2, 32, 0.2, 1, modes=modes)):
-        sc = make()
-        for o in sc.objects:
-            sc.enqueue(bh.impact_event(po, o, 1.0))
-        signals.append(sc.render(3, bh.BLOCK))
-    assert np.abs(signals[0]).max() > 0 and np.array_equal(signals[0], signals[1]), "device bank differs from the oracle"

@@ -1,2 +1,2 @@
 #pragma once
-#include "../modal/bank.hpp"
+#include "../modal/surface.hpp"

@@ -5,6 +5,7 @@
 #include "modal/solver.hpp"
 
 #include <cstring>
+#include <type_traits>
 #include <exception>
 #include <string>
 
@@ -24,84 +25,118 @@ ModalModes MakeModes(uint32_t n_modes, uint32_t n_pos, const float *freqs, const
 }
 } // namespace
 
+// One scene in either precision.  `dbl` picks which pair is live; every entry point dispatches on it.
 struct mhx_scene {
+    bool dbl{false};
     ModalAudio audio;
     ModalBank next;
+    ModalAudio64 audio64;
+    ModalBank64 next64;
 };
+
+namespace {
+// f(audio, bank under construction) in the scene's precision
+template<typename F> auto Dispatch(mhx_scene *s, F &&f) { return s->dbl ? f(s->audio64, s->next64) : f(s->audio, s->next); }
+template<typename Audio, typename Bank> Bank &Pick(Audio &a, Bank &next, int live) { return live ? static_cast<Bank &>(LiveBank(a)) : next; }
+} // namespace
 
 extern "C" {
 const char *mhx_last_error() { return g_error.c_str(); }
 
-mhx_scene *mhx_scene_create(float sample_rate, int device) {
+static mhx_scene *NewScene(float sample_rate, int device, bool dbl) {
     auto *s = new mhx_scene;
+    s->dbl = dbl;
     s->next.SampleRate = sample_rate;
-    s->audio.Device = device;
+    s->next64.SampleRate = sample_rate;
+    s->audio.Device = s->audio64.Device = device;
     return s;
 }
+mhx_scene *mhx_scene_create(float sample_rate, int device) { return NewScene(sample_rate, device, false); }
+// The fp64 bank behind the same API (ModalBank64 / ModalAudio64): columns, impacts and output in double.
+mhx_scene *mhx_scene_create_f64(float sample_rate, int device) { return NewScene(sample_rate, device, true); }
 void mhx_scene_destroy(mhx_scene *s) { delete s; }
+int mhx_scene_is_f64(mhx_scene *s) { return s->dbl ? 1 : 0; }
 uint32_t mhx_add_object(mhx_scene *s, uint32_t entity, uint32_t n_modes, uint32_t n_pos, const float *shapes, const float *positions, uint32_t n_idx, const uint32_t *idx) {
-    return AddModalObject(s->next, entt::entity{entity}, MakeModes(n_modes, n_pos, nullptr, nullptr, shapes, positions, n_idx, idx));
+    const auto modes = MakeModes(n_modes, n_pos, nullptr, nullptr, shapes, positions, n_idx, idx);
+    return Dispatch(s, [&](auto &, auto &next) { return AddModalObject(next, entt::entity{entity}, modes); });
 }
 void mhx_tune_object(mhx_scene *s, int live, uint32_t object, uint32_t n, const float *freqs, const float *t60s, float radius_scale) {
-    TuneModalObject(live ? LiveBank(s->audio) : s->next, object, std::span<const float>(freqs, n), std::span<const float>(t60s, n), radius_scale);
+    Dispatch(s, [&](auto &a, auto &next) { TuneModalObject(Pick(a, next, live), object, std::span<const float>(freqs, n), std::span<const float>(t60s, n), radius_scale); return 0; });
 }
 int mhx_set_shapes(mhx_scene *s, int live, uint32_t object, uint32_t n_modes, uint32_t n_pos, const float *shapes) {
-    return SetModalObjectShapes(live ? LiveBank(s->audio) : s->next, object, MakeModes(n_modes, n_pos, nullptr, nullptr, shapes, nullptr, 0, nullptr)) ? 1 : 0;
+    const auto modes = MakeModes(n_modes, n_pos, nullptr, nullptr, shapes, nullptr, 0, nullptr);
+    return Dispatch(s, [&](auto &a, auto &next) { return SetModalObjectShapes(Pick(a, next, live), object, modes) ? 1 : 0; });
 }
 void mhx_set_gains(mhx_scene *s, int live, uint32_t object, float out_gain, float listener_gain) {
-    auto &b = live ? LiveBank(s->audio) : s->next;
-    b.OutGain[object] = out_gain;
-    b.ListenerGain[object] = listener_gain;
+    Dispatch(s, [&](auto &a, auto &next) {
+        auto &b = Pick(a, next, live);
+        b.OutGain[object] = out_gain;
+        b.ListenerGain[object] = listener_gain;
+        return 0;
+    });
 }
 int mhx_install(mhx_scene *s) {
     try {
-        InstallModalBank(s->audio, s->next);
-        s->next = ModalBank{};
-        s->next.SampleRate = LiveBank(s->audio).SampleRate;
-        return 0;
+        return Dispatch(s, [&](auto &a, auto &next) {
+            InstallModalBank(a, next);
+            next = std::remove_reference_t<decltype(next)>{};
+            next.SampleRate = LiveBank(a).SampleRate;
+            return 0;
+        });
     } catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
-void mhx_set_renderers(mhx_scene *s, uint32_t n) { s->audio.RenderPool.SetSize(n); }
-void mhx_set_click_gain(mhx_scene *s, float g) { s->audio.ClickGain.store(g); }
-void mhx_set_max_impacts(mhx_scene *s, uint32_t n) { s->audio.MaxImpacts.store(n); }
+void mhx_set_renderers(mhx_scene *s, uint32_t n) { s->audio.RenderPool.SetSize(n); s->audio64.RenderPool.SetSize(n); }
+void mhx_set_click_gain(mhx_scene *s, float g) { s->audio.ClickGain.store(g); s->audio64.ClickGain.store(g); }
+void mhx_set_max_impacts(mhx_scene *s, uint32_t n) { s->audio.MaxImpacts.store(n); s->audio64.MaxImpacts.store(n); }
 int mhx_enqueue(mhx_scene *s, const ModalEvent *e) {
-    const auto before = s->audio.EventsDropped;
-    EnqueueModalEvent(s->audio, *e);
-    return s->audio.EventsDropped == before ? 1 : 0;
+    return Dispatch(s, [&](auto &a, auto &) {
+        const auto before = a.EventsDropped;
+        EnqueueModalEvent(a, *e);
+        return a.EventsDropped == before ? 1 : 0;
+    });
 }
-int mhx_render(mhx_scene *s, float *out, uint32_t frames) {
+// `out`: float samples for an fp32 scene, double samples for an fp64 scene
+int mhx_render(mhx_scene *s, void *out, uint32_t frames) {
     try {
-        RenderModal(s->audio, out, frames);
+        if (s->dbl) RenderModal(s->audio64, static_cast<double *>(out), frames);
+        else RenderModal(s->audio, static_cast<float *>(out), frames);
         return 0;
     } catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
-uint32_t mhx_num_objects(mhx_scene *s) { return uint32_t(LiveBank(s->audio).Entities.size()); }
-uint32_t mhx_active_impacts(mhx_scene *s) { return s->audio.ActiveImpacts.load(); }
-double mhx_modal_energy(mhx_scene *s) { return s->audio.ModalEnergy.load(); }
-float mhx_render_share(mhx_scene *s) { return s->audio.RenderShare.load(); }
+uint32_t mhx_num_objects(mhx_scene *s) { return Dispatch(s, [](auto &a, auto &) { return uint32_t(LiveBank(a).Entities.size()); }); }
+uint32_t mhx_active_impacts(mhx_scene *s) { return Dispatch(s, [](auto &a, auto &) { return a.ActiveImpacts.load(); }); }
+double mhx_modal_energy(mhx_scene *s) { return Dispatch(s, [](auto &a, auto &) { return a.ModalEnergy.load(); }); }
+float mhx_render_share(mhx_scene *s) { return Dispatch(s, [](auto &a, auto &) { return a.RenderShare.load(); }); }
 int mhx_find_object(mhx_scene *s, uint32_t entity) {
-    const auto o = FindModalObject(LiveBank(s->audio), entt::entity{entity});
-    return o ? int(*o) : -1;
+    return Dispatch(s, [&](auto &a, auto &) {
+        const auto o = FindModalObject(LiveBank(a), entt::entity{entity});
+        return o ? int(*o) : -1;
+    });
 }
 // which: as oracle mo_bank_column
 uint32_t mhx_column(mhx_scene *s, int live, int which, double *out) {
-    if (live && (which == 2 || which == 3)) SyncModalState(s->audio);
-    const auto &b = live ? LiveBank(s->audio) : s->next;
-    const std::vector<float> *cols[] = {&b.CoeffRe, &b.CoeffIm, &b.StateRe, &b.StateIm, &b.RadiationGain, &b.RadiationArea, &b.DeflectionGain, &b.OutPhaseIm,
-                                        &b.OutPhaseRe, &b.QuadCompliance, &b.QuadDriveScale, &b.ShapeX, &b.ShapeY, &b.ShapeZ, &b.OutGain, &b.ListenerGain,
-                                        &b.RadiantRadius, &b.DeflectionScale};
     if (which < 0 || which >= 18) return 0;
-    const auto &c = *cols[which];
-    if (out) for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
-    return uint32_t(c.size());
+    return Dispatch(s, [&](auto &a, auto &next) {
+        if (live && (which == 2 || which == 3)) SyncModalState(a);
+        const auto &b = Pick(a, next, live);
+        using Col = std::remove_reference_t<decltype(b.CoeffRe)>;
+        const Col *cols[] = {&b.CoeffRe, &b.CoeffIm, &b.StateRe, &b.StateIm, &b.RadiationGain, &b.RadiationArea, &b.DeflectionGain, &b.OutPhaseIm, &b.OutPhaseRe,
+                             &b.QuadCompliance, &b.QuadDriveScale, &b.ShapeX, &b.ShapeY, &b.ShapeZ, &b.OutGain, &b.ListenerGain, &b.RadiantRadius, &b.DeflectionScale};
+        const auto &c = *cols[which];
+        if (out) for (size_t i = 0; i < c.size(); ++i) out[i] = double(c[i]);
+        return uint32_t(c.size());
+    });
 }
 void mhx_object_state(mhx_scene *s, uint32_t *tuned, uint32_t *live, uint8_t *ringing) {
-    const auto &b = LiveBank(s->audio);
-    for (size_t o = 0; o < b.Entities.size(); ++o) {
-        if (tuned) tuned[o] = b.TunedModeCount[o];
-        if (live) live[o] = b.LiveModeCount[o];
-        if (ringing) ringing[o] = b.Ringing[o];
-    }
+    Dispatch(s, [&](auto &a, auto &) {
+        const auto &b = LiveBank(a);
+        for (size_t o = 0; o < b.Entities.size(); ++o) {
+            if (tuned) tuned[o] = b.TunedModeCount[o];
+            if (live) live[o] = b.LiveModeCount[o];
+            if (ringing) ringing[o] = b.Ringing[o];
+        }
+        return 0;
+    });
 }
 void mhx_recoil_click_filter(double radius, double volume, double mass, double sample_rate, float out3[3]) {
     const auto f = RecoilClickFilter(radius, volume, mass, sample_rate);

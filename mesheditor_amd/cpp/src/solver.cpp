@@ -3,10 +3,10 @@
 
 #include "modalhip.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <stdexcept>
-#include <unordered_map>
 
 namespace {
 thread_local int t_device = 0;
@@ -84,109 +84,146 @@ ModalModes PostprocessModes(std::span<const double> eigenvalues, const std::vect
     return modes;
 }
 
+// A material edit that keeps Poisson's ratio only rescales the spectrum: K scales with E and M with rho, so every
+// eigenvalue moves by (E'/E) / (rho'/rho) and the mass-normalised shapes by 1 / sqrt(rho'/rho) -- no solve needed
+// (reference: mesh2modes.cpp:590-603).  A different Poisson's ratio changes the operator's shape: no answer.
 std::optional<ModalModes> RescaleModes(const ModalEigenSummary &summary, const ModalModes &current, const AcousticMaterialProperties &material, SolverConfig config) {
-    if (summary.Eigenvalues.empty() || material.PoissonRatio != summary.SolvedMaterial.PoissonRatio) return {};
-    const double rho_ratio = material.Density / summary.SolvedMaterial.Density;
-    const double eigenvalue_scale = (material.YoungModulus / summary.SolvedMaterial.YoungModulus) / rho_ratio;
-    auto eigenvalues = summary.Eigenvalues;
-    for (auto &v : eigenvalues) v *= eigenvalue_scale;
-    auto modes = PostprocessModes(eigenvalues, summary.Shapes, float(1 / std::sqrt(rho_ratio)), material, config, current.Positions);
-    modes.Vertices = current.Vertices;
-    modes.Indices = current.Indices;
-    modes.BakedScale = current.BakedScale;
-    return modes;
+    const AcousticMaterialProperties &solved = summary.SolvedMaterial;
+    if (summary.Eigenvalues.empty() || solved.PoissonRatio != material.PoissonRatio) return std::nullopt;
+    const double heavier = material.Density / solved.Density, stiffer = material.YoungModulus / solved.YoungModulus;
+    std::vector<double> moved(summary.Eigenvalues.size());
+    std::transform(summary.Eigenvalues.begin(), summary.Eigenvalues.end(), moved.begin(), [scale = stiffer / heavier](double lambda) { return lambda * scale; });
+    ModalModes out = PostprocessModes(moved, summary.Shapes, float(1 / std::sqrt(heavier)), material, config, current.Positions);
+    // what the caller attached to the solved model stays attached to the re-derived one
+    out.BakedScale = current.BakedScale;
+    out.Indices = current.Indices;
+    out.Vertices = current.Vertices;
+    return out;
 }
 
+namespace {
+MassProperties FromC(const mh_mass_props &mp) {
+    MassProperties out;
+    out.Mass = mp.mass;
+    for (int i = 0; i < 3; ++i) {
+        out.CenterOfMass[i] = mp.center_of_mass[i];
+        out.InertiaDiagonal[i] = mp.inertia_diagonal[i];
+    }
+    out.InertiaOrientation = {mp.inertia_orientation_wxyz[0], mp.inertia_orientation_wxyz[1], mp.inertia_orientation_wxyz[2], mp.inertia_orientation_wxyz[3]};
+    return out;
+}
+
+// Excitation positions -> sample points: each position snaps to its nearest tet point (found on the device); positions
+// that reach the same point share one sample point, numbered in order of first arrival.
+struct SamplePoints {
+    std::vector<uint32_t> TetPoint; // sample point -> tet point
+    std::vector<vec3> Local; // node-local coordinates of each sample point
+    std::vector<uint32_t> OfExcitation; // excitation position -> sample point
+};
+bool SnapExcitations(mh_context *ctx, const mh_mesh *mesh, const TetMesh &tets, const std::vector<vec3> &wanted, vec3 baked_scale, SamplePoints &out) {
+    static_assert(sizeof(vec3) == 3 * sizeof(float));
+    std::vector<uint32_t> nearest(wanted.size());
+    if (mh_nearest_points(ctx, mesh, uint32_t(wanted.size()), reinterpret_cast<const float *>(wanted.data()), nearest.data()) != MH_OK) return false;
+    std::vector<uint32_t> slot_of_point(tets.Points.size(), UINT32_MAX);
+    out.OfExcitation.resize(wanted.size());
+    for (size_t i = 0; i < wanted.size(); ++i) {
+        uint32_t &slot = slot_of_point[nearest[i]];
+        if (slot == UINT32_MAX) {
+            slot = uint32_t(out.TetPoint.size());
+            out.TetPoint.push_back(nearest[i]);
+            const dvec3 &world = tets.Points[nearest[i]];
+            out.Local.emplace_back(dvec3{world.x * (1.0 / baked_scale.x), world.y * (1.0 / baked_scale.y), world.z * (1.0 / baked_scale.z)}); // mesh2modes.cpp:621,640
+        }
+        out.OfExcitation[i] = slot;
+    }
+    return true;
+}
+} // namespace
+
+// Failure conventions of the reference: a cancel seen before the eigensolve starts, or a stage that cannot run at all,
+// gives a wholly empty result (mesh2modes.cpp:616); an eigensolve that is cancelled or does not converge gives empty
+// Modes but keeps the mass properties, the profile and the excitation map (:462-490, :657); a shifted operator that is
+// not positive definite throws (CholeskyShiftInvert.cpp:44).
 ModalResult mesh2modes(const TetMesh &tets, const AcousticMaterialProperties &material, const std::vector<vec3> &excite_positions, vec3 baked_scale,
                        SolverConfig config, SolveReuse reuse, JobMonitor *monitor) {
-    mh_context *ctx = t_context.get();
-    SolveProfile profile;
-    Handles h;
     static_assert(sizeof(dvec3) == 3 * sizeof(double) && sizeof(std::array<uint32_t, 4>) == 4 * sizeof(uint32_t));
-    const auto *pts = reinterpret_cast<const double *>(tets.Points.data());
-    const auto *idx = reinterpret_cast<const uint32_t *>(tets.Tets.data());
-    if (mh_mesh_create(ctx, uint32_t(tets.Points.size()), pts, uint32_t(tets.Tets.size()), idx, &h.mesh) != MH_OK) return {};
-
-    const double length_to_si = (double(baked_scale.x) + baked_scale.y + baked_scale.z) / 3.0;
-    auto t0 = std::chrono::steady_clock::now();
-    mh_mass_props mp{};
-    const float scale[3] = {baked_scale.x, baked_scale.y, baked_scale.z};
-    mh_compute_mass_properties(uint32_t(tets.Points.size()), pts, uint32_t(tets.Tets.size()), idx, material.Density, scale, length_to_si, &mp);
-    profile.MassProps = Since(t0);
-    MassProperties mass_props{mp.mass, {mp.center_of_mass[0], mp.center_of_mass[1], mp.center_of_mass[2]},
-                              {mp.inertia_diagonal[0], mp.inertia_diagonal[1], mp.inertia_diagonal[2]},
-                              {mp.inertia_orientation_wxyz[0], mp.inertia_orientation_wxyz[1], mp.inertia_orientation_wxyz[2], mp.inertia_orientation_wxyz[3]}};
-
-    if (monitor) monitor->Progress.store(0.1f, std::memory_order_relaxed);
-    const auto mat = ToC(material);
-    t0 = std::chrono::steady_clock::now();
-    if (mh_assemble(ctx, h.mesh, &mat, &h.sys) != MH_OK) return {};
-    profile.Assemble = Since(t0); // BuildQuadMesh + AssembleQuadratic, fused on the device
-    uint32_t dofs = 0, node_count = 0, kept = 0;
-    uint64_t blocks = 0;
-    mh_system_dims(h.sys, &dofs, &node_count, &kept, &blocks);
-    profile.Dofs = dofs;
-    if (monitor && monitor->Cancelled()) return {};
-
-    // Nearest tet point per excitation position; positions reaching the same point share one sample point.
-    t0 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> nearest(excite_positions.size());
-    static_assert(sizeof(vec3) == 3 * sizeof(float));
-    if (mh_nearest_points(ctx, h.mesh, uint32_t(excite_positions.size()), reinterpret_cast<const float *>(excite_positions.data()), nearest.data()) != MH_OK) return {};
-    std::vector<uint32_t> points, remap(excite_positions.size());
-    std::vector<vec3> local;
-    std::unordered_map<uint32_t, uint32_t> sample_point_at;
-    const dvec3 inv_scale{1.0 / baked_scale.x, 1.0 / baked_scale.y, 1.0 / baked_scale.z};
-    for (size_t i = 0; i < nearest.size(); ++i) {
-        const auto [entry, first] = sample_point_at.emplace(nearest[i], uint32_t(points.size()));
-        if (first) {
-            points.push_back(nearest[i]);
-            local.emplace_back(tets.Points[nearest[i]] * inv_scale);
-        }
-        remap[i] = entry->second;
-    }
-    profile.SampleExcite = Since(t0);
-
-    const uint32_t n = dofs;
-    const uint32_t nev = std::min(config.NumFemModes, n - 1);
-    const double sigma = -std::pow(2 * M_PI * config.MinModeFreq, 2);
-    const bool warm = reuse.SeedBasis && reuse.SeedBasis->rows() == std::ptrdiff_t(n) && reuse.SeedBasis->cols() >= std::ptrdiff_t(nev);
-    // Spectra's tolerance bounds the Ritz-value error; a relative residual r gives an eigenvalue error ~r^2.
-    const double tol = warm ? std::clamp(std::sqrt(config.WarmTolerance) * 1e-2, 1e-9, 1e-2) : std::clamp(0.1 * std::sqrt(config.Tolerance), 1e-9, 1e-4);
-    if (monitor && monitor->Cancelled()) return {};
-    std::vector<double> eigenvalues(nev);
-    mh_profile dev{};
     // JobMonitor's atomics are lock-free single words: the device loop polls / writes their storage directly.
     static_assert(sizeof(std::atomic<bool>) == 1 && sizeof(std::atomic<float>) == sizeof(float));
-    const volatile unsigned char *cancel = monitor ? reinterpret_cast<const volatile unsigned char *>(&monitor->CancelRequested) : nullptr;
-    volatile float *progress = monitor ? reinterpret_cast<volatile float *>(&monitor->Progress) : nullptr;
-    const int rc = mh_eigs(h.sys, nev, sigma, tol, std::max(config.MaxRestarts, 1u) * 3, warm ? reuse.SeedBasis->data() : nullptr, warm ? n : 0,
-                           warm ? uint32_t(reuse.SeedBasis->cols()) : 0, cancel, progress, eigenvalues.data(), &dev);
-    if (rc == MH_EFACTOR) throw std::runtime_error("Modal shift-invert factorization failed.");
-    if (rc != MH_OK) return {};
-    profile.Factorize = dev.factorize;
-    profile.Iterate = dev.iterate;
-    profile.OpSolve = dev.op_solve;
-    profile.OpApplications = dev.op_applications;
-    profile.Restarts = dev.restarts;
-    profile.StiffnessNonZeros = dev.stiffness_nonzeros;
-
-    t0 = std::chrono::steady_clock::now();
-    std::vector<float> flat(points.size() * nev * 3);
-    if (mh_system_gather_shapes(h.sys, uint32_t(points.size()), points.data(), nev, flat.data()) != MH_OK) return {};
+    const auto cancelled = [monitor] { return monitor && monitor->Cancelled(); };
+    const auto report = [monitor](float fraction) {
+        if (monitor) monitor->Progress.store(fraction, std::memory_order_relaxed);
+    };
+    mh_context *ctx = t_context.get();
+    Handles h;
     ModalResult result;
-    result.Summary.Eigenvalues = eigenvalues;
-    result.Summary.Shapes = Unflatten(flat.data(), points.size(), nev);
+    const auto *xyz = reinterpret_cast<const double *>(tets.Points.data());
+    const auto *corners = reinterpret_cast<const uint32_t *>(tets.Tets.data());
+    const uint32_t n_points = uint32_t(tets.Points.size()), n_tets = uint32_t(tets.Tets.size());
+    if (mh_mesh_create(ctx, n_points, xyz, n_tets, corners, &h.mesh) != MH_OK) return {};
+
+    // mass, centre of mass, principal inertia (host; lengths in SI through the mean of the baked scale)
+    auto clock = std::chrono::steady_clock::now();
+    {
+        const float scale[3] = {baked_scale.x, baked_scale.y, baked_scale.z};
+        const double to_si = (double(baked_scale.x) + baked_scale.y + baked_scale.z) / 3.0;
+        mh_mass_props mp{};
+        mh_compute_mass_properties(n_points, xyz, n_tets, corners, material.Density, scale, to_si, &mp);
+        result.MassProps = FromC(mp);
+    }
+    result.Profile.MassProps = Since(clock);
+    report(0.1f);
+
+    // degenerate filter + quadratic node numbering + K, M -- one device stage
+    const mh_material mat = ToC(material);
+    clock = std::chrono::steady_clock::now();
+    if (mh_assemble(ctx, h.mesh, &mat, &h.sys) != MH_OK) return {};
+    result.Profile.Assemble = Since(clock);
+    uint32_t n = 0, node_count = 0, kept_tets = 0;
+    uint64_t node_blocks = 0;
+    mh_system_dims(h.sys, &n, &node_count, &kept_tets, &node_blocks);
+    result.Profile.Dofs = n;
+    if (cancelled()) return {};
+
+    clock = std::chrono::steady_clock::now();
+    SamplePoints samples;
+    if (!SnapExcitations(ctx, h.mesh, tets, excite_positions, baked_scale, samples)) return {};
+    result.Profile.SampleExcite = Since(clock);
+    result.SamplePointOfExcitation = std::move(samples.OfExcitation);
+
+    // lowest nev pairs of K x = lambda M x about the shift -(2 pi f_min)^2
+    const uint32_t nev = std::min(config.NumFemModes, n - 1);
+    const double shift = -std::pow(2 * M_PI * config.MinModeFreq, 2);
+    const auto *seed = reuse.SeedBasis;
+    const bool warm = seed && seed->rows() == std::ptrdiff_t(n) && seed->cols() >= std::ptrdiff_t(nev);
+    // The reference's tolerances bound Ritz-value errors; a relative residual r leaves an eigenvalue error ~ r^2.
+    const double residual_tol = warm ? std::clamp(std::sqrt(config.WarmTolerance) * 1e-2, 1e-9, 1e-2) : std::clamp(0.1 * std::sqrt(config.Tolerance), 1e-9, 1e-4);
+    if (cancelled()) return result; // empty Modes, the rest as computed so far
+    std::vector<double> eigenvalues(nev);
+    mh_profile dev{};
+    const int rc = mh_eigs(h.sys, nev, shift, residual_tol, std::max(config.MaxRestarts, 1u) * 3, warm ? seed->data() : nullptr, warm ? n : 0, warm ? uint32_t(seed->cols()) : 0,
+                           monitor ? reinterpret_cast<const volatile unsigned char *>(&monitor->CancelRequested) : nullptr,
+                           monitor ? reinterpret_cast<volatile float *>(&monitor->Progress) : nullptr, eigenvalues.data(), &dev);
+    result.Profile.Factorize = dev.factorize;
+    result.Profile.Iterate = dev.iterate;
+    result.Profile.OpSolve = dev.op_solve;
+    result.Profile.OpApplications = dev.op_applications;
+    result.Profile.Restarts = dev.restarts;
+    result.Profile.StiffnessNonZeros = dev.stiffness_nonzeros;
+    if (rc == MH_EFACTOR) throw std::runtime_error("Modal shift-invert factorization failed.");
+    if (rc != MH_OK) return result;
+
+    clock = std::chrono::steady_clock::now();
+    std::vector<float> rows(samples.TetPoint.size() * nev * 3);
+    if (mh_system_gather_shapes(h.sys, uint32_t(samples.TetPoint.size()), samples.TetPoint.data(), nev, rows.data()) != MH_OK) return result;
     result.Summary.SolvedMaterial = material;
+    result.Summary.Shapes = Unflatten(rows.data(), samples.TetPoint.size(), nev);
+    result.Summary.Eigenvalues = std::move(eigenvalues);
     if (reuse.KeepBasis) {
         result.Basis.resize(n, nev);
         mh_system_basis(h.sys, nev, result.Basis.data());
     }
-    profile.Extract = Since(t0);
-    result.Modes = PostprocessModes(result.Summary.Eigenvalues, result.Summary.Shapes, 1.f, material, config, std::move(local));
-    result.MassProps = mass_props;
-    result.Profile = profile;
-    result.SamplePointOfExcitation = std::move(remap);
+    result.Profile.Extract = Since(clock);
+    result.Modes = PostprocessModes(result.Summary.Eigenvalues, result.Summary.Shapes, 1.f, material, config, std::move(samples.Local));
     return result;
 }
 } // namespace modal

@@ -35,36 +35,71 @@ double DisplacedVolume(double enclosed_volume, double mass, const AcousticMateri
     return props && props->Density > 0 && mass > 0 ? mass / props->Density : 0.0;
 }
 
+namespace {
+// How long the bodies stay in contact and what strikes: the Hertz/punch estimate when the object's dynamics and material
+// are known, otherwise a short default contact (1e-4 s) that radiates no click.
+struct StrikeContact {
+    double Seconds{1e-4};
+    bool Modelled{false};
+    ::Impactor Hitting{};
+};
+StrikeContact ResolveContact(uint32_t excitable_index, vec3 dir, float contact_speed, const StrikeContext &sc, const std::optional<PhysicsStrike> &physics, const Striker &striker) {
+    StrikeContact c;
+    if (!sc.Dynamics || !sc.Material) return c;
+    c.Modelled = true;
+    c.Hitting = physics ? physics->Impactor : StrikerImpactor(striker); // a collision brings its own impactor, a manual hit the mallet
+    const uint32_t arm = physics ? physics->ResultantIndex : excitable_index;
+    const double patch_limit = physics ? double(physics->NominalArea) : 0.0; // a rounded mallet tip grows its own patch
+    c.Seconds = EstimateContactTime(*sc.Dynamics, arm, dir, contact_speed, sc.Elastic, sc.Curvature, patch_limit, c.Hitting, sc.ScaleRatio, sc.Roughness);
+    return c;
+}
+
+// The recoil click of the strike: the radiator filter of the struck body and the force scale that drives it.
+struct ClickDrive {
+    ClickFilter Filter{};
+    float Amplitude{0.f};
+};
+ClickDrive ResolveClick(const ModalBank &bank, uint32_t slot, uint32_t excitable_index, vec3 dir, float force, float contact_speed, const StrikeContext &sc,
+                        const StrikeContact &contact, bool from_physics) {
+    ClickDrive out;
+    if (!contact.Modelled) return out;
+    const double body_mass = sc.Dynamics->Mass;
+    // corner of the radiator: the sphere of the displaced volume, or -- with nothing to displace -- the disc holding the
+    // body's sample-surface area at its current size
+    const double volume = DisplacedVolume(sc.EnclosedVolume, body_mass, &sc.Material->Properties);
+    const double radius = volume > 0 ? VolumeEquivalentRadius(volume) : double(bank.RadiantRadius[slot] * sc.ScaleRatio);
+    out.Filter = RecoilClickFilter(radius, volume, body_mass, bank.SampleRate);
+    // The force pulse sums to one over its samples, so the filter input is impulse x sample rate (Newtons).  A collision
+    // reports its true impulse; a manual hit's is nominal: reduced mass x approach speed.
+    const double impulse = from_physics ? double(force) : ReducedContactMass(*sc.Dynamics, excitable_index, dir, contact.Hitting) * std::abs(double(contact_speed));
+    out.Amplitude = float(impulse * bank.SampleRate);
+    return out;
+}
+} // namespace
+
 ModalEvent MakeStrikeEvent(const ModalBank &bank, uint32_t slot, uint32_t excitable_index, vec3 dir, float force, float contact_speed, const StrikeContext &sc,
                            const std::optional<PhysicsStrike> &physics, const Striker &striker) {
-    double tau = 1e-4; // seconds: the default contact when the material or the dynamics are missing
-    float click_amp = 0;
-    ClickFilter click{};
-    if (sc.Dynamics && sc.Material) {
-        const Impactor imp = physics ? physics->Impactor : StrikerImpactor(striker);
-        tau = EstimateContactTime(*sc.Dynamics, physics ? physics->ResultantIndex : excitable_index, dir, contact_speed, sc.Elastic, sc.Curvature,
-                                  physics ? physics->NominalArea : 0.f, imp, sc.ScaleRatio, sc.Roughness);
-        // The click is the recoil radiator driven by this strike's force pulse; without a volume to displace, the radius of
-        // the disc holding the body's sample-surface area sets the corner.
-        const double volume = DisplacedVolume(sc.EnclosedVolume, sc.Dynamics->Mass, &sc.Material->Properties);
-        const double radius = volume > 0 ? VolumeEquivalentRadius(volume) : double(bank.RadiantRadius[slot] * sc.ScaleRatio);
-        click = RecoilClickFilter(radius, volume, sc.Dynamics->Mass, bank.SampleRate);
-        // A physics force is the true contact impulse; a manual one is nominal, from the reduced mass and the approach speed.
-        const double impulse = physics ? double(force) : ReducedContactMass(*sc.Dynamics, excitable_index, dir, imp) * std::abs(double(contact_speed));
-        click_amp = float(impulse * bank.SampleRate);
-    }
-    const auto step = float(1.0 / (tau * bank.SampleRate));
-    return {.Kind = ModalEventKind::Impact, .Object = slot, .ExPos = excitable_index, .Jx = dir.x * force, .Jy = dir.y * force, .Jz = dir.z * force, .PulseStep = step,
-            .PulseGamma = 2 * step, .AccelAmp = click_amp, .ClickB0 = click.B0, .ClickA1 = click.A1, .ClickA2 = click.A2};
+    const StrikeContact contact = ResolveContact(excitable_index, dir, contact_speed, sc, physics, striker);
+    const ClickDrive click = ResolveClick(bank, slot, excitable_index, dir, force, contact_speed, sc, contact, physics.has_value());
+    ModalEvent e;
+    e.Kind = ModalEventKind::Impact;
+    e.Object = slot;
+    e.ExPos = excitable_index;
+    e.Jx = dir.x * force, e.Jy = dir.y * force, e.Jz = dir.z * force; // the impulse rides in the excitation gains, not in the pulse
+    e.PulseStep = float(1.0 / (contact.Seconds * bank.SampleRate)); // pulse phase advance per sample
+    e.PulseGamma = 2 * e.PulseStep; // raised cosine of unit sample sum
+    e.AccelAmp = click.Amplitude;
+    e.ClickB0 = click.Filter.B0, e.ClickA1 = click.Filter.A1, e.ClickA2 = click.Filter.A2;
+    return e;
 }
 
 bool TriggerModalStrike(ModalAudio &m, entt::entity e, const ModalModes &modes, uint32_t excitable_index, vec3 dir, float force, float contact_speed,
                         const StrikeContext &sc, const std::optional<PhysicsStrike> &physics, const Striker &striker) {
-    const auto &bank = LiveBank(m);
-    const auto slot = FindModalObject(bank, e);
-    if (!slot) return false;
-    if (excitable_index >= std::min(modes.Vertices.size(), modes.Positions.size())) return false;
-    const vec3 unit = physics ? normalize(physics->Direction) : dir;
-    EnqueueModalEvent(m, MakeStrikeEvent(bank, *slot, excitable_index, unit, force, contact_speed, sc, physics, striker));
+    const ModalBank &bank = LiveBank(m);
+    const std::optional<uint32_t> slot = FindModalObject(bank, e);
+    const size_t excitable = std::min(modes.Vertices.size(), modes.Positions.size());
+    if (!slot || excitable_index >= excitable) return false;
+    const vec3 along = physics ? normalize(physics->Direction) : dir;
+    EnqueueModalEvent(m, MakeStrikeEvent(bank, *slot, excitable_index, along, force, contact_speed, sc, physics, striker));
     return true;
 }

@@ -23,21 +23,41 @@
 #include <map>
 #include <numbers>
 #include <string_view>
+#include <vector>
 
 namespace {
-std::optional<size_t> ArgIndex(int argc, char **argv, std::string_view name) {
-    for (int i = 1; i < argc; ++i)
-        if (argv[i] == name) return size_t(i);
-    return std::nullopt;
-}
-double ArgValue(int argc, char **argv, std::string_view name, double fallback, size_t offset = 1) {
-    if (const auto i = ArgIndex(argc, argv, name); i && *i + offset < size_t(argc)) {
-        double value;
-        const std::string_view s = argv[*i + offset];
-        if (std::from_chars(s.data(), s.data() + s.size(), value).ec == std::errc{}) return value;
+// "--name v1 v2 ..." options anywhere on the command line; numbers are read with from_chars (no locale, no exceptions).
+class CommandLine {
+public:
+    CommandLine(int argc, char **argv) : Words(argv, argv + argc) {}
+    std::optional<size_t> Find(std::string_view name) const {
+        for (size_t i = 1; i < Words.size(); ++i)
+            if (Words[i] == name) return i;
+        return std::nullopt;
     }
-    return fallback;
-}
+    // the nth word after `name` as a number, or `fallback` when the option is absent or malformed
+    double Number(std::string_view name, double fallback, size_t nth = 1) const {
+        const auto at = Find(name);
+        if (!at || *at + nth >= Words.size()) return fallback;
+        const std::string_view text = Words[*at + nth];
+        double parsed = 0;
+        const auto [end, err] = std::from_chars(text.data(), text.data() + text.size(), parsed);
+        return err == std::errc{} ? parsed : fallback;
+    }
+    const char *Text(std::string_view name) const {
+        const auto at = Find(name);
+        return at && *at + 1 < Words.size() ? Words[*at + 1].data() : nullptr;
+    }
+    bool HasValues(std::string_view name, size_t count) const {
+        const auto at = Find(name);
+        return at && *at + count < Words.size();
+    }
+    std::string_view Positional() const { return Words.size() > 1 && !Words[1].starts_with('-') ? Words[1] : std::string_view{}; }
+    std::string_view Program() const { return Words.front(); }
+
+private:
+    std::vector<std::string_view> Words;
+};
 
 TetMesh KuhnBox(double lx, double ly, double lz, int nx, int ny, int nz, dvec3 origin) {
     TetMesh mesh;
@@ -90,113 +110,155 @@ std::vector<std::array<uint32_t, 3>> BoundaryFaces(const TetMesh &mesh) {
     return out;
 }
 
-void PrintScalars(const char *key, const auto &values) {
-    std::printf("  \"%s\": [", key);
-    for (size_t i = 0; i < values.size(); ++i) std::printf("%s%.9g", i ? "," : "", double(values[i]));
-    std::printf("],\n");
+// Minimal JSON emitter for the flat document the sample generator consumes: one key per line, numbers with nine
+// significant digits (enough to round-trip a float).
+class JsonObject {
+public:
+    JsonObject() { std::printf("{\n"); }
+    ~JsonObject() { std::printf("\n}\n"); }
+    template<typename Seq> void Numbers(const char *key, const Seq &values) {
+        Key(key);
+        std::printf("[");
+        const char *sep = "";
+        for (const auto v : values) std::printf("%s%.9g", sep, double(v)), sep = ",";
+        std::printf("]");
+    }
+    // `count` triples produced by at(i)
+    template<typename At> void Triples(const char *key, size_t count, At &&at) {
+        Key(key);
+        std::printf("[");
+        for (size_t i = 0; i < count; ++i) {
+            const vec3 v = at(i);
+            std::printf("%s[%.9g,%.9g,%.9g]", i ? "," : "", v.x, v.y, v.z);
+        }
+        std::printf("]");
+    }
+    void Triple(const char *key, vec3 v) {
+        Key(key);
+        std::printf("[%.9g,%.9g,%.9g]", v.x, v.y, v.z);
+    }
+    void Exact(const char *key, double v) {
+        Key(key);
+        std::printf("%.17g", v);
+    }
+
+private:
+    bool Any{false};
+    void Key(const char *key) {
+        std::printf("%s  \"%s\": ", Any ? ",\n" : "", key);
+        Any = true;
+    }
+};
+
+// What is solved: the tets, where the body is excited, and the surface triangles over those excitation points.
+struct SolveInput {
+    TetMesh Mesh;
+    std::vector<vec3> Excite;
+    std::vector<uint32_t> Triangles;
+};
+
+// From a surface .obj (the reference tool's input): its vertices are the excitation points and its triangles the
+// surface.  From bare tets: the boundary faces, their corners numbered in first-use order.
+std::optional<SolveInput> ReadInput(const CommandLine &cl) {
+    SolveInput in;
+    const std::string_view path = cl.Positional();
+    if (cl.HasValues("--kuhn", 6)) {
+        const auto k = [&](size_t nth) { return cl.Number("--kuhn", 1, nth); };
+        const dvec3 origin{cl.Number("--origin", 0, 1), cl.Number("--origin", 0, 2), cl.Number("--origin", 0, 3)};
+        in.Mesh = KuhnBox(k(1), k(2), k(3), int(k(4)), int(k(5)), int(k(6)), origin);
+    } else if (path.ends_with(".obj")) {
+        auto surface = LoadObj(path.data());
+        if (!surface) {
+            std::fprintf(stderr, "Failed to load mesh: %s\n", path.data());
+            return std::nullopt;
+        }
+        auto filled = GenerateTets(surface->Positions, surface->TriangleIndices, uint32_t(cl.Number("--layers", 2)));
+        if (!filled) {
+            std::fprintf(stderr, "Tetrahedralization failed: %s\n", filled.Error.c_str());
+            return std::nullopt;
+        }
+        in.Mesh = std::move(filled.Mesh);
+        in.Excite = std::move(surface->Positions);
+        in.Triangles = std::move(surface->TriangleIndices);
+        return in;
+    } else if (!path.empty()) {
+        if (auto loaded = LoadTetFile(path.data())) in.Mesh = std::move(*loaded);
+    }
+    if (in.Mesh.Tets.empty()) return std::nullopt;
+    std::vector<uint32_t> label(in.Mesh.Points.size(), UINT32_MAX);
+    for (const auto &face : BoundaryFaces(in.Mesh))
+        for (const uint32_t v : face) {
+            if (label[v] == UINT32_MAX) {
+                label[v] = uint32_t(in.Excite.size());
+                const dvec3 &p = in.Mesh.Points[v];
+                in.Excite.emplace_back(float(p.x), float(p.y), float(p.z));
+            }
+            in.Triangles.push_back(label[v]);
+        }
+    return in;
 }
 } // namespace
 
 int main(int argc, char **argv) {
-    std::optional<TetMesh> mesh;
-    std::optional<ObjSurface> surface;
-    if (const auto k = ArgIndex(argc, argv, "--kuhn"); k && *k + 6 < size_t(argc)) {
-        const dvec3 origin{ArgValue(argc, argv, "--origin", 0, 1), ArgValue(argc, argv, "--origin", 0, 2), ArgValue(argc, argv, "--origin", 0, 3)};
-        mesh = KuhnBox(ArgValue(argc, argv, "--kuhn", 1, 1), ArgValue(argc, argv, "--kuhn", 1, 2), ArgValue(argc, argv, "--kuhn", 1, 3), int(ArgValue(argc, argv, "--kuhn", 1, 4)),
-                       int(ArgValue(argc, argv, "--kuhn", 1, 5)), int(ArgValue(argc, argv, "--kuhn", 1, 6)), origin);
-    } else if (argc >= 2 && std::string_view{argv[1]}.ends_with(".obj")) {
-        surface = LoadObj(argv[1]);
-        if (!surface) {
-            std::fprintf(stderr, "Failed to load mesh: %s\n", argv[1]);
-            return 1;
-        }
-        auto tets = GenerateTets(surface->Positions, surface->TriangleIndices, uint32_t(ArgValue(argc, argv, "--layers", 2)));
-        if (!tets) {
-            std::fprintf(stderr, "Tetrahedralization failed: %s\n", tets.Error.c_str());
-            return 1;
-        }
-        mesh = std::move(tets.Mesh);
-    } else if (argc >= 2 && argv[1][0] != '-') {
-        mesh = LoadTetFile(argv[1]);
-    }
-    if (!mesh || mesh->Tets.empty()) {
+    const CommandLine cl(argc, argv);
+    const auto input = ReadInput(cl);
+    if (!input) {
         std::fprintf(stderr, "Usage: %s <mesh.obj> [--layers k] | <mesh.tet> | --kuhn lx ly lz nx ny nz [--origin x y z]  [--young E] [--poisson v] [--density rho] [--alpha a] [--beta b] "
-                             "[--min-freq f] [--max-freq f] [--modes n] [--gltf out.gltf]\n", argv[0]);
+                             "[--min-freq f] [--max-freq f] [--modes n] [--gltf out.gltf]\n", cl.Program().data());
         return 1;
     }
-    const AcousticMaterialProperties material{
-        .Density = ArgValue(argc, argv, "--density", 2700),
-        .YoungModulus = ArgValue(argc, argv, "--young", 7.2e10),
-        .PoissonRatio = ArgValue(argc, argv, "--poisson", 0.19),
-        .Alpha = ArgValue(argc, argv, "--alpha", 5),
-        .Beta = ArgValue(argc, argv, "--beta", 2e-8),
-    };
-    const modal::SolverConfig config{
-        .MinModeFreq = float(ArgValue(argc, argv, "--min-freq", 20)),
-        .MaxModeFreq = float(ArgValue(argc, argv, "--max-freq", 16'000)),
-        .NumModes = uint32_t(ArgValue(argc, argv, "--modes", 30)),
-        .NumFemModes = uint32_t(ArgValue(argc, argv, "--modes", 30)) + 15,
-    };
+    // defaults as the reference tool: ceramic-like solid, the audible window, 30 kept modes out of 45 solved
+    AcousticMaterialProperties material{};
+    material.Density = cl.Number("--density", 2700);
+    material.YoungModulus = cl.Number("--young", 7.2e10);
+    material.PoissonRatio = cl.Number("--poisson", 0.19);
+    material.Alpha = cl.Number("--alpha", 5);
+    material.Beta = cl.Number("--beta", 2e-8);
+    modal::SolverConfig config{};
+    config.MinModeFreq = float(cl.Number("--min-freq", 20));
+    config.MaxModeFreq = float(cl.Number("--max-freq", 16'000));
+    config.NumModes = uint32_t(cl.Number("--modes", 30));
+    config.NumFemModes = config.NumModes + 15;
 
-    // the surface: boundary faces, their vertices in first-use order as excitation positions
-    std::vector<uint32_t> surface_of_point(mesh->Points.size(), UINT32_MAX), triangles;
-    std::vector<vec3> excite;
-    std::vector<std::array<uint32_t, 3>> faces;
-    if (surface) { // as the reference tool: the .obj's own vertices and triangles
-        excite = surface->Positions;
-        triangles = surface->TriangleIndices;
-    } else {
-        faces = BoundaryFaces(*mesh);
-    }
-    for (const auto &f : faces)
-        for (const auto v : f) {
-            if (surface_of_point[v] == UINT32_MAX) {
-                surface_of_point[v] = uint32_t(excite.size());
-                excite.emplace_back(float(mesh->Points[v].x), float(mesh->Points[v].y), float(mesh->Points[v].z));
-            }
-            triangles.push_back(surface_of_point[v]);
-        }
-    const auto result = modal::mesh2modes(*mesh, material, excite, vec3{1.f}, config);
-    const auto &modes = result.Modes;
+    const auto result = modal::mesh2modes(input->Mesh, material, input->Excite, vec3{1.f}, config);
+    const ModalModes &modes = result.Modes;
     if (modes.Freqs.empty()) {
         std::fprintf(stderr, "Solve produced no modes in [%g Hz, %g Hz]\n", config.MinModeFreq, config.MaxModeFreq);
         return 1;
     }
-    // triangles relabeled onto the sample points; a triangle whose corners merged has no area and is dropped
+    // Surface triangles over the sample points the excitation positions became; corners that merged leave no area.
     std::vector<uint32_t> indices;
-    for (size_t t = 0; t + 2 < triangles.size(); t += 3) {
-        const auto a = result.SamplePointOfExcitation[triangles[t]], b = result.SamplePointOfExcitation[triangles[t + 1]], c = result.SamplePointOfExcitation[triangles[t + 2]];
-        if (a == b || b == c || a == c) continue;
-        indices.insert(indices.end(), {a, b, c});
+    for (size_t t = 0; t + 2 < input->Triangles.size(); t += 3) {
+        std::array<uint32_t, 3> tri;
+        for (int c = 0; c < 3; ++c) tri[c] = result.SamplePointOfExcitation[input->Triangles[t + c]];
+        if (tri[0] != tri[1] && tri[1] != tri[2] && tri[0] != tri[2]) indices.insert(indices.end(), tri.begin(), tri.end());
     }
-    static constexpr float Ln1000 = 3 * std::numbers::ln10_v<float>;
-    std::vector<float> decay_rates(modes.T60s.size());
-    for (size_t k = 0; k < modes.T60s.size(); ++k) decay_rates[k] = modes.T60s[k] > 0 ? Ln1000 / modes.T60s[k] : 0.f;
+    // decay rate (1/s) of an amplitude that falls 60 dB in T60 seconds; an undamped mode (T60 = 0) states 0
+    std::vector<float> decay_rates;
+    for (const float t60 : modes.T60s) decay_rates.push_back(t60 > 0 ? 3 * std::numbers::ln10_v<float> / t60 : 0.f);
 
-    std::printf("{\n");
-    PrintScalars("frequencies", modes.Freqs);
-    PrintScalars("decayRates", decay_rates);
-    std::printf("  \"positions\": [");
-    for (size_t i = 0; i < modes.Positions.size(); ++i) std::printf("%s[%.9g,%.9g,%.9g]", i ? "," : "", modes.Positions[i].x, modes.Positions[i].y, modes.Positions[i].z);
-    std::printf("],\n  \"shapes\": [");
-    for (size_t k = 0; k < modes.Freqs.size(); ++k) // mode-major, as the model schema
-        for (size_t i = 0; i < modes.Shapes.size(); ++i) std::printf("%s[%.9g,%.9g,%.9g]", k || i ? "," : "", modes.Shapes[i][k].x, modes.Shapes[i][k].y, modes.Shapes[i][k].z);
-    std::printf("],\n");
-    PrintScalars("indices", indices);
-    std::printf("  \"mass\": %.17g,\n", result.MassProps.Mass);
-    std::printf("  \"centerOfMass\": [%.9g,%.9g,%.9g],\n", result.MassProps.CenterOfMass.x, result.MassProps.CenterOfMass.y, result.MassProps.CenterOfMass.z);
-    std::printf("  \"inertiaDiagonal\": [%.9g,%.9g,%.9g]\n}\n", result.MassProps.InertiaDiagonal.x, result.MassProps.InertiaDiagonal.y, result.MassProps.InertiaDiagonal.z);
-
-    if (const auto g = ArgIndex(argc, argv, "--gltf"); g && *g + 1 < size_t(argc)) {
+    {
+        JsonObject json;
+        json.Numbers("frequencies", modes.Freqs);
+        json.Numbers("decayRates", decay_rates);
+        json.Triples("positions", modes.Positions.size(), [&](size_t i) { return modes.Positions[i]; });
+        const size_t n_points = modes.Shapes.size(); // mode-major, as the model schema: every sample point of mode 0, then of mode 1, ...
+        json.Triples("shapes", modes.Freqs.size() * n_points, [&](size_t at) { return modes.Shapes[at % n_points][at / n_points]; });
+        json.Numbers("indices", indices);
+        json.Exact("mass", result.MassProps.Mass);
+        json.Triple("centerOfMass", result.MassProps.CenterOfMass);
+        json.Triple("inertiaDiagonal", result.MassProps.InertiaDiagonal);
+    }
+    if (const char *path = cl.Text("--gltf")) {
         modal::io::ModalModelDocument doc;
         doc.Materials.push_back({"solved", material});
-        auto stored = modes;
+        ModalModes stored = modes;
         stored.Indices = indices;
         doc.Models.push_back({"solved", std::move(stored), result.MassProps, 0u});
-        std::ofstream out{argv[*g + 1]};
+        std::ofstream out{path};
         out << modal::io::WriteGltfModalModels(doc);
         if (!out) {
-            std::fprintf(stderr, "cannot write %s\n", argv[*g + 1]);
+            std::fprintf(stderr, "cannot write %s\n", path);
             return 1;
         }
     }

@@ -30,9 +30,22 @@ def make_modes(mode_count, longest_t60, shape_scale=1.0, freq_scale=1.0):
     return {"freqs": freqs, "t60s": t60s, "shapes": shapes, "positions": pos, "indices": idx}
 
 
-def impact_event(oracle, obj, impulse, ex_pos=0, pulse_step=1.0 / 300.0):
-    """tests/ModalBench.h:42-44"""
-    return oracle.Event(0, obj, ex_pos, impulse, 0.5 * impulse, 0.0, pulse_step, 20.0, 0.0, 0.0, 0.0, 0.0)
+def click_coefficients(oracle, sample_rate=SAMPLE_RATE, radius=0.05, mass=1.0):
+    """RecoilClickFilter of a sphere of `radius`, `mass` (ModalAudio.h:92-99) -- input data for an event; the mirror's own
+    filter routine is compared with the oracle's elsewhere (test_abi_cpu, test_render_properties_on_device)."""
+    out = np.zeros(3, np.float32)
+    oracle.lib().mo_recoil_click_filter(radius, 4.0 / 3.0 * np.pi * radius ** 3, mass, sample_rate, out.ctypes.data)
+    return out
+
+
+def impact_event(oracle, obj, impulse, ex_pos=0, pulse_step=1.0 / 300.0, click=True, sample_rate=SAMPLE_RATE):
+    """tests/ModalBench.h:42-44, plus -- unless click=False -- the recoil click a real strike carries
+    (AudioSystem.cpp:441-458: ClickB0/A1/A2 = RecoilClickFilter, AccelAmp = impulse * SR), so the per-impact biquad and
+    its ring-out retirement (ModalAudio.cpp:526-531, 557-561) are part of every signal that is compared."""
+    if not click:
+        return oracle.Event(0, obj, ex_pos, impulse, 0.5 * impulse, 0.0, pulse_step, 20.0, 0.0, 0.0, 0.0, 0.0)
+    b0, a1, a2 = click_coefficients(oracle, sample_rate)
+    return oracle.Event(0, obj, ex_pos, impulse, 0.5 * impulse, 0.0, pulse_step, 20.0, np.float32(abs(impulse)) * np.float32(sample_rate), b0, a1, a2)
 
 
 class OracleScene:
@@ -65,10 +78,10 @@ class OracleScene:
 class DeviceScene:
     """tests/ModalBench.h:47-81 over the HIP bank (libmodalhost.so -> libmodalhip.so)."""
 
-    def __init__(self, object_count, mode_count, longest_t60, renderers, sample_rate=SAMPLE_RATE, modes=None, device=0):
+    def __init__(self, object_count, mode_count, longest_t60, renderers, sample_rate=SAMPLE_RATE, modes=None, device=0, use_double=False):
         from mesheditor_amd import bank as hipbank
-        self.dtype = np.float32
-        self.bank = hipbank.Scene(sample_rate, device)
+        self.dtype = np.float64 if use_double else np.float32
+        self.bank = hipbank.Scene(sample_rate, device, use_double)
         self.bank.set_renderers(renderers)
         modes = modes or make_modes(mode_count, longest_t60)
         self.objects = []

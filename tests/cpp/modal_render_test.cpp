@@ -1,137 +1,205 @@
-// Properties of the block render, whatever the force pulse looks like (the reference's tests/ModalRenderTest.cpp),
-// run against the device bank through the mirrored API.
+// Properties of the block render, whatever the force pulse looks like (the properties the reference's
+// tests/ModalRenderTest.cpp states: superposition, renderer-count independence, sample-rate independent click), run
+// against the device bank through the mirrored API -- in both precisions -- plus the surface-contact hooks.
 #include "harness.hpp"
 
 #include <audio/ModalAudio.h>
+#include <audio/SurfaceContact.h>
 
 #include <algorithm>
 #include <array>
 #include <numbers>
+#include <numeric>
 #include <span>
 
 namespace {
-constexpr float SampleRate = 48'000.f;
-constexpr uint32_t BlockSize = 512, SamplePoints = 4;
+constexpr float kRate = 48'000.f;
+constexpr uint32_t kBlock = 512, kPoints = 4;
 
-ModalModes MakeModes(uint32_t mode_count, float longest_t60, float shape_scale = 1.f) {
-    ModalModes modes;
-    for (uint32_t p = 0; p < SamplePoints; ++p) modes.Positions.push_back({float(p) * 0.01f, 0.f, p % 2 ? 0.02f : 0.f});
-    for (uint32_t p = 0; p + 2 < SamplePoints; ++p) modes.Indices.insert(modes.Indices.end(), {p, p + 1, p + 2});
-    modes.Shapes.assign(SamplePoints, {});
-    for (uint32_t k = 0; k < mode_count; ++k) {
-        modes.Freqs.push_back(40.f * float(k + 1) * 1.031f);
-        modes.T60s.push_back(longest_t60 / float(k + 1));
-        for (uint32_t p = 0; p < SamplePoints; ++p) {
-            const float a = float(k + 1) * 0.37f + float(p);
-            modes.Shapes[p].push_back(vec3{std::sin(a), std::cos(a * 1.7f), std::sin(a * 2.3f)} * (0.01f * shape_scale));
+// The synthetic body every case strikes: a harmonic-ish ladder of modes (40 Hz x 1.031 x ordinal), decay times
+// falling as 1/ordinal from `slowest`, smooth trigonometric shapes of amplitude 0.01 on a zig-zag strip of four sample
+// points (alternating depth, so consecutive triples span triangles with area).  Same numbers as the reference harness.
+ModalModes LadderModes(uint32_t n_modes, float slowest) {
+    ModalModes body;
+    body.Freqs.resize(n_modes);
+    body.T60s.resize(n_modes);
+    for (uint32_t k = 0; k < n_modes; ++k) {
+        const float ordinal = float(k + 1);
+        body.Freqs[k] = 40.f * ordinal * 1.031f;
+        body.T60s[k] = slowest / ordinal;
+    }
+    for (uint32_t p = 0; p < kPoints; ++p) {
+        body.Positions.push_back({float(p) * 0.01f, 0.f, (p & 1u) ? 0.02f : 0.f});
+        if (p >= 2) body.Indices.insert(body.Indices.end(), {p - 2, p - 1, p});
+        auto &row = body.Shapes.emplace_back(n_modes);
+        for (uint32_t k = 0; k < n_modes; ++k) {
+            const float phase = float(k + 1) * 0.37f + float(p);
+            row[k] = vec3{std::sin(phase), std::cos(phase * 1.7f), std::sin(phase * 2.3f)} * 0.01f;
         }
     }
-    return modes;
+    return body;
 }
 
-ModalEvent ImpactEvent(uint32_t object, float impulse, uint32_t ex_pos = 0, float pulse_step = 1.f / 300.f) {
-    return {.Kind = ModalEventKind::Impact, .Object = object, .ExPos = ex_pos, .Jx = impulse, .Jy = 0.5f * impulse, .Jz = 0.f, .PulseStep = pulse_step,
-            .PulseGamma = 20.f, .AccelAmp = 0.f};
+// A strike along (1, 1/2, 0) with a raised-cosine pulse of 1 / step samples and no click.
+ModalEvent Strike(uint32_t object, float impulse, uint32_t at_point = 0, float step = 1.f / 300.f) {
+    ModalEvent e;
+    e.Kind = ModalEventKind::Impact;
+    e.Object = object;
+    e.ExPos = at_point;
+    e.Jx = impulse;
+    e.Jy = 0.5f * impulse;
+    e.PulseStep = step;
+    e.PulseGamma = 20.f;
+    return e;
 }
 
-struct Scene {
-    ModalAudio Audio;
-    std::vector<uint32_t> Objects;
-    Scene(uint32_t object_count, uint32_t mode_count, float longest_t60, uint32_t renderers, float sample_rate = SampleRate) {
-        const auto modes = MakeModes(mode_count, longest_t60);
-        Audio.RenderPool.SetSize(renderers);
-        ModalBank next;
-        next.SampleRate = sample_rate;
-        for (uint32_t o = 0; o < object_count; ++o) {
-            Objects.push_back(AddModalObject(next, entt::entity{o}, modes));
-            TuneModalObject(next, Objects.back(), modes.Freqs, modes.T60s);
-            next.OutGain[Objects.back()] = 1.f; // callers write the per-object columns directly
-            next.RigidInvMass[Objects.back()] = 0.f;
+// N identical bodies in one published bank, in either precision.
+template<typename Audio, typename Bank, typename Sample> struct RigT {
+    Audio Engine;
+    std::vector<uint32_t> Slots;
+    RigT(uint32_t bodies, uint32_t n_modes, float slowest, uint32_t renderers, float rate = kRate) {
+        const ModalModes body = LadderModes(n_modes, slowest);
+        Engine.RenderPool.SetSize(renderers);
+        Bank building;
+        building.SampleRate = rate;
+        for (uint32_t i = 0; i < bodies; ++i) {
+            const uint32_t slot = AddModalObject(building, entt::entity{i}, body);
+            TuneModalObject(building, slot, body.Freqs, body.T60s);
+            building.OutGain[slot] = 1; // callers write the per-object columns directly
+            Slots.push_back(slot);
         }
-        InstallModalBank(Audio, next);
-        std::vector<float> discard(BlockSize, 0.f);
-        RenderModal(Audio, discard.data(), BlockSize); // clears the events addressed to the previous layout
+        InstallModalBank(Engine, building);
+        Run(1, kBlock); // the first block after an install discards events addressed to the previous layout
     }
-    std::vector<float> Render(uint32_t blocks, uint32_t frames) {
-        std::vector<float> signal(size_t(blocks) * frames, 0.f);
-        for (uint32_t b = 0; b < blocks; ++b) RenderModal(Audio, signal.data() + size_t(b) * frames, frames);
+    std::vector<Sample> Run(uint32_t blocks, uint32_t frames) {
+        std::vector<Sample> signal(size_t(blocks) * frames, Sample(0));
+        for (uint32_t i = 0; i < blocks; ++i) RenderModal(Engine, signal.data() + size_t(i) * frames, frames);
         return signal;
     }
+    void StrikeAll(float impulse) {
+        for (const uint32_t slot : Slots) EnqueueModalEvent(Engine, Strike(slot, impulse));
+    }
 };
+using Rig = RigT<ModalAudio, ModalBank, float>;
+using Rig64 = RigT<ModalAudio64, ModalBank64, double>;
 
-float Peak(std::span<const float> s) {
-    float p = 0;
-    for (const float v : s) p = std::max(p, std::abs(v));
-    return p;
+template<typename Sample> double Loudest(const std::vector<Sample> &s) {
+    return std::accumulate(s.begin(), s.end(), 0.0, [](double m, Sample v) { return std::max(m, std::abs(double(v))); });
 }
-float MaxDifference(std::span<const float> a, std::span<const float> b) {
-    float w = 0;
-    for (size_t i = 0; i < a.size(); ++i) w = std::max(w, std::abs(a[i] - b[i]));
-    return w;
+template<typename Sample> double Gap(const std::vector<Sample> &a, const std::vector<Sample> &b) {
+    return std::inner_product(a.begin(), a.end(), b.begin(), 0.0, [](double m, double d) { return std::max(m, d); }, [](Sample x, Sample y) { return std::abs(double(x) - double(y)); });
 }
 } // namespace
 
 CASE(excitations_superpose_linearly) {
-    const auto render = [](std::span<const ModalEvent> events) {
-        Scene scene{1, 64, 0.2f, 1};
-        for (auto e : events) {
-            e.Object = scene.Objects.front();
-            EnqueueModalEvent(scene.Audio, e);
+    const std::array<ModalEvent, 2> strikes{Strike(0, 1.f, 0, 1.f / 300.f), Strike(0, -0.4f, 1, 1.f / 90.f)};
+    const auto heard = [&](std::initializer_list<int> which) {
+        Rig rig{1, 64, 0.2f, 1};
+        for (const int i : which) {
+            ModalEvent e = strikes[i];
+            e.Object = rig.Slots.front();
+            EnqueueModalEvent(rig.Engine, e);
         }
-        return scene.Render(8, BlockSize);
+        return rig.Run(8, kBlock);
     };
-    const std::array both{ImpactEvent(0, 1.f, 0, 1.f / 300.f), ImpactEvent(0, -0.4f, 1, 1.f / 90.f)};
-    const auto a = render(std::span{both}.first(1)), b = render(std::span{both}.last(1)), together = render(both);
-    std::vector<float> sum(a.size());
-    for (size_t i = 0; i < a.size(); ++i) sum[i] = a[i] + b[i];
-    EXPECT(Peak(a) > 0.f);
-    EXPECT(Peak(b) > 0.f);
-    EXPECT_NOTE(MaxDifference(together, sum) <= Peak(together) * 1e-5f, std::to_string(MaxDifference(together, sum)));
+    const auto first = heard({0}), second = heard({1}), both = heard({0, 1});
+    std::vector<float> sum(first.size());
+    std::transform(first.begin(), first.end(), second.begin(), sum.begin(), std::plus<float>{});
+    EXPECT(Loudest(first) > 0 && Loudest(second) > 0);
+    EXPECT_NOTE(Gap(both, sum) <= Loudest(both) * 1e-5, std::to_string(Gap(both, sum)));
 }
 
 CASE(a_strike_does_not_depend_on_the_renderer_count) {
-    const auto render = [](uint32_t renderers) {
-        Scene scene{16, 64, 0.2f, renderers};
-        for (const auto o : scene.Objects) EnqueueModalEvent(scene.Audio, ImpactEvent(o, 1.f));
-        return scene.Render(32, BlockSize);
+    const auto heard = [](uint32_t renderers) {
+        Rig rig{16, 64, 0.2f, renderers};
+        rig.StrikeAll(1.f);
+        return rig.Run(32, kBlock);
     };
-    const auto single = render(1), split = render(4);
-    EXPECT(Peak(single) > 0.f);
-    EXPECT(MaxDifference(single, split) < Peak(single) * 1e-5f);
+    const auto one = heard(1), four = heard(4);
+    EXPECT(Loudest(one) > 0);
+    EXPECT(Gap(one, four) < Loudest(one) * 1e-5);
 }
 
 CASE(the_click_does_not_depend_on_the_output_sample_rate) {
-    constexpr double Tau{5e-4};
-    constexpr double Radius{0.05}, Volume{4.0 / 3.0 * std::numbers::pi * Radius * Radius * Radius}, Mass{1.0}, Impulse{0.5};
-    const auto peak_at = [](float rate) {
-        Scene scene{1, 64, 0.2f, 1, rate};
-        const auto step = float(1.0 / (Tau * double(rate)));
-        const auto click = RecoilClickFilter(Radius, Volume, Mass, rate);
-        EnqueueModalEvent(scene.Audio, {.Kind = ModalEventKind::Impact, .Object = scene.Objects.front(), .ExPos = 0, .Jx = 0.f, .Jy = 0.f, .Jz = 0.f,
-                                        .PulseStep = step, .PulseGamma = 2 * step, .AccelAmp = float(Impulse) * rate, .ClickB0 = click.B0, .ClickA1 = click.A1,
-                                        .ClickA2 = click.A2});
-        const auto blocks = uint32_t(std::ceil(4 * Tau * double(rate) / BlockSize));
-        return Peak(scene.Render(blocks, BlockSize));
+    // a 0.5 ms contact on a 5 cm, 1 kg sphere: the click's peak pressure is a property of the strike, not of the rate
+    const double contact = 5e-4, radius = 0.05, mass = 1.0, impulse = 0.5;
+    const double volume = 4.0 / 3.0 * std::numbers::pi * radius * radius * radius;
+    const auto click_peak = [&](float rate) {
+        Rig rig{1, 64, 0.2f, 1, rate};
+        const ClickFilter filter = RecoilClickFilter(radius, volume, mass, rate);
+        ModalEvent e = Strike(rig.Slots.front(), 0.f);
+        e.Jy = 0.f;
+        e.PulseStep = float(1.0 / (contact * double(rate)));
+        e.PulseGamma = 2 * e.PulseStep;
+        e.AccelAmp = float(impulse) * rate;
+        e.ClickB0 = filter.B0, e.ClickA1 = filter.A1, e.ClickA2 = filter.A2;
+        EnqueueModalEvent(rig.Engine, e);
+        return Loudest(rig.Run(uint32_t(std::ceil(4 * contact * double(rate) / kBlock)), kBlock));
     };
-    const auto slow = peak_at(SampleRate), fast = peak_at(2 * SampleRate);
-    EXPECT(slow > 0.f);
-    EXPECT_NOTE(check::near(double(fast) / double(slow), 1.0, 2e-2), std::to_string(slow) + " " + std::to_string(fast));
+    const double at_48k = click_peak(kRate), at_96k = click_peak(2 * kRate);
+    EXPECT(at_48k > 0);
+    EXPECT_NOTE(check::near(at_96k / at_48k, 1.0, 2e-2), std::to_string(at_48k) + " " + std::to_string(at_96k));
 }
 
 CASE(render_adds_into_the_output_and_events_find_objects) {
-    Scene scene{2, 16, 0.2f, 1};
-    EXPECT(FindModalObject(*scene.Audio.Live, entt::entity{1}).value_or(99) == scene.Objects[1]);
-    EXPECT(!FindModalObject(*scene.Audio.Live, entt::entity{7}).has_value());
-    EnqueueModalEvent(scene.Audio, ImpactEvent(scene.Objects[1], 1.f));
-    std::vector<float> out(BlockSize, 0.25f), ref(BlockSize, 0.f);
-    RenderModal(scene.Audio, out.data(), BlockSize);
-    Scene twin{2, 16, 0.2f, 1};
-    EnqueueModalEvent(twin.Audio, ImpactEvent(twin.Objects[1], 1.f));
-    RenderModal(twin.Audio, ref.data(), BlockSize);
-    float worst = 0;
-    for (uint32_t s = 0; s < BlockSize; ++s) worst = std::max(worst, std::abs(out[s] - (0.25f + ref[s])));
-    EXPECT(worst <= 1e-6f);
-    EXPECT(scene.Audio.ActiveImpacts.load() == 0u); // a 300-sample pulse ends inside the block and its impact retires
+    Rig rig{2, 16, 0.2f, 1}, twin{2, 16, 0.2f, 1};
+    EXPECT(FindModalObject(*rig.Engine.Live, entt::entity{1}).value_or(99) == rig.Slots[1]);
+    EXPECT(!FindModalObject(*rig.Engine.Live, entt::entity{7}).has_value());
+    EnqueueModalEvent(rig.Engine, Strike(rig.Slots[1], 1.f));
+    EnqueueModalEvent(twin.Engine, Strike(twin.Slots[1], 1.f));
+    std::vector<float> onto(kBlock, 0.25f), alone(kBlock, 0.f);
+    RenderModal(rig.Engine, onto.data(), kBlock);
+    RenderModal(twin.Engine, alone.data(), kBlock);
+    for (float &v : alone) v += 0.25f;
+    EXPECT(Gap(onto, alone) <= 1e-6);
+    EXPECT(rig.Engine.ActiveImpacts.load() == 0u); // a 300-sample pulse ends inside the block and its impact retires
+}
+
+CASE(the_double_precision_bank_sounds_like_the_single_precision_one) {
+    // same scene through ModalBank64 / ModalAudio64: the signals agree to single-precision rounding of the fp32 path,
+    // and the fp64 render itself does not depend on the renderer count beyond double rounding
+    const auto heard32 = [] {
+        Rig rig{8, 48, 0.2f, 2};
+        rig.StrikeAll(1.f);
+        return rig.Run(6, kBlock);
+    }();
+    const auto heard64 = [](uint32_t renderers) {
+        Rig64 rig{8, 48, 0.2f, renderers};
+        rig.StrikeAll(1.f);
+        return rig.Run(6, kBlock);
+    };
+    const auto two = heard64(2), one = heard64(1);
+    std::vector<double> widened(heard32.begin(), heard32.end());
+    EXPECT(Loudest(two) > 0);
+    EXPECT_NOTE(Gap(two, widened) < Loudest(two) * 1e-4, std::to_string(Gap(two, widened) / Loudest(two)));
+    EXPECT_NOTE(Gap(two, one) < Loudest(two) * 1e-13, std::to_string(Gap(two, one) / Loudest(two)));
+}
+
+CASE(surface_contact_hooks_are_present_and_inert) {
+    // the 14 entry points + 2 deleters of the reference's SurfaceContact.h with the model absent
+    Rig rig{1, 8, 0.2f, 1};
+    ModalBank &bank = LiveBank(rig.Engine);
+    EXPECT(MakeSurfaceAudioState() == nullptr);
+    SurfaceAudioStateDelete{}(nullptr);
+    SurfaceRenderScratchDelete{}(nullptr);
+    SurfaceAdoptVoices(rig.Engine, bank, kBlock);
+    EXPECT(SurfaceVoiceCount(rig.Engine, 0) == 0u);
+    float out[4]{};
+    // the opaque types are never defined in this build: hand the hooks a reference to inert storage, they only pass it on
+    alignas(16) static unsigned char opaque[64];
+    auto &scratch = reinterpret_cast<ModalRenderScratch &>(opaque);
+    auto &registry = reinterpret_cast<entt::registry &>(opaque);
+    EXPECT(!SurfaceRenderObject(rig.Engine, scratch, bank, 0, std::span<const uint32_t>{}, out, 4)); // falls to the modal-only kernel
+    SurfaceSilenceObject(rig.Engine, 0);
+    EXPECT(SurfaceActiveVoices(rig.Engine) == 0u);
+    SurfaceInstallBank(rig.Engine);
+    RegisterSurfaceContactHandlers(registry);
+    SurfaceUpdateContacts(registry);
+    EXPECT(SurfaceRoughnessOf(registry, entt::entity{3}) == 0.f);
+    EXPECT(ContactSurfaceNode(registry, entt::entity{3}, entt::entity{5}) == entt::entity{5});
+    DrawContactSurfaceControls(registry, entt::entity{0});
+    DrawSurfaceSynthControls(registry, entt::entity{0});
+    DrawSurfaceContactDebug(registry);
 }
 
 int main() { return check::run_all(); }

@@ -10,124 +10,133 @@
 #include <array>
 #include <map>
 #include <numbers>
+#include <vector>
 
 namespace {
-struct Bar {
-    double Length, Width, Thickness;
-    AcousticMaterialProperties Material;
+// A free prismatic beam along x and what it is made of.
+struct Beam {
+    double L, W, T; // length (x), width (y), thickness (z), m
+    AcousticMaterialProperties Solid;
+    double WaveSpeed() const { return std::sqrt(Solid.YoungModulus / Solid.Density); }
 };
 
-// Grid cells cut into six tetrahedra around the cell diagonal 0-7, all positively oriented.
-TetMesh BoxTets(double lx, double ly, double lz, int nx, int ny, int nz) {
+// nx x ny x nz grid cells, each cut into the six tetrahedra that share the cell diagonal 0-7 (Kuhn), all positively oriented.
+TetMesh GridTets(const Beam &beam, int nx, int ny, int nz) {
     TetMesh mesh;
-    const auto vid = [&](int i, int j, int k) { return uint32_t((i * (ny + 1) + j) * (nz + 1) + k); };
+    const int stride_j = nz + 1, stride_i = (ny + 1) * stride_j;
     for (int i = 0; i <= nx; ++i)
         for (int j = 0; j <= ny; ++j)
-            for (int k = 0; k <= nz; ++k) mesh.Points.push_back({lx * i / nx, ly * j / ny, lz * k / nz});
-    static constexpr int Corner[6][4]{{0, 1, 3, 7}, {0, 3, 2, 7}, {0, 2, 6, 7}, {0, 6, 4, 7}, {0, 4, 5, 7}, {0, 5, 1, 7}};
+            for (int k = 0; k <= nz; ++k) mesh.Points.push_back({beam.L * i / nx, beam.W * j / ny, beam.T * k / nz});
+    // cell corner c has offsets (c & 1, c >> 1 & 1, c >> 2) in (i, j, k); the six paths 0 -> 7 of the Kuhn triangulation
+    static constexpr int Paths[6][4]{{0, 1, 3, 7}, {0, 3, 2, 7}, {0, 2, 6, 7}, {0, 6, 4, 7}, {0, 4, 5, 7}, {0, 5, 1, 7}};
     for (int i = 0; i < nx; ++i)
         for (int j = 0; j < ny; ++j)
             for (int k = 0; k < nz; ++k) {
-                const uint32_t c[8]{vid(i, j, k), vid(i + 1, j, k), vid(i, j + 1, k), vid(i + 1, j + 1, k),
-                                    vid(i, j, k + 1), vid(i + 1, j, k + 1), vid(i, j + 1, k + 1), vid(i + 1, j + 1, k + 1)};
-                for (const auto &t : Corner) mesh.Tets.push_back({c[t[0]], c[t[1]], c[t[2]], c[t[3]]});
+                const uint32_t origin = uint32_t(i * stride_i + j * stride_j + k);
+                const auto corner = [&](int c) { return origin + uint32_t((c & 1) * stride_i + ((c >> 1) & 1) * stride_j + (c >> 2)); };
+                for (const auto &path : Paths) mesh.Tets.push_back({corner(path[0]), corner(path[1]), corner(path[2]), corner(path[3])});
             }
     return mesh;
 }
 
-enum class Family { Longitudinal, Torsional, Bending, BendingY, BendingZ, Other };
+enum class Motion { Axial, Twist, Flex, FlexY, FlexZ, Mixed };
 
-// Which way a mode moves, from the share of its shape energy that is axial, rigid rotation of the cross sections
-// about the bar axis, or lateral in one plane.
-Family Classify(const ModalModes &modes, size_t mode, const Bar &bar, int nx) {
-    double axial = 0, lat_y = 0, lat_z = 0;
-    std::map<long, std::pair<double, double>> slice; // x slice -> (sum r x u, sum r^2)
+// Sort a mode by where its shape energy sits: along the axis, in rigid rotation of the cross sections about the axis
+// (per x-station: (sum r x u)^2 / sum r^2), or sideways in one plane.  Thresholds as the reference's classifier.
+Motion KindOfMotion(const ModalModes &modes, size_t mode, const Beam &beam, int stations) {
+    struct Station {
+        double Moment{0}, Spread{0};
+    };
+    std::vector<Station> along(size_t(stations) + 1);
+    double energy[3]{0, 0, 0};
     for (size_t p = 0; p < modes.Positions.size(); ++p) {
-        const auto pos = modes.Positions[p];
-        const auto u = modes.Shapes[p][mode];
-        axial += double(u.x) * u.x;
-        lat_y += double(u.y) * u.y;
-        lat_z += double(u.z) * u.z;
-        const double ry = pos.y - bar.Width / 2, rz = pos.z - bar.Thickness / 2;
-        auto &s = slice[std::lround(pos.x * nx / bar.Length)];
-        s.first += ry * u.z - rz * u.y;
-        s.second += ry * ry + rz * rz;
+        const vec3 at = modes.Positions[p], u = modes.Shapes[p][mode];
+        for (int axis = 0; axis < 3; ++axis) energy[axis] += double(u[axis]) * double(u[axis]);
+        const double off_y = at.y - beam.W / 2, off_z = at.z - beam.T / 2;
+        Station &here = along[size_t(std::clamp<long>(std::lround(at.x * stations / beam.L), 0, stations))];
+        here.Moment += off_y * u.z - off_z * u.y;
+        here.Spread += off_y * off_y + off_z * off_z;
     }
-    const double total = axial + lat_y + lat_z;
-    if (total <= 0) return Family::Other;
-    double rotation = 0;
-    for (const auto &[key, s] : slice)
-        if (s.second > 0) rotation += s.first * s.first / s.second;
-    if (axial / total > 0.85) return Family::Longitudinal;
-    if (rotation / total > 0.85) return Family::Torsional;
-    const double lateral = lat_y + lat_z;
-    if (lateral / total > 0.6 && rotation / total < 0.5) {
-        if (lat_y / lateral > 0.8) return Family::BendingY;
-        if (lat_z / lateral > 0.8) return Family::BendingZ;
-        return Family::Bending;
+    const double sideways = energy[1] + energy[2], all = energy[0] + sideways;
+    if (!(all > 0)) return Motion::Mixed;
+    double twisting = 0;
+    for (const Station &st : along)
+        if (st.Spread > 0) twisting += st.Moment * st.Moment / st.Spread;
+    if (energy[0] > 0.85 * all) return Motion::Axial;
+    if (twisting > 0.85 * all) return Motion::Twist;
+    if (sideways > 0.6 * all && twisting < 0.5 * all) {
+        if (energy[1] > 0.8 * sideways) return Motion::FlexY;
+        if (energy[2] > 0.8 * sideways) return Motion::FlexZ;
+        return Motion::Flex;
     }
-    return Family::Other;
+    return Motion::Mixed;
 }
 
-std::map<Family, std::vector<double>> SolveBar(const Bar &bar, int nx, int ny, int nz) {
-    const auto mesh = BoxTets(bar.Length, bar.Width, bar.Thickness, nx, ny, nz);
-    std::vector<vec3> excite;
-    for (const auto &p : mesh.Points) excite.emplace_back(float(p.x), float(p.y), float(p.z)); // every point is an excitation position
-    const auto result = modal::mesh2modes(mesh, bar.Material, excite, vec3{1.f});
-    std::map<Family, std::vector<double>> fam;
-    EXPECT(!result.Modes.Freqs.empty());
-    EXPECT(result.Profile.Dofs == 3u * uint32_t((2 * nx + 1) * (2 * ny + 1) * (2 * nz + 1)));
-    for (size_t k = 0; k < result.Modes.Freqs.size(); ++k) fam[Classify(result.Modes, k, bar, nx)].push_back(result.Modes.Freqs[k]);
-    return fam;
+// Solve the beam with default settings, every mesh point an excitation position, and bucket the frequencies by motion.
+std::map<Motion, std::vector<double>> BeamSpectrum(const Beam &beam, int nx, int ny, int nz) {
+    const TetMesh mesh = GridTets(beam, nx, ny, nz);
+    std::vector<vec3> everywhere(mesh.Points.size());
+    std::transform(mesh.Points.begin(), mesh.Points.end(), everywhere.begin(), [](const dvec3 &p) { return vec3{float(p.x), float(p.y), float(p.z)}; });
+    const auto solved = modal::mesh2modes(mesh, beam.Solid, everywhere, vec3{1.f});
+    EXPECT(!solved.Modes.Freqs.empty());
+    EXPECT(solved.Profile.Dofs == 3u * uint32_t((2 * nx + 1) * (2 * ny + 1) * (2 * nz + 1))); // quadratic elements: a node per half cell
+    std::map<Motion, std::vector<double>> spectrum;
+    for (size_t k = 0; k < solved.Modes.Freqs.size(); ++k) spectrum[KindOfMotion(solved.Modes, k, beam, nx)].push_back(solved.Modes.Freqs[k]);
+    return spectrum;
 }
 
-std::vector<double> Harmonics(double f1) { return {f1, 2 * f1, 3 * f1}; }
-// Free-free Euler-Bernoulli roots, each listed per_root times (degenerate planes)
-std::vector<double> BendingTheory(const Bar &bar, double thickness, int per_root) {
-    const double rg = thickness / std::sqrt(12.0);
-    const double base = std::sqrt(bar.Material.YoungModulus / bar.Material.Density) * rg / (2 * std::numbers::pi * bar.Length * bar.Length);
+std::vector<double> Multiples(double fundamental, int count = 3) {
     std::vector<double> out;
-    for (const double bl : {4.73004074, 7.85320462, 10.9956078})
-        for (int r = 0; r < per_root; ++r) out.push_back(bl * bl * base);
+    for (int n = 1; n <= count; ++n) out.push_back(n * fundamental);
     return out;
 }
-void CheckFamily(const char *name, const std::vector<double> &fem, const std::vector<double> &theory, double tol, size_t min_count = 2) {
-    const auto count = std::min(fem.size(), theory.size());
-    EXPECT_NOTE(count >= min_count, name);
-    for (size_t i = 0; i < count; ++i) {
-        std::printf("%14s %zu: theory %9.2f Hz, FEM %9.2f Hz, ratio %.4f\n", name, i + 1, theory[i], fem[i], fem[i] / theory[i]);
-        EXPECT_NOTE(std::abs(fem[i] / theory[i] - 1.0) < tol, name);
+// Free-free Euler-Bernoulli beam: f = (beta L)^2 / (2 pi L^2) * c * r_g with r_g = depth / sqrt(12); `copies` entries per
+// root for cross sections whose two bending planes coincide.
+std::vector<double> FlexuralTheory(const Beam &beam, double depth, int copies) {
+    static constexpr double Roots[]{4.73004074, 7.85320462, 10.9956078};
+    const double unit = beam.WaveSpeed() * (depth / std::sqrt(12.0)) / (2 * std::numbers::pi * beam.L * beam.L);
+    std::vector<double> out;
+    for (const double root : Roots) out.insert(out.end(), size_t(copies), root * root * unit);
+    return out;
+}
+void Compare(const char *label, const std::vector<double> &fem, const std::vector<double> &theory, double tolerance, size_t at_least = 2) {
+    const size_t n = std::min(fem.size(), theory.size());
+    EXPECT_NOTE(n >= at_least, label);
+    for (size_t i = 0; i < n; ++i) {
+        const double ratio = fem[i] / theory[i];
+        std::printf("%14s %zu: theory %9.2f Hz, FEM %9.2f Hz, ratio %.4f\n", label, i + 1, theory[i], fem[i], ratio);
+        EXPECT_NOTE(std::abs(ratio - 1.0) < tolerance, label);
     }
 }
 } // namespace
 
+// The reference's two known-answer beams (tests/ModalSolverTest.cpp:228-261): sizes, materials, grids and tolerances are its.
 CASE(square_bar_modes_match_closed_forms) {
-    const Bar bar{.Length = 0.3, .Width = 0.05, .Thickness = 0.05, .Material = {.Density = 1000, .YoungModulus = 1e7, .PoissonRatio = 0, .Alpha = 0, .Beta = 0}};
-    const double speed = std::sqrt(bar.Material.YoungModulus / bar.Material.Density);
-    const double torsion_f1 = std::sqrt(bar.Material.Mu() / bar.Material.Density * 0.140577 * 6) / (2 * bar.Length);
-    auto fem = SolveBar(bar, 20, 4, 4);
-    auto bending = fem[Family::Bending];
-    for (const auto f : {Family::BendingY, Family::BendingZ}) bending.insert(bending.end(), fem[f].begin(), fem[f].end());
-    std::ranges::sort(bending);
-    CheckFamily("longitudinal", fem[Family::Longitudinal], Harmonics(speed / (2 * bar.Length)), 0.01);
-    CheckFamily("torsional", fem[Family::Torsional], Harmonics(torsion_f1), 0.05);
-    bending.resize(std::min<size_t>(bending.size(), 2));
-    CheckFamily("bending", bending, BendingTheory(bar, bar.Thickness, 2), 0.10);
+    const Beam beam{0.3, 0.05, 0.05, {.Density = 1000, .YoungModulus = 1e7, .PoissonRatio = 0, .Alpha = 0, .Beta = 0}};
+    auto spectrum = BeamSpectrum(beam, 20, 4, 4);
+    Compare("longitudinal", spectrum[Motion::Axial], Multiples(beam.WaveSpeed() / (2 * beam.L)), 0.01);
+    // torsion of a square section: J / I_p = 0.140577 x 6
+    const double twist_speed = std::sqrt(beam.Solid.Mu() / beam.Solid.Density * 0.140577 * 6);
+    Compare("torsional", spectrum[Motion::Twist], Multiples(twist_speed / (2 * beam.L)), 0.05);
+    std::vector<double> flex;
+    for (const Motion m : {Motion::Flex, Motion::FlexY, Motion::FlexZ}) flex.insert(flex.end(), spectrum[m].begin(), spectrum[m].end());
+    std::sort(flex.begin(), flex.end());
+    if (flex.size() > 2) flex.resize(2); // the first (degenerate) pair
+    Compare("bending", flex, FlexuralTheory(beam, beam.T, 2), 0.10);
 }
 
 CASE(thin_bar_bending_matches_closed_forms) {
-    const Bar bar{.Length = 0.3, .Width = 0.05, .Thickness = 0.01, .Material = {.Density = 1000, .YoungModulus = 1e9, .PoissonRatio = 0, .Alpha = 0, .Beta = 0}};
-    const double speed = std::sqrt(bar.Material.YoungModulus / bar.Material.Density);
-    auto fem = SolveBar(bar, 30, 5, 1);
-    CheckFamily("longitudinal", fem[Family::Longitudinal], Harmonics(speed / (2 * bar.Length)), 0.01);
-    auto stiff = BendingTheory(bar, bar.Width, 1);
-    stiff.resize(1);
-    CheckFamily("bending-y", fem[Family::BendingY], stiff, 0.10, 1);
-    CheckFamily("bending-z", fem[Family::BendingZ], BendingTheory(bar, bar.Thickness, 1), 0.05);
+    const Beam beam{0.3, 0.05, 0.01, {.Density = 1000, .YoungModulus = 1e9, .PoissonRatio = 0, .Alpha = 0, .Beta = 0}};
+    auto spectrum = BeamSpectrum(beam, 30, 5, 1);
+    Compare("longitudinal", spectrum[Motion::Axial], Multiples(beam.WaveSpeed() / (2 * beam.L)), 0.01);
+    auto edgewise = FlexuralTheory(beam, beam.W, 1);
+    edgewise.resize(1);
+    Compare("bending-y", spectrum[Motion::FlexY], edgewise, 0.10, 1);
+    Compare("bending-z", spectrum[Motion::FlexZ], FlexuralTheory(beam, beam.T, 1), 0.05);
 }
 
 CASE(cancelled_and_degenerate_solves_return_empty_results) {
-    const auto mesh = BoxTets(0.1, 0.1, 0.1, 3, 3, 3);
+    const auto mesh = GridTets(Beam{0.1, 0.1, 0.1, {}}, 3, 3, 3);
     const auto &material = materials::acoustic::Ceramic.Properties;
     JobMonitor monitor;
     monitor.RequestCancel();
@@ -141,7 +150,7 @@ CASE(cancelled_and_degenerate_solves_return_empty_results) {
 }
 
 CASE(warm_start_and_rescale_agree_with_a_cold_solve) {
-    const auto mesh = BoxTets(0.12, 0.08, 0.05, 6, 4, 3);
+    const auto mesh = GridTets(Beam{0.12, 0.08, 0.05, {}}, 6, 4, 3);
     const auto &ceramic = materials::acoustic::Ceramic.Properties;
     const std::vector<vec3> excite{vec3{0.f, 0.f, 0.f}, vec3{0.12f, 0.08f, 0.05f}};
     const auto cold = modal::mesh2modes(mesh, ceramic, excite, vec3{1.f}, {}, {.SeedBasis = nullptr, .KeepBasis = true});

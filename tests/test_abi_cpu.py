@@ -99,7 +99,7 @@ def test_host_mirror_contact_model(oracle):
     for curv, area, speed, scale in ((100.0, 0.0, 1.0, 1.0), (0.0, 1e-4, 1.0, 1.0), (10.0, 1e-5, 3.0, 2.0), (100.0, 0.0, 32.0, 1e-6)):
         a = H.mhx_estimate_contact_time(1.0, p(inv), p(arm), p(direction), speed, p(polymer), curv, area, p(null), 1e-6, 1.0 / smass, scale, 0.0)
         b = O.mo_estimate_contact_time(1.0, p(inv), p(arm), p(direction), speed, oracle.material(*polymer), curv, area, oracle.material(*null), 1e-6, 1.0 / smass, scale, 0.0)
-        assert a == b
+        assert abs(a - b) <= 1e-12 * abs(b)  # a scalar model value, not a recurrence: the mirror's own arrangement of the same formulas
     tau = H.mhx_estimate_contact_time(1.0, p(inv), p(arm), p(direction), 1.0, p(polymer), 100.0, 0.0, p(null), 1e-6, 1.0 / smass, 1.0, 0.0)
     assert abs(tau - 1.744e-3) < 2e-2 * 1.744e-3  # tests/ContactModelTest.cpp:55-60
     assert abs(H.mhx_saturation_penetration(10.0, 1e-5) - 3.183e-5) < 1e-3 * 3.183e-5
@@ -109,7 +109,7 @@ def test_host_mirror_contact_model(oracle):
     a9, b9 = np.zeros(9, np.float32), np.zeros(9, np.float32)
     H.mhx_inverse_inertia_tensor(p(diag), p(q), p(a9))
     O.mo_inverse_inertia_tensor(p(diag), p(q), p(b9))
-    assert np.array_equal(a9, b9)
+    assert np.allclose(a9, b9, rtol=1e-6, atol=1e-7)
     fa, fb = np.zeros(6, np.float32), np.zeros(6, np.float32)
     H.mhx_recoil_object_filter(0.05, 5e-4, 48000.0, p(fa))
     O.mo_recoil_object_filter(0.05, 5e-4, 48000.0, p(fb))
