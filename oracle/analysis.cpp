@@ -12,6 +12,7 @@
 //     retained Ritz vectors follow Spectra/ARPACK: |beta * s_last,i| < tol * max(eps^(2/3), |theta_i|).
 //   Eigen setFromTriplets: duplicate (row, col) triplets are summed.
 //   glm::quat_cast / normalize: standard matrix-to-quaternion with the largest component first.
+#include <omp.h>
 #include "modal_oracle.h"
 
 #include "dense.h"
@@ -998,6 +999,9 @@ uint32_t PackModes(const ModalModes &m, float *freqs, float *t60s, float *shapes
 } // namespace
 
 extern "C" {
+// Size of the OpenMP team the dense front kernels and front solves run on (1 = one job thread, as the reference).
+void mo_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+int mo_max_threads() { return omp_get_max_threads(); }
 void mo_default_config(mo_solver_config *c) {
     *c = mo_solver_config{20.f, 16000.f, 30, 45, 1e-8, 1e-4, 100, 0, 0.f};
 }

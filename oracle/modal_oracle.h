@@ -37,6 +37,9 @@ typedef struct {
 } mo_profile; /* modal::SolveProfile, mesh2modes.h:29-34 */
 
 void mo_default_config(mo_solver_config *cfg);
+/* OpenMP team size for the sparse factorisation and solves (the arithmetic does not depend on it). */
+void mo_set_threads(int n);
+int mo_max_threads(void);
 
 /* ---- whole path: modal::mesh2modes (mesh2modes.cpp:605-658) ---- */
 typedef struct mo_result mo_result;

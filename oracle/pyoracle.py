@@ -90,6 +90,8 @@ def lib():
         L.mo_rescale_modes.restype = u32
         L.mo_mass_properties.argtypes = [u32, vp, u32, vp, C.c_double, vp, C.c_double, vp, vp, vp, vp]
         L.mo_default_config.argtypes = [C.POINTER(SolverConfig)]
+        L.mo_set_threads.argtypes = [C.c_int]
+        L.mo_max_threads.restype = C.c_int
         # synthesis
         L.mo_bank_create.restype = vp
         L.mo_bank_create.argtypes = [C.c_float, C.c_int]
@@ -129,6 +131,11 @@ def lib():
         L.mo_estimate_contact_time.restype = C.c_double
         _LIB = L
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP team of the sparse factorisation / solves (1 = the reference's single job thread)."""
+    lib().mo_set_threads(int(n))
 
 
 def _p(a):

@@ -16,8 +16,12 @@ constexpr int PanelWidth = 48;
 // kb-wide panel starting at column k0 of the same column-major array.  Register-blocked: 4 columns x 8 rows.
 void trailing_update(double *__restrict F, int ld, int f, int k0, int kb, int c0) {
     constexpr int JB = 4, IB = 8;
-    int j = c0;
-    for (; j + JB <= f; j += JB) {
+    const int nblocks = (f - c0) / JB;
+    // column blocks are independent (each writes its own four columns): deal them to the OpenMP team; the arithmetic
+    // per entry is the same with any thread count
+#pragma omp parallel for schedule(dynamic, 2) if (nblocks >= 64)
+    for (int jb = 0; jb < nblocks; ++jb) {
+        const int j = c0 + jb * JB;
         int i = j;
         for (; i + IB <= f; i += IB) {
             double a0[IB] = {}, a1[IB] = {}, a2[IB] = {}, a3[IB] = {};
@@ -49,7 +53,7 @@ void trailing_update(double *__restrict F, int ld, int f, int k0, int kb, int c0
             }
         }
     }
-    for (; j < f; ++j) {
+    for (int j = c0 + nblocks * JB; j < f; ++j) {
         for (int i = j; i < f; ++i) {
             double s = 0;
             for (int k = 0; k < kb; ++k) s += F[size_t(k0 + k) * ld + i] * F[size_t(k0 + k) * ld + j];
@@ -317,60 +321,119 @@ bool MultifrontalCholesky::factorize(const CscLower &a) {
             }
         }
     }
+    // ---- Solve schedule: fronts of equal height above the leaves are independent of one another ----
+    {
+        std::vector<int> height(fronts.size(), 1), where(n, -1);
+        int top = 0;
+        update_total = 0;
+        for (int t = 0; t < int(fronts.size()); ++t) {
+            auto &fr = fronts[t];
+            for (const int c : fr.children) height[t] = std::max(height[t], height[c] + 1);
+            top = std::max(top, height[t]);
+            fr.uoff = update_total;
+            update_total += fr.urows.size();
+            // local index of every row this front holds, for its children's extend-add
+            for (int k = 0; k < fr.nj; ++k) where[fr.j0 + k] = k;
+            for (int k = 0; k < int(fr.urows.size()); ++k) where[fr.urows[k]] = fr.nj + k;
+            for (const int c : fr.children) {
+                auto &ch = fronts[c];
+                ch.to_parent.resize(ch.urows.size());
+                for (size_t i = 0; i < ch.urows.size(); ++i) ch.to_parent[i] = where[ch.urows[i]];
+            }
+        }
+        levels.assign(size_t(top), {});
+        for (int t = 0; t < int(fronts.size()); ++t) levels[size_t(height[t] - 1)].push_back(t);
+    }
     return true;
 }
 
 void MultifrontalCholesky::solve(const double *b, double *x, int width) const {
-    std::vector<double> y(size_t(n) * width);
+    // Multifrontal solve.  Forward: every front assembles its children's update vectors into a local vector
+    // (extend-add, children in stored order), eliminates its pivots and leaves its own update vector for its parent.
+    // Backward: every front reads the finished unknowns at its update rows and back-substitutes its pivots.  Fronts of
+    // one level (equal height above the leaves) touch disjoint data, so a level is a parallel loop; the few wide fronts
+    // near the root run one at a time with the OpenMP team inside their dense kernels instead.  Every sum is formed in
+    // a fixed order: the result does not depend on the team size.
+    std::vector<double> y(size_t(n) * width), upd(update_total);
     for (int w = 0; w < width; ++w)
         for (int i = 0; i < n; ++i) y[size_t(w) * n + i] = b[size_t(w) * n + perm[i]];
-    std::vector<double> z;
-    // Forward: L z = y.
-    for (const auto &fr : fronts) {
+    constexpr size_t Wide = 200000; // panel entries from which a front is worth a team of its own
+    constexpr int Strip = 512;
+
+    auto forward = [&](int t, double *yw, std::vector<double> &v, bool team) {
+        const auto &fr = fronts[size_t(t)];
         const int nj = fr.nj, nu = int(fr.urows.size()), f = nj + nu;
         const double *panel = L.data() + fr.loff;
-        for (int w = 0; w < width; ++w) {
-            double *yw = y.data() + size_t(w) * n;
-            double *yj = yw + fr.j0;
+        v.assign(size_t(f), 0.0);
+        for (int k = 0; k < nj; ++k) v[size_t(k)] = yw[fr.j0 + k];
+        for (const int c : fr.children) {
+            const auto &ch = fronts[size_t(c)];
+            const double *u = upd.data() + ch.uoff;
+            for (size_t i = 0; i < ch.to_parent.size(); ++i) v[size_t(ch.to_parent[i])] += u[i];
+        }
+        double *vp = v.data();
+        for (int k = 0; k < nj; ++k) { // L11 z = v (column sweeps inside the pivot block)
+            const double *col = panel + size_t(k) * f;
+            const double zk = vp[k] / col[k];
+            vp[k] = zk;
+            if (zk == 0) continue;
+            for (int i = k + 1; i < nj; ++i) vp[i] -= col[i] * zk;
+        }
+        const int strips = (nu + Strip - 1) / Strip; // update rows -= L21 z, row strips
+#pragma omp parallel for schedule(static) if (team && strips > 1)
+        for (int sidx = 0; sidx < strips; ++sidx) {
+            const int i0 = nj + sidx * Strip, i1 = std::min(f, i0 + Strip);
             for (int k = 0; k < nj; ++k) {
                 const double *col = panel + size_t(k) * f;
-                const double zk = yj[k] / col[k];
-                yj[k] = zk;
+                const double zk = vp[k];
                 if (zk == 0) continue;
-                for (int i = k + 1; i < nj; ++i) yj[i] -= col[i] * zk;
+                for (int i = i0; i < i1; ++i) vp[i] -= col[i] * zk;
             }
-            if (nu == 0) continue;
-            z.assign(nu, 0.0);
-            for (int k = 0; k < nj; ++k) {
-                const double *col = panel + size_t(k) * f + nj;
-                const double zk = yj[k];
-                if (zk == 0) continue;
-                for (int i = 0; i < nu; ++i) z[i] += col[i] * zk;
-            }
-            for (int i = 0; i < nu; ++i) yw[fr.urows[i]] -= z[i];
         }
-    }
-    // Backward: L^T x = z.
-    for (auto it = fronts.rbegin(); it != fronts.rend(); ++it) {
-        const auto &fr = *it;
+        for (int k = 0; k < nj; ++k) yw[fr.j0 + k] = vp[k];
+        std::copy(vp + nj, vp + f, upd.begin() + std::ptrdiff_t(fr.uoff));
+    };
+    auto backward = [&](int t, double *yw, std::vector<double> &z, bool team) {
+        const auto &fr = fronts[size_t(t)];
         const int nj = fr.nj, nu = int(fr.urows.size()), f = nj + nu;
         const double *panel = L.data() + fr.loff;
-        for (int w = 0; w < width; ++w) {
-            double *yw = y.data() + size_t(w) * n;
-            double *yj = yw + fr.j0;
-            if (nu > 0) {
-                z.resize(nu);
-                for (int i = 0; i < nu; ++i) z[i] = yw[fr.urows[i]];
-            }
-            for (int k = nj - 1; k >= 0; --k) {
-                const double *col = panel + size_t(k) * f;
-                double s = yj[k];
-                for (int i = k + 1; i < nj; ++i) s -= col[i] * yj[i];
-                const double *lower = col + nj;
-                for (int i = 0; i < nu; ++i) s -= lower[i] * z[i];
-                yj[k] = s / col[k];
-            }
+        double *yj = yw + fr.j0;
+        z.resize(size_t(nu));
+        for (int i = 0; i < nu; ++i) z[size_t(i)] = yw[fr.urows[size_t(i)]];
+        const double *zp = z.data();
+#pragma omp parallel for schedule(static) if (team && nj > 64)
+        for (int k = 0; k < nj; ++k) { // the update-row part of every pivot's sum: independent dot products
+            const double *lower = panel + size_t(k) * f + nj;
+            double s = 0;
+            for (int i = 0; i < nu; ++i) s += lower[i] * zp[i];
+            yj[k] -= s;
         }
+        for (int k = nj - 1; k >= 0; --k) {
+            const double *col = panel + size_t(k) * f;
+            double s = yj[k];
+            for (int i = k + 1; i < nj; ++i) s -= col[i] * yj[i];
+            yj[k] = s / col[k];
+        }
+    };
+    auto sweep = [&](const std::vector<int> &level, double *yw, auto &&kernel) {
+        size_t widest = 0;
+        for (const int t : level) widest = std::max(widest, (fronts[size_t(t)].urows.size() + size_t(fronts[size_t(t)].nj)) * size_t(fronts[size_t(t)].nj));
+        if (level.size() < 4 || widest >= 16 * Wide) { // near the root: one front at a time, the team inside it
+            std::vector<double> scratch;
+            for (const int t : level) kernel(t, yw, scratch, (fronts[size_t(t)].urows.size() + size_t(fronts[size_t(t)].nj)) * size_t(fronts[size_t(t)].nj) >= Wide);
+            return;
+        }
+#pragma omp parallel
+        {
+            std::vector<double> scratch;
+#pragma omp for schedule(dynamic, 1)
+            for (int idx = 0; idx < int(level.size()); ++idx) kernel(level[size_t(idx)], yw, scratch, false);
+        }
+    };
+    for (int w = 0; w < width; ++w) {
+        double *yw = y.data() + size_t(w) * n;
+        for (size_t h = 0; h < levels.size(); ++h) sweep(levels[h], yw, forward);
+        for (size_t h = levels.size(); h-- > 0;) sweep(levels[h], yw, backward);
     }
     for (int w = 0; w < width; ++w)
         for (int i = 0; i < n; ++i) x[size_t(w) * n + perm[i]] = y[size_t(w) * n + i];

@@ -34,10 +34,14 @@ private:
         std::vector<int> urows; // update rows (permuted indices > j0+nj-1), ascending
         std::vector<int> children;
         size_t loff{0}; // offset of the (nj+nu) x nj column-major panel [L11; L21] in L
+        std::vector<int> to_parent; // update row i -> index in the parent's local vector [pivots; update rows]
+        size_t uoff{0}; // offset of this front's update vector in the solve workspace
     };
     int n{0};
     std::vector<int> perm, iperm; // perm[new] = old, iperm[old] = new
     std::vector<Front> fronts; // postorder
+    std::vector<std::vector<int>> levels; // fronts grouped by height above the leaves: members of one level are independent
+    size_t update_total{0};
     std::vector<double> L;
     double Flops{0};
 };

@@ -8,109 +8,137 @@
 #include <numbers>
 
 namespace {
-const Striker NullStriker{.Material = {.Name = "null", .Properties = {.Density = 1e6, .YoungModulus = 1e30, .PoissonRatio = 0, .Alpha = 0, .Beta = 0}},
-                          .TipRadius = 1e6f, .Length = 1e6f};
 constexpr AcousticMaterialProperties Polymer{.Density = 1000, .YoungModulus = 1e9, .PoissonRatio = 0.3, .Alpha = 0, .Beta = 0};
 constexpr AcousticMaterialProperties Ceramic{.Density = 2700, .YoungModulus = 7.2e10, .PoissonRatio = 0.19, .Alpha = 0, .Beta = 0};
 
-mat3 Scaled(float s) {
-    mat3 m;
-    for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r) m[c][r] = c == r ? s : 0.f;
-    return m;
+// An impactor that contributes nothing: rigid, flat and immovable, so the closed forms of the struck body alone apply.
+Striker Immovable() {
+    Striker s;
+    s.Material = {"immovable", {.Density = 1e6, .YoungModulus = 1e30, .PoissonRatio = 0, .Alpha = 0, .Beta = 0}};
+    s.TipRadius = s.Length = 1e6f;
+    return s;
 }
-ContactDynamics Body(double mass, mat3 inverse_inertia, vec3 arm = vec3{0}) {
-    ContactDynamics d;
-    d.Mass = mass;
-    d.InverseInertia = inverse_inertia;
-    d.ContactArm = {arm};
-    return d;
-}
-double ContactTime(const ContactDynamics &d, const AcousticMaterialProperties &material, double curvature, double area = 0, double speed = 1, double scale = 1,
-                   const Striker &striker = NullStriker) {
-    return EstimateContactTime(d, 0, vec3{0, 0, 1}, speed, material, curvature, area, StrikerImpactor(striker), scale);
-}
+
+// One head-on collision along +z; every case varies a field or two and asks for the contact time.
+struct Collision {
+    double Mass{1};
+    float RotationalCompliance{1}; // the inverse inertia tensor is this times the identity
+    vec3 Arm{0.f};
+    AcousticMaterialProperties Solid{Polymer};
+    double Curvature{100}, Area{0}, Speed{1}, Scale{1};
+    Striker With{Immovable()};
+
+    ContactDynamics Dynamics() const {
+        ContactDynamics d;
+        d.Mass = Mass;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) d.InverseInertia[i][j] = i == j ? RotationalCompliance : 0.f;
+        d.ContactArm.push_back(Arm);
+        return d;
+    }
+    double Seconds() const { return EstimateContactTime(Dynamics(), 0, vec3{0, 0, 1}, Speed, Solid, Curvature, Area, StrikerImpactor(With), Scale); }
+    Collision At(double speed) const { auto c = *this; c.Speed = speed; return c; }
+    Collision Over(double area) const { auto c = *this; c.Area = area; return c; }
+};
 using check::near;
 } // namespace
 
 CASE(inverse_inertia_undoes_a_principal_decomposition) {
+    // I = R diag(2, 5, 9) R^T for an arbitrary unit quaternion; I * InverseInertiaTensor must be the identity
     MassProperties mp;
     mp.Mass = 1.0;
     mp.InertiaDiagonal = {2.f, 5.f, 9.f};
-    const float qn = std::sqrt(0.3f * 0.3f + 0.1f * 0.1f + 0.5f * 0.5f + 0.8f * 0.8f);
-    mp.InertiaOrientation = {0.3f / qn, 0.1f / qn, -0.5f / qn, 0.8f / qn};
-    const auto q = mp.InertiaOrientation;
-    // rotation matrix of the unit quaternion, column-major m[col][row]
-    const float R[3][3]{{1 - 2 * (q.y * q.y + q.z * q.z), 2 * (q.x * q.y + q.w * q.z), 2 * (q.x * q.z - q.w * q.y)},
-                        {2 * (q.x * q.y - q.w * q.z), 1 - 2 * (q.x * q.x + q.z * q.z), 2 * (q.y * q.z + q.w * q.x)},
-                        {2 * (q.x * q.z + q.w * q.y), 2 * (q.y * q.z - q.w * q.x), 1 - 2 * (q.x * q.x + q.y * q.y)}};
-    const float diag[3]{2, 5, 9};
-    double inertia[3][3]{}; // [col][row] of R diag R^T
-    for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r)
-            for (int k = 0; k < 3; ++k) inertia[c][r] += double(R[k][r]) * diag[k] * R[k][c];
-    const auto inv = InverseInertiaTensor(mp);
-    for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r) {
-            double v = 0;
-            for (int k = 0; k < 3; ++k) v += inertia[k][r] * double(inv[c][k]);
-            EXPECT(std::abs(v - (c == r ? 1.0 : 0.0)) < 1e-4);
+    const float raw[4]{0.3f, 0.1f, -0.5f, 0.8f};
+    const float norm = std::sqrt(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2] + raw[3] * raw[3]);
+    mp.InertiaOrientation = {raw[0] / norm, raw[1] / norm, raw[2] / norm, raw[3] / norm};
+    // rotate the basis vectors by the quaternion: v' = v + 2 w (u x v) + 2 u x (u x v)
+    const double w = mp.InertiaOrientation.w, u[3]{mp.InertiaOrientation.x, mp.InertiaOrientation.y, mp.InertiaOrientation.z};
+    double axis[3][3]; // axis[k] = image of basis vector k
+    for (int k = 0; k < 3; ++k) {
+        double v[3]{0, 0, 0};
+        v[k] = 1;
+        const double c1[3]{u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+        const double c2[3]{u[1] * c1[2] - u[2] * c1[1], u[2] * c1[0] - u[0] * c1[2], u[0] * c1[1] - u[1] * c1[0]};
+        for (int i = 0; i < 3; ++i) axis[k][i] = v[i] + 2 * w * c1[i] + 2 * c2[i];
+    }
+    const mat3 inverse = InverseInertiaTensor(mp);
+    for (int row = 0; row < 3; ++row)
+        for (int col = 0; col < 3; ++col) {
+            double product = 0; // (I * I^-1)[row][col]
+            for (int mid = 0; mid < 3; ++mid) {
+                double inertia = 0;
+                for (int k = 0; k < 3; ++k) inertia += axis[k][row] * double(mp.InertiaDiagonal[k]) * axis[k][mid];
+                product += inertia * double(inverse[col][mid]);
+            }
+            EXPECT(std::abs(product - (row == col ? 1.0 : 0.0)) < 1e-4);
         }
 }
 
 CASE(contact_time_matches_the_hertz_formula) {
-    const double tau = ContactTime(Body(1.0, Scaled(1.f)), Polymer, 100);
-    EXPECT_NOTE(near(tau, 1.744e-3, 2e-2), std::to_string(tau));
-    const double off_centre = ContactTime(Body(1.0, Scaled(1.f), vec3{0.2f, 0, 0}), Polymer, 100);
-    EXPECT(off_centre < tau); // a lever arm lowers the effective mass
+    const Collision centred;
+    EXPECT_NOTE(near(centred.Seconds(), 1.744e-3, 2e-2), std::to_string(centred.Seconds()));
+    Collision levered;
+    levered.Arm = vec3{0.2f, 0, 0};
+    EXPECT(levered.Seconds() < centred.Seconds()); // a lever arm lowers the effective mass
 }
 
 CASE(scale_ratio_and_clamps) {
-    const auto d = Body(1.0, Scaled(1.f));
-    const auto tau = [&d](double scale) { return ContactTime(d, Polymer, 100, 0, 1, scale); };
-    EXPECT(near(tau(2.0), 2 * tau(1.0), 1e-6));
-    EXPECT(near(tau(100.0), MaxContactTime, 1e-12));
-    EXPECT(near(tau(1e-6), MinContactTime, 1e-12));
+    const auto scaled = [](double scale) {
+        Collision c;
+        c.Scale = scale;
+        return c.Seconds();
+    };
+    EXPECT(near(scaled(2.0), 2 * scaled(1.0), 1e-6)); // contact time grows linearly with the body's size
+    EXPECT(near(scaled(100.0), MaxContactTime, 1e-12));
+    EXPECT(near(scaled(1e-6), MinContactTime, 1e-12));
 }
 
 CASE(the_contact_time_reaches_both_limits) {
-    const auto d = Body(1.0, Scaled(0.f));
-    constexpr double InvModulus = 0.91 / 1e9;
-    const auto tau = [&d](double curvature, double area, double speed) { return ContactTime(d, Polymer, curvature, area, speed); };
-    constexpr double Curvature = 100;
-    const double hertz = 2.868 * std::pow(std::pow(InvModulus, 2) * Curvature, 0.2);
-    EXPECT(near(tau(Curvature, 0.0, 1.0), hertz, 1e-3));
-    constexpr double Area = 1e-4;
-    const double punch = std::numbers::pi * std::sqrt(InvModulus / (2 * std::sqrt(Area / std::numbers::pi)));
-    EXPECT(near(tau(0.0, Area, 1.0), punch, 1e-3));
-    EXPECT(near(tau(Curvature, 0.0, 32.0) / tau(Curvature, 0.0, 1.0), std::pow(32.0, -0.2), 1e-3));
-    EXPECT(near(tau(0.0, Area, 32.0) / tau(0.0, Area, 1.0), 1.0, 1e-3));
+    Collision sphere; // no rotational give: the pure translational closed forms
+    sphere.RotationalCompliance = 0;
+    Collision flat = sphere;
+    flat.Curvature = 0;
+    flat.Area = 1e-4;
+    const double compliance = 0.91 / 1e9; // (1 - nu^2) / E of the polymer
+    // Hertz: tau = 2.868 (m^2 / (E*^2 R v))^(1/5); flat punch: half a period of the mass on the punch stiffness
+    EXPECT(near(sphere.Seconds(), 2.868 * std::pow(compliance * compliance * sphere.Curvature, 0.2), 1e-3));
+    EXPECT(near(flat.Seconds(), std::numbers::pi * std::sqrt(compliance / (2 * std::sqrt(flat.Area / std::numbers::pi))), 1e-3));
+    EXPECT(near(sphere.At(32).Seconds() / sphere.Seconds(), std::pow(32.0, -0.2), 1e-3)); // Hertz shortens as v^(-1/5)
+    EXPECT(near(flat.At(32).Seconds() / flat.Seconds(), 1.0, 1e-3)); // a linear spring does not care
 }
 
 CASE(filling_the_patch_stops_the_contact_stiffening) {
-    const auto d = Body(0.5, Scaled(0.f));
-    constexpr double Curvature = 10, Area = 1e-5;
-    const auto tau = [&d](double area, double speed) { return ContactTime(d, Ceramic, Curvature, area, speed); };
-    EXPECT(near(SaturationPenetration(Curvature, Area), 3.183e-5, 1e-3));
-    EXPECT(near(tau(Area, 0.1), tau(0.0, 0.1), 1e-6));
-    EXPECT(near(tau(1.0, 3.0), tau(0.0, 3.0), 1e-6));
-    EXPECT(tau(Area, 3.0) > tau(0.0, 3.0));
-    EXPECT(tau(Area, 3.0) > std::numbers::pi * std::sqrt(0.5 / PunchStiffness(0.91 / 7.2e10, Area)));
-    EXPECT(near(tau(1.7e-5, 1.0), tau(1.5e-5, 1.0), 1e-3));
-    const double hertz_ratio = tau(0.0, 3.0) / tau(0.0, 0.1), saturating_ratio = tau(Area, 3.0) / tau(Area, 0.1);
-    EXPECT(near(hertz_ratio, std::pow(30.0, -0.2), 1e-3));
-    EXPECT(saturating_ratio > hertz_ratio);
-    EXPECT(saturating_ratio < 1.0);
+    Collision base;
+    base.Mass = 0.5;
+    base.RotationalCompliance = 0;
+    base.Solid = Ceramic;
+    base.Curvature = 10;
+    const double patch = 1e-5;
+    EXPECT(near(SaturationPenetration(base.Curvature, patch), 3.183e-5, 1e-3));
+    EXPECT(near(base.Over(patch).At(0.1).Seconds(), base.At(0.1).Seconds(), 1e-6)); // a gentle hit never fills the patch
+    EXPECT(near(base.Over(1.0).At(3).Seconds(), base.At(3).Seconds(), 1e-6)); // nor does a hard one fill a huge patch
+    EXPECT(base.Over(patch).At(3).Seconds() > base.At(3).Seconds());
+    EXPECT(base.Over(patch).At(3).Seconds() > std::numbers::pi * std::sqrt(0.5 / PunchStiffness(0.91 / 7.2e10, patch)));
+    EXPECT(near(base.Over(1.7e-5).Seconds(), base.Over(1.5e-5).Seconds(), 1e-3)); // continuous across the fill depth
+    const double free_law = base.At(3).Seconds() / base.At(0.1).Seconds();
+    const double filled_law = base.Over(patch).At(3).Seconds() / base.Over(patch).At(0.1).Seconds();
+    EXPECT(near(free_law, std::pow(30.0, -0.2), 1e-3));
+    EXPECT(filled_law > free_law && filled_law < 1.0);
 }
 
 CASE(a_lighter_striker_shortens_the_contact) {
-    const auto d = Body(1000.0, Scaled(0.f));
-    Striker light;
-    light.Length = 0.05f;
-    Striker heavy = light;
-    heavy.Length = 5.f;
-    EXPECT(ContactTime(d, Ceramic, 5, 0, 1, 1, light) < ContactTime(d, Ceramic, 5, 0, 1, 1, heavy));
-    EXPECT(StrikerMass(heavy) > StrikerMass(light));
+    Collision c;
+    c.Mass = 1000;
+    c.RotationalCompliance = 0;
+    c.Solid = Ceramic;
+    c.Curvature = 5;
+    Collision heavy = c;
+    c.With = Striker{};
+    c.With.Length = 0.05f;
+    heavy.With = Striker{};
+    heavy.With.Length = 5.f;
+    EXPECT(c.Seconds() < heavy.Seconds());
+    EXPECT(StrikerMass(heavy.With) > StrikerMass(c.With));
 }
 
 // ---- strike translation (the reference's TriggerModalStrike, src/audio/AudioSystem.cpp:400-465) ------------
@@ -144,7 +172,10 @@ CASE(a_strike_becomes_the_event_the_bank_consumes) {
     EXPECT(plain.Object == slot && plain.ExPos == 1u && plain.Jz == 2.f && plain.Jx == 0.f);
     EXPECT(check::near(plain.PulseStep, 1.0 / (1e-4 * 48000.0), 1e-6) && plain.PulseGamma == 2 * plain.PulseStep && plain.AccelAmp == 0.f && plain.ClickB0 == 0.f);
     // with them: the contact time of the model, the recoil click of the displaced volume, a nominal impulse for a mallet
-    ContactDynamics dyn = Body(0.5, Scaled(0.f));
+    Collision struck;
+    struck.Mass = 0.5;
+    struck.RotationalCompliance = 0;
+    ContactDynamics dyn = struck.Dynamics();
     dyn.ContactArm = {vec3{0.f}, vec3{0.f}, vec3{0.f}};
     const AcousticMaterial ceramic{"c", Ceramic};
     StrikeContext sc{.Dynamics = &dyn, .Material = &ceramic, .Elastic = Ceramic, .Curvature = 10, .EnclosedVolume = 0, .ScaleRatio = 1.f, .Roughness = 0};
