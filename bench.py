@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: eigenpairs/sec of the modal solve (K/M assembly + 50-mode solve) on a 100k-tet mesh.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                (N > 1 without a launcher: starts N ranks itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one mesh already resident in HBM: mh_assemble (FilterDegenerate, BuildQuadMesh,
 element bases, K/M assembly) + excitation sampling + mh_eigs (65 eigenpairs requested for 50 kept modes, as the
 reference's NumFemModes = NumModes + 15) + shape gather + PostprocessModes + mass properties.  With N ranks every rank
-solves its own mesh of the same size (independent objects: weak scaling) and the per-mesh result records are gathered
-with one RCCL all_gather per step.  Rank 0 prints one JSON line.
+solves its own mesh of the same size (independent objects: weak scaling) and the per-mesh result records -- the whole
+SURVEY 8e record: eigenvalues, frequencies, decay times, shapes, mass properties, solve profile -- are gathered with one
+RCCL all_gather per step.  `--workload batch64` runs BASELINE config 4 instead: 64 jittered 29k-tet boxes dealt over the
+ranks by cost (8 per GPU at N = 8), three solves in flight per GPU, one gather per pass.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,24 +24,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable with a streaming copy
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5-6 TB/s achievable with a streaming copy
+NEV_MAX, POS_MAX = 256, 16  # record capacity of the gather
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never will) and leave with its exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
 def pmc_traffic():
     """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this command (profiles/, made by
     tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 rule and checked on a kernel of known byte count) -- a
     separate profiled run, never this one; None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["spmm_family"]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["spmm_family"]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def bank_metric(blocks=72):
     """Secondary figure: the 1024 x 256 resonator bank at 48 kHz through the C++
-    mirror's RenderModal, as x real time."""
+    mirror's RenderModal -- all-live and steady-state phases, the resonator kernel's share of the fp32 vector peak."""
     try:
         from tools import bank_bench
         return bank_bench.run(blocks=blocks)
@@ -73,21 +90,80 @@ def concurrent_throughput(api, device, pts, tets, mat, ex, cfg, threads=3, per_t
     return out
 
 
-def cpu_baseline(seconds_budget=60.0):
-    """The CPU oracle (restated reference algorithm: multifrontal Cholesky shift-invert + Lanczos, one thread) on a
-    bounded sample of the same workload: the 10k-tet cube with the same 65 requested eigenpairs."""
+def cpu_baseline(workload="cube_s10k"):
+    """The CPU oracle (restated reference algorithm: nested-dissection multifrontal Cholesky shift-invert + restarted
+    Lanczos) on a bounded sample of the metric's workload, timed on this box's host cores: once on one thread (the
+    reference runs one solve per job thread) and once with an OpenMP team on every core, stage by stage as the
+    reference's SolveProfile."""
     from oracle import pyoracle as po
     from mesheditor_amd import meshes
-    pts, tets, m, kw = meshes.workload("cube_s10k")
+    pts, tets, m, kw = meshes.workload(workload)
     cfg = po.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"])
     ex = pts[:: len(pts) // 10][:10].astype(np.float32)
-    t0 = time.perf_counter()
-    r = po.mesh2modes(pts, tets, po.material(*m), ex, config=cfg)
-    dt = time.perf_counter() - t0
-    nev = len(r.eigenvalues)
-    return {"value": nev / dt if dt > 0 and nev else 0.0, "unit": "eigenpairs/s", "cores": 1, "kind": "port", "seconds": dt,
-            "sample": "cube_s10k: 10,368 tets / 46,875 DOF, 65 eigenpairs, whole mesh2modes path on 1 host thread "
-                      "(1/10 of the metric's mesh; the direct solve grows ~quadratically with size)"}
+    cores = os.cpu_count() or 1
+    runs = {}
+    for threads in (1, cores) if cores > 1 else (1,):
+        po.set_threads(threads)
+        t0 = time.perf_counter()
+        r = po.mesh2modes(pts, tets, po.material(*m), ex, config=cfg)
+        dt = time.perf_counter() - t0
+        nev = len(r.eigenvalues)
+        runs[threads] = {"threads": threads, "seconds": dt, "eigenpairs_per_s": nev / dt if dt > 0 and nev else 0.0, "eigenpairs": nev,
+                         "stages_s": {k: r.profile[k] for k in ("mass_props", "quad_mesh", "assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract")}}
+    po.set_threads(1)
+    best = runs[max(runs)]
+    return {"value": best["eigenpairs_per_s"], "unit": "eigenpairs/s", "cores": best["threads"], "kind": "port", "host_cores": cores,
+            "sample": "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path (1/10 of the metric's mesh; the direct solve grows ~quadratically with size; "
+                      "larger samples, run once: profiles/README.md)" % (workload, len(tets), int(r.profile.get("dofs", 0)), best["eigenpairs"]),
+            "single_thread": runs[1], "all_cores": runs[max(runs)]}
+
+
+def cpu_bank_baseline(blocks=2):
+    """The oracle's bank (the reference's RenderObjectFast loop, fp32) on config 5 with every mode live: seconds per
+    512-frame block and RenderShare (= seconds x SR / frames; > 1 underruns) at 1 and 4 renderers (the reference's
+    default pool, AudioTypes.h:26)."""
+    try:
+        from oracle import pyoracle as po
+        from tools import bank_bench as bb
+        out = {}
+        for renderers in (1, 4):
+            b = po.Bank(bb.SR)
+            b.set_renderers(renderers)
+            pos = np.array([[p * 0.01, 0.0, 0.02 if p % 2 else 0.0] for p in range(bb.POINTS)], np.float32)
+            idx = np.array([[p, p + 1, p + 2] for p in range(bb.POINTS - 2)], np.uint32).reshape(-1)
+            for o in range(1024):
+                f, t, sh = bb.modes_for(o, 256)
+                s = b.add_object(o, sh, pos, idx)
+                b.tune_object(s, f, t)
+                b.set_gains(s, 1.0, 1.0)
+            b.install()
+            b.set_max_impacts(4096)
+            buf = np.zeros(bb.BLOCK, np.float32)
+            b.render(buf)
+            step = np.float32(1.0 / (4 * bb.BLOCK))
+            times = []
+            for blk in range(4 + blocks):  # four blocks to strike everything (256 events per block), then timed all-live blocks
+                for o in range((blk % 4) * 256, (blk % 4 + 1) * 256):
+                    b.enqueue(po.Event(0, o, 0, 1.0, 0.5, 0.0, step, 2 * step, 0.0, 0.0, 0.0, 0.0))
+                t0 = time.perf_counter()
+                b.render(buf)
+                times.append(time.perf_counter() - t0)
+            sec = float(np.mean(times[4:]))
+            out["renderers_%d" % renderers] = {"seconds_per_block": sec, "render_share": sec * bb.SR / bb.BLOCK, "x_real_time": bb.BLOCK / bb.SR / sec}
+        out["sample"] = "oracle bank 1024x256 @48k, all 262,144 modes live, %d timed 512-frame blocks" % blocks
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:200]}
+
+
+def batch_meshes(count=64, n=17):
+    """BASELINE config 4: `count` jittered boxes of the RealImpact size (29,478 tets), materials cycled, 45 eigenpairs."""
+    from mesheditor_amd import meshes
+    out = []
+    for i in range(count):
+        p, t = meshes.jittered_box(n, 1000 + i)
+        out.append((p, t, meshes.MATERIALS[meshes.MATERIAL_ORDER[i % len(meshes.MATERIAL_ORDER)]], {"num_modes": 30, "num_fem_modes": 45}))
+    return out
 
 
 def main():
@@ -95,75 +171,121 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cube_s100k")
+    ap.add_argument("--workload", default="cube_s100k", help="a meshes.workload name (one mesh per rank per step) or batch64 (BASELINE config 4)")
+    ap.add_argument("--threads", type=int, default=3, help="batch64: solves in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))  # before anything here touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    share_gpu = bool(os.environ.get("BENCH_SHARE_GPU"))  # test mode: every rank on device 0, gloo instead of RCCL
     import torch
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if torch.cuda.is_available() else 0
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = 0 if share_gpu or not torch.cuda.is_available() else local_rank
+    gather_device = "cpu" if share_gpu or dist is None else "cuda"
 
-    from mesheditor_amd import api, meshes
-    ctx = api.Context(device)
-    pts, tets, m, kw = meshes.workload(args.workload)
-    if world > 1:  # every rank its own object of the same size: jitter the extents deterministically per rank
-        rng = np.random.Generator(np.random.MT19937(1000 + rank))
-        pts = pts * rng.uniform(0.9, 1.1, 3)[None, :]
-    mat = api.material(*m)
-    cfg = api.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"])
-    ex = pts[:: len(pts) // 10][:10].astype(np.float32)  # P = 10 excitation positions, as the app and bench use
-    mesh = api.Mesh(ctx, pts, tets)  # inputs resident in HBM before the timed region
+    from mesheditor_amd import api, meshes, sharding
 
-    def sync():
-        ctx.synchronize()
+    def sync(ctxs):
+        for c in ctxs:
+            c.synchronize()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
-    record = None
+    batch = args.workload == "batch64"
+    if batch:
+        items = batch_meshes()
+        ctxs = [api.Context(device) for _ in range(max(1, args.threads))]
+        ex_of = [m[0][:: len(m[0]) // 10][:10].astype(np.float32) for m in items]
+        resident = {}  # meshes of this rank's share, uploaded before the timed region
 
-    def step():
-        nonlocal record
-        r = api.mesh2modes(ctx, pts, tets, mat, ex, config=cfg, mesh=mesh)
-        if len(r.eigenvalues) == 0:
-            raise RuntimeError("solve failed: %s" % r.profile)
-        if dist is not None:  # the final gather: fixed-size record per mesh over RCCL
-            rec = torch.zeros(256, dtype=torch.float64, device="cuda")
-            rec[: len(r.eigenvalues)] = torch.from_numpy(r.eigenvalues).to("cuda")
-            out = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(out, rec)
-            record = out
-        return r
+        def solve(i, m, worker=0):
+            c = ctxs[worker]
+            key = (i, worker)
+            if key not in resident:
+                resident[key] = api.Mesh(c, m[0], m[1])
+            return api.mesh2modes(c, m[0], m[1], api.material(*m[2]), ex_of[i], config=api.default_config(**m[3]), mesh=resident[key])
+        records = None
+
+        def step():
+            nonlocal records
+            records = sharding.solve_batch(items, solve, NEV_MAX, dist, gather_device, threads=len(ctxs), pos_max=POS_MAX)
+            return records
+    else:
+        ctx = api.Context(device)
+        ctxs = [ctx]
+        pts, tets, m, kw = meshes.workload(args.workload)
+        if world > 1:  # every rank its own object of the same size: jitter the extents deterministically per rank
+            rng = np.random.Generator(np.random.MT19937(1000 + rank))
+            pts = pts * rng.uniform(0.9, 1.1, 3)[None, :]
+        mat = api.material(*m)
+        cfg = api.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"])
+        ex = pts[:: len(pts) // 10][:10].astype(np.float32)  # P = 10 excitation positions, as the app and bench use
+        mesh = api.Mesh(ctx, pts, tets)  # inputs resident in HBM before the timed region
+        records = None
+
+        def step():
+            nonlocal records
+            t0 = time.perf_counter()
+            r = api.mesh2modes(ctx, pts, tets, mat, ex, config=cfg, mesh=mesh)
+            if len(r.eigenvalues) == 0:
+                raise RuntimeError("solve failed: %s" % r.profile)
+            if dist is not None:  # the final gather: the whole fixed-size record of every rank's mesh, one collective
+                rec = sharding.pack_record(rank, r, NEV_MAX, POS_MAX, time.perf_counter() - t0)
+                records = [sharding.unpack_record(x, NEV_MAX, POS_MAX) for x in sharding.gather_records({rank: rec}, world, dist, gather_device)]
+            return r
 
     for _ in range(args.warmup):
         step()
-    ctx.time_kernels(True)
-    sync()
+    for c in ctxs:
+        c.time_kernels(True)
+    sync(ctxs)
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = step()
-    sync()
+    sync(ctxs)
     dt = time.perf_counter() - t0
-    stats = ctx.kernel_stats()
-    ctx.time_kernels(False)
+    stats = [{k: sum(c.kernel_stats(cls)[k] for c in ctxs) for k in ("launches", "total_ms", "total_bytes")} for cls in (0, 1)]
+    for c in ctxs:
+        c.time_kernels(False)
 
-    nev = len(last.eigenvalues)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=gather_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_pairs = nev * args.steps * world
+    if batch:
+        pairs_per_step = sum(len(r["eigenvalues"]) for r in last)  # every rank holds every record after the gather
+        modes_per_step = sum(len(r["freqs"]) for r in last)
+        total_pairs, total_modes = pairs_per_step * args.steps, modes_per_step * args.steps
+        workload = ("batch64: 64 jittered Kuhn boxes of %d tets (RealImpact size), 7 materials cycled, NumModes=30 NumFemModes=45, P=10, LPT deal over %d GPU(s), "
+                    "%d solves in flight per GPU" % (len(items[0][1]), world, len(ctxs)))
+        config = {"workload": workload, "meshes": len(items), "eigenpairs_per_mesh": 45, "parallelism": "lpt-deal x%d" % world}
+        scaling = "strong"
+    else:
+        nev = len(last.eigenvalues)
+        total_pairs, total_modes = nev * args.steps * world, len(last.freqs) * args.steps * world
+        config = {"workload": "%s: Kuhn mesh %d tets / %d DOF, NumModes=%d NumFemModes=%d, P=10 excitation points, one mesh per GPU"
+                              % (args.workload, len(tets), last.profile.get("dofs", 0), cfg.num_modes, cfg.num_fem_modes),
+                  "eigenpairs_per_mesh": nev, "kept_modes_per_mesh": len(last.freqs), "lobpcg_iterations": last.profile.get("restarts"), "parallelism": "mesh-per-gpu x%d" % world}
+        scaling = "weak"
     line = {
         "metric": "eigenpairs/sec (K/M assembly + 50-mode solve, 100k-tet mesh)",
         "value": total_pairs / dt,
@@ -173,31 +295,48 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "%s: Kuhn cube %d tets / %d DOF, Iron, NumModes=%d NumFemModes=%d, P=10 excitation points, one mesh per GPU"
-                               % (args.workload, len(tets), last.profile.get("dofs", 0), cfg.num_modes, cfg.num_fem_modes),
-                   "eigenpairs_per_mesh": nev, "lobpcg_iterations": last.profile.get("restarts"), "parallelism": "mesh-per-gpu x%d" % world},
+        "config": config,
+        "modes_per_s": total_modes / dt,  # kept modes only (`value` counts every converged pair: 6 rigid-body + guard pairs included)
     }
-    if stats["launches"]:
-        achieved = stats["total_bytes"] / (stats["total_ms"] * 1e-3) / 1e9
+    if dist is not None and records:
+        line["gathered_records"] = {"count": len(records), "words_per_record": sharding.record_length(NEV_MAX, POS_MAX),
+                                    "fields": "eigenvalues, freqs, t60s, positions, shapes, mass properties, solve profile"}
+    spmm, asm = stats
+    if spmm["launches"]:
+        achieved = spmm["total_bytes"] / (spmm["total_ms"] * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm",
                             "kernel": "k_spmm_wide / k_spmm: BSR 3x3 SpMM of the P2 and P1 operators over n-by-w panels "
                                       "(every launch of the solve: fp32 smoother products, mixed fp64-A x fp32-panel residuals, fp64 operator products)",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                            "launches": stats["launches"], "avg_launch_us": 1e3 * stats["total_ms"] / stats["launches"],
-                            "algorithmic_bytes_per_launch": stats["total_bytes"] / stats["launches"]}
-    line["profile"] = {k: last.profile.get(k) for k in ("assemble", "factorize", "iterate", "op_solve", "restarts", "op_applications")}
+                            "launches": spmm["launches"], "avg_launch_us": 1e3 * spmm["total_ms"] / spmm["launches"],
+                            "algorithmic_bytes_per_launch": spmm["total_bytes"] / spmm["launches"]}
+    if asm["launches"]:
+        achieved = asm["total_bytes"] / (asm["total_ms"] * 1e-3) / 1e9
+        line["roofline_assembly"] = {"bound": "hbm", "kernel": "K/M assembly of the quadratic level (SURVEY 8d bytes: 152 B read per tet, 80 B written per node block)",
+                                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                     "launches": asm["launches"], "avg_launch_us": 1e3 * asm["total_ms"] / asm["launches"],
+                                     "algorithmic_bytes_per_launch": asm["total_bytes"] / asm["launches"]}
+    if not batch:
+        line["profile"] = {k: last.profile.get(k) for k in ("assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract", "restarts", "op_applications")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["concurrent_solves"] = concurrent_throughput(api, device, pts, tets, mat, ex, cfg)
+        if not batch:
+            line["concurrent_solves"] = concurrent_throughput(api, device, pts, tets, mat, ex, cfg)
         line["cpu_baseline"] = cpu_baseline()
-        line["resonator_bank"] = bank_metric()
+        bank = bank_metric()
+        line["resonator_bank"] = bank
+        if isinstance(bank.get("all_live"), dict):
+            line["roofline_bank"] = bank["all_live"]["roofline_bank"]
+        line["cpu_bank_baseline"] = cpu_bank_baseline()
     if rank == 0:
         print(json.dumps(line), flush=True)
-    mesh.close()
-    ctx.close()
+    if not batch:
+        mesh.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -72,12 +72,18 @@ int mh_context_synchronize(mh_context *);
 /* The context's hipStream_t, for callers that time with HIP events. */
 void *mh_context_stream(mh_context *);
 void mh_default_config(mh_solver_config *);
-/* Measurement aid (no reference counterpart): when enabled, every launch of the dominant kernel -- the P2-operator
- * SpMM y = (K - sigma M) x over an n x w panel -- is bracketed by HIP events on the context's stream.  Stats are the
- * totals since the last enable: launches, summed device milliseconds, summed algorithmic bytes
- * (76 B per node block + 4 B per row pointer + 16 B per panel entry). */
+/* Measurement aid (no reference counterpart): when enabled, every launch of the path's named kernels is bracketed by
+ * HIP events on the context's stream.  Kernel classes and their algorithmic work unit:
+ *   MH_KERNEL_SPMM     the operator products y = (K - sigma M) x over n x w panels (both levels, all precisions);
+ *                      bytes: (9 values + 1 index) per node block + 4 B per row pointer + every panel pass
+ *   MH_KERNEL_ASSEMBLY the K/M assembly kernel of the quadratic level; bytes: per tet 16 B corners + 96 B coordinates
+ *                      + 40 B node ids read, 80 B per node block written
+ *   MH_KERNEL_BANK     the resonator kernel (RenderObjectFast); flops: 11 per rendered mode-sample
+ * Stats are the totals since the last enable: launches, summed device milliseconds, summed work. */
+enum { MH_KERNEL_SPMM = 0, MH_KERNEL_ASSEMBLY = 1, MH_KERNEL_BANK = 2, MH_KERNEL_CLASSES = 3 };
 int mh_context_time_kernels(mh_context *, int enable);
-int mh_context_kernel_stats(mh_context *, uint64_t *launches, double *total_ms, double *total_bytes);
+int mh_context_kernel_stats(mh_context *, uint64_t *launches, double *total_ms, double *total_bytes); /* MH_KERNEL_SPMM */
+int mh_context_kernel_class_stats(mh_context *, int kernel_class, uint64_t *launches, double *total_ms, double *total_work);
 
 /* ---- analysis half: modal::mesh2modes (src/audio/mesh2modes.cpp:605-658), stage by stage ---- */
 

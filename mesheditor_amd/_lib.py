@@ -59,7 +59,7 @@ def lib():
     sig = {
         "mh_context_create": (i32, [i32, pp]), "mh_context_destroy": (None, [vp]), "mh_last_error": (C.c_char_p, [vp]),
         "mh_context_synchronize": (i32, [vp]), "mh_context_time_kernels": (i32, [vp, i32]),
-        "mh_context_kernel_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(f64), C.POINTER(f64)]), "mh_context_stream": (vp, [vp]), "mh_default_config": (None, [C.POINTER(SolverConfig)]),
+        "mh_context_kernel_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(f64), C.POINTER(f64)]), "mh_context_kernel_class_stats": (i32, [vp, i32, C.POINTER(C.c_uint64), C.POINTER(f64), C.POINTER(f64)]), "mh_context_stream": (vp, [vp]), "mh_default_config": (None, [C.POINTER(SolverConfig)]),
         "mh_mesh_create": (i32, [vp, u32, vp, u32, vp, pp]), "mh_mesh_destroy": (None, [vp]),
         "mh_assemble": (i32, [vp, vp, C.POINTER(Material), pp]), "mh_system_destroy": (None, [vp]),
         "mh_system_dims": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]),

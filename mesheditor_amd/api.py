@@ -62,9 +62,11 @@ class Context:
         self.check(self.L.mh_context_bench_dense(self.h, kind, n, wa, wb, reps, C.byref(ms)))
         return ms.value
 
-    def kernel_stats(self):
+    def kernel_stats(self, kernel_class=0):
+        """Totals of a timed kernel class since time_kernels(True): 0 = operator products (bytes), 1 = assembly kernel (bytes),
+        2 = resonator kernel (flops)."""
         n, ms, by = C.c_uint64(0), C.c_double(0), C.c_double(0)
-        self.check(self.L.mh_context_kernel_stats(self.h, C.byref(n), C.byref(ms), C.byref(by)))
+        self.check(self.L.mh_context_kernel_class_stats(self.h, kernel_class, C.byref(n), C.byref(ms), C.byref(by)))
         return {"launches": n.value, "total_ms": ms.value, "total_bytes": by.value}
 
     @property

@@ -37,6 +37,7 @@ def lib():
         "mhx_set_renderers": (None, [vp, u32]), "mhx_set_click_gain": (None, [vp, f32]), "mhx_set_max_impacts": (None, [vp, u32]),
         "mhx_enqueue": (i32, [vp, C.POINTER(Event)]), "mhx_render": (i32, [vp, vp, u32]), "mhx_num_objects": (u32, [vp]),
         "mhx_active_impacts": (u32, [vp]), "mhx_modal_energy": (f64, [vp]), "mhx_render_share": (f32, [vp]), "mhx_find_object": (i32, [vp, u32]),
+        "mhx_time_kernels": (i32, [vp, i32]), "mhx_kernel_class_stats": (i32, [vp, i32, C.POINTER(C.c_uint64), C.POINTER(f64), C.POINTER(f64)]),
         "mhx_column": (u32, [vp, i32, i32, vp]), "mhx_object_state": (None, [vp, vp, vp, vp]),
         "mhx_recoil_click_filter": (None, [f64, f64, f64, f64, vp]), "mhx_recoil_object_filter": (None, [f64, f64, f64, vp]),
         "mhx_estimate_contact_time": (f64, [f64, vp, vp, vp, f64, vp, f64, f64, vp, f64, f64, f64, f64]),
@@ -107,6 +108,18 @@ class Scene:
         assert out.dtype == self.dtype and out.flags["C_CONTIGUOUS"]
         if self.L.mhx_render(self.h, _p(out), len(out)):
             raise RuntimeError(self.L.mhx_last_error().decode())
+
+    def time_kernels(self, enable=True):
+        """HIP-event timing of the bank's kernels on its device context (measurement aid)."""
+        if self.L.mhx_time_kernels(self.h, int(enable)):
+            raise RuntimeError(self.L.mhx_last_error().decode())
+
+    def kernel_stats(self, kernel_class=2):
+        """{"launches", "total_ms", "work"} of a kernel class since time_kernels(True); class 2 = the resonator kernel, work in flops."""
+        n, ms, work = C.c_uint64(0), C.c_double(0), C.c_double(0)
+        if self.L.mhx_kernel_class_stats(self.h, kernel_class, C.byref(n), C.byref(ms), C.byref(work)):
+            raise RuntimeError(self.L.mhx_last_error().decode())
+        return {"launches": n.value, "total_ms": ms.value, "work": work.value}
 
     def column(self, name, live=True):
         which = COLUMNS.index(name)

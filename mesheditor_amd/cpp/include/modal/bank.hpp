@@ -173,6 +173,10 @@ void EnqueueModalEvent(ModalAudio64 &, const ModalEvent &);
 // Adds frame_count mono samples into `out`.  Events take effect at the start of the block.
 void RenderModal(ModalAudio &, float *out, uint32_t frame_count);
 void RenderModal(ModalAudio64 &, double *out, uint32_t frame_count);
+// Not in the reference: the libmodalhip context the bank's device mirror lives on (created on demand), for callers that
+// time its kernels (mh_context_time_kernels / mh_context_kernel_class_stats).
+mh_context *ModalDeviceContext(ModalAudio &);
+mh_context *ModalDeviceContext(ModalAudio64 &);
 // Not in the reference: copies the device-resident StateRe / StateIm back into the host bank for inspection.
 void SyncModalState(ModalAudio &);
 void SyncModalState(ModalAudio64 &);

@@ -610,5 +610,7 @@ void EnqueueModalEvent(ModalAudio &m, const ModalEvent &e) { RingPush(m, e); }
 void EnqueueModalEvent(ModalAudio64 &m, const ModalEvent &e) { RingPush(m, e); }
 void RenderModal(ModalAudio &m, float *out, uint32_t frame_count) { RenderBlock<ModalAudio, float>(m, out, frame_count); }
 void RenderModal(ModalAudio64 &m, double *out, uint32_t frame_count) { RenderBlock<ModalAudio64, double>(m, out, frame_count); }
+mh_context *ModalDeviceContext(ModalAudio &m) { return NeedContext(m), m.Dev->Context; }
+mh_context *ModalDeviceContext(ModalAudio64 &m) { return NeedContext(m), m.Dev->Context; }
 void SyncModalState(ModalAudio &m) { PullState(m); }
 void SyncModalState(ModalAudio64 &m) { PullState(m); }

@@ -4,6 +4,8 @@
 #include "modal/contact.hpp"
 #include "modal/solver.hpp"
 
+#include "modalhip.h"
+
 #include <cstring>
 #include <type_traits>
 #include <exception>
@@ -101,6 +103,17 @@ int mhx_render(mhx_scene *s, void *out, uint32_t frames) {
         if (s->dbl) RenderModal(s->audio64, static_cast<double *>(out), frames);
         else RenderModal(s->audio, static_cast<float *>(out), frames);
         return 0;
+    } catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+// Kernel timing of the scene's device context: enable / read one class (modalhip.h MH_KERNEL_*)
+int mhx_time_kernels(mhx_scene *s, int enable) {
+    try {
+        return Dispatch(s, [&](auto &a, auto &) { return mh_context_time_kernels(ModalDeviceContext(a), enable); });
+    } catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+int mhx_kernel_class_stats(mhx_scene *s, int kernel_class, uint64_t *launches, double *total_ms, double *total_work) {
+    try {
+        return Dispatch(s, [&](auto &a, auto &) { return mh_context_kernel_class_stats(ModalDeviceContext(a), kernel_class, launches, total_ms, total_work); });
     } catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 uint32_t mhx_num_objects(mhx_scene *s) { return Dispatch(s, [](auto &a, auto &) { return uint32_t(LiveBank(a).Entities.size()); }); }

@@ -161,20 +161,23 @@ int mh_context_time_kernels(mh_context *ctx, int enable) {
     try {
         mh_timer_flush(ctx);
         ctx->time_kernels = enable != 0;
-        ctx->spmm_ms = ctx->spmm_bytes = 0;
-        ctx->spmm_launches = 0;
+        for (auto &t : ctx->totals) t = {};
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+int mh_context_kernel_class_stats(mh_context *ctx, int kernel_class, uint64_t *launches, double *total_ms, double *total_work) {
+    if (!ctx || kernel_class < 0 || kernel_class >= MH_KERNEL_CLASSES) return MH_EINVAL;
+    try {
+        mh_timer_flush(ctx);
+        const auto &t = ctx->totals[kernel_class];
+        if (launches) *launches = t.launches;
+        if (total_ms) *total_ms = t.ms;
+        if (total_work) *total_work = t.work;
         return MH_OK;
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 int mh_context_kernel_stats(mh_context *ctx, uint64_t *launches, double *total_ms, double *total_bytes) {
-    if (!ctx) return MH_EINVAL;
-    try {
-        mh_timer_flush(ctx);
-        if (launches) *launches = ctx->spmm_launches;
-        if (total_ms) *total_ms = ctx->spmm_ms;
-        if (total_bytes) *total_bytes = ctx->spmm_bytes;
-        return MH_OK;
-    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+    return mh_context_kernel_class_stats(ctx, MH_KERNEL_SPMM, launches, total_ms, total_bytes);
 }
 void mh_default_config(mh_solver_config *c) {
     if (c) *c = mh_solver_config{20.f, 16000.f, 30, 45, 1e-8, 1e-4, 100, 0, 0.f};

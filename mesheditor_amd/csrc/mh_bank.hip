@@ -494,6 +494,9 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
         ensure(ctx, B.gain_scratch, size_t(n_waves + 1) * max_imp * WAVE);
         const uint32_t *d_deal = A.d<uint32_t>(o_deal), *d_count = A.d<uint32_t>(o_count), *d_chunk_base = A.d<uint32_t>(o_chunk_base), *d_imp_ptr = A.d<uint32_t>(o_imp_ptr);
         if (n_waves) {
+            uint64_t rendered_modes = 0;
+            for (uint32_t d = 0; d < n_dealt; ++d) rendered_modes += render_count[d];
+            TimedLaunch timed(ctx, MH_KERNEL_BANK, 11.0 * double(rendered_modes) * double(frames)); // ~11 flop per mode-sample
             k_bank_modes<Real><<<n_waves, WAVE, 0, st>>>(B.cols(), A.d<WaveDesc>(o_waves), d_deal, d_count, d_chunk_base, d_imp_ptr, A.d<uint32_t>(o_imp_idx), d_impacts,
                                                          B.force, d_out_gain, d_listener, frames, B.partial, B.chunk_energy, B.gain_scratch, max_imp);
             KERNEL_CHECK();

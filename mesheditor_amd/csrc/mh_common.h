@@ -101,16 +101,46 @@ struct mh_context {
     void *gram_ws{nullptr}; // partial-Gram workspace of mh_gram, grown on demand
     size_t gram_ws_bytes{0};
     uint32_t *iota{nullptr}; // 0, 1, 2, ... (1 024 entries): the identity column map, created on first use
-    // Optional per-launch timing of the level-2 SpMM (the path's dominant kernel): HIP events on this stream around
-    // every launch, resolved lazily.  Totals feed bench.py's roofline object.
+    // Optional per-launch timing of the path's named kernels (measurement aid for bench.py's roofline objects): HIP
+    // events on this stream around every launch of a kernel class, resolved lazily.  `work` is the class's algorithmic
+    // unit: bytes for the HBM-bound classes, flops for the resonator bank.
     bool time_kernels{false};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timer_events;
-    std::vector<double> timer_bytes;
+    std::vector<double> timer_work;
+    std::vector<int> timer_class;
     size_t timer_used{0};
-    double spmm_ms{0}, spmm_bytes{0};
-    uint64_t spmm_launches{0};
+    struct ClassTotals {
+        double ms{0}, work{0};
+        uint64_t launches{0};
+    } totals[MH_KERNEL_CLASSES];
 };
 void mh_timer_flush(mh_context *ctx); // mh_spmm.hip
+// HIP events around one launch on the context's stream, booked under a kernel class; resolved by mh_timer_flush.
+struct TimedLaunch {
+    mh_context *ctx;
+    bool on;
+    size_t slot{0};
+    TimedLaunch(mh_context *c, int kernel_class, double work) : ctx(c), on(c->time_kernels) {
+        if (!on) return;
+        if (ctx->timer_used == ctx->timer_events.size()) {
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a));
+            HIP_CHECK(hipEventCreate(&b));
+            ctx->timer_events.emplace_back(a, b);
+            ctx->timer_work.push_back(0);
+            ctx->timer_class.push_back(0);
+        }
+        slot = ctx->timer_used++;
+        ctx->timer_work[slot] = work;
+        ctx->timer_class[slot] = kernel_class;
+        HIP_CHECK(hipEventRecord(ctx->timer_events[slot].first, ctx->stream));
+    }
+    ~TimedLaunch() {
+        if (on) (void)hipEventRecord(ctx->timer_events[slot].second, ctx->stream);
+    }
+    TimedLaunch(const TimedLaunch &) = delete;
+    TimedLaunch &operator=(const TimedLaunch &) = delete;
+};
 
 // RAII device array bound to a context's pool.
 template<typename T> struct DevArray {

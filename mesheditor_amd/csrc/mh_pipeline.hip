@@ -446,7 +446,12 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
     KERNEL_CHECK();
     const double lambda = (mat.poisson_ratio * mat.young_modulus) / ((1 + mat.poisson_ratio) * (1 - 2 * mat.poisson_ratio));
     const double mu = mat.young_modulus / (2 * (1 + mat.poisson_ratio));
-    k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
+    {
+        // SURVEY 8d's count for the assembly: per tet 16 B corner ids + 4 x 24 B coordinates + 40 B node ids read (the
+        // element bases are built from them), 80 B (9 K values + 1 M value) written per node block
+        TimedLaunch timed(ctx, MH_KERNEL_ASSEMBLY, NN == 10 ? 152.0 * double(nt) + 80.0 * double(nb) : 0.0);
+        k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
+    }
     KERNEL_CHECK();
 }
 

@@ -383,36 +383,15 @@ void mh_timer_flush(mh_context *ctx) {
     for (size_t i = 0; i < ctx->timer_used; ++i) {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->timer_events[i].first, ctx->timer_events[i].second));
-        ctx->spmm_ms += ms;
-        ctx->spmm_bytes += ctx->timer_bytes[i];
-        ++ctx->spmm_launches;
+        auto &t = ctx->totals[ctx->timer_class[i]];
+        t.ms += ms;
+        t.work += ctx->timer_work[i];
+        ++t.launches;
     }
     ctx->timer_used = 0;
 }
 
 namespace {
-// HIP events around one launch on the context's stream; resolved lazily by mh_timer_flush.
-struct TimedLaunch {
-    mh_context *ctx;
-    bool on;
-    size_t slot{0};
-    TimedLaunch(mh_context *c, bool enable, double algorithmic_bytes) : ctx(c), on(enable) {
-        if (!on) return;
-        if (ctx->timer_used == ctx->timer_events.size()) {
-            hipEvent_t a, b;
-            HIP_CHECK(hipEventCreate(&a));
-            HIP_CHECK(hipEventCreate(&b));
-            ctx->timer_events.emplace_back(a, b);
-            ctx->timer_bytes.push_back(0);
-        }
-        slot = ctx->timer_used++;
-        ctx->timer_bytes[slot] = algorithmic_bytes;
-        HIP_CHECK(hipEventRecord(ctx->timer_events[slot].first, ctx->stream));
-    }
-    ~TimedLaunch() {
-        if (on) (void)hipEventRecord(ctx->timer_events[slot].second, ctx->stream);
-    }
-};
 // algorithmic bytes of one product: the block values read (9 per node block for A, 1 for M) + column index, the row
 // pointers, x read once, every output panel written once
 double spmm_bytes(const BsrLevel &lvl, uint32_t w, size_t value_bytes, size_t x_bytes, size_t y_bytes, bool with_a, bool with_m) {
@@ -424,7 +403,7 @@ double spmm_bytes(const BsrLevel &lvl, uint32_t w, size_t value_bytes, size_t x_
 
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w) {
     if (w == 0) return;
-    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 8, 8, 8, vals9 != nullptr, mscal != nullptr));
+    TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, w, 8, 8, 8, vals9 != nullptr, mscal != nullptr));
     if (vals9 && mscal) launch_spmm<double, true, true>(ctx, lvl, vals9, x, y, mscal, y2, w);
     else if (vals9) {
         launch_spmm<double, false, true>(ctx, lvl, vals9, x, y, nullptr, nullptr, w);
@@ -443,7 +422,7 @@ void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, c
     const uint32_t ranges = div_up(w, 128u), step = (div_up(w, ranges) + 1u) & ~1u;
     for (uint32_t c0 = 0; c0 < wreal; c0 += step) {
         const uint32_t wc = std::min(step, w - c0), wr = std::min(wc, wreal - c0);
-        TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, wr, 8, 8, 8, true, true));
+        TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, wr, 8, 8, 8, true, true));
         auto go = [&](auto cl_tag) {
             constexpr int CL = decltype(cl_tag)::value;
             k_spmm_wide<double, double, double, 2, CL, true, true, true><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x + c0, y, y2, lvl.n_nodes, wc, xcd, ldy, wr, omap + c0,
@@ -465,7 +444,7 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
     const bool aligned16 = !((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x)) & 15);
     if (w % 4 || w > 256 || !aligned16) return false;
     // algorithmic bytes: the product's (d read, no t written) plus the step's own passes: r and x read and written, d' written
-    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 4, 4, 0, true, false) + 5.0 * 4.0 * 3.0 * double(lvl.n_nodes) * w);
+    TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, w, 4, 4, 0, true, false) + 5.0 * 4.0 * 3.0 * double(lvl.n_nodes) * w);
     static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
     ChebStep epi;
@@ -488,7 +467,7 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
 // fp32 product with the level's single-precision copy of A (preconditioner only).
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w) {
     if (w == 0) return;
-    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 4, 4, 4, true, false));
+    TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, w, 4, 4, 4, true, false));
     launch_spmm<float, false, true>(ctx, lvl, lvl.aval32.get(), x, y, static_cast<const float *>(nullptr), static_cast<float *>(nullptr), w);
 }
 
@@ -496,7 +475,7 @@ void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y,
 // The pitch w must be a multiple of 4 (16-byte single-precision rows).
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w) {
     if (w == 0) return;
-    TimedLaunch timed(ctx, ctx->time_kernels, spmm_bytes(lvl, w, 8, 4, 8, true, false));
+    TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, w, 8, 4, 8, true, false));
     if (!launch_spmm_wide<double, float, double, false, true>(ctx, lvl, lvl.aval.get(), x, y, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), w))
         mh_throw(MH_EINVAL, "mixed-precision product needs a 16-byte aligned panel of pitch %% 4 == 0 (got %u)", w);
 }

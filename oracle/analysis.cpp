@@ -455,6 +455,28 @@ struct EigResult {
     uint OpApplications{0}, Restarts{0};
 };
 
+// Long-vector kernels of the Lanczos loop on the OpenMP team.  Dot products are summed over fixed blocks whose partial
+// sums are then added in block order, so the value does not depend on the team size.
+double BlockedDot(const double *a, const double *b, size_t n) {
+    constexpr size_t Block = 4096;
+    const size_t blocks = (n + Block - 1) / Block;
+    std::vector<double> partial(blocks);
+#pragma omp parallel for schedule(static) if (blocks >= 8)
+    for (size_t k = 0; k < blocks; ++k) {
+        const size_t lo = k * Block, hi = std::min(n, lo + Block);
+        double s = 0;
+        for (size_t r = lo; r < hi; ++r) s += a[r] * b[r];
+        partial[k] = s;
+    }
+    double total = 0;
+    for (const double v : partial) total += v;
+    return total;
+}
+void Axpy(double *y, double alpha, const double *x, size_t n) { // y += alpha x
+#pragma omp parallel for schedule(static) if (n >= 32768)
+    for (size_t r = 0; r < n; ++r) y[r] += alpha * x[r];
+}
+
 // One restarted Lanczos run on OP = (K - sigma M)^-1 M in the M inner product, optionally deflated against the
 // M-orthonormal vectors Q (every Krylov vector is kept M-orthogonal to them).  Returns the `nev` Ritz pairs of
 // largest |theta| (theta = 1/(lambda - sigma)) in `theta_out` / `vec_out` (n x nev), or false when not converged.
@@ -464,18 +486,12 @@ bool LanczosRun(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double
     std::vector<double> V(n * (ncv + 1)), MV(n * (ncv + 1)), T(size_t(ncv) * ncv, 0.0);
     std::vector<double> w(n), Mw(n), h(ncv + 1), theta(ncv), S(size_t(ncv) * ncv);
     auto col = [&](std::vector<double> &a, size_t j) { return a.data() + j * n; };
-    auto mnorm = [&](const double *x, const double *mx) {
-        double s = 0;
-        for (size_t i = 0; i < n; ++i) s += x[i] * mx[i];
-        return std::sqrt(std::max(s, 0.0));
-    };
+    auto mnorm = [&](const double *x, const double *mx) { return std::sqrt(std::max(BlockedDot(x, mx, n), 0.0)); };
     auto deflate = [&](double *x) { // x -= Q (MQ^T x), twice
         for (int pass = 0; pass < 2 && nq; ++pass)
             for (uint i = 0; i < nq; ++i) {
                 const double *mq = MQ.data() + size_t(i) * n, *q = Q.data() + size_t(i) * n;
-                double s = 0;
-                for (size_t r = 0; r < n; ++r) s += mq[r] * x[r];
-                for (size_t r = 0; r < n; ++r) x[r] -= s * q[r];
+                Axpy(x, -BlockedDot(mq, x, n), q, n);
             }
     };
     // Start vector: fixed-seed uniform noise pushed through the operator once (into the range of OP).
@@ -508,12 +524,9 @@ bool LanczosRun(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double
             std::fill(h.begin(), h.end(), 0.0);
             for (int pass = 0; pass < 2; ++pass) {
                 for (uint i = 0; i <= j; ++i) {
-                    const double *mv = col(MV, i);
-                    double s = 0;
-                    for (size_t r = 0; r < n; ++r) s += mv[r] * w[r];
+                    const double s = BlockedDot(col(MV, i), w.data(), n);
                     h[i] += s;
-                    const double *v = col(V, i);
-                    for (size_t r = 0; r < n; ++r) w[r] -= s * v[r];
+                    Axpy(w.data(), -s, col(V, i), n);
                 }
             }
             T[size_t(j) * ncv + j] = h[j];
@@ -552,6 +565,7 @@ bool LanczosRun(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double
         keep = std::min(keep, ncv - 1);
         // Thick restart: V <- V S(:, wanted[0..keep)), T <- diag(theta) bordered by the residual couplings.
         std::vector<double> Vn(n * keep), MVn(n * keep);
+#pragma omp parallel for schedule(dynamic, 1)
         for (uint c = 0; c < keep; ++c) {
             const double *s = S.data() + size_t(wanted[c]) * ncv;
             double *vo = Vn.data() + size_t(c) * n, *mo = MVn.data() + size_t(c) * n;
@@ -580,6 +594,7 @@ bool LanczosRun(ShiftInvertOp &op, const CscLower &M, uint nev, uint ncv, double
     }
     theta_out.resize(nev);
     vec_out.assign(n * nev, 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint c = 0; c < nev; ++c) {
         theta_out[c] = theta[wanted[c]];
         const double *s = S.data() + size_t(wanted[c]) * ncv;

@@ -351,6 +351,9 @@ class Bank:
     def set_click_gain(self, g):
         self.L.mo_bank_set_click_gain(self.h, g)
 
+    def set_max_impacts(self, n):
+        self.L.mo_bank_set_max_impacts(self.h, n)
+
     def enqueue(self, ev):
         return bool(self.L.mo_bank_enqueue(self.h, C.byref(ev)))
 

@@ -260,7 +260,11 @@ template<typename Real> void RenderModal(Audio<Real> &m, Real *out, uint32_t fra
     }
     DealObjects(m, b, m.PoolSize);
     for (auto &r : m.Renderers) r.Out.assign(frame_count, Real(0));
-    for (auto &w : m.Renderers) {
+    // The reference's render pool: one thread per renderer, each with a private Out (ModalAudio.cpp:189-273, 471-483).
+    // Renderers own disjoint objects, so the team only changes the wall time, never a sample.
+#pragma omp parallel for schedule(static, 1) if (m.Renderers.size() > 1)
+    for (size_t ri = 0; ri < m.Renderers.size(); ++ri) {
+        auto &w = m.Renderers[ri];
         for (const auto o : w.Objects) {
             w.Impacts.clear();
             for (uint32_t i = 0; i < impact_count; ++i)

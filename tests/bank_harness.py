@@ -58,8 +58,9 @@ class OracleScene:
         modes = modes or make_modes(mode_count, longest_t60)
         self.objects = []
         for o in range(object_count):
-            slot = self.bank.add_object(o, modes["shapes"], modes["positions"], modes["indices"])
-            self.bank.tune_object(slot, modes["freqs"], modes["t60s"])
+            mo = modes[o] if isinstance(modes, (list, tuple)) else modes  # one description for all, or one per object
+            slot = self.bank.add_object(o, mo["shapes"], mo["positions"], mo["indices"])
+            self.bank.tune_object(slot, mo["freqs"], mo["t60s"])
             self.bank.set_gains(slot, 1.0, 1.0)
             self.objects.append(slot)
         self.bank.install()
@@ -86,8 +87,9 @@ class DeviceScene:
         modes = modes or make_modes(mode_count, longest_t60)
         self.objects = []
         for o in range(object_count):
-            slot = self.bank.add_object(o, modes["shapes"], modes["positions"], modes["indices"])
-            self.bank.tune_object(slot, modes["freqs"], modes["t60s"])
+            mo = modes[o] if isinstance(modes, (list, tuple)) else modes  # one description for all, or one per object
+            slot = self.bank.add_object(o, mo["shapes"], mo["positions"], mo["indices"])
+            self.bank.tune_object(slot, mo["freqs"], mo["t60s"])
             self.bank.set_gains(slot, 1.0, 1.0)
             self.objects.append(slot)
         self.bank.install()

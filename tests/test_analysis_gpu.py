@@ -387,7 +387,7 @@ def test_results_do_not_depend_on_recycled_device_memory(api, ctx):
         "sc = bh.DeviceScene(8, 64, 0.5, 2)\n"
         "class O:  # the event type of the harness without the oracle\n"
         "    Event = lambda *a: hipbank.Event(*a)\n"
-        "for o in sc.objects: sc.enqueue(bh.impact_event(O, o, 1.0))\n"
+        "for o in sc.objects: sc.enqueue(bh.impact_event(O, o, 1.0, click=False))\n"
         "out['sig'] = [float(v).hex() for v in sc.render(2, bh.BLOCK)]\n"
         "print(json.dumps(out))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -421,3 +421,115 @@ def test_batch_of_meshes_through_the_sharding_path(api, ctx):
         assert len(r["eigenvalues"]) == 25 and np.array_equal(r["eigenvalues"], direct.eigenvalues)
         assert np.allclose(r["freqs"], direct.freqs, rtol=1e-6) and r["dofs"] == direct.profile["dofs"]
         assert abs(r["mass"] - direct.mass) <= 1e-12 * direct.mass
+
+
+def _residuals(sysg, ev, cols):
+    """Relative residuals ||K v - lambda M v|| / (|lambda - sigma| ||M v||) of the chosen eigenvector columns, with the
+    device's own products, and the largest deviation of their Gram block from the identity."""
+    V = sysg.eigenvectors(int(cols.max()) + 1)[:, cols]
+    KV, MV = sysg.matvec(0, V), sysg.matvec(1, V)
+    res = np.linalg.norm(KV - MV * ev[cols], axis=0) / (np.abs(ev[cols] - SIGMA) * np.linalg.norm(MV, axis=0))
+    return res, np.abs(V.T @ MV - np.eye(len(cols))).max()
+
+
+def test_skillet_config3_at_its_workload(api, ctx, oracle):
+    """BASELINE configs[2]: the thin iron skillet plate at ~100k tets (103,788) with 200 kept modes / 215 eigenpairs --
+    size-independent properties on the device result (residuals, M-orthonormality, rigid-body count, Leissa's free-plate
+    fundamental), then eigenvalue agreement with the oracle on the largest plate of the same family the oracle solves
+    within the test budget (6,912 tets, same 215 pairs)."""
+    import time
+    pts, tets, m, kw = meshes.workload("skillet_s100k")
+    assert 100_000 <= len(tets) <= 110_000 and kw["num_fem_modes"] == 215
+    mesh = api.Mesh(ctx, pts, tets)
+    sysg = api.System(ctx, mesh, api.material(*m))
+    nev = kw["num_fem_modes"]
+    t0 = time.perf_counter()
+    ev, prof = sysg.eigs(nev, SIGMA, 1e-5, max_iters=120)
+    print("skillet_s100k: %d tets, %d DOF, %d pairs in %.2f s, %d iterations" % (len(tets), sysg.n, nev, time.perf_counter() - t0, prof["restarts"]))
+    assert (np.abs(ev[:6]) < 1e-6 * ev[6]).all() and ev[6] > 0 and np.all(np.diff(ev[6:]) >= 0)
+    cols = np.r_[0:12, 12:nev:6, nev - 1]
+    res, ortho = _residuals(sysg, ev, cols)
+    assert res[6:].max() < 1.5e-5, res.max()
+    assert ortho < 1e-7
+    E, nu, rho, a, h = m[1], m[2], m[0], 0.26, 0.012
+    f_plate = 13.47 / (2 * np.pi * a * a) * np.sqrt(E * h ** 3 / (12 * (1 - nu ** 2)) / (rho * h))
+    assert abs(np.sqrt(ev[6]) / (2 * np.pi) / f_plate - 1) < 0.05
+    sysg.close()
+    mesh.close()
+    # the same family where the oracle can follow: every one of the 215 eigenvalues within 1e-6
+    pts, tets = meshes.kuhn_box(24, 24, 2, 0.26, 0.26, 0.012)
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), api.material(*m))
+    ev, _ = sysg.eigs(nev, SIGMA, 1e-6, max_iters=120)
+    evo, _, _ = oracle.System(pts, tets, oracle.material(*m)).eigs(nev, vectors=False)
+    elastic = evo > 1e-6 * evo[-1]
+    assert elastic.sum() == nev - 6
+    assert (np.abs(ev[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    sysg.close()
+
+
+def test_batch64_config4_through_solve_batch(api, oracle):
+    """BASELINE configs[3]: the 64 jittered RealImpact-size boxes (29,478 tets each, seven materials cycled, 45 eigenpairs)
+    through sharding.solve_batch on one rank with three solves in flight, as bench.py --workload batch64 runs them.  Every
+    mesh: converged, residuals of all its pairs below tolerance (checked with the device's own products before the system
+    is released), record fields consistent.  A sampled mesh is compared with the oracle's shift-invert result."""
+    import bench
+    from mesheditor_amd import sharding
+    items = bench.batch_meshes()
+    assert len(items) == 64 and all(len(m[1]) == 29478 for m in items)
+    ctxs = [api.Context(0) for _ in range(3)]
+    worst = {}
+
+    def solve(i, m, worker):
+        p, t, mat, kw = m
+        r = api.mesh2modes(ctxs[worker], p, t, api.material(*mat), p[:: len(p) // 10][:10].astype(np.float32), config=api.default_config(**kw), keep_system=True)
+        res, ortho = _residuals(r.system, r.eigenvalues, np.arange(len(r.eigenvalues)))
+        worst[i] = (float(res[6:].max()), float(ortho))
+        r.system.close()
+        return r
+    recs = sharding.solve_batch(items, solve, 64, None, threads=3, pos_max=16)
+    assert [r["index"] for r in recs] == list(range(64)) and all(r["ok"] for r in recs)
+    for r in recs:
+        i = r["index"]
+        assert len(r["eigenvalues"]) == 45 and r["dofs"] == 128625 and 0 < len(r["freqs"]) <= 30
+        assert (np.abs(r["eigenvalues"][:6]) < 1e-6 * r["eigenvalues"][6]).all()
+        assert worst[i][0] < 1.5e-5 and worst[i][1] < 1e-7, (i, worst[i])
+        rho = items[i][2][0]
+        p = items[i][0]
+        assert abs(r["mass"] - rho * np.prod(p.max(0) - p.min(0))) < 2e-6 * r["mass"]  # float (1.f / 6.f) in the reference's volume, SURVEY App. A
+        assert r["summary_shapes"].shape == (len(r["positions"]), 45, 3) and r["profile"]["iterate"] > 0
+    # materials differ, so do the spectra: no two meshes share a fundamental
+    f1 = np.array([r["freqs"][0] for r in recs])
+    assert len(np.unique(np.round(f1, 1))) > 50
+    i = 37
+    p, t, mat, kw = items[i]
+    evo, _, _ = oracle.System(p, t, oracle.material(*mat)).eigs(45, vectors=False)
+    elastic = evo > 1e-6 * evo[-1]
+    assert elastic.sum() == 39
+    assert (np.abs(recs[i]["eigenvalues"][elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    for c in ctxs:
+        c.close()
+
+
+def test_warm_start_against_the_oracles_warm_branch(api, ctx, oracle):
+    """The reference's warm path (SubspaceIterate, mesh2modes.cpp:339-428) restated in the oracle, side by side with the
+    device's seeded solve: same seed basis (the cold solve's eigenvectors as float, as ModalWarmStart keeps them), same
+    edited material.  The oracle's warm branch stops on a 1e-4 relative eigenvalue change, so it is the looser of the two;
+    both must agree with the oracle's cold solve of the edited body, and with each other within the warm tolerance."""
+    pts, tets, m, _ = meshes.workload("cube_small")
+    ex = pts[:: max(1, len(pts) // 10)].astype(np.float32)
+    kw = dict(num_modes=10, num_fem_modes=25, max_mode_freq=1e6)
+    edited = (m[0] * 1.1, m[1] * 1.21, m[2], m[3], m[4])
+    cold_o = oracle.mesh2modes(pts, tets, oracle.material(*m), ex, config=oracle.default_config(**kw), keep_basis=True)
+    cold_g = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(**kw), keep_basis=True)
+    assert cold_o.basis.shape == cold_g.basis.shape
+    for seed in (cold_o.basis, cold_g.basis):  # either side's basis seeds both
+        warm_o = oracle.mesh2modes(pts, tets, oracle.material(*edited), ex, config=oracle.default_config(**kw), seed_basis=seed)
+        warm_g = api.mesh2modes(ctx, pts, tets, api.material(*edited), ex, config=api.default_config(**kw), seed_basis=seed)
+        ref = oracle.mesh2modes(pts, tets, oracle.material(*edited), ex, config=oracle.default_config(**kw))
+        assert len(warm_o.freqs) == len(warm_g.freqs) == len(ref.freqs) == 10
+        assert abs(float(warm_g.freqs[0]) - float(warm_o.freqs[0])) < 0.05  # the reference bench's criterion (ModalSolverBench.cpp:384)
+        assert np.allclose(warm_o.freqs, ref.freqs, rtol=1e-4) and np.allclose(warm_g.freqs, ref.freqs, rtol=1e-6)
+        el = ref.eigenvalues > 1e-6 * ref.eigenvalues[-1]
+        assert (np.abs(warm_g.eigenvalues[el] - ref.eigenvalues[el]) / ref.eigenvalues[el]).max() < 1e-6
+        assert (np.abs(warm_o.eigenvalues[el] - ref.eigenvalues[el]) / ref.eigenvalues[el]).max() < 1e-3
+        assert np.allclose(warm_g.t60s, warm_o.t60s, rtol=1e-3)

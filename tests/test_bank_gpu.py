@@ -38,6 +38,52 @@ def test_signal_is_sample_exact(oracle, renderers, objects, modes, frames, block
     assert abs(so.bank.modal_energy - sg.bank.modal_energy) <= 1e-12 * max(so.bank.modal_energy, 1e-300)
 
 
+@pytest.mark.parametrize("renderers,objects,modes,frames,blocks", [(4, 16, 64, 512, 8), (1, 3, 40, 512, 30), (3, 7, 130, 333, 9)])
+def test_fp64_bank_through_the_mirror_is_sample_exact(oracle, renderers, objects, modes, frames, blocks):
+    """BASELINE north star 'sample-exact at fp64', behind the reference's API: ModalBank64 / ModalAudio64 (double columns,
+    impacts and output) against the oracle's double bank -- several renderers, overlapping impacts, real click filters,
+    decay to the audible prefix."""
+    def run(make):
+        sc = make()
+        _strike_all(sc, oracle)
+        a = sc.render(blocks // 2, frames)
+        for o in sc.objects[::2]:
+            sc.enqueue(bh.impact_event(oracle, o, -0.4, 1, 1.0 / 90.0))
+        b = sc.render(blocks - blocks // 2, frames)
+        return np.concatenate([a, b]), sc
+    ref, so = run(lambda: bh.OracleScene(oracle, objects, modes, 0.1, renderers, use_double=True))
+    got, sg = run(lambda: bh.DeviceScene(objects, modes, 0.1, renderers, use_double=True))
+    assert ref.dtype == got.dtype == np.float64 and np.abs(ref).max() > 0
+    assert np.array_equal(ref, got), np.abs(ref - got).max()
+    for name in ("CoeffRe", "CoeffIm", "RadiationGain", "OutPhaseIm", "OutPhaseRe", "StateRe", "StateIm"):
+        assert np.array_equal(so.bank.column(name), sg.bank.column(name)), name
+    for a, b in zip(so.bank.object_state(), sg.bank.object_state()):
+        assert np.array_equal(a, b)
+    assert so.bank.active_impacts == sg.bank.active_impacts
+
+
+def test_click_filter_and_impact_retirement_match_the_oracle(oracle):
+    """The per-impact recoil click (DF-II-T biquad driven by AccelAmp x force, ModalAudio.cpp:526-531) in isolation: an
+    impulse-free strike (J = 0) leaves only the click in the output.  Sample-exact against the oracle at two click gains,
+    and the impact retires in the same block on both sides once |z1| + |z2| < 1e-12 (:557-561)."""
+    for gain in (1.0, 0.37):
+        sigs, counts = [], []
+        for make in (lambda: bh.OracleScene(oracle, 2, 16, 0.05, 2), lambda: bh.DeviceScene(2, 16, 0.05, 2)):
+            sc = make()
+            sc.bank.set_click_gain(gain)
+            ev = bh.impact_event(oracle, sc.objects[1], 1.0, 0, 1.0 / 37.0)
+            ev.jx = ev.jy = ev.jz = 0.0
+            sc.enqueue(ev)
+            parts, n = [], []
+            for _ in range(6):
+                parts.append(sc.render(1, 256))
+                n.append(sc.bank.active_impacts)
+            sigs.append(np.concatenate(parts))
+            counts.append(n)
+        assert np.abs(sigs[0]).max() > 0 and np.array_equal(sigs[0], sigs[1]), np.abs(sigs[0] - sigs[1]).max()
+        assert counts[0] == counts[1] and counts[0][0] == 1 and counts[0][-1] == 0, counts
+
+
 def test_many_impacts_culling_and_silence(oracle):
     """More than four impacts on one object (the register fast path overflows), decay to silence, a re-strike from
     culled state, and a Silence event."""
@@ -162,7 +208,7 @@ def test_fp64_bank_sample_exact(oracle):
     events = [(o, 1.0 - 0.2 * o, o % 4, 1.0 / (100.0 + 50 * o)) for o in range(n_obj)]
     impacts = (_lib.Impact * len(events))()
     for i, (o, imp, ex, step) in enumerate(events):
-        ob.enqueue(bh.impact_event(oracle, o, imp, ex, step))
+        ob.enqueue(bh.impact_event(oracle, o, imp, ex, step, click=False))
         st = np.float32(step)
         theta = 2 * np.pi * np.float64(st)
         impacts[i] = _lib.Impact(o, ex, int(np.ceil(1.0 / np.float64(st))), 0, np.float32(imp), np.float32(0.5 * imp), 0.0, 1.0, 0.0, np.cos(theta), np.sin(theta),
@@ -206,11 +252,8 @@ def test_full_size_bank(oracle):
     the oracle, then real-time factor of the device render."""
     import time
     n_obj, n_modes = 1024, 256
-    modes = bh.make_modes(n_modes, 2.0)
-
-    def build(make_scene):
-        sc = make_scene()
-        return sc
+    # config 5's bank: every object its own frequencies (f_k x (1 + 0.001 o)), as the bench
+    modes = [bh.make_modes(n_modes, 2.0, freq_scale=1.0 + 0.001 * o) for o in range(n_obj)]
     so = bh.OracleScene(oracle, n_obj, n_modes, 2.0, 4, modes=modes)
     sg = bh.DeviceScene(n_obj, n_modes, 2.0, 4, modes=modes)
     # the SPSC queue holds 256 events: strike in waves of 256 per block, as a caller would
