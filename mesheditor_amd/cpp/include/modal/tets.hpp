@@ -1,9 +1,13 @@
-// A tet-generation front end for the path: fills a closed triangle surface that is
-// star-shaped about its centroid -- convex bodies, blobs, the boxes and spheres of the reference's own tests -- with
-// positively oriented tetrahedra.  It honours the contract of the reference's tetra::Tetrahedralize
-// (src/mesh/Tetrahedralize.h:49-61): input vertex i keeps index i, every input triangle is a boundary face, added points
-// lie strictly inside, triangle winding is ignored, and an open or unsuitable surface returns an error string.  The
-// reference's constrained Delaunay tetrahedraliser (10 k lines, any closed surface) is not rebuilt.
+// The tet-generation front end of the path, under the contract of the reference's
+// tetra::Tetrahedralize (src/mesh/Tetrahedralize.h:49-61): input vertex i keeps index i, every input triangle is on the
+// boundary, triangle winding is ignored, every tet is positively oriented, and an open or unrecoverable surface returns an
+// error string.  Two fills:
+//   tetra::Tetrahedralize   any closed, non-self-intersecting surface -- non-convex, non-star-shaped, any genus, nested
+//                           cavities: a conforming Delaunay tetrahedralisation on exact predicates.  Surface triangles the
+//                           Delaunay mesh lacks are recovered by splitting them (points ON the surface, as the reference's
+//                           own boundary Steiner points; its validator accepts refined faces).
+//   tetra::FillStarShaped   surfaces star-shaped about their centroid: layered shells, no point on the surface is added,
+//                           well-shaped elements (the Delaunay fill of a bare surface has long interior tets).
 #pragma once
 #include "types.hpp"
 
@@ -17,8 +21,13 @@ namespace tetra {
 struct Result {
     TetMesh Mesh;
     std::string Error; // empty on success
+    uint32_t BoundarySteinerCount{0}; // points added ON the surface (refined input triangles); always 0 for FillStarShaped
     explicit operator bool() const { return Error.empty(); }
 };
+struct Options {
+    size_t MaxSteinerPoints{0}; // boundary-recovery budget; 0 = 8 x the input vertices + 4096
+};
+Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options = {});
 // `layers` shells between the surface and the centroid (0: a plain fan of one tet per triangle).  Each layer is a copy of
 // the surface shrunk towards the centroid; the prisms between consecutive shells are cut into three tets with the
 // smallest-index diagonal rule, so neighbouring prisms agree on their shared faces.
@@ -31,6 +40,8 @@ struct ObjSurface {
     std::vector<vec3> Positions;
     std::vector<uint32_t> TriangleIndices;
 };
-// The reference's GenerateTets (src/mesh/Tets.cpp:265): float surface in, tet mesh out.
+// The reference's GenerateTets (src/mesh/Tets.cpp:265): float surface in, tet mesh out -- the general fill.
+tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, const tetra::Options &options);
+// With a layer count: the layered fill when the surface is star-shaped about its centroid, the general fill otherwise.
 tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, uint32_t layers = 2);
 std::optional<ObjSurface> LoadObj(const std::filesystem::path &);

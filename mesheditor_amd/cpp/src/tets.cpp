@@ -96,10 +96,23 @@ Result FillStarShaped(std::span<const dvec3> points, std::span<const uint32_t> t
 }
 } // namespace tetra
 
-tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, uint32_t layers) {
+namespace {
+std::vector<dvec3> Widened(const std::vector<vec3> &positions) {
     std::vector<dvec3> points(positions.size());
     for (size_t i = 0; i < positions.size(); ++i) points[i] = {double(positions[i].x), double(positions[i].y), double(positions[i].z)};
-    return tetra::FillStarShaped(points, triangle_indices, layers);
+    return points;
+}
+} // namespace
+
+tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, const tetra::Options &options) {
+    return tetra::Tetrahedralize(Widened(positions), triangle_indices, options);
+}
+
+tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, uint32_t layers) {
+    const auto points = Widened(positions);
+    auto layered = tetra::FillStarShaped(points, triangle_indices, layers);
+    if (layered || layered.Error.find("star-shaped") == std::string::npos) return layered;
+    return tetra::Tetrahedralize(points, triangle_indices); // not star-shaped: the general fill
 }
 
 std::optional<ObjSurface> LoadObj(const std::filesystem::path &path) {

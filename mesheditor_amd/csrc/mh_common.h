@@ -7,10 +7,12 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -44,11 +46,17 @@ struct MhError : std::runtime_error {
 #define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
 
 // Size-bucketed caching allocator: device buffers are recycled across solves so a steady-state solve performs no
-// hipMalloc/hipFree (which synchronise the device).
+// hipMalloc/hipFree (which synchronise the device).  The cache of idle blocks is capped (MH_POOL_CAP_MB, default 16 GiB):
+// a release that takes it over the cap frees the largest idle blocks first, so a long-lived process that once solved
+// a huge mesh does not sit on that memory for ever.
 struct DevicePool {
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> live;
-    size_t bytes_reserved{0};
+    size_t bytes_reserved{0}, bytes_idle{0};
+    static size_t idle_cap() {
+        static const size_t cap = (getenv("MH_POOL_CAP_MB") ? size_t(std::max(0, atoi(getenv("MH_POOL_CAP_MB")))) : size_t(16) << 10) << 20;
+        return cap;
+    }
     static size_t round_up(size_t n) {
         if (n < 256) return 256;
         if (n < (1u << 20)) return (n + 4095) & ~size_t(4095);
@@ -60,11 +68,16 @@ struct DevicePool {
         if (it != free_blocks.end() && it->first <= r + r / 4 + (size_t(1) << 20)) {
             void *p = it->second;
             live[p] = it->first;
+            bytes_idle -= it->first;
             free_blocks.erase(it);
             return p;
         }
         void *p = nullptr;
-        HIP_CHECK(hipMalloc(&p, r));
+        if (hipMalloc(&p, r) != hipSuccess) { // out of device memory: give the idle cache back and try once more
+            (void)hipGetLastError();
+            trim();
+            HIP_CHECK(hipMalloc(&p, r));
+        }
         bytes_reserved += r;
         live[p] = r;
         return p;
@@ -74,11 +87,20 @@ struct DevicePool {
         auto it = live.find(p);
         if (it == live.end()) return;
         free_blocks.emplace(it->second, p);
+        bytes_idle += it->second;
         live.erase(it);
+        while (bytes_idle > idle_cap() && !free_blocks.empty()) { // largest idle block first
+            auto big = std::prev(free_blocks.end());
+            (void)hipFree(big->second);
+            bytes_idle -= big->first;
+            bytes_reserved -= big->first;
+            free_blocks.erase(big);
+        }
     }
     void trim() {
         for (auto &kv : free_blocks) (void)hipFree(kv.second), bytes_reserved -= kv.first;
         free_blocks.clear();
+        bytes_idle = 0;
     }
     ~DevicePool() {
         trim();

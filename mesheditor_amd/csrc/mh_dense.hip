@@ -8,6 +8,14 @@
 //   result is bit-reproducible.  Roofline: max(8 n (wa + wb) bytes / HBM, 2 n wa wb flops / fp64 MFMA peak).
 #include "mh_common.h"
 
+// hipFuncSetAttribute once per (kernel, device): function attributes are per device, and first calls may race between the host
+// threads of concurrent solves -- a per-call-site table of once-flags indexed by the context's device.
+struct PerDeviceOnce {
+    static constexpr int MaxDevices = 64;
+    std::once_flag flag[MaxDevices];
+    template<typename F> void run(int device, F &&f) { std::call_once(flag[device >= 0 && device < MaxDevices ? device : 0], std::forward<F>(f)); }
+};
+
 namespace {
 constexpr int KC = 32; // rows staged per step
 
@@ -307,11 +315,8 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
         constexpr int PA = (CA * 16) % 32 == 16 ? CA * 16 : CA * 16 + 16, PB = (CB * 16) % 32 == 16 ? CB * 16 : CB * 16 + 16;
         const size_t fold = KS > 1 ? size_t(GI * GJ) * TI * TJ * 256 * sizeof(double) : 0;
         const size_t bytes = std::max(size_t(KC) * (PA + PB) * sizeof(double), fold);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gram_blocked<TI, TJ, GI, GJ, KS, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        static PerDeviceOnce attr;
+        attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gram_blocked<TI, TJ, GI, GJ, KS, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
         k_gram_blocked<TI, TJ, GI, GJ, KS, OCC><<<nwg, GI * GJ * KS * 64, bytes, ctx->stream>>>(x, int(ldx), int(wa), y, int(ldy), ymap, int(wb), n, rows_per_wg, workspace);
     };
 #define IC(v) std::integral_constant<int, v>{}
@@ -1078,11 +1083,8 @@ bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32
     if (m < 2 || m > 256 || k < 1 || k > m || k > 128) return false;
     const size_t lds = (size_t(7) * 256 + 1024 + 512 + size_t(m) * k) * sizeof(double);
     if (lds > 158 * 1024) return false;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tridiag_lowest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr;
+    attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tridiag_lowest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     static const bool spread = !(getenv("MH_TRIDIAG_SPREAD") && atoi(getenv("MH_TRIDIAG_SPREAD")) == 0);
     if (spread) {
         k_tridiag_values<<<k, 256, 0, ctx->stream>>>(d, e, int(m), lam_scratch);
@@ -1211,11 +1213,8 @@ void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32
 
 void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "potrf_small: order %u outside 1..128", w);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr;
+    attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });
     k_potrf_small<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
     KERNEL_CHECK();
 }

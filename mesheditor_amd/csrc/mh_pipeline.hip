@@ -328,6 +328,116 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
     mval[b] = m;
 }
 
+// The same sums, organised by node row: one wave per row of node blocks.
+//   * The contributors of a row are (element, a, c) for every element e around the row's node (a = the node's place in e,
+//     c = 0 .. NN-1): NN per element, contiguous in the sorted contributor list.  Lanes take ONE contributor each, 64 per
+//     round, so the expensive part -- the 4 x 4 x 3 x 3 contraction of the gradient table with the element's barycentric
+//     gradients -- is perfectly balanced (in the one-thread-per-block form the lane of the diagonal block walks through
+//     every element around the node, 7 .. 30 of them, while its neighbours idle after one to three).
+//   * The element data a row needs (volume + four gradients = 13 doubles per element; the elements are exactly the
+//     contributors of the row's diagonal block) is staged once per row in a wave-private LDS slice; the shape-function
+//     tables live in LDS for the workgroup.
+//   * A round's 64 contributions go through LDS to the lanes that own the blocks, which add them in contributor order --
+//     the order the one-thread-per-block kernel uses, so both produce the same bits.
+//   * The finished 3 x 3 blocks of a row leave through LDS as whole contiguous runs of doubles (coalesced), not as nine
+//     72-byte-strided stores per lane.
+template<int NN> __global__ void __launch_bounds__(256) k_assemble_rows(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ seg,
+                                                                      const uint32_t *__restrict__ payload, uint32_t nrows, const double *__restrict__ basis,
+                                                                      const double *__restrict__ tables, double rho, double lambda, double mu,
+                                                                      double *__restrict__ kval, double *__restrict__ mval) {
+    constexpr int NT = NN * NN + NN * 4 * NN * 4, WPB = 4, MAXE = 32;
+    __shared__ double s_tab[NT];
+    __shared__ double s_basis[WPB][MAXE * 13];
+    __shared__ uint32_t s_tet[WPB][MAXE];
+    __shared__ double s_x[WPB][64 * 10]; // a round's contributions [value][lane]; afterwards the row's blocks [block][9]
+    for (int i = threadIdx.x; i < NT; i += 256) s_tab[i] = tables[i];
+    __syncthreads();
+    const double *s_mass = s_tab, *s_grad = s_tab + NN * NN;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * WPB + wave;
+    if (row >= nrows) return; // no workgroup barrier below this line
+    const uint32_t p0 = row_ptr[row], p1 = row_ptr[row + 1], nblk = p1 - p0;
+    // the row's elements = contributors of its diagonal block
+    uint32_t diag = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+        const bool hit = b0 + lane < nblk && col[p0 + b0 + lane] == row;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            diag = b0 + uint32_t(__ffsll(m)) - 1;
+            break;
+        }
+    }
+    const uint32_t e0 = seg[p0 + diag], ne = seg[p0 + diag + 1] - e0;
+    const bool staged = ne <= uint32_t(MAXE); // more elements around one node than the slice holds: read them from memory
+    double *sb = s_basis[wave], *sx = s_x[wave];
+    uint32_t *st = s_tet[wave];
+    if (staged) {
+        if (lane < ne) st[lane] = payload[e0 + lane] / (NN * NN);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t f = lane; f < ne * 13; f += 64) sb[f] = basis[13 * size_t(st[f / 13]) + f % 13];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) { // 64 blocks of the row at a time (a row rarely has more)
+        const uint32_t nb = min(64u, nblk - b0);
+        const bool owner = lane < nb;
+        const uint32_t mine0 = owner ? seg[p0 + b0 + lane] : 0u, mine1 = owner ? seg[p0 + b0 + lane + 1] : 0u;
+        const uint32_t qa = seg[p0 + b0], qb = seg[p0 + b0 + nb];
+        double k[9] = {}, m = 0;
+        for (uint32_t r = qa; r < qb; r += 64) {
+            const uint32_t q = r + lane;
+            double cv[10] = {};
+            if (q < qb) {
+                const uint32_t pl = payload[q];
+                const uint32_t t = pl / (NN * NN), ac = pl % (NN * NN), a = ac / NN, c = ac % NN;
+                double eb[13];
+                if (staged) {
+                    uint32_t slot = 0;
+                    for (uint32_t e = 0; e < ne; ++e) slot = st[e] == t ? e : slot;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) eb[i] = sb[13 * slot + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) eb[i] = basis[13 * size_t(t) + i];
+                }
+                const double vol = eb[0];
+                cv[9] = rho * vol * s_mass[a * NN + c];
+                double g[3][3] = {};
+                for (int kk = 0; kk < 4; ++kk) {
+                    for (int ll = 0; ll < 4; ++ll) {
+                        const double w = s_grad[((a * 4 + kk) * NN + c) * 4 + ll];
+                        if (w == 0) continue;
+                        for (int pp = 0; pp < 3; ++pp)
+                            for (int qq = 0; qq < 3; ++qq) g[pp][qq] += w * (eb[1 + 3 * kk + pp] * eb[1 + 3 * ll + qq]);
+                    }
+                }
+                const double trace = g[0][0] + g[1][1] + g[2][2];
+                for (int pp = 0; pp < 3; ++pp)
+                    for (int qq = 0; qq < 3; ++qq) cv[3 * pp + qq] = vol * (lambda * g[pp][qq] + mu * g[qq][pp] + (pp == qq ? mu * trace : 0.0));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the previous round has been consumed
+#pragma unroll
+            for (int e = 0; e < 10; ++e) sx[e * 64 + lane] = cv[e];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t lo = max(mine0, r), hi = min(mine1, r + 64);
+            for (uint32_t qq = lo; qq < hi; ++qq) { // contributor order
+                const uint32_t j = qq - r;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) k[e] += sx[e * 64 + j];
+                m += sx[9 * 64 + j];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (owner) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) sx[9 * lane + e] = k[e];
+            mval[p0 + b0 + lane] = m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double *out = kval + 9 * size_t(p0 + b0);
+        for (uint32_t f = lane; f < 9 * nb; f += 64) out[f] = sx[f];
+    }
+}
+
 
 // ---- level 0: rigid-body aggregates ------------------------------------------------------------------------
 __global__ void k_aggregate_t(const double *__restrict__ p1_xyz, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ tmat) {
@@ -450,7 +560,11 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
         // SURVEY 8d's count for the assembly: per tet 16 B corner ids + 4 x 24 B coordinates + 40 B node ids read (the
         // element bases are built from them), 80 B (9 K values + 1 M value) written per node block
         TimedLaunch timed(ctx, MH_KERNEL_ASSEMBLY, NN == 10 ? 152.0 * double(nt) + 80.0 * double(nb) : 0.0);
-        k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
+        static const bool by_block = getenv("MH_ASSEMBLE_BY_BLOCK") && atoi(getenv("MH_ASSEMBLE_BY_BLOCK")) != 0; // the one-thread-per-block form, kept for comparison
+        if (by_block) k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
+        else
+            k_assemble_rows<NN><<<div_up(nnodes, 4), 256, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, seg, pay_s, nnodes, basis, tables_dev, mat.density, lambda, mu, lvl.kval,
+                                                                           lvl.mval);
     }
     KERNEL_CHECK();
 }
@@ -622,6 +736,12 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
 
     // --- rigid-body aggregates over runs of consecutive (Morton-ordered) P1 nodes
     if (const char *e = getenv("MH_AGG")) sys->agg_size = std::max(2, atoi(e));
+    // The coarse operator is dense of order 6 n_agg and inverted explicitly (O(n0^2) memory, 2 n0^3 flops): with a fixed
+    // aggregate size it would grow with the mesh (33 k at a million tets: 9 GB and 7e13 flops per set-up).  Aggregates
+    // grow instead so that the order stays at or below MaxCoarseOrder (3 690 at the 100k-tet metric mesh is untouched);
+    // larger aggregates make a weaker coarse correction (more iterations), never a failure.
+    constexpr uint32_t MaxCoarseOrder = 6144;
+    if (uint64_t(6) * (npts / sys->agg_size) > MaxCoarseOrder) sys->agg_size = uint32_t((uint64_t(6) * npts + MaxCoarseOrder - 1) / MaxCoarseOrder);
     sys->n_agg = std::max(1u, npts / sys->agg_size);
     sys->agg_t.reset(ctx, size_t(npts) * 18);
     k_aggregate_t<<<div_up(sys->n_agg, 64), 64, 0, st>>>(sys->p1_xyz, npts, sys->agg_size, sys->n_agg, sys->agg_t);

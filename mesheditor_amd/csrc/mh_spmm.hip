@@ -134,12 +134,16 @@ struct ChebStep {
 #else
 #define MH_SPMM_OCC
 #endif
-template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false, int EPI = 0>
+// UR = gather rounds in flight per wave, PRE = the Chebyshev step's own rows requested before the products.  The big (P2) level
+// runs UR = 1, PRE = false: occupancy hides its gathers best.  A level with fewer rows than the chip has wave slots (the P1
+// operator: 20 k rows for 8 k slots) is a chain of dependent round trips per wave instead -- there every row's gathers go out
+// together (UR = 4) and the epilogue's operands are prefetched.
+template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool WITH_A, bool MAPOUT = false, int EPI = 0, int UR = MH_SPMM_U, bool PRE = false>
 __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
                                                  uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{},
                                                  uint32_t xpitch = 0) { // xpitch (MAPOUT): row pitch of x when the launch covers a column range of a wider panel
-    constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = MH_SPMM_U; // V = panel entries per lane (16 bytes; 1 for odd pitches)
+    constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = UR; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
     __shared__ __attribute__((aligned(16))) TV sv[TB / 64][WITH_A ? STRIP * VP : 1];
@@ -156,11 +160,10 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
     Acc acc[3], macc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = macc[i] = Acc(0);
-#ifdef MH_SPMM_EPI_PREFETCH
-    // EPI: the rows the step updates are requested now, so they arrive while the products are formed
-    Acc er[3], ed[3], ex[3];
-    TY edinv[3];
-    if constexpr (EPI == 1) {
+    // EPI with PRE: the rows the step updates are requested now, so they arrive while the products are formed
+    Acc er[PRE ? 3 : 1], ed[PRE ? 3 : 1], ex[PRE ? 3 : 1];
+    TY edinv[PRE ? 3 : 1];
+    if constexpr (EPI == 1 && PRE) {
         if (g == 0 && act) {
             const size_t o = size_t(3) * row * w + coff;
 #pragma unroll
@@ -172,7 +175,6 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
             }
         }
     }
-#endif
     const uint32_t p0 = __builtin_amdgcn_readfirstlane(row_ptr[row]), p1 = __builtin_amdgcn_readfirstlane(row_ptr[row + 1]);
     TV *svw = sv[wave];
     TV *smw = sm[wave];
@@ -272,17 +274,18 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const size_t oi = o + size_t(i) * w;
-#ifdef MH_SPMM_EPI_PREFETCH
-                const Acc rv = er[i] - acc[i];
-                const Acc dv = epi.c1 * ed[i] + (epi.c2 * edinv[i]) * rv;
-                const Acc xn = ex[i] + dv;
-#else
-                // loaded here rather than up front: nine more vector registers per lane would cost two waves of occupancy,
-                // and occupancy is what hides the gathers
-                const Acc rv = *reinterpret_cast<const Acc *>(epi.r + oi) - acc[i];
-                const Acc dv = epi.c1 * __builtin_convertvector(*reinterpret_cast<const Vec *>(x + oi), Acc) + (epi.c2 * epi.dinv[size_t(3) * row + i]) * rv;
-                const Acc xn = *reinterpret_cast<const Acc *>(epi.x + oi) + dv;
-#endif
+                Acc rv, dv, xn;
+                if constexpr (PRE) {
+                    rv = er[i] - acc[i];
+                    dv = epi.c1 * ed[i] + (epi.c2 * edinv[i]) * rv;
+                    xn = ex[i] + dv;
+                } else {
+                    // loaded here rather than up front: nine more vector registers per lane would cost two waves of occupancy,
+                    // and occupancy is what hides the gathers of the big level
+                    rv = *reinterpret_cast<const Acc *>(epi.r + oi) - acc[i];
+                    dv = epi.c1 * __builtin_convertvector(*reinterpret_cast<const Vec *>(x + oi), Acc) + (epi.c2 * epi.dinv[size_t(3) * row + i]) * rv;
+                    xn = *reinterpret_cast<const Acc *>(epi.x + oi) + dv;
+                }
                 *reinterpret_cast<Acc *>(epi.r + oi) = rv;
                 *reinterpret_cast<Acc *>(epi.d_out + oi) = dv;
                 *reinterpret_cast<Acc *>(epi.x + oi) = xn;
@@ -317,6 +320,13 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
     }
 }
 
+// Fewer rows than ~4 waves per wave slot of the chip (256 CUs x 4 SIMDs x 8 waves): the launch is a latency chain per wave,
+// not a throughput problem (MH_SPMM_SMALL=0 disables the distinction).
+inline bool latency_bound_level(const BsrLevel &lvl) {
+    static const bool on = !(getenv("MH_SPMM_SMALL") && atoi(getenv("MH_SPMM_SMALL")) == 0);
+    return on && lvl.n_nodes < 32768;
+}
+
 template<typename TV, typename TX, typename TY, bool WITH_M, bool WITH_A>
 bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const TV *vals9, const TX *x, TY *y, const TV *mscal, TY *y2, uint32_t w) {
     constexpr uint32_t VFULL = 16 / sizeof(TX);
@@ -329,7 +339,10 @@ bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const TV *vals9, con
         constexpr int V = decltype(v_tag)::value;
         auto go = [&](auto cl_tag) {
             constexpr int CL = decltype(cl_tag)::value;
-            k_spmm_wide<TV, TX, TY, V, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
+            if (latency_bound_level(lvl))
+                k_spmm_wide<TV, TX, TY, V, CL, WITH_M, WITH_A, false, 0, 4><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
+            else
+                k_spmm_wide<TV, TX, TY, V, CL, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, lvl.n_nodes, w, xcd);
         };
         const uint32_t lanes = div_up(w, uint32_t(V));
         if (lanes <= 8) go(std::integral_constant<int, 8>{});
@@ -451,8 +464,12 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
     epi.r = r; epi.dinv = dinv; epi.d_out = d_out; epi.x = x; epi.c1 = c1; epi.c2 = c2;
     auto go = [&](auto cl_tag) {
         constexpr int CL = decltype(cl_tag)::value;
-        k_spmm_wide<float, float, float, 4, CL, false, true, false, 1><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval32.get(), static_cast<const float *>(nullptr), d_in,
-                                                                                                   static_cast<float *>(nullptr), static_cast<float *>(nullptr), lvl.n_nodes, w, xcd, 0, 0, nullptr, epi);
+        if (latency_bound_level(lvl))
+            k_spmm_wide<float, float, float, 4, CL, false, true, false, 1, 4, true><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval32.get(), static_cast<const float *>(nullptr), d_in,
+                                                                                                                static_cast<float *>(nullptr), static_cast<float *>(nullptr), lvl.n_nodes, w, xcd, 0, 0, nullptr, epi);
+        else
+            k_spmm_wide<float, float, float, 4, CL, false, true, false, 1><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval32.get(), static_cast<const float *>(nullptr), d_in,
+                                                                                                       static_cast<float *>(nullptr), static_cast<float *>(nullptr), lvl.n_nodes, w, xcd, 0, 0, nullptr, epi);
     };
     const uint32_t lanes = w / 4;
     if (lanes <= 8) go(std::integral_constant<int, 8>{});

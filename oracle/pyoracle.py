@@ -129,6 +129,10 @@ def lib():
         L.mo_estimate_contact_time.argtypes = [C.c_double, vp, vp, vp, C.c_double, C.POINTER(Material), C.c_double, C.c_double,
                                                C.POINTER(Material), C.c_double, C.c_double, C.c_double, C.c_double]
         L.mo_estimate_contact_time.restype = C.c_double
+        # OpenMP team of the sparse factorisation / solves / Lanczos kernels: a modest team by default.  The loops are
+        # short (a front, a panel column); on a many-core host (the GPU box has 256) a team of every core spends its time in
+        # fork/join -- measured: a 20 s solve became 650 s.  bench.py sets the team size explicitly for its timed rows.
+        L.mo_set_threads(max(1, min(os.cpu_count() or 1, 16)))
         _LIB = L
     return _LIB
 

@@ -4,8 +4,10 @@
 #include "harness.hpp"
 
 #include <modal/tets.hpp>
+#include <predicates.hpp> // the mirror's exact orient3d (mesheditor_amd/cpp/src), as the reference validator uses its exact predicate
 
 #include <algorithm>
+#include <cmath>
 #include <array>
 #include <fstream>
 #include <map>
@@ -139,6 +141,232 @@ CASE(unsuitable_surfaces_return_an_error) {
     bad.T[0] = 99;
     EXPECT(!tetra::FillStarShaped(bad.P, bad.T));
     EXPECT(!tetra::FillStarShaped({}, {}));
+}
+
+// ---- the general fill: any closed surface ---------------------------------------------------------------------------------
+namespace {
+// p on triangle (a, b, c), to the scaled tolerance of the reference's validator (tests/ValidateTetMesh.h: 1e-9)
+bool OnTriangle(const dvec3 &a, const dvec3 &b, const dvec3 &c, const dvec3 &p) {
+    const dvec3 u = b - a, v = c - a, w = p - a;
+    const dvec3 n{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    const double n2 = n.x * n.x + n.y * n.y + n.z * n.z;
+    if (n2 == 0) return false;
+    const double scale = std::sqrt((u.x * u.x + u.y * u.y + u.z * u.z) * (v.x * v.x + v.y * v.y + v.z * v.z));
+    if (std::abs((n.x * w.x + n.y * w.y + n.z * w.z) / std::sqrt(n2)) > 1e-9 * std::sqrt(scale)) return false;
+    // barycentric coordinates by projected areas
+    const auto tri_area = [&](const dvec3 &p0, const dvec3 &p1, const dvec3 &p2) {
+        const dvec3 e = p1 - p0, f = p2 - p0;
+        return (e.y * f.z - e.z * f.y) * n.x + (e.z * f.x - e.x * f.z) * n.y + (e.x * f.y - e.y * f.x) * n.z;
+    };
+    const double l0 = tri_area(p, b, c) / n2, l1 = tri_area(a, p, c) / n2, l2 = tri_area(a, b, p) / n2;
+    return l0 > -1e-9 && l1 > -1e-9 && l2 > -1e-9;
+}
+// The reference validator's rules for a general fill: input vertices unmoved, tets positive, faces paired, every boundary face
+// is an input triangle or lies inside one (a refinement), every input triangle is present or covered by boundary faces
+// inside it, and the tets fill the surface's volume (divergence theorem on the input triangles).
+std::string ValidateGeneral(const Surface &s, const TetMesh &mesh, bool oriented_input = true) {
+    for (size_t i = 0; i < s.P.size(); ++i)
+        if (mesh.Points[i].x != s.P[i].x || mesh.Points[i].y != s.P[i].y || mesh.Points[i].z != s.P[i].z) return "input vertex moved";
+    std::map<std::array<uint32_t, 3>, int> faces;
+    double volume6 = 0;
+    static constexpr int F[4][3]{{1, 3, 2}, {0, 2, 3}, {0, 3, 1}, {0, 1, 2}};
+    for (const auto &t : mesh.Tets) {
+        // exact sign, as the reference's validator (geom::Orient3D): four nearly coplanar input points (the corners of a
+        // latitude-longitude quad) legitimately span a tet of volume ~1e-18, which the analysis' degenerate filter drops
+        if (exact::Orient3D(mesh.Points[t[0]], mesh.Points[t[1]], mesh.Points[t[2]], mesh.Points[t[3]]) <= 0) return "non-positive tet";
+        volume6 += Vol6(mesh.Points[t[0]], mesh.Points[t[1]], mesh.Points[t[2]], mesh.Points[t[3]]);
+        for (const auto &f : F) ++faces[Sorted(t[f[0]], t[f[1]], t[f[2]])];
+    }
+    std::vector<std::array<uint32_t, 3>> boundary, input;
+    for (size_t i = 0; i < s.T.size(); i += 3) input.push_back(Sorted(s.T[i], s.T[i + 1], s.T[i + 2]));
+    for (const auto &[f, count] : faces) {
+        if (count > 2) return "a face shared by more than two tets";
+        if (count == 1) boundary.push_back(f);
+    }
+    const auto within = [&](const std::array<uint32_t, 3> &in, const std::array<uint32_t, 3> &f) {
+        for (const uint32_t v : f)
+            if (!OnTriangle(s.P[in[0]], s.P[in[1]], s.P[in[2]], mesh.Points[v])) return false;
+        return true;
+    };
+    std::vector<int> covered(input.size(), 0);
+    for (const auto &f : boundary) {
+        bool placed = false;
+        for (size_t i = 0; i < input.size() && !placed; ++i)
+            if (input[i] == f || within(input[i], f)) placed = true, covered[i] = 1;
+        if (!placed) return "boundary face is not on the input surface";
+    }
+    for (size_t i = 0; i < input.size(); ++i)
+        if (!covered[i] && !faces.count(input[i])) return "input triangle missing from the tet mesh";
+    if (oriented_input) {
+        double surface6 = 0;
+        for (size_t i = 0; i < s.T.size(); i += 3) {
+            const dvec3 &a = s.P[s.T[i]], &b = s.P[s.T[i + 1]], &c = s.P[s.T[i + 2]];
+            surface6 += a.x * (b.y * c.z - b.z * c.y) - a.y * (b.x * c.z - b.z * c.x) + a.z * (b.x * c.y - b.y * c.x);
+        }
+        if (std::abs(std::abs(volume6) - std::abs(surface6)) > 1e-6 * std::abs(surface6)) return "mesh volume does not match the surface: " + std::to_string(volume6 / 6) + " vs " + std::to_string(surface6 / 6);
+    }
+    return {};
+}
+// a parametric quad grid closed in both directions (torus) or with poles welded (sphere); consistently wound
+Surface Torus(double R, double r, int nu, int nv) {
+    Surface s;
+    for (int i = 0; i < nu; ++i)
+        for (int j = 0; j < nv; ++j) {
+            const double u = 2 * M_PI * i / nu, v = 2 * M_PI * j / nv;
+            s.P.push_back({(R + r * std::cos(v)) * std::cos(u), (R + r * std::cos(v)) * std::sin(u), r * std::sin(v)});
+        }
+    const auto id = [&](int i, int j) { return uint32_t((i % nu) * nv + j % nv); };
+    for (int i = 0; i < nu; ++i)
+        for (int j = 0; j < nv; ++j) {
+            s.T.insert(s.T.end(), {id(i, j), id(i + 1, j), id(i + 1, j + 1)});
+            s.T.insert(s.T.end(), {id(i, j), id(i + 1, j + 1), id(i, j + 1)});
+        }
+    return s;
+}
+Surface Sphere(double radius, int rings, int segments, double noise, unsigned seed, dvec3 centre = {0, 0, 0}, bool inward = false) {
+    Surface s;
+    unsigned state = seed * 2654435761u + 1u;
+    const auto jitter = [&] {
+        state = state * 1664525u + 1013904223u;
+        return 1.0 + noise * (double(state >> 8) / double(1u << 24) - 0.5);
+    };
+    const auto put = [&](double x, double y, double z) {
+        const double k = jitter();
+        s.P.push_back({centre.x + k * x, centre.y + k * y, centre.z + k * z});
+    };
+    put(0, 0, radius);
+    for (int i = 1; i < rings; ++i)
+        for (int j = 0; j < segments; ++j) {
+            const double th = M_PI * i / rings, ph = 2 * M_PI * j / segments;
+            put(radius * std::sin(th) * std::cos(ph), radius * std::sin(th) * std::sin(ph), radius * std::cos(th));
+        }
+    put(0, 0, -radius);
+    const uint32_t south = uint32_t(s.P.size() - 1);
+    const auto id = [&](int i, int j) { return uint32_t(1 + (i - 1) * segments + j % segments); };
+    const auto tri = [&](uint32_t a, uint32_t b, uint32_t c) {
+        if (inward) s.T.insert(s.T.end(), {a, c, b});
+        else s.T.insert(s.T.end(), {a, b, c});
+    };
+    for (int j = 0; j < segments; ++j) {
+        tri(0, id(1, j), id(1, j + 1));
+        tri(south, id(rings - 1, j + 1), id(rings - 1, j));
+        for (int i = 1; i + 1 < rings; ++i) {
+            tri(id(i, j), id(i + 1, j), id(i + 1, j + 1));
+            tri(id(i, j), id(i + 1, j + 1), id(i, j + 1));
+        }
+    }
+    return s;
+}
+// a bowl: the lower half of a thick spherical shell, closed by a flat annular rim (thin-walled and non-star-shaped)
+Surface Bowl(double outer, double inner, int rings, int segments) {
+    Surface s;
+    const auto ring = [&](double radius, int i) { // ring i of `rings` from the rim (i = 0, z = 0) down towards the pole
+        const double th = M_PI / 2 + (M_PI / 2) * i / rings;
+        std::vector<uint32_t> ids;
+        for (int j = 0; j < segments; ++j) {
+            const double ph = 2 * M_PI * j / segments;
+            ids.push_back(uint32_t(s.P.size()));
+            s.P.push_back({radius * std::sin(th) * std::cos(ph), radius * std::sin(th) * std::sin(ph), radius * std::cos(th)});
+        }
+        return ids;
+    };
+    const auto band = [&](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, bool flip) {
+        for (int j = 0; j < segments; ++j) {
+            const uint32_t a0 = a[j], a1 = a[(j + 1) % segments], b0 = b[j], b1 = b[(j + 1) % segments];
+            if (flip) s.T.insert(s.T.end(), {a0, b1, b0, a0, a1, b1});
+            else s.T.insert(s.T.end(), {a0, b0, b1, a0, b1, a1});
+        }
+    };
+    std::vector<std::vector<uint32_t>> out, in;
+    for (int i = 0; i < rings; ++i) out.push_back(ring(outer, i)), in.push_back(ring(inner, i));
+    const uint32_t pole_out = uint32_t(s.P.size());
+    s.P.push_back({0, 0, -outer});
+    const uint32_t pole_in = uint32_t(s.P.size());
+    s.P.push_back({0, 0, -inner});
+    for (int i = 0; i + 1 < rings; ++i) band(out[i], out[i + 1], false), band(in[i], in[i + 1], true);
+    for (int j = 0; j < segments; ++j) {
+        s.T.insert(s.T.end(), {out[rings - 1][j], pole_out, out[rings - 1][(j + 1) % segments]});
+        s.T.insert(s.T.end(), {in[rings - 1][j], in[rings - 1][(j + 1) % segments], pole_in});
+    }
+    band(in[0], out[0], false); // the rim
+    return s;
+}
+void Append(Surface &to, const Surface &from) {
+    const uint32_t base = uint32_t(to.P.size());
+    to.P.insert(to.P.end(), from.P.begin(), from.P.end());
+    for (const uint32_t v : from.T) to.T.push_back(base + v);
+}
+} // namespace
+
+CASE(non_star_shaped_and_higher_genus_surfaces_fill) {
+    struct Named {
+        const char *Name;
+        Surface S;
+    };
+    Surface hollow = Sphere(1.0, 8, 12, 0, 1); // a ball with an off-centre spherical cavity
+    Append(hollow, Sphere(0.4, 6, 9, 0, 2, {0.2, 0.1, -0.1}, true));
+    const Named cases[]{{"L bracket", LPrism()}, {"torus", Torus(1.0, 0.35, 16, 10)}, {"bowl", Bowl(1.0, 0.85, 6, 16)}, {"hollow ball", hollow}};
+    for (const auto &c : cases) {
+        const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
+        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        if (!r) continue;
+        const auto defect = ValidateGeneral(c.S, r.Mesh);
+        EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
+        std::printf("%12s: %zu surface triangles -> %zu tets, %u boundary Steiner points\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(), r.BoundarySteinerCount);
+    }
+    // the star-shaped filler refuses the bracket, the layered front end falls through to the general fill
+    const Surface bent = LPrism();
+    std::vector<vec3> as_float;
+    for (const auto &p : bent.P) as_float.emplace_back(float(p.x), float(p.y), float(p.z));
+    const auto r = GenerateTets(as_float, bent.T, 2);
+    EXPECT_NOTE(bool(r), r.Error);
+    EXPECT(ValidateGeneral(bent, r.Mesh).empty());
+}
+
+CASE(degenerate_and_noisy_point_sets_fill) {
+    // the reference's own synthetic cases (tests/ModalSolverTest.cpp:266-272): exact coordinates put every predicate on its
+    // degenerate case -- coplanar faces, cospherical corners, collinear edges; noise moves them to near-degenerate instead
+    struct Named {
+        const char *Name;
+        Surface S;
+        bool Oriented;
+    };
+    const Named cases[]{{"cube", BoxSurface(1, 1, 1, 1), false}, {"grid box 4", BoxSurface(1, 1, 1, 4), false}, {"grid box 7", BoxSurface(2, 1, 0.5, 7), false},
+                        {"sphere", Sphere(1.0, 8, 12, 0, 0), true}, {"noisy sphere", Sphere(1.0, 8, 12, 0.05, 7), true}};
+    for (const auto &c : cases) {
+        const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
+        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        if (!r) continue;
+        const auto defect = ValidateGeneral(c.S, r.Mesh, c.Oriented);
+        EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
+        if (!c.Oriented) { // a box: the volume is known even though the test surface winds every other quad the wrong way
+            double v6 = 0;
+            for (const auto &t : r.Mesh.Tets) v6 += Vol6(r.Mesh.Points[t[0]], r.Mesh.Points[t[1]], r.Mesh.Points[t[2]], r.Mesh.Points[t[3]]);
+            double lo[3]{1e300, 1e300, 1e300}, hi[3]{-1e300, -1e300, -1e300};
+            for (const auto &p : c.S.P)
+                for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], p[d]), hi[d] = std::max(hi[d], p[d]);
+            EXPECT(check::near(v6 / 6, (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]), 1e-12));
+        }
+        std::printf("%12s: %zu surface triangles -> %zu tets, %u boundary Steiner points\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(), r.BoundarySteinerCount);
+    }
+}
+
+CASE(the_general_fill_reports_unsuitable_surfaces) {
+    auto open = BoxSurface(1, 1, 1, 2);
+    open.T.resize(open.T.size() - 3);
+    const auto r = tetra::Tetrahedralize(open.P, open.T);
+    EXPECT(!r && r.Error.find("open") != std::string::npos);
+    auto bad = BoxSurface(1, 1, 1, 1);
+    bad.T[0] = 99;
+    EXPECT(!tetra::Tetrahedralize(bad.P, bad.T));
+    EXPECT(!tetra::Tetrahedralize({}, {}));
+    // two interpenetrating boxes: the surface intersects itself; whatever comes back, it is an error or a valid mesh, never a crash
+    Surface crossed = BoxSurface(1, 1, 1, 2);
+    Surface other = BoxSurface(1, 1, 1, 2);
+    for (auto &p : other.P) p = {p.x + 0.5, p.y + 0.25, p.z + 0.125};
+    Append(crossed, other);
+    const auto x = tetra::Tetrahedralize(crossed.P, crossed.T);
+    EXPECT(!x || !x.Mesh.Tets.empty());
 }
 
 CASE(an_obj_file_loads_welded_and_fanned) {

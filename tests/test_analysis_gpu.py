@@ -414,7 +414,7 @@ def test_batch_of_meshes_through_the_sharding_path(api, ctx):
         p, t, mat, kw = m
         cfg = api.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"], max_mode_freq=1e6)
         return api.mesh2modes(ctx, p, t, api.material(*mat), p[::20].astype(np.float32), config=cfg)
-    recs = sharding.solve_batch(batch, solve, 25)
+    recs = sharding.solve_batch(batch, solve, 25, pos_max=32)
     assert [r["index"] for r in recs] == [0, 1, 2]
     for i, r in enumerate(recs):
         direct = solve(i, batch[i])

@@ -25,7 +25,7 @@ def norm_lines(path):
 
 def main():
     ref = set()
-    for pat in ("src/audio/*.cpp", "src/audio/*.h", "tests/*.cpp", "tests/*.h", "src/mesh/Tets.cpp", "src/mesh/TetMesh.h", "src/Job.h"):
+    for pat in ("src/audio/*.cpp", "src/audio/*.h", "tests/*.cpp", "tests/*.h", "src/mesh/Tets.cpp", "src/mesh/TetMesh.h", "src/mesh/Tetrahedralize.*", "src/numeric/Predicates.*", "src/Job.h"):
         for f in glob.glob(f"{REF}/{pat}"):
             ref.update(norm_lines(f))
     for path in sys.argv[1:]:
