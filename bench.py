@@ -40,14 +40,14 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
-def pmc_traffic():
-    """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this command (profiles/, made by
-    tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 rule and checked on a kernel of known byte count) -- a
+def pmc_traffic(family="spmm_family"):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes of this command (profiles/, made
+    by tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 rule and checked on a kernel of known byte count) -- a
     separate profiled run, never this one; None when the summary is absent."""
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return float(json.load(f)["spmm_family"]["hbm_bytes_per_launch"])
+                return float(json.load(f)[family]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -100,8 +100,8 @@ def cpu_baseline(workload="cube_s10k"):
     pts, tets, m, kw = meshes.workload(workload)
     cfg = po.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"])
     ex = pts[:: len(pts) // 10][:10].astype(np.float32)
-    cores = os.cpu_count() or 1
-    team = min(cores, 32)  # the oracle's loops are front- and panel-sized: beyond a few dozen threads fork/join costs more than it buys
+    cores = po.available_cores()  # affinity mask cut to the cgroup CPU quota (the GPU box: 256 logical CPUs, quota 16)
+    team = min(cores, 16)  # the oracle's loops are front- and panel-sized: it stops scaling at 8-16 threads
     runs = {}
     for threads in (1, team) if team > 1 else (1,):
         po.set_threads(threads)
@@ -117,7 +117,8 @@ def cpu_baseline(workload="cube_s10k"):
             "sample": "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path (1/10 of the metric's mesh; the direct solve grows ~quadratically with size; "
                       "larger samples, run once: profiles/README.md)" % (workload, len(tets), int(r.profile.get("dofs", 0)), best["eigenpairs"]),
             "single_thread": runs[1], "threaded": runs[max(runs)],
-            "note": "threaded row: OpenMP team of min(host cores, 32) -- the multifrontal fronts and Lanczos panels do not feed more"}
+            "logical_cpus": os.cpu_count(),
+            "note": "host_cores = CPUs this container may use (affinity and cgroup quota); threaded row: OpenMP team of min(host_cores, 16)"}
 
 
 def cpu_bank_baseline(blocks=2):
@@ -319,7 +320,7 @@ def main():
     if asm["launches"]:
         achieved = asm["total_bytes"] / (asm["total_ms"] * 1e-3) / 1e9
         line["roofline_assembly"] = {"bound": "hbm", "kernel": "K/M assembly of the quadratic level (SURVEY 8d bytes: 152 B read per tet, 80 B written per node block)",
-                                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("assembly"),
                                      "launches": asm["launches"], "avg_launch_us": 1e3 * asm["total_ms"] / asm["launches"],
                                      "algorithmic_bytes_per_launch": asm["total_bytes"] / asm["launches"]}
     if not batch:

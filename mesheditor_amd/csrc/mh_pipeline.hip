@@ -11,10 +11,13 @@
 // operator of the P2 one (P1 is a subspace of P2), so it is assembled directly by the same kernel with linear tables.
 #include "mh_common.h"
 
+#include <optional>
+
 #include <hipcub/hipcub.hpp>
 
 namespace {
 constexpr int TB = 256;
+constexpr int EB = 14; // doubles per element-basis row: volume, four barycentric gradients, one pad (16-byte aligned rows)
 
 // ---- small utilities -------------------------------------------------------------------------------------
 struct CubTemp {
@@ -244,7 +247,8 @@ __global__ void k_element_basis(const double *__restrict__ pts, const uint32_t *
     const double cx = v[2][0] - v[0][0], cy = v[2][1] - v[0][1], cz = v[2][2] - v[0][2];
     const double dx = v[3][0] - v[0][0], dy = v[3][1] - v[0][1], dz = v[3][2] - v[0][2];
     const double det = dx * (by * cz - cy * bz) + dy * (bz * cx - cz * bx) + dz * (bx * cy - cx * by);
-    double *out = basis + 13 * size_t(el);
+    double *out = basis + EB * size_t(el); // EB = 14: 13 values + one pad, so that a row is seven aligned 16-byte words
+    out[13] = 0.0;
     out[0] = fabs(det / 6);
     // Gradient of barycentric function i along j = signed 3x3 cofactor / det (mesh2modes.cpp:144-161).
     for (int i = 0; i < 4; ++i) {
@@ -300,14 +304,23 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
     for (int i = threadIdx.x; i < NT; i += TB) s_tab[i] = tables[i];
     __syncthreads();
     const double *s_mass = s_tab, *s_grad = s_tab + NN * NN;
+    __shared__ double s_out[TB * 9];
     const uint32_t b = blockIdx.x * TB + threadIdx.x;
-    if (b >= nblocks) return;
+    const bool valid = b < nblocks;
     double k[3][3] = {}, m = 0;
-    const uint32_t p0 = seg[b], p1 = seg[b + 1];
+    const uint32_t p0 = valid ? seg[b] : 0u, p1 = valid ? seg[b + 1] : 0u;
     for (uint32_t p = p0; p < p1; ++p) {
         const uint32_t pl = payload[p];
         const uint32_t t = pl / (NN * NN), ac = pl % (NN * NN), a = ac / NN, c = ac % NN;
-        const double *eb = basis + 13 * size_t(t);
+        double eb[EB];
+        {
+            const double2 *src = reinterpret_cast<const double2 *>(basis + EB * size_t(t)); // seven 16-byte gathers instead of thirteen 8-byte ones:
+#pragma unroll                                                                        // the kernel is bound by the address path of its gathers
+            for (int i = 0; i < EB / 2; ++i) {
+                const double2 v = src[i];
+                eb[2 * i] = v.x, eb[2 * i + 1] = v.y;
+            }
+        }
         const double vol = eb[0];
         m += rho * vol * s_mass[a * NN + c];
         double g[3][3] = {};
@@ -323,9 +336,15 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
         for (int pp = 0; pp < 3; ++pp)
             for (int qq = 0; qq < 3; ++qq) k[pp][qq] += vol * (lambda * g[pp][qq] + mu * g[qq][pp] + (pp == qq ? mu * trace : 0.0));
     }
+    // the workgroup's 256 blocks are contiguous in kval: through LDS (stride 9 words of 8 bytes: conflict-free) they leave as
+    // whole runs of doubles instead of nine 72-byte-strided stores per lane
     for (int pp = 0; pp < 3; ++pp)
-        for (int qq = 0; qq < 3; ++qq) kval[9 * size_t(b) + 3 * pp + qq] = k[pp][qq];
-    mval[b] = m;
+        for (int qq = 0; qq < 3; ++qq) s_out[9 * threadIdx.x + 3 * pp + qq] = k[pp][qq];
+    if (valid) mval[b] = m;
+    __syncthreads();
+    const size_t first = size_t(blockIdx.x) * TB;
+    const uint32_t count = uint32_t(min(size_t(TB), size_t(nblocks) - first)) * 9;
+    for (uint32_t f = threadIdx.x; f < count; f += TB) kval[9 * first + f] = s_out[f];
 }
 
 // The same sums, organised by node row: one wave per row of node blocks.
@@ -357,37 +376,57 @@ template<int NN> __global__ void __launch_bounds__(256) k_assemble_rows(const ui
     const uint32_t row = blockIdx.x * WPB + wave;
     if (row >= nrows) return; // no workgroup barrier below this line
     const uint32_t p0 = row_ptr[row], p1 = row_ptr[row + 1], nblk = p1 - p0;
+    // Everything that depends only on the row's extent is requested at once (one memory round trip): the column and the
+    // contributor offset of block `lane`.  A row of fewer than 64 blocks then gets every other offset from a neighbouring lane.
+    const uint32_t c_lane = lane < nblk ? col[p0 + lane] : 0xffffffffu;
+    const uint32_t s_lane = lane <= nblk ? seg[p0 + lane] : 0u;
+    const bool narrow = nblk < 64;
     // the row's elements = contributors of its diagonal block
     uint32_t diag = 0;
-    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
-        const bool hit = b0 + lane < nblk && col[p0 + b0 + lane] == row;
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            diag = b0 + uint32_t(__ffsll(m)) - 1;
-            break;
-        }
+    {
+        const unsigned long long m = __ballot(c_lane == row);
+        if (m) diag = uint32_t(__ffsll(m)) - 1;
+        else // (a row of more than 64 blocks whose diagonal block lies beyond the first 64)
+            for (uint32_t b0 = 64; b0 < nblk; b0 += 64) {
+                const unsigned long long m2 = __ballot(b0 + lane < nblk && col[p0 + b0 + lane] == row);
+                if (m2) {
+                    diag = b0 + uint32_t(__ffsll(m2)) - 1;
+                    break;
+                }
+            }
     }
-    const uint32_t e0 = seg[p0 + diag], ne = seg[p0 + diag + 1] - e0;
+    const uint32_t e0 = diag < 63 ? uint32_t(__shfl(int(s_lane), int(diag), 64)) : seg[p0 + diag];
+    const uint32_t ne = (diag < 63 ? uint32_t(__shfl(int(s_lane), int(diag) + 1, 64)) : seg[p0 + diag + 1]) - e0;
     const bool staged = ne <= uint32_t(MAXE); // more elements around one node than the slice holds: read them from memory
     double *sb = s_basis[wave], *sx = s_x[wave];
     uint32_t *st = s_tet[wave];
+    // the first round's contributor descriptors travel together with the element list (one more round trip)
+    const uint32_t q_first = uint32_t(__shfl(int(s_lane), 0, 64)) + lane, q_end_first = narrow ? uint32_t(__shfl(int(s_lane), int(nblk), 64)) : seg[p0 + 64];
+    const uint32_t pl_first = q_first < q_end_first ? payload[q_first] : 0u;
     if (staged) {
         if (lane < ne) st[lane] = payload[e0 + lane] / (NN * NN);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t f = lane; f < ne * 13; f += 64) sb[f] = basis[13 * size_t(st[f / 13]) + f % 13];
+        for (uint32_t f = lane; f < ne * 13; f += 64) sb[f] = basis[EB * size_t(st[f / 13]) + f % 13];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     for (uint32_t b0 = 0; b0 < nblk; b0 += 64) { // 64 blocks of the row at a time (a row rarely has more)
         const uint32_t nb = min(64u, nblk - b0);
         const bool owner = lane < nb;
-        const uint32_t mine0 = owner ? seg[p0 + b0 + lane] : 0u, mine1 = owner ? seg[p0 + b0 + lane + 1] : 0u;
-        const uint32_t qa = seg[p0 + b0], qb = seg[p0 + b0 + nb];
+        uint32_t mine0, mine1, qa, qb;
+        if (narrow) { // offsets from the neighbouring lanes
+            const uint32_t next = uint32_t(__shfl_down(int(s_lane), 1, 64));
+            mine0 = owner ? s_lane : 0u, mine1 = owner ? next : 0u;
+            qa = uint32_t(__shfl(int(s_lane), 0, 64)), qb = uint32_t(__shfl(int(s_lane), int(nblk), 64));
+        } else {
+            mine0 = owner ? seg[p0 + b0 + lane] : 0u, mine1 = owner ? seg[p0 + b0 + lane + 1] : 0u;
+            qa = seg[p0 + b0], qb = seg[p0 + b0 + nb];
+        }
         double k[9] = {}, m = 0;
         for (uint32_t r = qa; r < qb; r += 64) {
             const uint32_t q = r + lane;
             double cv[10] = {};
             if (q < qb) {
-                const uint32_t pl = payload[q];
+                const uint32_t pl = (b0 == 0 && r == qa) ? pl_first : payload[q];
                 const uint32_t t = pl / (NN * NN), ac = pl % (NN * NN), a = ac / NN, c = ac % NN;
                 double eb[13];
                 if (staged) {
@@ -397,7 +436,7 @@ template<int NN> __global__ void __launch_bounds__(256) k_assemble_rows(const ui
                     for (int i = 0; i < 13; ++i) eb[i] = sb[13 * slot + i];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 13; ++i) eb[i] = basis[13 * size_t(t) + i];
+                    for (int i = 0; i < 13; ++i) eb[i] = basis[EB * size_t(t) + i];
                 }
                 const double vol = eb[0];
                 cv[9] = rho * vol * s_mass[a * NN + c];
@@ -559,8 +598,13 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
     {
         // SURVEY 8d's count for the assembly: per tet 16 B corner ids + 4 x 24 B coordinates + 40 B node ids read (the
         // element bases are built from them), 80 B (9 K values + 1 M value) written per node block
-        TimedLaunch timed(ctx, MH_KERNEL_ASSEMBLY, NN == 10 ? 152.0 * double(nt) + 80.0 * double(nb) : 0.0);
-        static const bool by_block = getenv("MH_ASSEMBLE_BY_BLOCK") && atoi(getenv("MH_ASSEMBLE_BY_BLOCK")) != 0; // the one-thread-per-block form, kept for comparison
+        std::optional<TimedLaunch> timed; // the quadratic level's launch is the one the roofline object reports
+        if (NN == 10) timed.emplace(ctx, MH_KERNEL_ASSEMBLY, 152.0 * double(nt) + 80.0 * double(nb));
+        // The row-wise form (k_assemble_rows: balanced contributor lanes, LDS-staged element data, coalesced block stores) was
+        // built to replace the one-thread-per-block form and measured beside it (tools/ab_assembly.sh, S100k): 426 us against
+        // 327 us -- its LDS round trips and fences cost more than the imbalance and the strided stores they remove.  It stays
+        // selectable (MH_ASSEMBLE_BY_ROW=1); both produce the same bits.
+        static const bool by_block = !(getenv("MH_ASSEMBLE_BY_ROW") && atoi(getenv("MH_ASSEMBLE_BY_ROW")) != 0);
         if (by_block) k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
         else
             k_assemble_rows<NN><<<div_up(nnodes, 4), 256, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, seg, pay_s, nnodes, basis, tables_dev, mat.density, lambda, mu, lvl.kval,
@@ -720,7 +764,7 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
     }
 
     // --- element bases, tables, patterns, assembly (P2 and its Galerkin P1 coarse operator)
-    sys->elem_basis.reset(ctx, size_t(nt) * 13);
+    sys->elem_basis.reset(ctx, size_t(nt) * EB);
     k_element_basis<<<div_up(nt, TB), TB, 0, st>>>(mesh->points, tets, nt, sys->elem_basis);
     KERNEL_CHECK();
     std::vector<double> tq, tl;

@@ -321,9 +321,12 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
 }
 
 // Fewer rows than ~4 waves per wave slot of the chip (256 CUs x 4 SIMDs x 8 waves): the launch is a latency chain per wave,
-// not a throughput problem (MH_SPMM_SMALL=0 disables the distinction).
+// not a throughput problem -- so the thinking went.  Measured (tools/ab_r02d.sh, S100k, P1 level = 19 683 rows): the
+// unrolled / prefetching variant makes the average product launch SLOWER (104.0 us against 98.5 us over the 601 launches of
+// a solve; the extra registers cost more occupancy than the overlapped round trips give back), the solve time is unchanged.
+// Off by default; MH_SPMM_SMALL=1 selects it.
 inline bool latency_bound_level(const BsrLevel &lvl) {
-    static const bool on = !(getenv("MH_SPMM_SMALL") && atoi(getenv("MH_SPMM_SMALL")) == 0);
+    static const bool on = getenv("MH_SPMM_SMALL") && atoi(getenv("MH_SPMM_SMALL")) != 0;
     return on && lvl.n_nodes < 32768;
 }
 

@@ -41,6 +41,23 @@ class Event(C.Structure):
                 ("click_b0", C.c_float), ("click_a1", C.c_float), ("click_a2", C.c_float)]
 
 
+def available_cores():
+    """CPUs this process can actually use: its affinity mask, cut to the cgroup CPU quota when there is one (a container on a
+    256-core host may be entitled to 16: os.cpu_count() alone would size thread teams sixteen times too large)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libmodal_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
@@ -132,7 +149,7 @@ def lib():
         # OpenMP team of the sparse factorisation / solves / Lanczos kernels: a modest team by default.  The loops are
         # short (a front, a panel column); on a many-core host (the GPU box has 256) a team of every core spends its time in
         # fork/join -- measured: a 20 s solve became 650 s.  bench.py sets the team size explicitly for its timed rows.
-        L.mo_set_threads(max(1, min(os.cpu_count() or 1, 16)))
+        L.mo_set_threads(max(1, min(available_cores(), 16)))
         _LIB = L
     return _LIB
 

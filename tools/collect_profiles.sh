@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round-end evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r01
+# Round-end evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r02
 # Writes the rocprofv3 summaries judged under profiles/ into gpurun_out/final/ (copied into profiles/ afterwards).
-R=${1:-r01}
+# Counter passes (--pmc) run on their own, without any trace option beside them.
+R=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -17,3 +18,4 @@ cd $ROOT
 python3 tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/${R}_pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 python3 tools/prof_summary.py /tmp/prof_bench 30 > $OUT/summary_bench.txt 2>&1
 python3 tools/prof_summary.py /tmp/prof_bank 10 > $OUT/summary_bank.txt 2>&1
+python3 tools/trace_by_grid.py /tmp/prof_bench 0.5 > $OUT/${R}_bench_by_grid.txt 2>&1

@@ -55,6 +55,9 @@ def main():
     tot_l = sum(r["launches"] for r in fam)
     if tot_l:
         out["spmm_family"] = {"launches": tot_l, "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in fam) / tot_l}
+    asm = [r for r in rows if r["kernel"].startswith("k_assemble_rows<10>") or r["kernel"].startswith("k_assemble<10>")]
+    if asm:
+        out["assembly"] = {"kernel": asm[0]["kernel"], "launches": asm[0]["launches"], "hbm_bytes_per_launch": asm[0]["hbm_bytes_per_launch"]}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for r in rows[:14]:
         print(f"{r['kernel'][:60]:60s} x{r['launches']:5d}  read {r['read_bytes_per_launch']/1e6:9.1f} MB  write {r['write_bytes_per_launch']/1e6:9.1f} MB")
