@@ -130,6 +130,7 @@ def cpu_bank_baseline(blocks=2):
         from tools import bank_bench as bb
         out = {}
         for renderers in (1, 4):
+            po.set_threads(renderers)  # one OpenMP thread per renderer, as the reference's render pool
             b = po.Bank(bb.SR)
             b.set_renderers(renderers)
             pos = np.array([[p * 0.01, 0.0, 0.02 if p % 2 else 0.0] for p in range(bb.POINTS)], np.float32)
@@ -154,6 +155,7 @@ def cpu_bank_baseline(blocks=2):
             sec = float(np.mean(times[4:]))
             out["renderers_%d" % renderers] = {"seconds_per_block": sec, "render_share": sec * bb.SR / bb.BLOCK, "x_real_time": bb.BLOCK / bb.SR / sec}
         out["sample"] = "oracle bank 1024x256 @48k, all 262,144 modes live, %d timed 512-frame blocks" % blocks
+        po.set_threads(min(po.available_cores(), 16))
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)[:200]}

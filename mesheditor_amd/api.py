@@ -158,6 +158,12 @@ class System:
         self.ctx.check(self.ctx.L.mh_system_bench_spmm(self.h, width, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
 
+    def bench_elementwise(self, width, reps=20):
+        """Average ms of the element-by-element (matrix-free, atomic scatter) product over a resident n x width panel."""
+        ms = C.c_double(0)
+        self.ctx.check(self.ctx.L.mh_system_bench_elementwise(self.h, width, reps, C.byref(ms)))
+        return ms.value
+
     def eigs(self, nev, sigma=-(2 * np.pi * 20.0) ** 2, residual_tol=1e-6, max_iters=200, seed_basis=None):
         ev = np.zeros(nev)
         prof = Profile()

@@ -289,6 +289,8 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
                 mh_spmm_mixed(ctx, s->L2, xf, yp, width);
             }
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else if (which == 5) { // the same shifted operator applied element by element, no assembled matrix (mh_elem.hip)
+            mh_elementwise_apply(ctx, s, -15791.367041742974, xp, yp, width);
         } else { // which == 2: the shifted operator A = K - sigma M of the eigensolver at the reference's shift
             std::lock_guard<std::mutex> lock(mh_solve_mutex());
             mh_build_hierarchy(s, -15791.367041742974);
@@ -326,6 +328,34 @@ int mh_system_bench_spmm(mh_system *s, uint32_t width, uint32_t reps, double *av
         (void)hipEventDestroy(e1);
         *avg_ms = ms / reps;
         if (algorithmic_bytes) *algorithmic_bytes = 76.0 * double(s->L2.n_blocks) + 4.0 * (double(s->n_nodes) + 1) + 16.0 * double(n) * width;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+int mh_system_bench_elementwise(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms) {
+    if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * s->n_nodes;
+        DevArray<double> x(ctx, n * width), y(ctx, n * width);
+        std::vector<double> hx(n * width);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        x.upload(hx.data(), hx.size());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int warm = 0; warm < 2; ++warm) mh_elementwise_apply(ctx, s, -15791.367041742974, x, y, width);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t r = 0; r < reps; ++r) mh_elementwise_apply(ctx, s, -15791.367041742974, x, y, width);
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
         return MH_OK;
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }

@@ -319,4 +319,5 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
                            uint32_t w); // mh_spmm.hip: product + Chebyshev step in one launch
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w); // double A x of a float panel
+void mh_elementwise_apply(mh_context *ctx, const mh_system *sys, double sigma, const double *x, double *y, uint32_t w); // mh_elem.hip: (K - sigma M) x without the matrix (atomics)
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

@@ -533,3 +533,19 @@ def test_warm_start_against_the_oracles_warm_branch(api, ctx, oracle):
         assert (np.abs(warm_g.eigenvalues[el] - ref.eigenvalues[el]) / ref.eigenvalues[el]).max() < 1e-6
         assert (np.abs(warm_o.eigenvalues[el] - ref.eigenvalues[el]) / ref.eigenvalues[el]).max() < 1e-3
         assert np.allclose(warm_g.t60s, warm_o.t60s, rtol=1e-3)
+
+
+def test_elementwise_operator_matches_the_assembled_one(api, ctx):
+    """The matrix-free element-by-element product (mh_elem.hip: corner displacement gradients, seven-entry mass matrix, atomic
+    scatter) against the assembled BSR product of the same shifted operator: equal to rounding at every lane grouping.  It is a
+    measurement variant; the eigensolver does not use it (atomics are not bit-reproducible)."""
+    for name in ("cube_small", "bar_thin"):
+        pts, tets, m, _ = meshes.workload(name)
+        sysg = api.System(ctx, api.Mesh(ctx, pts, tets), api.material(*m))
+        rng = np.random.default_rng(11)
+        for width in (1, 7, 16, 24, 32, 48, 64, 80, 130):
+            x = rng.standard_normal((sysg.n, width))
+            ref = sysg.matvec(2, x)
+            got = sysg.matvec(5, x)
+            assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (name, width, np.abs(got - ref).max() / np.abs(ref).max())
+        sysg.close()
