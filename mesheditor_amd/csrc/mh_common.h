@@ -243,7 +243,7 @@ struct mh_system {
     DevArray<double> points; // copy of mesh points (P1 node coordinates), reference numbering
     DevArray<uint32_t> elem_nodes_ref; // kept_tets x 10, reference numbering
     DevArray<uint32_t> elem_nodes; // kept_tets x 10, internal numbering
-    DevArray<double> elem_basis; // kept_tets x 14: volume, Phig[4][3], one pad (16-byte aligned rows)
+    DevArray<double> elem_basis; // kept_tets x 16: four (gradient xyz, volume) quadruples = one 128-byte line per tet
     DevArray<uint32_t> perm; // internal -> reference node id
     DevArray<uint32_t> inv_perm; // reference -> internal
     DevArray<double> node_xyz; // n_nodes x 3, internal numbering

@@ -32,7 +32,7 @@ __device__ __forceinline__ constexpr int mid_of(int a, int b) {
 template<int CL, int MODE = 0> // lanes per element (16, 32 or 64): a wave works on 64 / CL elements.  MODE 1 / 2: timing experiments only (plain stores / one store)
 __global__ void __launch_bounds__(64) k_elem_apply(const uint32_t *__restrict__ elem_nodes, const double *__restrict__ basis, uint32_t nt, double lambda, double mu,
                                                    double mass_scale /* -sigma rho / 420 */, const double *__restrict__ x, double *__restrict__ y, uint32_t w) {
-    constexpr int EPW = 64 / CL, EBs = 14;
+    constexpr int EPW = 64 / CL, EBs = 16; // one basis line: gradient k at [4 k .. 4 k + 2], the volume at [3]
     const uint32_t lane = threadIdx.x, wave = blockIdx.x;
     const uint32_t el = wave * EPW + lane / CL;
     if (el >= nt) return;
@@ -41,12 +41,12 @@ __global__ void __launch_bounds__(64) k_elem_apply(const uint32_t *__restrict__ 
 #pragma unroll
     for (int a = 0; a < 10; ++a) node[a] = elem_nodes[10 * size_t(el) + a];
     double g[4][3];
-    const double vol = basis[EBs * size_t(el)];
+    const double vol = basis[EBs * size_t(el) + 3];
     const double ms = mass_scale * vol;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) g[k][p] = basis[EBs * size_t(el) + 1 + 3 * k + p];
+        for (int p = 0; p < 3; ++p) g[k][p] = basis[EBs * size_t(el) + 4 * k + p];
     for (uint32_t col = c_in; col < w; col += CL) { // panels wider than the lane group go round again
         double u[10][3];
 #pragma unroll

@@ -2,10 +2,11 @@
 //
 //   FilterDegenerate      reference src/audio/mesh2modes.cpp:42-60   -> k_flag_tets + scan + compaction
 //   BuildQuadMesh         :246-264  midside ids in first-encounter order -> sort edge keys, rank by first occurrence
-//   ComputeElementBases   :137-165  -> k_element_basis (13 doubles per tet)
+//   ComputeElementBases   :137-165  -> k_element_basis (volume + four gradients per tet, one 128-byte line)
 //   AssembleQuadratic     :273-327  -> sorted (row node, col node) pair list = sparsity pattern + per-block
-//                                      contributor lists; one thread sums each 3x3 node block in a fixed order
-//                                      (no atomics, bit-reproducible), 30x30 element tables staged in LDS.
+//                                      contributor lists; one lane evaluates each contribution, the contributions
+//                                      of a block are staged in LDS and summed in list order by one thread
+//                                      (no atomics, bit-reproducible); finished blocks leave as coalesced runs.
 // Nodes are renumbered internally along a Morton curve so that the SpMM's gathers of x hit L2; results are mapped
 // back to the reference's numbering at the boundary.  The P1 (corner-node) operator is the exact Galerkin coarse
 // operator of the P2 one (P1 is a subspace of P2), so it is assembled directly by the same kernel with linear tables.
@@ -17,7 +18,7 @@
 
 namespace {
 constexpr int TB = 256;
-constexpr int EB = 14; // doubles per element-basis row: volume, four barycentric gradients, one pad (16-byte aligned rows)
+constexpr int EB = 16; // doubles per element-basis row = one 128-byte line: four barycentric gradients as (x, y, z, volume) quadruples
 
 // ---- small utilities -------------------------------------------------------------------------------------
 struct CubTemp {
@@ -247,9 +248,8 @@ __global__ void k_element_basis(const double *__restrict__ pts, const uint32_t *
     const double cx = v[2][0] - v[0][0], cy = v[2][1] - v[0][1], cz = v[2][2] - v[0][2];
     const double dx = v[3][0] - v[0][0], dy = v[3][1] - v[0][1], dz = v[3][2] - v[0][2];
     const double det = dx * (by * cz - cy * bz) + dy * (bz * cx - cz * bx) + dz * (bx * cy - cx * by);
-    double *out = basis + EB * size_t(el); // EB = 14: 13 values + one pad, so that a row is seven aligned 16-byte words
-    out[13] = 0.0;
-    out[0] = fabs(det / 6);
+    double *out = basis + EB * size_t(el); // gradient i at out[4 i .. 4 i + 2], the volume beside each one (whichever gradient a lane loads brings it along)
+    for (int i = 0; i < 4; ++i) out[4 * i + 3] = fabs(det / 6);
     // Gradient of barycentric function i along j = signed 3x3 cofactor / det (mesh2modes.cpp:144-161).
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < 3; ++j) {
@@ -267,7 +267,7 @@ __global__ void k_element_basis(const double *__restrict__ pts, const uint32_t *
             const double cry = col[0][2] * col[1][0] - col[1][2] * col[0][0];
             const double crz = col[0][0] * col[1][1] - col[1][0] * col[0][1];
             const double sign = ((i + j) % 2 == 0) ? -1.0 : 1.0;
-            out[1 + 3 * i + j] = sign * (crx + cry + crz) / det;
+            out[4 * i + j] = sign * (crx + cry + crz) / det;
         }
     }
 }
@@ -294,7 +294,104 @@ __global__ void k_block_index(const uint64_t *__restrict__ keys, const uint32_t 
     seg[b] = uint32_t(i);
 }
 
-// One thread per node block: sum the element contributions in contributor order.
+// The barycentric gradients a shape function's gradient is made of: a corner function's is a multiple of its own corner's,
+// a midside function's a combination of its edge's two (edges in the reference's order 01 02 03 12 13 23).
+__device__ __forceinline__ uint32_t support0(uint32_t a) { return uint32_t(0x2110003210ull >> (4 * a)) & 3u; }
+__device__ __forceinline__ uint32_t support1(uint32_t a) { return uint32_t(0x3323213210ull >> (4 * a)) & 3u; }
+
+// K/M assembly, one LANE PER CONTRIBUTION.  The contributor list (element, a, c) is sorted by node block, so a block's
+// contributions are a contiguous run and a workgroup's TB blocks own one contiguous stretch of the list.
+//   * Lanes walk that stretch TB contributions at a time: each evaluates ONE 3 x 3 stiffness contribution and one mass
+//     value -- perfectly balanced, where one-thread-per-block leaves a wave waiting for the lane of a diagonal block
+//     (6 .. 30 elements around its node, against one or two for most of its neighbours).
+//   * A contribution needs only the two gradients in the support of a and the two in the support of c:
+//         G = sum_{x, y in 0..1} W[a][c][x][y]  g_(s_a(x)) (x) g_(s_c(y)),   W = the integrals of the gradient coefficients,
+//     four weights per (a, c) in LDS (the full table is 4 x 4 per pair with at most these four non-zero), the gradients as
+//     four 32-byte reads from the element's 128-byte basis line.  ~70 fp64 instructions, no data-dependent branch.
+//   * The TB contributions of a round go through LDS (ten doubles per entry, 16-byte accesses); the lane that owns a block adds
+//     the entries of its run in list order -- every block is summed in one fixed order by one thread: no atomics,
+//     bit-reproducible.  The next round's list entry is requested a round ahead.
+//   * The finished blocks leave through LDS as whole runs of doubles (coalesced 2 KB stores per wave).
+// tables: mass[NN][NN] then W[NN][NN][2][2].
+template<int NN> __global__ void __launch_bounds__(TB) k_assemble_flat(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ payload, uint32_t nblocks,
+                                                                               const double *__restrict__ basis, const double *__restrict__ tables, double rho,
+                                                                               double lambda, double mu, double *__restrict__ kval, double *__restrict__ mval) {
+    constexpr int NT = NN * NN * 5;
+    __shared__ double s_tab[NT];
+    __shared__ __attribute__((aligned(16))) double s_c[10 * TB];
+    for (int i = threadIdx.x; i < NT; i += TB) s_tab[i] = tables[i];
+    const double *s_mass = s_tab;
+    const double2 *s_w = reinterpret_cast<const double2 *>(s_tab + NN * NN);
+    double2 *s_e = reinterpret_cast<double2 *>(s_c); // entry j = s_e[5 j .. 5 j + 4]
+    const uint32_t tid = threadIdx.x, first = blockIdx.x * TB, here = min(uint32_t(TB), nblocks - first);
+    const bool owner = tid < here;
+    const uint32_t mine0 = owner ? seg[first + tid] : 0u, mine1 = owner ? seg[first + tid + 1] : 0u;
+    const uint32_t q0 = seg[first], q1 = seg[first + here];
+    uint32_t pl0 = q0 + tid < q1 ? payload[q0 + tid] : 0u; // lanes past the end of the stretch work on entry 0; nobody reads what they stage
+    double k[9] = {}, m = 0;
+    __syncthreads();
+    for (uint32_t r = q0; r < q1; r += TB) {
+        const uint32_t qn = r + TB + tid;
+        const uint32_t pl1 = qn < q1 ? payload[qn] : 0u;
+        {
+            const uint32_t t = pl0 / (NN * NN), ac = pl0 % (NN * NN), a = ac / NN, c = ac % NN;
+            const double2 *line = reinterpret_cast<const double2 *>(basis + EB * size_t(t));
+            const uint32_t a0 = support0(a), a1 = support1(a), c0 = support0(c), c1 = support1(c);
+            const double2 ga0 = line[2 * a0], ga0z = line[2 * a0 + 1], ga1 = line[2 * a1], ga1z = line[2 * a1 + 1];
+            const double2 gc0 = line[2 * c0], gc0z = line[2 * c0 + 1], gc1 = line[2 * c1], gc1z = line[2 * c1 + 1];
+            const double2 w0 = s_w[2 * ac], w1 = s_w[2 * ac + 1]; // W[0][0], W[0][1]; W[1][0], W[1][1]
+            const double vol = ga0z.y;
+            const double h0[3] = {w0.x * gc0.x + w0.y * gc1.x, w0.x * gc0.y + w0.y * gc1.y, w0.x * gc0z.x + w0.y * gc1z.x};
+            const double h1[3] = {w1.x * gc0.x + w1.y * gc1.x, w1.x * gc0.y + w1.y * gc1.y, w1.x * gc0z.x + w1.y * gc1z.x};
+            const double u0[3] = {ga0.x, ga0.y, ga0z.x}, u1[3] = {ga1.x, ga1.y, ga1z.x};
+            double g[3][3], v[10];
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) g[pp][qq] = u0[pp] * h0[qq] + u1[pp] * h1[qq];
+            const double trace = g[0][0] + g[1][1] + g[2][2];
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) v[3 * pp + qq] = vol * (lambda * g[pp][qq] + mu * g[qq][pp] + (pp == qq ? mu * trace : 0.0));
+            v[9] = rho * vol * s_mass[ac];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) s_e[5 * tid + e] = double2{v[2 * e], v[2 * e + 1]};
+        }
+        __syncthreads();
+        const uint32_t lo = max(mine0, r), hi = min(mine1, r + TB);
+        {
+            auto add = [&](const double2 &e0, const double2 &e1, const double2 &e2, const double2 &e3, const double2 &e4) {
+                k[0] += e0.x, k[1] += e0.y, k[2] += e1.x, k[3] += e1.y, k[4] += e2.x, k[5] += e2.y, k[6] += e3.x, k[7] += e3.y, k[8] += e4.x, m += e4.y;
+            };
+            // most runs have one or two entries: those are read together (the second read does not wait for the first sum),
+            // the rest in a loop; always added in list order
+            if (lo < hi) {
+                const uint32_t j = lo - r, j2 = lo + 1 < hi ? j + 1 : j;
+                const double2 e0 = s_e[5 * j], e1 = s_e[5 * j + 1], e2 = s_e[5 * j + 2], e3 = s_e[5 * j + 3], e4 = s_e[5 * j + 4];
+                const double2 f0 = s_e[5 * j2], f1 = s_e[5 * j2 + 1], f2 = s_e[5 * j2 + 2], f3 = s_e[5 * j2 + 3], f4 = s_e[5 * j2 + 4];
+                add(e0, e1, e2, e3, e4);
+                if (lo + 1 < hi) add(f0, f1, f2, f3, f4);
+            }
+            for (uint32_t qq = lo + 2; qq < hi; ++qq) {
+                const uint32_t j = qq - r;
+                add(s_e[5 * j], s_e[5 * j + 1], s_e[5 * j + 2], s_e[5 * j + 3], s_e[5 * j + 4]);
+            }
+        }
+        __syncthreads();
+        pl0 = pl1;
+    }
+    // the finished blocks: stride 9 words of 8 bytes into LDS (conflict-free), out as whole runs
+#pragma unroll
+    for (int e = 0; e < 9; ++e) s_c[9 * tid + e] = k[e];
+    if (owner) mval[first + tid] = m;
+    __syncthreads();
+    double *out = kval + 9 * size_t(first);
+    for (uint32_t f = tid; f < 9 * here; f += TB) out[f] = s_c[f];
+}
+
+// The form it replaced, kept for the A/B record (MH_ASSEMBLE_BY_BLOCK=1): one thread per node block walks its own run of
+// contributors and contracts the full 4 x 4 gradient table for each (skipping its zeros).
 // tables: mass[NN][NN] then grad[NN][4][NN][4] (doubles), staged in LDS.
 template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ payload, uint32_t nblocks,
                                                                  const double *__restrict__ basis, const double *__restrict__ tables, double rho, double lambda,
@@ -314,14 +411,14 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
         const uint32_t t = pl / (NN * NN), ac = pl % (NN * NN), a = ac / NN, c = ac % NN;
         double eb[EB];
         {
-            const double2 *src = reinterpret_cast<const double2 *>(basis + EB * size_t(t)); // seven 16-byte gathers instead of thirteen 8-byte ones:
-#pragma unroll                                                                        // the kernel is bound by the address path of its gathers
+            const double2 *src = reinterpret_cast<const double2 *>(basis + EB * size_t(t));
+#pragma unroll
             for (int i = 0; i < EB / 2; ++i) {
                 const double2 v = src[i];
                 eb[2 * i] = v.x, eb[2 * i + 1] = v.y;
             }
         }
-        const double vol = eb[0];
+        const double vol = eb[3];
         m += rho * vol * s_mass[a * NN + c];
         double g[3][3] = {};
         for (int kk = 0; kk < 4; ++kk) {
@@ -329,15 +426,13 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
                 const double w = s_grad[((a * 4 + kk) * NN + c) * 4 + ll];
                 if (w == 0) continue;
                 for (int pp = 0; pp < 3; ++pp)
-                    for (int qq = 0; qq < 3; ++qq) g[pp][qq] += w * (eb[1 + 3 * kk + pp] * eb[1 + 3 * ll + qq]);
+                    for (int qq = 0; qq < 3; ++qq) g[pp][qq] += w * (eb[4 * kk + pp] * eb[4 * ll + qq]);
             }
         }
         const double trace = g[0][0] + g[1][1] + g[2][2];
         for (int pp = 0; pp < 3; ++pp)
             for (int qq = 0; qq < 3; ++qq) k[pp][qq] += vol * (lambda * g[pp][qq] + mu * g[qq][pp] + (pp == qq ? mu * trace : 0.0));
     }
-    // the workgroup's 256 blocks are contiguous in kval: through LDS (stride 9 words of 8 bytes: conflict-free) they leave as
-    // whole runs of doubles instead of nine 72-byte-strided stores per lane
     for (int pp = 0; pp < 3; ++pp)
         for (int qq = 0; qq < 3; ++qq) s_out[9 * threadIdx.x + 3 * pp + qq] = k[pp][qq];
     if (valid) mval[b] = m;
@@ -346,137 +441,6 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
     const uint32_t count = uint32_t(min(size_t(TB), size_t(nblocks) - first)) * 9;
     for (uint32_t f = threadIdx.x; f < count; f += TB) kval[9 * first + f] = s_out[f];
 }
-
-// The same sums, organised by node row: one wave per row of node blocks.
-//   * The contributors of a row are (element, a, c) for every element e around the row's node (a = the node's place in e,
-//     c = 0 .. NN-1): NN per element, contiguous in the sorted contributor list.  Lanes take ONE contributor each, 64 per
-//     round, so the expensive part -- the 4 x 4 x 3 x 3 contraction of the gradient table with the element's barycentric
-//     gradients -- is perfectly balanced (in the one-thread-per-block form the lane of the diagonal block walks through
-//     every element around the node, 7 .. 30 of them, while its neighbours idle after one to three).
-//   * The element data a row needs (volume + four gradients = 13 doubles per element; the elements are exactly the
-//     contributors of the row's diagonal block) is staged once per row in a wave-private LDS slice; the shape-function
-//     tables live in LDS for the workgroup.
-//   * A round's 64 contributions go through LDS to the lanes that own the blocks, which add them in contributor order --
-//     the order the one-thread-per-block kernel uses, so both produce the same bits.
-//   * The finished 3 x 3 blocks of a row leave through LDS as whole contiguous runs of doubles (coalesced), not as nine
-//     72-byte-strided stores per lane.
-template<int NN> __global__ void __launch_bounds__(256) k_assemble_rows(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ seg,
-                                                                      const uint32_t *__restrict__ payload, uint32_t nrows, const double *__restrict__ basis,
-                                                                      const double *__restrict__ tables, double rho, double lambda, double mu,
-                                                                      double *__restrict__ kval, double *__restrict__ mval) {
-    constexpr int NT = NN * NN + NN * 4 * NN * 4, WPB = 4, MAXE = 32;
-    __shared__ double s_tab[NT];
-    __shared__ double s_basis[WPB][MAXE * 13];
-    __shared__ uint32_t s_tet[WPB][MAXE];
-    __shared__ double s_x[WPB][64 * 10]; // a round's contributions [value][lane]; afterwards the row's blocks [block][9]
-    for (int i = threadIdx.x; i < NT; i += 256) s_tab[i] = tables[i];
-    __syncthreads();
-    const double *s_mass = s_tab, *s_grad = s_tab + NN * NN;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * WPB + wave;
-    if (row >= nrows) return; // no workgroup barrier below this line
-    const uint32_t p0 = row_ptr[row], p1 = row_ptr[row + 1], nblk = p1 - p0;
-    // Everything that depends only on the row's extent is requested at once (one memory round trip): the column and the
-    // contributor offset of block `lane`.  A row of fewer than 64 blocks then gets every other offset from a neighbouring lane.
-    const uint32_t c_lane = lane < nblk ? col[p0 + lane] : 0xffffffffu;
-    const uint32_t s_lane = lane <= nblk ? seg[p0 + lane] : 0u;
-    const bool narrow = nblk < 64;
-    // the row's elements = contributors of its diagonal block
-    uint32_t diag = 0;
-    {
-        const unsigned long long m = __ballot(c_lane == row);
-        if (m) diag = uint32_t(__ffsll(m)) - 1;
-        else // (a row of more than 64 blocks whose diagonal block lies beyond the first 64)
-            for (uint32_t b0 = 64; b0 < nblk; b0 += 64) {
-                const unsigned long long m2 = __ballot(b0 + lane < nblk && col[p0 + b0 + lane] == row);
-                if (m2) {
-                    diag = b0 + uint32_t(__ffsll(m2)) - 1;
-                    break;
-                }
-            }
-    }
-    const uint32_t e0 = diag < 63 ? uint32_t(__shfl(int(s_lane), int(diag), 64)) : seg[p0 + diag];
-    const uint32_t ne = (diag < 63 ? uint32_t(__shfl(int(s_lane), int(diag) + 1, 64)) : seg[p0 + diag + 1]) - e0;
-    const bool staged = ne <= uint32_t(MAXE); // more elements around one node than the slice holds: read them from memory
-    double *sb = s_basis[wave], *sx = s_x[wave];
-    uint32_t *st = s_tet[wave];
-    // the first round's contributor descriptors travel together with the element list (one more round trip)
-    const uint32_t q_first = uint32_t(__shfl(int(s_lane), 0, 64)) + lane, q_end_first = narrow ? uint32_t(__shfl(int(s_lane), int(nblk), 64)) : seg[p0 + 64];
-    const uint32_t pl_first = q_first < q_end_first ? payload[q_first] : 0u;
-    if (staged) {
-        if (lane < ne) st[lane] = payload[e0 + lane] / (NN * NN);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t f = lane; f < ne * 13; f += 64) sb[f] = basis[EB * size_t(st[f / 13]) + f % 13];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) { // 64 blocks of the row at a time (a row rarely has more)
-        const uint32_t nb = min(64u, nblk - b0);
-        const bool owner = lane < nb;
-        uint32_t mine0, mine1, qa, qb;
-        if (narrow) { // offsets from the neighbouring lanes
-            const uint32_t next = uint32_t(__shfl_down(int(s_lane), 1, 64));
-            mine0 = owner ? s_lane : 0u, mine1 = owner ? next : 0u;
-            qa = uint32_t(__shfl(int(s_lane), 0, 64)), qb = uint32_t(__shfl(int(s_lane), int(nblk), 64));
-        } else {
-            mine0 = owner ? seg[p0 + b0 + lane] : 0u, mine1 = owner ? seg[p0 + b0 + lane + 1] : 0u;
-            qa = seg[p0 + b0], qb = seg[p0 + b0 + nb];
-        }
-        double k[9] = {}, m = 0;
-        for (uint32_t r = qa; r < qb; r += 64) {
-            const uint32_t q = r + lane;
-            double cv[10] = {};
-            if (q < qb) {
-                const uint32_t pl = (b0 == 0 && r == qa) ? pl_first : payload[q];
-                const uint32_t t = pl / (NN * NN), ac = pl % (NN * NN), a = ac / NN, c = ac % NN;
-                double eb[13];
-                if (staged) {
-                    uint32_t slot = 0;
-                    for (uint32_t e = 0; e < ne; ++e) slot = st[e] == t ? e : slot;
-#pragma unroll
-                    for (int i = 0; i < 13; ++i) eb[i] = sb[13 * slot + i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 13; ++i) eb[i] = basis[EB * size_t(t) + i];
-                }
-                const double vol = eb[0];
-                cv[9] = rho * vol * s_mass[a * NN + c];
-                double g[3][3] = {};
-                for (int kk = 0; kk < 4; ++kk) {
-                    for (int ll = 0; ll < 4; ++ll) {
-                        const double w = s_grad[((a * 4 + kk) * NN + c) * 4 + ll];
-                        if (w == 0) continue;
-                        for (int pp = 0; pp < 3; ++pp)
-                            for (int qq = 0; qq < 3; ++qq) g[pp][qq] += w * (eb[1 + 3 * kk + pp] * eb[1 + 3 * ll + qq]);
-                    }
-                }
-                const double trace = g[0][0] + g[1][1] + g[2][2];
-                for (int pp = 0; pp < 3; ++pp)
-                    for (int qq = 0; qq < 3; ++qq) cv[3 * pp + qq] = vol * (lambda * g[pp][qq] + mu * g[qq][pp] + (pp == qq ? mu * trace : 0.0));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the previous round has been consumed
-#pragma unroll
-            for (int e = 0; e < 10; ++e) sx[e * 64 + lane] = cv[e];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t lo = max(mine0, r), hi = min(mine1, r + 64);
-            for (uint32_t qq = lo; qq < hi; ++qq) { // contributor order
-                const uint32_t j = qq - r;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) k[e] += sx[e * 64 + j];
-                m += sx[9 * 64 + j];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (owner) {
-#pragma unroll
-            for (int e = 0; e < 9; ++e) sx[9 * lane + e] = k[e];
-            mval[p0 + b0 + lane] = m;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        double *out = kval + 9 * size_t(p0 + b0);
-        for (uint32_t f = lane; f < 9 * nb; f += 64) out[f] = sx[f];
-    }
-}
-
 
 // ---- level 0: rigid-body aggregates ------------------------------------------------------------------------
 __global__ void k_aggregate_t(const double *__restrict__ p1_xyz, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ tmat) {
@@ -571,7 +535,7 @@ __global__ void k_fix_coarse_diag(double *__restrict__ a0, uint32_t n0, double r
 namespace {
 template<int NN>
 void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t nt, uint32_t nnodes, const double *basis, const double *tables_dev,
-                 const mh_material &mat, BsrLevel &lvl) {
+                 const double *support_tables_dev, const mh_material &mat, BsrLevel &lvl) {
     const size_t npairs = size_t(nt) * NN * NN;
     DevArray<uint64_t> keys(ctx, npairs), keys_s(ctx, npairs);
     DevArray<uint32_t> pay(ctx, npairs), pay_s(ctx, npairs), head(ctx, npairs), incl(ctx, npairs);
@@ -600,15 +564,12 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
         // element bases are built from them), 80 B (9 K values + 1 M value) written per node block
         std::optional<TimedLaunch> timed; // the quadratic level's launch is the one the roofline object reports
         if (NN == 10) timed.emplace(ctx, MH_KERNEL_ASSEMBLY, 152.0 * double(nt) + 80.0 * double(nb));
-        // The row-wise form (k_assemble_rows: balanced contributor lanes, LDS-staged element data, coalesced block stores) was
-        // built to replace the one-thread-per-block form and measured beside it (tools/ab_assembly.sh, S100k): 426 us against
-        // 327 us -- its LDS round trips and fences cost more than the imbalance and the strided stores they remove.  It stays
-        // selectable (MH_ASSEMBLE_BY_ROW=1); both produce the same bits.
-        static const bool by_block = !(getenv("MH_ASSEMBLE_BY_ROW") && atoi(getenv("MH_ASSEMBLE_BY_ROW")) != 0);
+        // One lane per contribution (k_assemble_flat) against one thread per node block (k_assemble), S100k, tools/ab_assembly.sh:
+        // DESIGN.md section 5 has the measured pair.  A third form (one wave per node row, LDS-staged element data) was built in
+        // between and measured slower than either (426 us; profiles/r02_ab_assembly.txt); it is gone.
+        static const bool by_block = getenv("MH_ASSEMBLE_BY_BLOCK") && atoi(getenv("MH_ASSEMBLE_BY_BLOCK")) != 0;
         if (by_block) k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
-        else
-            k_assemble_rows<NN><<<div_up(nnodes, 4), 256, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, seg, pay_s, nnodes, basis, tables_dev, mat.density, lambda, mu, lvl.kval,
-                                                                           lvl.mval);
+        else k_assemble_flat<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, support_tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
     }
     KERNEL_CHECK();
 }
@@ -665,6 +626,28 @@ void linear_tables(std::vector<double> &t) { // mass[4][4] = (1 + delta)/20, gra
             t[a * 4 + c] = (a == c ? 2.0 : 1.0) / 20.0;
             t[16 + ((a * 4 + a) * 4 + c) * 4 + c] = 1.0;
         }
+}
+// mass[NN][NN] then W[NN][NN][2][2]: the entries of grad[a][k][c][l] with k, l in the supports of a and c (k_assemble_flat).
+// Everything outside the supports must be an exact zero -- it is for Lagrange elements on barycentric coordinates.
+std::vector<double> support_tables(const std::vector<double> &full, int nn) {
+    static const int S0[10] = {0, 1, 2, 3, 0, 0, 0, 1, 1, 2}, S1[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+    std::vector<double> out(size_t(nn) * nn * 5, 0.0);
+    std::copy(full.begin(), full.begin() + nn * nn, out.begin());
+    for (int a = 0; a < nn; ++a)
+        for (int c = 0; c < nn; ++c) {
+            double *w = out.data() + nn * nn + (a * nn + c) * 4;
+            for (int k = 0; k < 4; ++k)
+                for (int l = 0; l < 4; ++l) {
+                    const double v = full[nn * nn + ((a * 4 + k) * nn + c) * 4 + l];
+                    const int x = k == S0[a] ? 0 : (k == S1[a] ? 1 : -1), y = l == S0[c] ? 0 : (l == S1[c] ? 1 : -1);
+                    if (x < 0 || y < 0) {
+                        if (v != 0) mh_throw(MH_EINVAL, "gradient table entry outside the shape functions' supports");
+                        continue;
+                    }
+                    w[2 * x + y] = v;
+                }
+        }
+    return out;
 }
 } // namespace
 
@@ -770,13 +753,16 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
     std::vector<double> tq, tl;
     quad_tables(tq);
     linear_tables(tl);
-    DevArray<double> tq_dev(ctx, tq.size()), tl_dev(ctx, tl.size());
+    const std::vector<double> sq = support_tables(tq, 10), sl = support_tables(tl, 4);
+    DevArray<double> tq_dev(ctx, tq.size()), tl_dev(ctx, tl.size()), sq_dev(ctx, sq.size()), sl_dev(ctx, sl.size());
     tq_dev.upload(tq.data(), tq.size());
     tl_dev.upload(tl.data(), tl.size());
+    sq_dev.upload(sq.data(), sq.size());
+    sl_dev.upload(sl.data(), sl.size());
     sys->L2.id = 2;
     sys->L1.id = 1;
-    build_level<10>(ctx, tmp, sys->elem_nodes, nt, nn, sys->elem_basis, tq_dev, mat, sys->L2);
-    build_level<4>(ctx, tmp, elem_p1, nt, npts, sys->elem_basis, tl_dev, mat, sys->L1);
+    build_level<10>(ctx, tmp, sys->elem_nodes, nt, nn, sys->elem_basis, tq_dev, sq_dev, mat, sys->L2);
+    build_level<4>(ctx, tmp, elem_p1, nt, npts, sys->elem_basis, tl_dev, sl_dev, mat, sys->L1);
 
     // --- rigid-body aggregates over runs of consecutive (Morton-ordered) P1 nodes
     if (const char *e = getenv("MH_AGG")) sys->agg_size = std::max(2, atoi(e));
