@@ -121,6 +121,12 @@ int mh_system_bench_elementwise(mh_system *, uint32_t width, uint32_t reps, doub
  * over resident random panels. */
 int mh_context_bench_dense(mh_context *, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms);
 
+/* Test and measurement aid for the Rayleigh-Ritz step's Householder tridiagonalisation (what Eigen's
+ * SelfAdjointEigenSolver does inside the reference's warm branch, mesh2modes.cpp:405-417, and Spectra inside the cold
+ * one): a (m x m, symmetric, both triangles, m <= 256) -> diagonal d[m] and subdiagonal e[m - 1] of Q^T a Q.
+ * variant 0 = one workgroup, 1 = several workgroups exchanging tagged values.  avg_ms (optional) = device time per run. */
+int mh_context_tridiagonalize(mh_context *, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms);
+
 /* The nearest tet point to each excitation position, first minimum wins (mesh2modes.cpp:626-636). */
 int mh_nearest_points(mh_context *, const mh_mesh *, uint32_t n, const float *positions_xyz, uint32_t *nearest);
 

@@ -67,6 +67,7 @@ def lib():
         "mh_system_matvec": (i32, [vp, i32, vp, vp, u32]), "mh_system_bench_spmm": (i32, [vp, u32, u32, C.POINTER(f64), C.POINTER(f64)]),
         "mh_system_bench_elementwise": (i32, [vp, u32, u32, C.POINTER(f64)]), "mh_nearest_points": (i32, [vp, vp, u32, vp, vp]),
         "mh_context_bench_dense": (i32, [vp, i32, C.c_uint64, u32, u32, u32, C.POINTER(f64)]),
+        "mh_context_tridiagonalize": (i32, [vp, i32, u32, vp, vp, vp, u32, C.POINTER(f64)]),
         "mh_eigs": (i32, [vp, u32, f64, f64, u32, vp, u32, u32, vp, vp, vp, C.POINTER(Profile)]),
         "mh_system_gather_shapes": (i32, [vp, u32, vp, u32, vp]), "mh_system_basis": (i32, [vp, u32, vp]),
         "mh_system_eigenvectors": (i32, [vp, u32, vp]),

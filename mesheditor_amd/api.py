@@ -62,6 +62,15 @@ class Context:
         self.check(self.L.mh_context_bench_dense(self.h, kind, n, wa, wb, reps, C.byref(ms)))
         return ms.value
 
+    def tridiagonalize(self, a, variant=0, reps=1):
+        """(d, e, ms): the tridiagonal form of the symmetric matrix a (order <= 256) by the Rayleigh-Ritz step's kernel
+        (variant 0: one workgroup, 1: several), and the device time per run."""
+        a = np.asfortranarray(a, dtype=np.float64)
+        m = a.shape[0]
+        d, e, ms = np.zeros(m), np.zeros(max(m - 1, 1)), C.c_double(0)
+        self.check(self.L.mh_context_tridiagonalize(self.h, variant, m, _p(a), _p(d), _p(e), reps, C.byref(ms)))
+        return d, e[: m - 1], ms.value
+
     def kernel_stats(self, kernel_class=0):
         """Totals of a timed kernel class since time_kernels(True): 0 = operator products (bytes), 1 = assembly kernel (bytes),
         2 = resonator kernel (flops)."""

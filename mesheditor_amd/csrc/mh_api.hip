@@ -393,6 +393,37 @@ int mh_context_bench_dense(mh_context *ctx, int kind, uint64_t n, uint32_t wa, u
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+int mh_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms) {
+    if (!ctx || !a || !d || !e || m < 2 || m > 256 || variant < 0 || variant > 1) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::lock_guard<std::mutex> lock(mh_solve_mutex());
+        DevArray<double> da(ctx, size_t(m) * m), work(ctx, size_t(m) * m), dd(ctx, m), de(ctx, m), dtau(ctx, m);
+        da.upload(a, size_t(m) * m);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float total = 0;
+        for (uint32_t r = 0; r < std::max(1u, reps); ++r) {
+            HIP_CHECK(hipMemcpyAsync(work, da, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_CHECK(hipEventRecord(e0, ctx->stream));
+            mh_sytrd_small(ctx, work, m, dd, de, dtau, variant);
+            HIP_CHECK(hipEventRecord(e1, ctx->stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        dd.download(d, m);
+        de.download(e, m - 1);
+        if (mh_sytrd_gave_up(ctx)) mh_throw(MH_EHIP, "tridiagonalisation: a workgroup timed out waiting for the others' values");
+        if (avg_ms) *avg_ms = total / std::max(1u, reps);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 int mh_nearest_points(mh_context *ctx, const mh_mesh *mesh, uint32_t n, const float *positions_xyz, uint32_t *nearest) {
     if (!ctx || !mesh || (n && (!positions_xyz || !nearest))) return MH_EINVAL;
     if (n == 0) return MH_OK;

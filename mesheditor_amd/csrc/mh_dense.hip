@@ -704,12 +704,186 @@ __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *
     }
 }
 
-void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau) {
+// ---- the same reduction on SEVERAL CUs ---------------------------------------------------------------------------
+// The one-workgroup kernel streams the trailing block from L2 twice per column through one CU's memory path (~60 GB/s:
+// 4 us per column, 0.9 ms at m = 230 -- the largest single kernel of a solve).  Here G workgroups hold the matrix in
+// their LDS, column c with workgroup c mod G, kept fully symmetric so that (A v)_c is the dot product of column c with v:
+//   per column k, every workgroup
+//     1. knows the previous reflector pair (v, w) and column k as its owner last stored it; forms the up-to-date column,
+//        its reflector v_k and tau_k for itself (redundantly: no broadcast hop);
+//     2. sweeps its own columns c > k once: applies the previous pair, takes the dot product with v_k, and PUBLISHES
+//        p_c -- and, if it owns column k + 1, that column as it now stands;
+//     3. collects all of p and column k + 1 from the others and forms w_k for itself.
+// One exchange per column, and it is not a barrier: every published double travels as two self-tagged 8-byte granules
+// (32 payload bits + a 32-bit tag = launch epoch and step), written with agent-scope relaxed atomic stores and polled with
+// agent-scope relaxed atomic loads until the tag matches -- no fence, no flag, no ordering needed (an aligned 8-byte
+// store is single-copy atomic).  Slots alternate by step parity: a workgroup can only write step k + 2 after it has read
+// all of step k + 1, which exists only after every workgroup has finished reading step k.
+// Only workgroups with blockIdx % 8 == 0 take part (blocks b and b + 8 share an XCD and its L2 as the dispatcher is
+// observed to deal them; correctness does not depend on it).  Sums run in a fixed order for fixed G: bit-reproducible.
+// Every poll is bounded: a workgroup that gives up raises *gave_up and the result is garbage the caller must not use.
+#ifndef MH_SYTRD_GROUPS
+#define MH_SYTRD_GROUPS 16
+#endif
+namespace {
+constexpr int SYTRD_LD = 272; // LDS column stride in doubles: the four 16-lane column groups of a wave start 32 banks apart
+__device__ __forceinline__ void publish_tagged(unsigned long long *slot, double value, unsigned tag) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(value), t = (unsigned long long)tag << 32;
+    __hip_atomic_store(slot, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slot + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// two values at once: all four loads of a poll round are in flight together (one memory round trip per round, not two)
+__device__ __forceinline__ bool collect_tagged2(const unsigned long long *slot_a, const unsigned long long *slot_b, unsigned tag, double &a, double &b) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const unsigned long long alo = __hip_atomic_load(slot_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ahi = __hip_atomic_load(slot_a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long blo = __hip_atomic_load(slot_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long bhi = __hip_atomic_load(slot_b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (unsigned(alo >> 32) == tag && unsigned(ahi >> 32) == tag && unsigned(blo >> 32) == tag && unsigned(bhi >> 32) == tag) {
+            a = __longlong_as_double((long long)((alo & 0xffffffffull) | (ahi << 32)));
+            b = __longlong_as_double((long long)((blo & 0xffffffffull) | (bhi << 32)));
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU,
+                                                                   unsigned long long *__restrict__ xch, unsigned epoch, int *__restrict__ gave_up) {
+    if (blockIdx.x % 8) return;
+    const int g = blockIdx.x / 8, tid = threadIdx.x, lane = tid & 63;
+    __shared__ double a[16 * SYTRD_LD];
+    // xs: the up-to-date column of the step from its diagonal entry down; sq: its squares; pq: p . v terms; prs: p
+    __shared__ double v[256], vp[256], wp[256], xs[264], sq[264], pq[256], prs[256];
+    __shared__ int s_fail;
+    // exchange slots: [parity][kind: 0 = p, 1 = column][index][2 granules]
+    auto slot = [&](int parity, int kind, int index) { return xch + ((size_t(parity) * 2 + kind) * 256 + index) * 2; };
+    const int jl = tid >> 4, t16 = tid & 15, cl = g + jl * G; // this thread's local column in the sweep
+    const int last_col = g + G * ((m - 1 - g) / G);           // the last column this workgroup owns
+    for (int j = 0; j < 16; ++j) {
+        const int c = g + j * G;
+        if (c < m && tid < m) a[j * SYTRD_LD + tid] = A[size_t(c) * m + tid];
+    }
+    if (tid < m) {
+        const double x = A[tid]; // column 0
+        xs[tid] = x;
+        sq[tid] = tid >= 2 ? x * x : 0.0;
+    }
+    v[tid] = 0.0, vp[tid] = 0.0, wp[tid] = 0.0;
+    if (tid == 0) s_fail = 0;
+    for (int k = 0; k + 1 < m; ++k) {
+        const int l = m - k - 1; // order of the trailing block, rows/cols k+1 .. m-1
+        const unsigned tag = (epoch << 9) | unsigned(k + 1);
+        const int parity = k & 1;
+        const bool mine = g == k % G; // column k is this workgroup's: it reports the step's scalars and stores the reflector
+        __syncthreads(); // (1) xs, sq and the pending pair (vp, wp) are in place
+        const double xnorm2 = wave_sum_lds(sq, l + 1, lane);
+        const double alpha = xs[1];
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (xnorm2 > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (mine && tid == 0) {
+            D[k] = xs[0];
+            E[k] = beta;
+            TAU[k] = tau;
+        }
+        double vi = 0.0;
+        if (tid < l) {
+            vi = tau == 0.0 ? 0.0 : (tid == 0 ? 1.0 : xs[tid + 1] * scale);
+            v[k + 1 + tid] = vi;
+            // the subdiagonal entry, then the reflector tail (tau = 0: the column is zero below it), for the back-transformation.
+            // Step 0's store waits until this step's values have been collected: every workgroup reads column 0 of A at its
+            // start, and only the collection proves that all of them are past that.
+            if (mine && k > 0) A[size_t(k) * m + k + 1 + tid] = tid == 0 ? beta : vi;
+        }
+        // A workgroup without a column beyond k is done: nobody waits for anything from it any more.  (Every workgroup that
+        // stays publishes at every step, so collecting a step's values proves that all the others have finished reading
+        // the step before -- which is what allows the slots to alternate.)
+        if (last_col <= k) return;
+        __syncthreads(); // (2) reflector published inside the workgroup
+        if (cl > k && cl < m) {
+            const double vpc = vp[cl], wpc = wp[cl];
+            double *col = a + jl * SYTRD_LD;
+            double acc = 0.0;
+            for (int r = k + 1 + t16; r < m; r += 16) {
+                const double aa = col[r] - (vp[r] * wpc + wp[r] * vpc);
+                col[r] = aa;
+                acc += aa * v[r];
+                if (cl == k + 1) publish_tagged(slot(parity, 1, r), aa, tag);
+            }
+            for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+            if (t16 == 0) publish_tagged(slot(parity, 0, cl), acc, tag);
+        }
+        double pr = 0.0, xn = 0.0;
+        bool ok = true;
+        if (tid < l) {
+            ok = collect_tagged2(slot(parity, 0, k + 1 + tid), slot(parity, 1, k + 1 + tid), tag, pr, xn);
+            pr *= tau;
+            prs[tid] = pr;
+            pq[tid] = pr * vi;
+        }
+        if (!ok) s_fail = 1;
+        __syncthreads(); // (3) p and its products with v published inside the workgroup
+        if (s_fail) { // (uniform) give up: the others will time out in their own polls
+            if (tid == 0) *gave_up = 1;
+            return;
+        }
+        const double pv = wave_sum_lds(pq, l, lane);
+        if (tid < l) {
+            const double wi = pr - 0.5 * tau * pv * vi;
+            const double v0 = v[k + 1], w0 = prs[0] - 0.5 * tau * pv * v0;
+            const double xc = xn - (vi * w0 + wi * v0); // column k + 1 brought up to date with this step's pair
+            if (mine && k == 0) A[size_t(k) * m + k + 1 + tid] = tid == 0 ? beta : vi;
+            vp[k + 1 + tid] = vi;
+            wp[k + 1 + tid] = wi;
+            xs[tid] = xc;
+            sq[tid] = tid >= 2 ? xc * xc : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // (the owner of column m - 1 is the one workgroup that gets here)
+        D[m - 1] = xs[0];
+        TAU[m - 1] = 0.0;
+    }
+}
+} // namespace
+
+void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant) {
     if (m < 1 || m > 256) mh_throw(MH_EINVAL, "sytrd_small: order %u outside 1..256", m);
     static const bool fused = !(getenv("MH_SYTRD_FUSED") && atoi(getenv("MH_SYTRD_FUSED")) == 0);
-    if (fused) k_sytrd_small_fused<<<1, MH_SYTRD_THREADS, 0, ctx->stream>>>(a, int(m), d, e, tau);
+    // several workgroups from order 64 up (measured: 287 against 363 us at 96, 861 against 1 812 us at 222); MH_SYTRD_MULTI=0: always one
+    static const bool multi_default = !(getenv("MH_SYTRD_MULTI") && atoi(getenv("MH_SYTRD_MULTI")) == 0);
+    const bool multi = variant < 0 ? (multi_default && m >= 64) : variant == 1;
+    if (multi && m >= 32) {
+        constexpr int G = MH_SYTRD_GROUPS;
+        constexpr size_t xch_words = 2 * 2 * 256 * 2;
+        if (!ctx->sytrd_xch) {
+            ctx->sytrd_xch = static_cast<unsigned long long *>(ctx->pool.alloc(xch_words * sizeof(unsigned long long) + 64));
+            HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch, 0, xch_words * sizeof(unsigned long long) + 64, ctx->stream));
+        }
+        if ((++ctx->sytrd_epoch & 0x7fffffu) == 0) { // the tag's epoch field wraps: clear the slots so that no old tag can match
+            ctx->sytrd_epoch = 1;
+            HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch, 0, xch_words * sizeof(unsigned long long) + 64, ctx->stream));
+        }
+        k_sytrd_multi<G><<<8 * G, 256, 0, ctx->stream>>>(a, int(m), d, e, tau, ctx->sytrd_xch, ctx->sytrd_epoch, reinterpret_cast<int *>(ctx->sytrd_xch + xch_words));
+        ctx->sytrd_flag = reinterpret_cast<int *>(ctx->sytrd_xch + xch_words);
+    } else if (fused) k_sytrd_small_fused<<<1, MH_SYTRD_THREADS, 0, ctx->stream>>>(a, int(m), d, e, tau);
     else k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
     KERNEL_CHECK();
+}
+
+// Whether a workgroup of the multi-workgroup reduction ever gave up waiting for the others on this context (their values never
+// arrived within ~4 s): its output is then garbage.  Reads four bytes back; call it where the stream is synchronised anyway.
+bool mh_sytrd_gave_up(mh_context *ctx) {
+    if (!ctx->sytrd_flag) return false;
+    int flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, ctx->sytrd_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return flag != 0;
 }
 
 // Z <- Q Z for the orthogonal factor of mh_sytrd_small (LAPACK's lower storage: reflector k has v[k+1] = 1 and its tail in

@@ -640,6 +640,10 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         // rocSOLVER's divide and conquer on T and the back-transformation Z <- Q Z
         DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
         mh_sytrd_small(ctx, gA, m, evals, ework, tau); // gA is fully symmetric here (k_symmetrize_lower above / the reduction)
+        // the multi-workgroup reduction's give-up flag travels with the next read-back of this step (both paths below have one)
+        int sytrd_gave_up = 0;
+        if (ctx->sytrd_flag) HIP_CHECK(hipMemcpyAsync(&sytrd_gave_up, ctx->sytrd_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        bool flag_read = false;
         // only the nwant lowest pairs are needed: our one-launch multisection + inverse iteration (mh_tridiag_lowest) instead of
         // the full divide and conquer, accepted when its residual check passes
         const bool own_tridiag = switches().own_tridiag;
@@ -651,6 +655,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
                 double qv[5] = {1, 0, 0, 0, 0};
                 HIP_CHECK(hipMemcpyAsync(qv, wv.get() + m, sizeof(qv), hipMemcpyDeviceToHost, ctx->stream));
                 HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                flag_read = true;
                 const double quality = qv[0];
                 const bool verbose = switches().verbose;
                 if (verbose)
@@ -666,8 +671,11 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         if (!done) {
             ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
             info.download(&hinfo, 1);
+            flag_read = true;
             if (hinfo != 0) return hinfo;
         }
+        if (!flag_read) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (sytrd_gave_up) mh_throw(MH_EHIP, "tridiagonalisation: a workgroup timed out waiting for the others' values");
         const bool own_ormtr = switches().own_ormtr;
         if (own_ormtr) mh_apply_q(ctx, gA, tau, m, z, m, ncols);
         else ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, ncols, gA, m, tau, z, m));

@@ -549,3 +549,24 @@ def test_elementwise_operator_matches_the_assembled_one(api, ctx):
             got = sysg.matvec(5, x)
             assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (name, width, np.abs(got - ref).max() / np.abs(ref).max())
         sysg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("m", [33, 96, 160, 222, 240, 256])
+def test_small_tridiagonalisation_keeps_the_spectrum(ctx, variant, m):
+    """The Rayleigh-Ritz step's Householder reduction (one workgroup / several workgroups exchanging tagged values):
+    Q^T A Q = T must have A's eigenvalues, to rounding, and both variants must be reproducible run to run."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    rng = np.random.default_rng(1000 + m)
+    q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    lam = np.sort(rng.uniform(1.0, 1e4, m))
+    lam[:3] = lam[3]  # an exact multiplet, as the cube meshes produce
+    a = (q * lam) @ q.T
+    a = 0.5 * (a + a.T)
+    d, e, _ = ctx.tridiagonalize(a, variant=variant)
+    got = eigvalsh_tridiagonal(d, e)
+    want = np.linalg.eigvalsh(a)
+    assert np.max(np.abs(got - want)) <= 1e-12 * lam[-1] * m
+    d2, e2, _ = ctx.tridiagonalize(a, variant=variant)
+    assert np.array_equal(d, d2) and np.array_equal(e, e2)
