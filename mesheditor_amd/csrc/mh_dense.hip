@@ -715,9 +715,9 @@ __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *
 //        p_c -- and, if it owns column k + 1, that column as it now stands;
 //     3. collects all of p and column k + 1 from the others and forms w_k for itself.
 // One exchange per column, and it is not a barrier: every published double travels as two self-tagged 8-byte granules
-// (32 payload bits + a 32-bit tag = launch epoch and step), written with agent-scope relaxed atomic stores and polled with
-// agent-scope relaxed atomic loads until the tag matches -- no fence, no flag, no ordering needed (an aligned 8-byte
-// store is single-copy atomic).  Slots alternate by step parity: a workgroup can only write step k + 2 after it has read
+// (32 payload bits + a 32-bit tag = launch epoch and step), written by a write-through (sc0 sc1) store and polled with
+// cache-bypassing loads until both tags match -- no fence, no flag, no ordering needed (an aligned 8-byte granule is
+// written whole).  Slots alternate by step parity: a workgroup can only write step k + 2 after it has read
 // all of step k + 1, which exists only after every workgroup has finished reading step k.
 // Only workgroups with blockIdx % 8 == 0 take part (blocks b and b + 8 share an XCD and its L2 as the dispatcher is
 // observed to deal them; correctness does not depend on it).  Sums run in a fixed order for fixed G: bit-reproducible.
@@ -727,21 +727,22 @@ __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *
 #endif
 namespace {
 constexpr int SYTRD_LD = 272; // LDS column stride in doubles: the four 16-lane column groups of a wave start 32 banks apart
+typedef unsigned granule_pair __attribute__((ext_vector_type(4))); // {payload low, tag, payload high, tag}: two self-tagged 8-byte granules
+// One 16-byte write-through store per value (a scalar-sized sc1 store is a fabric write of its own: half as many this way).
+// If the store were ever torn, it would tear between the two granules, each of which carries its own tag.
 __device__ __forceinline__ void publish_tagged(unsigned long long *slot, double value, unsigned tag) {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(value), t = (unsigned long long)tag << 32;
-    __hip_atomic_store(slot, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(value);
+    const granule_pair g = {unsigned(bits), tag, unsigned(bits >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(g) : "memory");
 }
-// two values at once: all four loads of a poll round are in flight together (one memory round trip per round, not two)
+// two values at once: both loads of a poll round are in flight together (one memory round trip per round)
 __device__ __forceinline__ bool collect_tagged2(const unsigned long long *slot_a, const unsigned long long *slot_b, unsigned tag, double &a, double &b) {
     for (int spin = 0; spin < (1 << 22); ++spin) {
-        const unsigned long long alo = __hip_atomic_load(slot_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long ahi = __hip_atomic_load(slot_a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long blo = __hip_atomic_load(slot_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long bhi = __hip_atomic_load(slot_b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (unsigned(alo >> 32) == tag && unsigned(ahi >> 32) == tag && unsigned(blo >> 32) == tag && unsigned(bhi >> 32) == tag) {
-            a = __longlong_as_double((long long)((alo & 0xffffffffull) | (ahi << 32)));
-            b = __longlong_as_double((long long)((blo & 0xffffffffull) | (bhi << 32)));
+        granule_pair ga, gb;
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ga), "=&v"(gb) : "v"(slot_a), "v"(slot_b) : "memory");
+        if (ga.y == tag && ga.w == tag && gb.y == tag && gb.w == tag) {
+            a = __longlong_as_double((long long)((unsigned long long)ga.x | ((unsigned long long)ga.z << 32)));
+            b = __longlong_as_double((long long)((unsigned long long)gb.x | ((unsigned long long)gb.z << 32)));
             return true;
         }
         __builtin_amdgcn_s_sleep(1);
