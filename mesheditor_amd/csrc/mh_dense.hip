@@ -1316,6 +1316,96 @@ __global__ void __launch_bounds__(256) k_potrf_small(double *__restrict__ A, int
 }
 } // namespace
 
+// The same factorisation eight columns at a time: two barriers per PANEL instead of three per column.  Every thread factors
+// the 8 x 8 diagonal block for itself in registers (uniform work, no broadcast), a thread per row solves the panel below
+// it, then the trailing triangle takes the panel's eight rank-1 updates one after the other.  Every entry goes through
+// exactly the operations of the column-by-column kernel in the same order: the two produce the same bits.
+namespace {
+__global__ void __launch_bounds__(256) k_potrf_panels(double *__restrict__ A, int w, int *__restrict__ info) {
+    constexpr int NB = 8;
+    extern __shared__ __attribute__((aligned(16))) double L[]; // w x w, column-major, pitch w + 1 (bank spread)
+    const int tid = threadIdx.x, pitch = w + 1;
+    for (int idx = tid; idx < w * w; idx += 256) L[(idx / w) * pitch + idx % w] = A[idx];
+    __syncthreads();
+    int fail = 0; // uniform
+    for (int k0 = 0; k0 < w && !fail; k0 += NB) {
+        const int nb = min(NB, w - k0);
+        double blk[NB][NB], inv[NB]; // lower triangle of the diagonal block, column q in blk[.][q]
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int p = q; p < NB; ++p) blk[p][q] = (p < nb) ? L[(k0 + q) * pitch + k0 + p] : (p == q ? 1.0 : 0.0); // identity padding: inert
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const double akk = blk[q][q];
+            if (!(akk > 0.0) && !fail) fail = k0 + q + 1;
+            const double d = sqrt(akk);
+            inv[q] = 1.0 / d;
+            blk[q][q] = d;
+#pragma unroll
+            for (int p = q + 1; p < NB; ++p) blk[p][q] *= inv[q];
+#pragma unroll
+            for (int j = q + 1; j < NB; ++j)
+#pragma unroll
+                for (int p = j; p < NB; ++p) blk[p][j] -= blk[p][q] * blk[j][q];
+        }
+        if (fail) break;
+        __syncthreads(); // everyone has read the block before anyone overwrites it
+        if (tid < NB * NB) {
+            const int q = tid / NB, pr = tid % NB;
+            if (pr >= q && pr < nb) {
+                double val = 0.0;
+#pragma unroll
+                for (int qq = 0; qq < NB; ++qq)
+#pragma unroll
+                    for (int pp = qq; pp < NB; ++pp)
+                        if (qq == q && pp == pr) val = blk[pp][qq]; // (register arrays cannot be indexed dynamically)
+                L[(k0 + q) * pitch + k0 + pr] = val;
+            }
+        }
+        for (int i = k0 + nb + tid; i < w; i += 256) { // the panel's rows below the block: x L_kk^T = a
+            double x[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) x[q] = q < nb ? L[(k0 + q) * pitch + i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                for (int qq = 0; qq < q; ++qq) x[q] -= x[qq] * blk[q][qq];
+                x[q] *= inv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (q < nb) L[(k0 + q) * pitch + i] = x[q];
+        }
+        __syncthreads();
+        // trailing lower triangle: columns j beyond the panel, rows i >= j
+        const int rem = w - k0 - nb;
+        for (int idx = tid; idx < rem * rem; idx += 256) {
+            const int j = k0 + nb + idx / rem, i = k0 + nb + idx % rem;
+            if (i >= j) {
+                double a = L[j * pitch + i];
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    if (q < nb) a -= L[(k0 + q) * pitch + i] * L[(k0 + q) * pitch + j];
+                L[j * pitch + i] = a;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int j = idx / w, i = idx % w;
+        if (i >= j) A[idx] = L[j * pitch + i]; // the strictly upper part keeps the input, as potrf
+    }
+    if (tid == 0) {
+        info[0] = fail;
+        double lo = 1.7976931348623157e308, hi = 0;
+        for (int k = 0; k < w; ++k) { const double v = L[k * pitch + k]; lo = fmin(lo, v); hi = fmax(hi, v); }
+        info[1] = fail || !(lo > 0) ? 1 << 20 : int(16.0 * log2(hi / lo)); // as k_potrf_small
+    }
+}
+} // namespace
+
 // Inverse of a symmetric positive definite block of order w <= 128 (column-major, leading dimension lda) into out (w x w,
 // leading dimension ldo): in-place Gauss-Jordan without pivoting in registers, one workgroup.  Every pivot of an SPD matrix is
 // positive; a pivot that is not sets *info = its index + 1 (info is only ever raised: clear it before a sequence of calls).
@@ -1390,6 +1480,11 @@ void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "potrf_small: order %u outside 1..128", w);
     static PerDeviceOnce attr;
     attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });
-    k_potrf_small<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
+    static const bool panels = !(getenv("MH_POTRF_PANELS") && atoi(getenv("MH_POTRF_PANELS")) == 0);
+    if (panels) {
+        static PerDeviceOnce attr2;
+        attr2.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_panels), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });
+        k_potrf_panels<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
+    } else k_potrf_small<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
     KERNEL_CHECK();
 }
