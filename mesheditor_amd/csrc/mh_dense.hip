@@ -164,18 +164,22 @@ __global__ void __launch_bounds__(GI * GJ * KS * 64) __attribute__((amdgpu_waves
     }
 }
 
-// 8 threads per output entry: each sums a strided eighth of the partial Grams, then a fixed-order combine
-__global__ void k_gram_reduce(const double *__restrict__ partial, int nwg, int wa, int wb, double *__restrict__ g, int ld) {
-    __shared__ double s[256];
-    const int idx = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+// Sum of the workgroups' partial Grams, in a fixed order: a workgroup owns 64 consecutive entries (lanes: whole 512-byte
+// runs of a partial), each of its 16 waves adds every 16th partial, then wave 0 adds the 16 sums in order.
+__global__ void __launch_bounds__(1024) k_gram_reduce(const double *__restrict__ partial, int nwg, int wa, int wb, double *__restrict__ g, int ld) {
+    __shared__ double s[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, idx = blockIdx.x * 64 + lane, total = wa * wb;
     double acc = 0;
-    if (idx < wa * wb)
-        for (int w = part; w < nwg; w += 8) acc += partial[size_t(w) * wa * wb + idx];
-    s[threadIdx.x] = acc;
+    if (idx < total) {
+#pragma unroll 8
+        for (int w = wv; w < nwg; w += 16) acc += partial[size_t(w) * total + idx];
+    }
+    s[wv][lane] = acc;
     __syncthreads();
-    if (part == 0 && idx < wa * wb) {
+    if (wv == 0 && idx < total) {
         double t = 0;
-        for (int k = 0; k < 8; ++k) t += s[threadIdx.x + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s[k][lane];
         g[size_t(idx / wa) * ld + idx % wa] = t;
     }
 }
@@ -334,7 +338,7 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
     else mh_throw(MH_EINVAL, "gram block %u x %u too wide", wa, wb);
 #undef IC
     KERNEL_CHECK();
-    k_gram_reduce<<<div_up(size_t(wa) * wb, 32), 256, 0, ctx->stream>>>(workspace, nwg, int(wa), int(wb), g, int(ld));
+    k_gram_reduce<<<div_up(size_t(wa) * wb, 64), 1024, 0, ctx->stream>>>(workspace, nwg, int(wa), int(wb), g, int(ld));
     KERNEL_CHECK();
 }
 } // namespace
