@@ -1182,33 +1182,38 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
     __syncthreads();
     const long long t_invit = wall_clock64();
     // 3. classical Gram-Schmidt, left-looking over the vectors; a second pass only when the first cancelled more than half of
-    //    the (unit) vector ("twice is enough")
+    //    the (unit) vector ("twice is enough").  Two barriers per pass: the coefficients come out of lane shuffles (eight
+    //    adjacent lanes per earlier vector), finished vectors stay UNNORMALISED until the end (the coefficient of vector a
+    //    carries 1 / |x_a|^2, which the eight threads that own a remember), and the squared norm is read by every wave for
+    //    itself.  (A panel-wise form -- block projection twice, then Cholesky-QR of eight vectors twice -- was built and
+    //    measured slower: 308 against 217 us at m = 222, k = 74; its tiny in-register factorisations are dependent chains of
+    //    square roots and divisions.)
+    double my_inv2 = 1.0; // 1 / |x_a|^2 of the earlier vector this thread takes coefficients for (a = tid >> 3)
     for (int j = 0; j < k; ++j) {
         double left = 1.0;
         for (int pass = 0; pass < 2; ++pass) {
             // coefficient of vector a in vector j: eight threads per a, each a strided eighth of the rows, added in a fixed order
             {
                 const int a = tid >> 3, part = tid & 7;
-                if (a < j) {
-                    double s = 0;
-                    for (int i = part; i < m; i += 8) s += X[i * k + a] * X[i * k + j];
-                    red[tid] = s;
-                }
-            }
-            __syncthreads();
-            if (tid < j) {
                 double s = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s += red[tid * 8 + q];
-                coef[tid] = s;
+                if (a < j) {
+#pragma unroll 8
+                    for (int i = part; i < m; i += 8) s += X[i * k + a] * X[i * k + j];
+                }
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                if (a < j && part == 0) coef[a] = s * my_inv2;
             }
             __syncthreads();
             // x_j -= X[:, :j] c: four threads per row; the squares of the new entries go out for the norm
             {
                 const int i = tid >> 2, part = tid & 3;
                 double s = 0;
-                if (i < m)
+                if (i < m) {
+#pragma unroll 8
                     for (int a = part; a < j; a += 4) s += coef[a] * X[i * k + a];
+                }
                 s += __shfl_xor(s, 1, 64);
                 s += __shfl_xor(s, 2, 64);
                 if (part == 0) {
@@ -1221,14 +1226,15 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
                 }
             }
             __syncthreads();
-            left = wave_sum_lds(red, m, lane); // every wave the same bits
-            __syncthreads();
+            left = wave_sum_lds(red, m, lane); // every wave the same bits; red is next written behind the next barrier
             if (left > 0.5 || j == 0) break; // uniform
         }
-        const double inv = 1.0 / sqrt(left);
-        if (tid < m) X[tid * k + j] *= inv;
-        __syncthreads();
+        if ((tid >> 3) == j) my_inv2 = 1.0 / left;
+        if (tid == 0) lo[j] = 1.0 / sqrt(left); // (lo / hi are free after the multisection) the vector's final scale
     }
+    __syncthreads();
+    for (int idx = tid; idx < m * k; idx += 1024) X[idx] *= lo[idx % k];
+    __syncthreads();
     const long long t_gs = wall_clock64();
     // 4. residual of the finished pairs, and output
     double worst = 0;
