@@ -114,8 +114,8 @@ def cpu_baseline(workload="cube_s10k"):
     po.set_threads(1)
     best = runs[max(runs)]
     return {"value": best["eigenpairs_per_s"], "unit": "eigenpairs/s", "cores": best["threads"], "kind": "port", "host_cores": cores,
-            "sample": "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path (1/10 of the metric's mesh; the direct solve grows ~quadratically with size; "
-                      "larger samples, run once: profiles/README.md)" % (workload, len(tets), int(r.profile.get("dofs", 0)), best["eigenpairs"]),
+            "sample": "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path (1/10 of the metric's mesh; the direct solve grows ~quadratically with size: "
+                      "the metric's own mesh took the oracle 431 s on 8 threads, profiles/r02_oracle_openmp_scaling.txt)" % (workload, len(tets), int(r.profile.get("dofs", 0)), best["eigenpairs"]),
             "single_thread": runs[1], "threaded": runs[max(runs)],
             "logical_cpus": os.cpu_count(),
             "note": "host_cores = CPUs this container may use (affinity and cgroup quota); threaded row: OpenMP team of min(host_cores, 16)"}
