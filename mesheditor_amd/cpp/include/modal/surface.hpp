@@ -14,35 +14,36 @@
 
 struct ModalRenderScratch; // a renderer's scratch in the reference; opaque here (the device owns all render scratch)
 
+// Owning handles of the model's two opaque objects (defined by the model, which this build does not have).
 struct SurfaceAudioState;
 struct SurfaceAudioStateDelete {
-    void operator()(SurfaceAudioState *) const;
+    void operator()(SurfaceAudioState *state) const;
 };
-using SurfaceAudioStatePtr = std::unique_ptr<SurfaceAudioState, SurfaceAudioStateDelete>;
-
 struct SurfaceRenderScratch;
 struct SurfaceRenderScratchDelete {
-    void operator()(SurfaceRenderScratch *) const;
+    void operator()(SurfaceRenderScratch *scratch) const;
 };
+using SurfaceAudioStatePtr = std::unique_ptr<SurfaceAudioState, SurfaceAudioStateDelete>;
 using SurfaceRenderScratchPtr = std::unique_ptr<SurfaceRenderScratch, SurfaceRenderScratchDelete>;
 
 SurfaceAudioStatePtr MakeSurfaceAudioState(); // null without the model
 
-// audio thread
-void SurfaceAdoptVoices(ModalAudio &, ModalBank &, uint32_t frame_count);
-uint32_t SurfaceVoiceCount(const ModalAudio &, uint32_t object);
-bool SurfaceRenderObject(ModalAudio &, ModalRenderScratch &, ModalBank &, uint32_t object, std::span<const uint32_t> impacts, float *out, uint32_t frame_count);
-void SurfaceSilenceObject(ModalAudio &, uint32_t object);
-uint32_t SurfaceActiveVoices(const ModalAudio &);
+// ---- called from RenderModal (the reference's audio thread)
+void SurfaceAdoptVoices(ModalAudio &audio, ModalBank &bank, uint32_t frame_count);
+uint32_t SurfaceVoiceCount(const ModalAudio &audio, uint32_t object);
+bool SurfaceRenderObject(ModalAudio &audio, ModalRenderScratch &scratch, ModalBank &bank, uint32_t object, std::span<const uint32_t> impacts, float *out,
+                         uint32_t frame_count);
+void SurfaceSilenceObject(ModalAudio &audio, uint32_t object);
+uint32_t SurfaceActiveVoices(const ModalAudio &audio);
 
-// main thread
-void SurfaceInstallBank(ModalAudio &);
-void RegisterSurfaceContactHandlers(entt::registry &);
-void SurfaceUpdateContacts(entt::registry &);
-float SurfaceRoughnessOf(const entt::registry &, entt::entity node);
-entt::entity ContactSurfaceNode(const entt::registry &, entt::entity collider, entt::entity body);
+// ---- called from the scene update (the reference's main thread)
+void SurfaceInstallBank(ModalAudio &audio);
+void RegisterSurfaceContactHandlers(entt::registry &registry);
+void SurfaceUpdateContacts(entt::registry &registry);
+float SurfaceRoughnessOf(const entt::registry &registry, entt::entity node);
+entt::entity ContactSurfaceNode(const entt::registry &registry, entt::entity collider, entt::entity body);
 
-// user interface
-void DrawContactSurfaceControls(entt::registry &, entt::entity sound_entity);
-void DrawSurfaceSynthControls(entt::registry &, entt::entity viewport);
-void DrawSurfaceContactDebug(const entt::registry &);
+// ---- called from the editor's panels
+void DrawContactSurfaceControls(entt::registry &registry, entt::entity sound_entity);
+void DrawSurfaceSynthControls(entt::registry &registry, entt::entity viewport);
+void DrawSurfaceContactDebug(const entt::registry &registry);
