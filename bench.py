@@ -90,6 +90,21 @@ def concurrent_throughput(api, device, pts, tets, mat, ex, cfg, threads=3, per_t
     return out
 
 
+def operator_forms(api, ctx, mesh, mat, widths=(16, 64, 80)):
+    """One fp64 product y = (K - sigma M) x over an n x w panel of the metric's mesh, in both forms that exist: the BSR SpMM the
+    solver uses and the matrix-free element-by-element product (csrc/mh_elem.hip, atomic scatter).  Both are priced with the
+    BSR count of algorithmic bytes; the faster one per width is the one the solver uses (BSR at every width)."""
+    system = api.System(ctx, mesh, mat)
+    out = []
+    for w in widths:
+        ms, by = system.bench_spmm(w, 10)
+        em = system.bench_elementwise(w, 10)
+        out.append({"w": w, "algorithmic_bytes": by, "bsr_us": 1e3 * ms, "bsr_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "elementwise_us": 1e3 * em, "elementwise_frac": by / (em * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    system.close()
+    return out
+
+
 def cpu_baseline(workload="cube_s10k"):
     """The CPU oracle (restated reference algorithm: nested-dissection multifrontal Cholesky shift-invert + restarted
     Lanczos) on a bounded sample of the metric's workload, timed on this box's host cores: once on one thread (the
@@ -328,6 +343,8 @@ def main():
     if not batch:
         line["profile"] = {k: last.profile.get(k) for k in ("assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract", "restarts", "op_applications")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if not batch and "roofline" in line:
+            line["roofline"]["single_launch"] = operator_forms(api, ctxs[0], mesh, mat)
         if not batch:
             line["concurrent_solves"] = concurrent_throughput(api, device, pts, tets, mat, ex, cfg)
         line["cpu_baseline"] = cpu_baseline()

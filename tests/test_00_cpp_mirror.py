@@ -94,6 +94,62 @@ def test_solve_tool_takes_a_surface_obj(tmp_path):
     assert r.returncode == 1 and "Tetrahedralization failed" in r.stderr
 
 
+def _voxel_surface(cells, h):
+    """Boundary of a union of grid cubes of edge h (cells: set of integer triples) as (points, triangles): every cube face that is
+    not shared by two cells, split along one diagonal."""
+    ids, pts, tris = {}, [], []
+    def vid(c):
+        if c not in ids:
+            ids[c] = len(pts)
+            pts.append([h * v for v in c])
+        return ids[c]
+    for (i, j, k) in sorted(cells):
+        for axis in range(3):
+            for side in (0, 1):
+                nb = [i, j, k]
+                nb[axis] += 1 if side else -1
+                if tuple(nb) in cells:
+                    continue
+                u, v = (axis + 1) % 3, (axis + 2) % 3
+                def corner(du, dv):
+                    c = [i, j, k]
+                    c[axis] += side
+                    c[u] += du
+                    c[v] += dv
+                    return vid(tuple(c))
+                a, b, c, d = corner(0, 0), corner(1, 0), corner(1, 1), corner(0, 1)
+                tris += [(a, b, c), (a, c, d)]
+    return pts, tris
+
+
+@pytest.mark.gpu
+def test_solve_tool_fills_a_surface_that_is_not_star_shaped(tmp_path):
+    """obj -> tets -> modes through the GENERAL tetrahedraliser (an L-bracket is not star-shaped about its
+    centroid, which lies outside it) and the device solve: the mass is the bracket's, the input vertices come back as the
+    sample points, and a bracket twice the size rings exactly one octave lower (f ~ 1 / L at fixed material) with eight times the mass."""
+    import json
+    import numpy as np
+    _build()
+    n = 3  # grid cells per unit length
+    cells = {(i, j, k) for i in range(2 * n) for j in range(2 * n) for k in range(n) if i < n or j < n}  # an L of three unit cubes
+    tool = os.path.join(ROOT, "mesheditor_amd", "cpp", "bin", "modal_solve")
+    common = ["--young", "7.2e10", "--poisson", "0.19", "--density", "2700", "--modes", "6", "--max-freq", "200000"]
+    runs = []
+    for unit in (0.05, 0.10):
+        pts, tris = _voxel_surface(cells, unit / n)
+        obj = tmp_path / f"bracket_{unit}.obj"
+        obj.write_text("".join(f"v {x!r} {y!r} {z!r}\n" for x, y, z in pts) + "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in tris))
+        p = subprocess.run([tool, str(obj), *common], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = json.loads(p.stdout)
+        assert abs(out["mass"] / (2700 * 3 * unit ** 3) - 1) < 1e-6
+        assert len(out["positions"]) >= len(pts) and np.allclose(np.array(out["positions"][: len(pts)]), np.array(pts, dtype=np.float32), atol=1e-7)
+        runs.append(np.array(out["frequencies"]))
+    small, large = runs
+    assert len(small) == len(large) == 6 and small[0] > 1000
+    assert np.abs(small / (2 * large) - 1).max() < 1e-4, (small, large)
+
+
 @pytest.mark.gpu
 def test_solve_tool_reproduces_the_reference_sample_model(golden):
     """The JSON solve tool (the reference's MeshEditorModalSolve, which its sample generator shells out to) on the
