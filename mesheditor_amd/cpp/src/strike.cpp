@@ -103,3 +103,31 @@ bool TriggerModalStrike(ModalAudio &m, entt::entity e, const ModalModes &modes, 
     EnqueueModalEvent(m, MakeStrikeEvent(bank, *slot, excitable_index, along, force, contact_speed, sc, physics, striker));
     return true;
 }
+
+uint32_t StrikeContacts(ModalAudio &audio, std::span<const ContactImpact> impacts, const StrikeScene &scene, const ContactFloors &floors) {
+    uint32_t queued = 0;
+    for (const ContactImpact &hit : impacts) {
+        if (hit.Speed < floors.MinContactSpeed) continue; // a loaded body at rest must not buzz
+        const ModalModes *modes = scene.ModesOf ? scene.ModesOf(hit.Entity) : nullptr;
+        if (!modes || modes->Positions.empty()) continue;
+        const auto to_local = [&](const std::function<vec3(entt::entity, vec3)> &map, vec3 world) { return map ? map(hit.Entity, world) : world; };
+        const vec3 at = to_local(scene.LocalPoint, hit.Point), along = to_local(scene.LocalDirection, hit.Direction);
+        const uint32_t sample_point = NearestSamplePoint(modes->Positions, at);
+        // audibility is decided on what the strike excites, not on the momentum behind it
+        if (PeakModalDrive(*modes, sample_point, UnitOrZero(along) * hit.Impulse) < floors.MinContactExcitation) continue;
+        // the other body is the impactor: its stiffness, mass and curvature shape the contact time
+        PhysicsStrike physics;
+        physics.Direction = along;
+        physics.Impactor.Material = scene.MaterialOf ? scene.MaterialOf(hit.Other) : materials::acoustic::Ceramic.Properties;
+        const std::optional<double> curvature = scene.CurvatureAt ? scene.CurvatureAt(hit.Other, hit.Point) : std::nullopt;
+        physics.Impactor.Curvature = curvature.value_or(SphereEquivalentCurvature(physics.Impactor.Material.Density, hit.OtherInvMass));
+        physics.Impactor.InvMass = hit.OtherInvMass;
+        physics.NominalArea = hit.NominalArea;
+        physics.ResultantIndex = NearestSamplePoint(modes->Positions, to_local(scene.LocalPoint, hit.ResultantPoint));
+        StrikeContext struck = scene.StruckBody ? scene.StruckBody(hit.Entity, hit.Point) : StrikeContext{};
+        const double own = scene.RoughnessOf ? scene.RoughnessOf(hit.Entity) : 0.0, other = scene.RoughnessOf ? scene.RoughnessOf(hit.Other) : 0.0;
+        struck.Roughness = std::hypot(own, other); // the pair's combined RMS roughness
+        queued += TriggerModalStrike(audio, hit.Entity, *modes, sample_point, along, hit.Impulse, hit.Speed, struck, physics) ? 1u : 0u;
+    }
+    return queued;
+}

@@ -200,4 +200,53 @@ CASE(a_strike_becomes_the_event_the_bank_consumes) {
     EXPECT(audio.EventWrite.load() - audio.EventRead.load() == 1u);
 }
 
+CASE(collisions_strike_the_objects_they_hit) {
+    // The physics event source (reference: PhysicsContact.h ContactImpact, drained by AudioSystem.cpp:1007-1037): speed and
+    // excitation floors, nearest sample point, the other body as impactor, one queued strike per audible contact point.
+    const auto modes = TwoPointModes();
+    ModalAudio audio;
+    ModalBank &bank = LiveBank(audio);
+    bank.SampleRate = 48'000.f;
+    AddModalObject(bank, entt::entity{7}, modes);
+    Collision struck_body;
+    struck_body.Mass = 0.5;
+    struck_body.RotationalCompliance = 0;
+    ContactDynamics dyn = struck_body.Dynamics();
+    dyn.ContactArm = {vec3{0.f}, vec3{0.f}, vec3{0.f}};
+    const AcousticMaterial ceramic{"c", Ceramic};
+    int context_calls = 0;
+    StrikeScene scene;
+    scene.ModesOf = [&](entt::entity e) { return e == entt::entity{7} ? &modes : nullptr; };
+    scene.LocalPoint = [](entt::entity, vec3 world) { return world - vec3{1.f, 0.f, 0.f}; }; // the body sits at x = 1
+    scene.StruckBody = [&](entt::entity, vec3) {
+        ++context_calls;
+        return StrikeContext{.Dynamics = &dyn, .Material = &ceramic, .Elastic = Ceramic, .Curvature = 10};
+    };
+    scene.MaterialOf = [](entt::entity) { return Polymer; };
+    scene.RoughnessOf = [](entt::entity e) { return e == entt::entity{7} ? 3e-6f : 4e-6f; };
+    ContactImpact hit;
+    hit.Entity = entt::entity{7}, hit.Other = entt::entity{9};
+    hit.Point = vec3{1.09f, 0.01f, 0.f}, hit.ResultantPoint = vec3{1.f, 0.09f, 0.f}; // nearest sample points 1 and 2
+    hit.Direction = vec3{1.f, 0.f, 0.f};
+    hit.Impulse = 0.02f, hit.Speed = 1.2f, hit.OtherInvMass = 4.f, hit.NominalArea = 0.f;
+    ContactImpact slow = hit;
+    slow.Speed = 0.001f; // below the speed floor
+    ContactImpact mute = hit;
+    mute.Direction = vec3{0.f, 0.f, 1.f}; // point 1's shapes have no z component: nothing is excited
+    mute.Impulse = 1e-9f;
+    ContactImpact stranger = hit;
+    stranger.Entity = entt::entity{8}; // not a sounding object
+    const ContactImpact all[] = {slow, mute, stranger, hit};
+    EXPECT(StrikeContacts(audio, all, scene) == 1u && context_calls == 1);
+    EXPECT(audio.EventWrite.load() - audio.EventRead.load() == 1u);
+    // the queued event is the one MakeStrikeEvent builds for that contact
+    const ModalEvent &queued = audio.Events[audio.EventRead.load() % audio.Events.size()];
+    PhysicsStrike phys{.Direction = vec3{1.f, 0.f, 0.f}, .Impactor = Impactor{Polymer, SphereEquivalentCurvature(Polymer.Density, 4.0), 4.0}, .NominalArea = 0.f, .ResultantIndex = 2};
+    StrikeContext sc{.Dynamics = &dyn, .Material = &ceramic, .Elastic = Ceramic, .Curvature = 10};
+    sc.Roughness = 5e-6; // hypot(3, 4) um
+    const ModalEvent want = MakeStrikeEvent(bank, 0, 1, vec3{1.f, 0.f, 0.f}, 0.02f, 1.2f, sc, phys);
+    EXPECT(queued.Object == want.Object && queued.ExPos == 1u && queued.Jx == want.Jx && queued.Jy == 0.f);
+    EXPECT(check::near(queued.PulseStep, want.PulseStep, 1e-6) && queued.AccelAmp == want.AccelAmp && queued.ClickB0 == want.ClickB0);
+}
+
 int main() { return check::run_all(); }
