@@ -397,7 +397,7 @@ int mh_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const do
     if (!ctx || !a || !d || !e || m < 2 || m > 256 || variant < 0 || variant > 1) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        std::lock_guard<std::mutex> lock(mh_solve_mutex());
+        MhSharedPhase not_during_a_factorisation; // (no process-wide lock: calls on different contexts are meant to overlap)
         DevArray<double> da(ctx, size_t(m) * m), work(ctx, size_t(m) * m), dd(ctx, m), de(ctx, m), dtau(ctx, m);
         da.upload(a, size_t(m) * m);
         hipEvent_t e0, e1;

@@ -570,3 +570,50 @@ def test_small_tridiagonalisation_keeps_the_spectrum(ctx, variant, m):
     assert np.max(np.abs(got - want)) <= 1e-12 * lam[-1] * m
     d2, e2, _ = ctx.tridiagonalize(a, variant=variant)
     assert np.array_equal(d, d2) and np.array_equal(e, e2)
+
+
+@pytest.mark.gpu
+def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
+    """The tagged-value exchange between the workgroups of k_sytrd_multi must not depend on timing: four host threads (one
+    context each) reduce matrices of different orders over and over while a fifth keeps the device busy with operator
+    products; every result must equal, bit for bit, the one the same context produced alone."""
+    import threading
+    rng = np.random.default_rng(77)
+    orders = [64, 131, 200, 240]
+    mats = []
+    for m in orders:
+        a = rng.standard_normal((m, m))
+        mats.append(a + a.T + 2 * m * np.eye(m))
+    ctxs = [api.Context(0) for _ in orders]
+    alone = [c.tridiagonalize(a, variant=1)[:2] for c, a in zip(ctxs, mats)]
+    busy_ctx = api.Context(0)
+    p, t, mat, _ = meshes.workload("cube_s10k")
+    system = api.System(busy_ctx, api.Mesh(busy_ctx, p, t), api.material(*mat))
+    stop = threading.Event()
+    bad, errs = [], []
+
+    def load():
+        try:
+            while not stop.is_set():
+                system.bench_spmm(32, 5)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    def work(i):
+        try:
+            for rep in range(120):
+                d, e, _ = ctxs[i].tridiagonalize(mats[i], variant=1)
+                if not (np.array_equal(d, alone[i][0]) and np.array_equal(e, alone[i][1])):
+                    bad.append((orders[i], rep))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(orders))] + [threading.Thread(target=load)]
+    [x.start() for x in th]
+    [x.join() for x in th[:-1]]
+    stop.set()
+    th[-1].join()
+    system.close()
+    [c.close() for c in ctxs + [busy_ctx]]
+    assert not errs, errs
+    assert not bad, bad
