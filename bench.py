@@ -90,16 +90,21 @@ def concurrent_throughput(api, device, pts, tets, mat, ex, cfg, threads=3, per_t
     return out
 
 
-def operator_forms(api, ctx, mesh, mat, widths=(16, 64, 80)):
-    """One fp64 product y = (K - sigma M) x over an n x w panel of the metric's mesh, in both forms that exist: the BSR SpMM the
-    solver uses and the matrix-free element-by-element product (csrc/mh_elem.hip, atomic scatter).  Both are priced with the
-    BSR count of algorithmic bytes; the faster one per width is the one the solver uses (BSR at every width)."""
+def operator_forms(api, ctx, mesh, mat, widths=(1, 16, 64, 80)):
+    """One fp64 product y = (K - sigma M) x over an n x w panel of the metric's mesh (w = 1 is the north star's literal SpMV), in
+    both forms that exist: the BSR SpMM the solver uses and the matrix-free element-by-element product (csrc/mh_elem.hip,
+    atomic scatter).  Fractions of the 8 TB/s roofline on two byte counts, both from SURVEY 8(d): the BSR bytes the kernel
+    moves (76 B per node block + 4 B per row pointer + 16 B per panel entry; `roofline.frac` uses this one) and the canonical
+    scalar-CSR count the 40 % target is quoted on (12 B per non-zero + 4 B per row pointer + 16 B per panel entry)."""
     system = api.System(ctx, mesh, mat)
+    n_nodes, n_blocks = system.node_count, system.node_blocks
     out = []
     for w in widths:
         ms, by = system.bench_spmm(w, 10)
         em = system.bench_elementwise(w, 10)
-        out.append({"w": w, "algorithmic_bytes": by, "bsr_us": 1e3 * ms, "bsr_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        csr = 12.0 * 9 * n_blocks + 4.0 * (3 * n_nodes + 1) + 16.0 * 3 * n_nodes * w
+        out.append({"w": w, "algorithmic_bytes": by, "canonical_csr_bytes": csr, "bsr_us": 1e3 * ms, "bsr_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "bsr_frac_on_csr_bytes": csr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "elementwise_us": 1e3 * em, "elementwise_frac": by / (em * 1e-3) / 1e9 / HBM_PEAK_GBS})
     system.close()
     return out
