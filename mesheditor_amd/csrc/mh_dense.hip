@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_small(double *__restrict__ A, in
 #define MH_SYTRD_THREADS 1024
 #endif
 __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
-    __shared__ double xs[256], v[256], wv[256], vp[256], wp[256], sq[256], xnext[256], part[MH_SYTRD_THREADS];
+    __shared__ double xs[256], v[256], vp[256], wp[256], sq[256], xnext[256], part[MH_SYTRD_THREADS];
     const int tid = threadIdx.x, lane = tid & 63;
     bool pending = false; // (vp, wp): reflector and w of the previous step, indexed over ITS trailing block (this step's index + 1)
     for (int k = 0; k + 1 < m; ++k) {

@@ -1418,7 +1418,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
                     if (p_implicit && wp) {
                         // W' = W - P Hp:  P^T A W' = Bp - App Hp,  W'^T A W' = Bw - U - U^T + Hp^T App Hp with U = Hp^T Bp  (P^T A P = App, X^T A P = 0)
-                        const double minus = -1, plus = 1, nil = 0;
+                        const double plus = 1, nil = 0;
                         double *bw = gA.get() + size_t(wa) * m + wa, *bp = gA.get() + size_t(wa) * m + wa + w;
                         gram(ctx, n, P, wp, AW, w, bp, m);
                         ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), bp,
