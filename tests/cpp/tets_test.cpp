@@ -208,12 +208,17 @@ std::string ValidateGeneral(const Surface &s, const TetMesh &mesh, bool oriented
     return {};
 }
 // a parametric quad grid closed in both directions (torus) or with poles welded (sphere); consistently wound
-Surface Torus(double R, double r, int nu, int nv) {
+Surface Torus(double R, double r, int nu, int nv, double noise = 0.0, double flatten = 1.0, unsigned seed = 3) {
     Surface s;
+    unsigned state = seed * 2654435761u + 1u;
+    const auto jitter = [&] { // tube radius varied point by point: irregular triangles, still a closed torus
+        state = state * 1664525u + 1013904223u;
+        return 1.0 + noise * (double(state >> 8) / double(1u << 24) - 0.5);
+    };
     for (int i = 0; i < nu; ++i)
         for (int j = 0; j < nv; ++j) {
-            const double u = 2 * M_PI * i / nu, v = 2 * M_PI * j / nv;
-            s.P.push_back({(R + r * std::cos(v)) * std::cos(u), (R + r * std::cos(v)) * std::sin(u), r * std::sin(v)});
+            const double u = 2 * M_PI * i / nu, v = 2 * M_PI * j / nv, rr = r * jitter();
+            s.P.push_back({(R + rr * std::cos(v)) * std::cos(u), (R + rr * std::cos(v)) * std::sin(u), flatten * rr * std::sin(v)});
         }
     const auto id = [&](int i, int j) { return uint32_t((i % nu) * nv + j % nv); };
     for (int i = 0; i < nu; ++i)
@@ -305,7 +310,12 @@ CASE(non_star_shaped_and_higher_genus_surfaces_fill) {
     };
     Surface hollow = Sphere(1.0, 8, 12, 0, 1); // a ball with an off-centre spherical cavity
     Append(hollow, Sphere(0.4, 6, 9, 0, 2, {0.2, 0.1, -0.1}, true));
-    const Named cases[]{{"L bracket", LPrism()}, {"torus", Torus(1.0, 0.35, 16, 10)}, {"bowl", Bowl(1.0, 0.85, 6, 16)}, {"hollow ball", hollow}};
+    const Named cases[]{{"L bracket", LPrism()},
+                        {"torus", Torus(1.0, 0.35, 16, 10)},
+                        {"rough torus", Torus(1.0, 0.35, 40, 16, 0.16)},        // +-8 % tube radius, point by point
+                        {"flat rough torus", Torus(1.0, 0.35, 48, 10, 0.1, 0.4)}, // the same, squashed to 40 % height: slivers
+                        {"bowl", Bowl(1.0, 0.85, 6, 16)},
+                        {"hollow ball", hollow}};
     for (const auto &c : cases) {
         const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
         EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
