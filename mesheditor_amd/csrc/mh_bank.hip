@@ -283,12 +283,14 @@ __global__ void __launch_bounds__(WAVE) k_bank_objects(BankCols<Real> b, const u
 // in registers while the current one is consumed) and its first wave runs the ordered chain out of LDS.
 template<typename Real, int SW>
 __global__ void __launch_bounds__(1024) k_bank_renderer_sum(const Real *__restrict__ partial, const uint32_t *__restrict__ renderer_chunk_ptr, uint32_t frames,
-                                                           Real *__restrict__ rout) {
+                                                           Real *__restrict__ rout, const Real *__restrict__ start = nullptr, uint32_t only_begin = 0, uint32_t only_end = 0) {
+    // renderer_chunk_ptr == nullptr: ONE chain over rows only_begin .. only_end - 1, continuing from start[s] (may alias rout:
+    // a workgroup reads its own strip's start values before it writes them) -- the impacts' click rows added to the block
     constexpr int RPT = 8, ROUND = 1024 / SW, TILE = RPT * ROUND;
     __shared__ Real xs[TILE * SW];
     const uint32_t tid = threadIdx.x, col = tid % SW, rr = tid / SW;
     const uint32_t s = blockIdx.x * SW + col, r = blockIdx.y;
-    const uint32_t c_begin = renderer_chunk_ptr[r], c_end = renderer_chunk_ptr[r + 1];
+    const uint32_t c_begin = renderer_chunk_ptr ? renderer_chunk_ptr[r] : only_begin, c_end = renderer_chunk_ptr ? renderer_chunk_ptr[r + 1] : only_end;
     const bool in_range = s < frames;
     Real pre[RPT];
     auto fetch = [&](uint32_t base) {
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(1024) k_bank_renderer_sum(const Real *__restri
 #pragma unroll
         for (int j = 0; j < RPT; ++j) xs[(j * ROUND + rr) * SW + col] = pre[j];
     };
-    Real acc = 0;
+    Real acc = (start && tid < SW && in_range) ? start[s] : Real(0);
     if (c_begin < c_end) {
         fetch(c_begin);
         commit();
@@ -508,7 +510,17 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     } else if (n_renderers) {
         HIP_CHECK(hipMemsetAsync(B.rout.get(), 0, size_t(n_renderers) * frames * sizeof(Real), st));
     }
-    k_bank_mix<Real><<<div_up(frames, 64), 64, 0, st>>>(B.click, n_impacts, B.rout, n_renderers, frames, d_out);
+    // out[s] += clicks in impact order, then the renderers in order.  With many impacts in flight the click chain is the
+    // same latency problem as a renderer's chunks (1 024 impacts: 100 us as a per-sample loop): it goes through the streaming
+    // kernel, continuing from what the caller left in the block, and the mix then starts from its result.
+    uint32_t clicks_in_mix = n_impacts;
+    if (n_impacts > 64) {
+        constexpr int SW = 16;
+        k_bank_renderer_sum<Real, SW><<<dim3(div_up(frames, SW), 1), 1024, 0, st>>>(B.click, nullptr, frames, d_out, d_out, 0u, n_impacts);
+        KERNEL_CHECK();
+        clicks_in_mix = 0;
+    }
+    k_bank_mix<Real><<<div_up(frames, 64), 64, 0, st>>>(B.click, clicks_in_mix, B.rout, n_renderers, frames, d_out);
     KERNEL_CHECK();
     // ---- one copy back ----
     HIP_CHECK(hipMemcpyAsync(A.host + both_begin, A.dev + both_begin, (n_dealt ? total : both_end) - both_begin, hipMemcpyDeviceToHost, st));
