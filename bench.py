@@ -359,6 +359,13 @@ def main():
             line["roofline_bank"] = bank["all_live"]["roofline_bank"]
         line["cpu_bank_baseline"] = cpu_bank_baseline()
     if rank == 0:
+        # RCCL prints a version banner through C stdio, which sits in that buffer until the process exits when stdout is a
+        # file or a pipe: push it out first, so that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(line), flush=True)
     if not batch:
         mesh.close()
