@@ -1038,6 +1038,607 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues)
 }
 } // namespace
 
+namespace {
+// Block LOBPCG on the pencil (A, M) = (K - sigma M, M) with hard locking: one object per solve; the
+// stages of an iteration are its member functions, in the order run() calls them.
+struct BlockLobpcg {
+    // ---- the solve
+    mh_system *sys;
+    mh_context *ctx;
+    hipStream_t st;
+    const size_t n;
+    const uint32_t nev, b, mmax;
+    const double sigma, residual_tol;
+    const uint32_t max_iters;
+    const float *seed_basis;
+    const uint32_t seed_rows, seed_cols;
+    const volatile unsigned char *cancel;
+    volatile float *progress;
+    mh_profile &prof;
+    mh_profile *profile;
+    SharedPhase iterating; // released and re-taken at the top of every iteration so that a waiting factorisation gets in
+    Timer t_iter;
+    double precond_seconds = 0;
+    // ---- panels (n x b) and small matrices
+    DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, AP, MP, Pn, APn, MPn, R, Rw;
+    DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
+    DevArray<uint32_t> idx_d;
+    DevArray<int> info; // [1]: conditioning report of mh_potrf_small
+    std::unique_ptr<Precond<float>> prec32;
+    std::unique_ptr<Precond<double>> prec64;
+    // ---- switches (read once) and what follows from them
+    const bool verbose = switches().verbose, implicit_p = switches().implicit_p, fp32_prec = switches().fp32_prec;
+    const bool implicit_w_env = switches().implicit_w_env, lazy_env = switches().lazy_env, fresh_env = switches().fresh_env, trsm_env = switches().trsm_env;
+    const bool lazy_images_ok = lazy_env && fresh_env && implicit_p && !trsm_env;
+    // W is orthogonalised against P in coefficient space (no M P panel, no tall projection against P): MH_IMPLICIT_PPROJ=0 disables
+    const bool pproj_env = switches().pproj_env;
+    const bool pproj_ok;
+    // ---- state across iterations
+    bool warm = false;
+    bool w_implicit = false;       // W itself left untransformed this iteration (see chol_orthonormalise)
+    int last_spread = 1 << 20;     // 16 log2(max / min diagonal of the last Cholesky factor of a unit-diagonal Gram matrix)
+    bool p_needs_explicit = false; // the implicit projection against P was refused (ill-conditioned Gram matrix): caller redoes it explicitly
+    uint32_t wp = 0;               // width of P
+    uint32_t iters = 0, nconv = 0;
+    std::vector<double> theta, rn, mn, xn, norms, theta_act, hist_worst;
+    double anorm = 0;
+    std::vector<uint32_t> act, order, hist_nconv;
+    std::vector<uint8_t> locked; // hard locking: a converged column leaves the Rayleigh-Ritz basis for good
+    bool converged = false;
+    bool gm_identity = false; // this iteration's gM0 is exactly I (all blocks placed, none measured)
+    bool p_implicit = false;  // this iteration: the basis is [X, (W - P Hp) L^-T, P] with W, P stored
+    bool lazy_images = false;
+    // ---- this iteration
+    uint32_t w = 0, wa = 0, m = 0, wp_new = 0; // active columns (= width of W), their count as the X part, order of the small problem, width of the next P
+
+    BlockLobpcg(mh_system *system, uint32_t nev_, uint32_t block, double sigma_, double residual_tol_, uint32_t max_iters_, const float *seed_basis_, uint32_t seed_rows_,
+                uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_)
+        : sys(system), ctx(system->ctx), st(system->ctx->stream), n(size_t(3) * system->n_nodes), nev(nev_), b(block), mmax(3 * block), sigma(sigma_), residual_tol(residual_tol_),
+          max_iters(max_iters_), seed_basis(seed_basis_), seed_rows(seed_rows_), seed_cols(seed_cols_), cancel(cancel_), progress(progress_), prof(prof_), profile(profile_),
+          t_iter(system->ctx), pproj_ok(pproj_env && lazy_images_ok && implicit_w_env && block <= 128), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
+          theta_act(block), order(block), locked(block, 0) {
+        for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &AP, &MP, &Pn, &APn, &MPn, &R, &Rw}) panel->reset(ctx, n * b);
+        for (DevArray<double> *small : {&gA, &gM, &gM0, &gA0}) small->reset(ctx, size_t(mmax) * mmax);
+        for (DevArray<double> *small : {&App, &H, &H2, &Linv, &Hp, &Up, &Vp, &T1p}) small->reset(ctx, size_t(b) * b);
+        for (DevArray<double> *small : {&Cp, &T1}) small->reset(ctx, size_t(mmax) * b);
+        for (DevArray<double> *small : {&evals, &ework}) small->reset(ctx, mmax);
+        for (DevArray<double> *small : {&dscale, &theta_d, &rn_d, &mn_d, &theta_act_d}) small->reset(ctx, b);
+        G.reset(ctx, size_t(b) * 2 * b);
+        Ct.reset(ctx, size_t(mmax) * 2 * b);
+        norms_d.reset(ctx, 3 * size_t(b));
+        idx_d.reset(ctx, b);
+        info.reset(ctx, 2);
+        if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, b);
+        else prec64 = std::make_unique<Precond<double>>(sys, b);
+        auto hd = sys->L2.dinv.to_host();
+        double dmin = 1e300;
+        for (double v : hd) dmin = std::min(dmin, v);
+        anorm = sys->L2.lmax / dmin; // lambda_max(A) <= lambda_max(D^-1 A) * max diag(A)
+    }
+
+    // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for M V, A V).  False: the block is rank deficient.
+
+    bool chol_orthonormalise(double *V, double *MV, double *AV, uint32_t w, bool transform_images = true, bool allow_implicit = false,
+                             const double *hp = nullptr, uint32_t hp_rows = 0) {
+        // hp (hp_rows x w, = P^T M V): V is to be taken as V - P hp without forming it: G -= hp^T hp (P is M-orthonormal).  Only
+        // valid together with the implicit treatment of V; when that is refused nothing is transformed and p_needs_explicit is set.
+        // allow_implicit: with a well-conditioned Gram matrix not even V is transformed (w_implicit is set): the caller works
+        // with V L^-T through L^-1 on the small matrices
+        // transform_images = false: M V is only read (for the Gram matrix); the caller keeps the images untransformed
+        // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
+        gram(ctx, n, V, w, MV, w, G, w);
+        if (hp) {
+            const double minus = -1, plus = 1;
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(hp_rows), &minus, hp,
+                                        rocblas_int(hp_rows), hp, rocblas_int(hp_rows), &plus, G, rocblas_int(w)));
+        }
+        k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
+        KERNEL_CHECK();
+        double *Gs = G.get() + size_t(w) * w;
+        int hinfo = 0;
+        {
+            last_spread = 1 << 20;
+            if (w <= 128) {
+                mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
+                int both[2] = {0, 0};
+                info.download(both, 2);
+                hinfo = both[0];
+                last_spread = both[1];
+            } else {
+                SolverLock solver_lock(g_rocsolver_mutex);
+                ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                info.download(&hinfo, 1);
+            }
+        }
+        p_needs_explicit = false;
+        if (hp && (hinfo != 0 || last_spread >= 16 * 8)) { // V - P hp is nearly dependent: project in the tall space instead
+            p_needs_explicit = true;
+            return true;
+        }
+        if (hinfo != 0) return false;
+        k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
+        KERNEL_CHECK();
+        const bool trsm_rocblas = switches().trsm_rocblas;
+        if (trsm_rocblas || w > 256) {
+            panel_trsm(ctx, n, V, w, Gs, w);
+            if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
+            if (AV) panel_trsm(ctx, n, AV, w, Gs, w);
+        } else {
+            // V <- V L^-T through the explicit small inverse and the MFMA basis-update kernel (in place: a workgroup
+            // reads its rows before it writes them): L^-1 column-major IS the k-major coefficient matrix of V L^-T
+            HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
+            ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
+            w_implicit = allow_implicit && !transform_images && last_spread < 16 * 8;
+            if (!w_implicit) mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
+            if (MV && transform_images) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);
+            if (AV && transform_images) mh_combine(ctx, n, AV, w, nullptr, 0, nullptr, 0, Linv, w, AV, w, nullptr);
+        }
+        return true;
+    }
+
+    // The initial block: seed columns (warm start), then Gaussian noise, the exact rigid-body modes, one smoothing pass;
+    // M-orthonormalised and rotated into its Ritz vectors.
+    void start() {
+        k_random_panel<<<grid1(n * b), TB, 0, st>>>(X, n * b, 20260710ull);
+        KERNEL_CHECK();
+        warm = seed_basis && seed_rows == n && seed_cols >= nev;
+        if (warm) {
+            const uint32_t ncols = std::min(seed_cols, b);
+            DevArray<float> seed(ctx, n * ncols);
+            seed.upload(seed_basis, n * ncols);
+            k_load_seed<<<grid1(n * ncols), TB, 0, st>>>(seed, sys->perm, sys->n_nodes, ncols, b, X);
+            KERNEL_CHECK();
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (b >= 12) {
+            // A free body's six rigid-body modes are exact eigenvectors (lambda = 0): start from them -- also on a warm
+            // start, where they replace the six seeded (single-precision) copies: a rigid mode known only to 1e-7
+            // leaves A x = |sigma| M x as the difference of terms 12 orders larger, and its Ritz value is then noise.
+            auto hx = sys->node_xyz.to_host();
+            double c[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < sys->n_nodes; ++i)
+                for (int d = 0; d < 3; ++d) c[d] += hx[3 * size_t(i) + d];
+            for (double &v : c) v /= double(sys->n_nodes);
+            k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
+            KERNEL_CHECK();
+        }
+        // A cold start begins from B M x for Gaussian noise x (one preconditioner application: the high-frequency content
+        // of the noise is damped before the first Rayleigh-Ritz step), with the exact rigid-body modes put back: one
+        // iteration fewer on every workload measured (18 -> 17 at S100k, 40 -> 39 on the ball, 17 -> 16 at S30k).
+        const int smooth_init = switches().smooth_init;
+        if (smooth_init && !warm) {
+            for (int rep = 0; rep < smooth_init; ++rep) {
+                mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
+                Timer tp(ctx);
+                if (prec32) prec32->apply(MX, Xn, b);
+                else prec64->apply(MX, Xn, b);
+                precond_seconds += tp.stop();
+                prof.op_applications += b;
+                HIP_CHECK(hipMemcpyAsync(X, Xn.get(), n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
+            if (b >= 12) {
+                auto hx = sys->node_xyz.to_host();
+                double c[3] = {0, 0, 0};
+                for (uint32_t i = 0; i < sys->n_nodes; ++i)
+                    for (int d = 0; d < 3; ++d) c[d] += hx[3 * size_t(i) + d];
+                for (double &v : c) v /= double(sys->n_nodes);
+                k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
+                KERNEL_CHECK();
+            }
+        }
+        mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
+        if (!chol_orthonormalise(X, MX, nullptr, b)) mh_throw(MH_ENOTCONVERGED, "initial block is rank deficient");
+        mh_spmm(ctx, sys->L2, sys->L2.aval, X, AX, sys->L2.mval, MX, b);
+        {
+            gram(ctx, n, X, b, AX, b, gA, b);
+            gram(ctx, n, X, b, MX, b, gM, b);
+            const int hinfo = rr_solve(ctx, gA, gM, b, evals, ework, info);
+            if (hinfo != 0) mh_throw(MH_ENOTCONVERGED, "initial Rayleigh-Ritz failed (info %d)", hinfo);
+            panel_mul(ctx, n, X, b, gA, b, Xn, b, 1.0, 0.0);
+            panel_mul(ctx, n, AX, b, gA, b, AXn, b, 1.0, 0.0);
+            panel_mul(ctx, n, MX, b, gA, b, MXn, b, 1.0, 0.0);
+            std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
+            evals.download(theta.data(), b);
+        }
+    }
+
+    // Residuals and column norms of the whole block, hard locking of the converged columns, the count of converged wanted pairs;
+    // true when the iteration is over (converged, nothing left to iterate on, or out of iterations).  Also the safety net
+    // of the single-precision smoothers.
+    bool converged_or_locked(uint32_t it) {
+        if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
+        if (g_concurrent) { // an exclusive holder synchronises the device itself: no need to drain our queue first
+            iterating.release();
+            iterating.acquire();
+        }
+        theta_d.upload(theta.data(), b);
+        {
+            const uint32_t rpb = 256, nblk = div_up(n, rpb);
+            if (scratch.count < size_t(nblk) * 3 * b) scratch.reset(ctx, size_t(nblk) * 3 * b);
+            dim3 grid(nblk, div_up(b, 64));
+            k_residual_norms<<<grid, 64, 0, st>>>(AX, MX, X, theta_d, 10.0 * std::abs(sigma), R, n, b, rpb, scratch);
+            KERNEL_CHECK();
+            k_colsumsq_final<<<3 * b, 256, 0, st>>>(scratch, nblk, 3 * b, norms_d); // partial rows are 3b wide
+            KERNEL_CHECK();
+            norms_d.download(norms.data(), 3 * size_t(b));
+            std::copy(norms.begin(), norms.begin() + b, rn.begin());
+            std::copy(norms.begin() + b, norms.begin() + 2 * b, mn.begin());
+            std::copy(norms.begin() + 2 * b, norms.end(), xn.begin());
+        }
+        act.clear();
+        for (uint32_t i = 0; i < b; ++i) {
+            // Converged: relative residual below tol, or at the rounding floor of forming A x (which is what
+            // limits the rigid-body pairs: theta = |sigma| sits 10-12 orders below ||A||).
+            const double rel = std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]));
+            // The floor clause is for those pairs only (theta within 10x of |sigma|): an elastic pair of a stiff, sliver-heavy
+            // mesh must not be accepted at a relative residual above the tolerance because ||A|| happens to be huge.
+            const bool near_shift = std::abs(theta[i]) < 10.0 * std::abs(sigma);
+            const bool ok = rel < residual_tol || (near_shift && std::sqrt(rn[i]) < 50 * 2.2e-16 * anorm * std::sqrt(xn[i]));
+            if (ok) locked[i] = 1;
+            if (!locked[i]) act.push_back(i);
+        }
+        // the nev smallest Ritz values must all belong to converged columns
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return theta[a] < theta[c]; });
+        nconv = 0;
+        for (uint32_t k = 0; k < nev; ++k) nconv += locked[order[k]];
+        if (progress) *progress = 0.3f + 0.65f * float(nconv) / float(nev);
+        if (verbose) {
+            double worst = 0;
+            for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
+            fprintf(stderr, "[lobpcg] it %3u conv %3u/%u active %zu wp %u worst %.2e  floor-ratio[0..7]:", it, nconv, nev, act.size(), wp, worst);
+            for (uint32_t i = 0; i < std::min(8u, b); ++i) fprintf(stderr, " %.1f", xn[i] > 0 ? std::sqrt(rn[i]) / (2.2e-16 * anorm * std::sqrt(xn[i])) : 0.0);
+            fprintf(stderr, "  theta0 %.6e\n", theta[0]);
+        }
+        iters = it;
+        if (nconv >= nev || act.empty()) { converged = nconv >= nev; return true; }
+        if (it == max_iters) return true;
+        // Safety net of the single-precision smoothers: no newly converged pair and no 20 % drop of the worst
+        // residual over 6 iterations switches the cycle to double precision for the rest of the solve.
+        {
+            double worst = 0;
+            for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
+            hist_worst.push_back(worst);
+            hist_nconv.push_back(nconv);
+            const size_t h = hist_worst.size();
+            // against the state six iterations ago (the first iterations are not monotone: the residuals of a
+            // random block first rise)
+            if (prec32 && it >= 10 && h > 6 && hist_nconv[h - 7] == nconv && worst > 0.5 * hist_worst[h - 7]) {
+                if (verbose) fprintf(stderr, "[lobpcg] it %3u stagnation: switching the preconditioner to double precision\n", it);
+                prec32.reset();
+                prec64 = std::make_unique<Precond<double>>(sys, b);
+            }
+        }
+        return false;
+    }
+
+    // W = preconditioned residuals of the active columns, projected against X (and P) and M-orthonormalised, with its images A W, M W.
+    void search_directions(uint32_t it) {
+        w = uint32_t(act.size());
+        idx_d.upload(act.data(), w);
+        k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
+        KERNEL_CHECK();
+        // The Rayleigh-Ritz basis is [X_active W P]; the active columns of X, A X, M X are addressed in place through
+        // the index list idx_d (column maps of the Gram and basis-update kernels), never copied out.
+        for (uint32_t k = 0; k < w; ++k) theta_act[k] = theta[act[k]];
+        theta_act_d.upload(theta_act.data(), w);
+        {
+            Timer tp(ctx);
+            if (prec32) prec32->apply(Rw, W, w);
+            else prec64->apply(Rw, W, w);
+            precond_seconds += tp.stop();
+            prof.op_applications += w;
+        }
+        // W <- (I - X X^T M - P P^T M) W (the coefficients come from M X and M P: no M W needed yet), then A W and M W in
+        // one fused product, then M-orthonormalise W carrying both images along.  Against "M W first, project W and
+        // M W, orthonormalise, then A W" this is one basis-update launch and one pass over the matrix fewer per iteration.
+        bool ok = true;
+        // One projection + Cholesky-QR pass suffices: the Rayleigh-Ritz step solves the full pencil (gA, gM), so the
+        // basis only has to be well conditioned, not orthonormal to working precision.
+        const int ortho_passes = switches().ortho_passes;
+        const bool fused_images = switches().fused_images;
+        p_implicit = false;
+        if (fused_images && ortho_passes == 1 && pproj_ok && wp && w <= 128) {
+            // project against X in the tall space, against P in coefficient space
+            gram(ctx, n, MX, b, W, w, H, b); // b x w
+            mh_pack_stacked(ctx, H, b, nullptr, 0, w, -1.0, Ct);
+            mh_combine(ctx, n, X, b, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
+            mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
+            gram(ctx, n, P, wp, MW, w, Hp, wp); // Hp = P^T M W, wp x w
+            lazy_images = true;
+            w_implicit = false;
+            ok = chol_orthonormalise(W, MW, AW, w, false, true, Hp, wp);
+            if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+            if (p_needs_explicit) { // rare: W - P Hp nearly dependent -> explicit projection, images again, ordinary Cholesky-QR
+                mh_pack_stacked(ctx, Hp, wp, nullptr, 0, w, -1.0, Ct);
+                mh_combine(ctx, n, P, wp, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
+                mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
+                lazy_images = lazy_images_ok && w <= 256;
+                ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
+                if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+            } else {
+                p_implicit = true;
+            }
+        } else if (fused_images && ortho_passes == 1) {
+            gram(ctx, n, MX, b, W, w, H, b); // b x w
+            if (wp) {
+                if (pproj_ok) mh_spmm(ctx, sys->L2, nullptr, P, nullptr, sys->L2.mval, MP, wp); // M P is not maintained in this mode: form it (wide block)
+                gram(ctx, n, MP, wp, W, w, H2, wp);
+            }
+            mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
+            mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
+            mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
+            // Only W itself is multiplied by L^-T.  Its images keep their pre-orthonormalisation form (A W L^T, M W L^T): the
+            // Gram blocks that involve them are corrected on the small matrices (B <- B L^-T), the recombination of M P folds
+            // L^-T into its coefficient rows, and A X, M X are recomputed from the new Ritz vectors anyway -- two tall
+            // basis-update launches fewer per iteration.
+            lazy_images = lazy_images_ok && w <= 256;
+            w_implicit = false;
+            ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
+            if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+        } else {
+            mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
+            for (int pass = 0; pass < ortho_passes && ok; ++pass) {
+                gram(ctx, n, MX, b, W, w, H, b); // b x w
+                if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
+                // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
+                mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
+                mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
+                mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
+                ok = chol_orthonormalise(W, MW, nullptr, w);
+            }
+            if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
+            mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
+        }
+    }
+
+    // The Gram matrices of [X_active W P] (most blocks known by construction), the small eigenproblem, the new Ritz values.
+    void rayleigh_ritz(uint32_t it) {
+        // Gram matrices of S = [X_active W P] (lower triangles), X block known: diag(theta) and I.  Locked columns are
+        // not part of the basis any more (W was projected against them above): the small problem has order
+        // 2w + wp instead of b + w + wp.
+        wa = w;
+        m = wa + w + wp;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            HIP_CHECK(hipMemsetAsync(gA, 0, size_t(m) * m * sizeof(double), st));
+            HIP_CHECK(hipMemsetAsync(gM, 0, size_t(m) * m * sizeof(double), st));
+            k_set_identity_blocks<<<grid1(wa), TB, 0, st>>>(gA, gM, theta_act_d, wa, m);
+            KERNEL_CHECK();
+            // W^T M X and P^T M W are zero by the projection that W just went through (measured 1e-14 .. 1e-12 in every run); they
+            // are formed only on request (MH_VERIFY_CROSS=1).  W^T M W, which carries the Cholesky-QR's error, is always measured.
+            const bool verify_cross = switches().verify_cross;
+            const double unit_one = 1;
+            auto left_corrected = [&](double *block, uint32_t cols) { // block (w x cols at leading dimension m) <- L^-1 block: W was not transformed
+                if (w_implicit)
+                    ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(w),
+                                                rocblas_int(cols), &unit_one, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
+            };
+            mh_gram(ctx, n, W, w, AX, wa, gA.get() + wa, m, b, idx_d);
+            left_corrected(gA.get() + wa, wa);
+            if (verify_cross) mh_gram(ctx, n, W, w, MX, wa, gM.get() + wa, m, b, idx_d);
+            const double unit = 1;
+            auto untransformed = [&](double *block, uint32_t rows) { // block (rows x w at leading dimension m) <- block L^-T
+                if (lazy_images)
+                    ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, rocblas_int(rows),
+                                                rocblas_int(w), &unit, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
+            };
+            gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
+            if (p_implicit && wp) {
+                // W' = W - P Hp:  P^T A W' = Bp - App Hp,  W'^T A W' = Bw - U - U^T + Hp^T App Hp with U = Hp^T Bp  (P^T A P = App, X^T A P = 0)
+                const double plus = 1, nil = 0;
+                double *bw = gA.get() + size_t(wa) * m + wa, *bp = gA.get() + size_t(wa) * m + wa + w;
+                gram(ctx, n, P, wp, AW, w, bp, m);
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), bp,
+                                            rocblas_int(m), &nil, Up, rocblas_int(w)));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(wp), rocblas_int(w), rocblas_int(wp), &plus, App, rocblas_int(wp), Hp,
+                                            rocblas_int(wp), &nil, T1p, rocblas_int(wp)));
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), T1p,
+                                            rocblas_int(wp), &nil, Vp, rocblas_int(w)));
+                k_sub_block<<<grid1(size_t(wp) * w), TB, 0, st>>>(bp, m, T1p, wp, wp, w); // Bp -= App Hp
+                k_wblock_fix<<<grid1(size_t(w) * w), TB, 0, st>>>(bw, m, Up, Vp, w);
+                KERNEL_CHECK();
+            }
+            untransformed(gA.get() + size_t(wa) * m + wa, w);
+            left_corrected(gA.get() + size_t(wa) * m + wa, w);
+            // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
+            // says cond(G) < 2^16 (deviation ~1e-11)
+            const bool w_block_trusted = !verify_cross && last_spread < 16 * 8 && !(p_implicit && wp == 0); // (a retry without P after an implicit P-projection: measure)
+            gm_identity = w_block_trusted && implicit_p; // every block of gM was set, not measured: gM0 is the identity exactly
+            if (w_block_trusted) {
+                k_place_block<<<grid1(size_t(w) * w), TB, 0, st>>>(gM.get() + size_t(wa) * m + wa, m, nullptr, w);
+                KERNEL_CHECK();
+            } else {
+                gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
+                untransformed(gM.get() + size_t(wa) * m + wa, w);
+            }
+            if (verbose) fprintf(stderr, "[lobpcg] it %3u Cholesky-QR diagonal spread 2^%.1f%s\n", it, last_spread / 16.0, w_block_trusted ? "" : " (W block measured)");
+            if (wp) {
+                if (!p_implicit) gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m); // (already formed and corrected above otherwise)
+                untransformed(gA.get() + size_t(wa) * m + wa + w, wp);
+                if (verify_cross || !implicit_p) {
+                    gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
+                    untransformed(gM.get() + size_t(wa) * m + wa + w, wp);
+                }
+                if (implicit_p) {
+                    // P = S_prev Cp with Cp gM-orthonormal and gM-orthogonal to the Ritz coefficients Cx, and
+                    // gA Cx = gM Cx Theta: hence P^T M P = I, P^T M X = P^T A X = 0 and P^T A P = Cp^T gA_prev Cp
+                    // (formed last iteration from the small matrices) -- four tall Gram products saved.
+                    k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gA.get() + size_t(wa + w) * m + wa + w, m, App, wp);
+                    k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(wa + w) * m + wa + w, m, nullptr, wp);
+                    KERNEL_CHECK();
+                } else {
+                    mh_gram(ctx, n, P, wp, AX, wa, gA.get() + wa + w, m, b, idx_d);
+                    mh_gram(ctx, n, P, wp, MX, wa, gM.get() + wa + w, m, b, idx_d);
+                    gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(wa + w) * m + wa + w, m);
+                    gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(wa + w) * m + wa + w, m);
+                }
+            }
+            k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, st>>>(gA, m, m);
+            KERNEL_CHECK();
+            HIP_CHECK(hipMemcpyAsync(gA0, gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(gM0, gM, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info, wa);
+            if (hinfo == 0) break;
+            if (attempt == 1 || wp == 0) mh_throw(MH_ENOTCONVERGED, "Rayleigh-Ritz failed at iteration %u (info %d)", it, hinfo);
+            wp = 0; // drop the previous directions and retry on [X W]
+            m = wa + w;
+        }
+        evals.download(theta_act.data(), wa); // ascending Ritz values into the (ascending) active slots
+        for (uint32_t k = 0; k < wa; ++k) theta[act[k]] = theta_act[k];
+    }
+
+    // The next conjugate directions in coefficient space (Cp), and P^T A P for the next iteration.
+    void conjugate_directions(uint32_t it) {
+        // New directions in coefficient space: the [W P] part of the active Ritz vectors, made
+        // gM-orthonormal against the new X coefficients and among themselves.
+        const double one = 1, zero = 0, mone = -1;
+        wp_new = w;
+        k_build_cp<<<grid1(size_t(m) * w), TB, 0, st>>>(gA, nullptr, wa, m, w, m, Cp, m);
+        KERNEL_CHECK();
+        // (gM0 Cp is Cp itself when gM0 is the identity by construction: the two symmetric products are skipped)
+        const double *mcp = gm_identity ? Cp.get() : T1.get();
+        if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, mcp, m, &zero, H, wa));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, wa, &mone, gA, m, H, wa, &one, Cp, m));
+        if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, mcp, m, &zero, G, w));
+        k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
+        KERNEL_CHECK();
+        {
+            double *Gs = G.get() + size_t(w) * w;
+            int hinfo = 0;
+            {
+                if (w <= 128) {
+                    mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
+                    info.download(&hinfo, 1);
+                } else {
+                    SolverLock solver_lock(g_rocsolver_mutex);
+                    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+                    info.download(&hinfo, 1);
+                }
+            }
+            if (hinfo != 0) {
+                wp_new = 0;
+            } else {
+                k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
+                KERNEL_CHECK();
+                ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, w, &one, Gs, w, Cp, m));
+            }
+        }
+        // No conjugate directions in the first iterations of a cold start, while the block is far from the invariant
+        // subspace: with residuals of order one the previous step carries no usable curvature information -- the iteration
+        // count is the same without it (18 and 18 at S100k) -- and an iteration on [X W] costs a third less
+        // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
+        const uint32_t skip_p = switches().skip_p;
+        if (!warm && it < skip_p && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
+        if (wp_new && implicit_p) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m));
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
+        }
+    }
+
+    // X <- S Cx, P <- S Cp, and the images the next iteration needs.
+    void update_basis(uint32_t it) {
+        // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
+        mh_pack_coefficients(ctx, gA, wa, Cp, wp_new, m, m, Ct);
+        // X_active <- S Cx (mapped columns of X), P <- S Cp.  One launch per image works in place (a workgroup reads its 64
+        // rows completely before writing them); more than 256 output columns take several launches over the same
+        // inputs, so those go through a contiguous copy and a scatter.
+        // Images of the new block.  A X and M X are formed from the new Ritz vectors by one fused product (written straight into
+        // the active columns) instead of being recombined from [A X, A W, A P] and [M X, M W, M P]: one pass over the matrix
+        // costs less than two passes over three tall panels each, the images carry no accumulated rounding, and A P is
+        // not needed at all (P^T A P comes from the small matrices, above).  M P, which the next projection needs, is
+        // still recombined -- before M X is overwritten.
+        const bool fresh_images = fresh_env;
+        const bool in_place = wa + wp_new <= 256;
+        if (fresh_images && implicit_p) {
+            const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
+            if (w_implicit) { // the basis holds W, not W L^-T: every coefficient row of the W part <- L^-T row (all columns)
+                const double unit = 1;
+                double *rows = Ct.get() + size_t(wa) * (wa + wp_new);
+                ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wa + wp_new),
+                                            rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
+            }
+            if (p_implicit && wp) { // ... and it holds W, not W - P Hp: the P rows take the difference, rows_P -= Hp rows_W (all columns)
+                const double minus = -1, plus = 1;
+                const rocblas_int pitchc = rocblas_int(wa + wp_new);
+                double *rows_w = Ct.get() + size_t(wa) * (wa + wp_new), *rows_p = Ct.get() + size_t(wa + w) * (wa + wp_new);
+                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, pitchc, rocblas_int(wp), rocblas_int(w), &minus, rows_w, pitchc, Hp,
+                                            rocblas_int(wp), &plus, rows_p, pitchc));
+            }
+            mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
+            if (wp_new && !pproj_ok) {
+                if (lazy_images && !w_implicit) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
+                    const double unit = 1;
+                    double *rows = Ct.get() + size_t(wa) * (wa + wp_new) + wa;
+                    ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wp_new),
+                                                rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
+                }
+                mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);
+            }
+            if (pitch == wa) k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), idx_d, X.get(), n, b, wa);
+            else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
+            KERNEL_CHECK();
+            mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d);
+        } else {
+        const bool refresh = (it + 1) % 8 == 0; // images of the new Ritz vectors recomputed instead of recombined: A X and
+                                                // M X otherwise inherit eight generations of rounding from the updates
+        auto update = [&](DevArray<double> &x_all, const double *wpanel, const double *ppanel, DevArray<double> &x_new, double *p_new, bool keep_contiguous) {
+            if (in_place && !keep_contiguous) {
+                mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_all, wa, p_new, false, b, idx_d, b, idx_d);
+            } else {
+                mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_new, wa, p_new, false, b, idx_d);
+                if (!keep_contiguous) {
+                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(x_new.get(), idx_d, x_all.get(), n, b, wa);
+                    KERNEL_CHECK();
+                }
+            }
+        };
+        update(X, W, P, Xn, Pn, refresh); // on a refresh Xn keeps the new vectors contiguously for the products below
+        update(AX, AW, AP, AXn, APn, refresh);
+        update(MX, MW, MP, MXn, MPn, refresh);
+        if (refresh) {
+            mh_spmm(ctx, sys->L2, sys->L2.aval, Xn, AXn, sys->L2.mval, MXn, wa);
+            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
+            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
+            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
+            KERNEL_CHECK();
+        }
+        }
+        std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
+        wp = wp_new;
+    }
+
+    void finish(double *eigenvalues) {
+        prof.restarts = iters;
+        prof.op_solve = precond_seconds;
+        if (!converged) mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged in %u iterations", nconv, nev, iters);
+        for (uint32_t k = 0; k < nev; ++k) eigenvalues[k] = theta[order[k]] + sigma;
+        sys->evecs.reset(ctx, n * nev);
+        sys->evec_cols = nev;
+        idx_d.upload(order.data(), nev);
+        k_gather_cols<<<grid1(n * nev), TB, 0, st>>>(X, idx_d, sys->evecs, n, b, nev);
+        KERNEL_CHECK();
+        HIP_CHECK(hipStreamSynchronize(st));
+        prof.iterate = t_iter.stop();
+        sys->profile = prof;
+        if (profile) *profile = prof;
+    }
+
+    void run(double *eigenvalues) {
+        start();
+        for (uint32_t it = 0; it <= max_iters; ++it) {
+            if (converged_or_locked(it)) break;
+            search_directions(it);
+            rayleigh_ritz(it);
+            conjugate_directions(it);
+            update_basis(it);
+        }
+        finish(eigenvalues);
+    }
+};
+} // namespace
+
 static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
                       uint32_t seed_cols, const volatile unsigned char *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {
     {
@@ -1070,542 +1671,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 prof.factorize = t.stop();
             }
             if (progress) *progress = 0.3f;
-            SharedPhase iterating; // released and re-taken at the top of every iteration so that a waiting factorisation gets in
-            Timer t_iter(ctx);
-            double precond_seconds = 0;
-            hipStream_t st = ctx->stream;
-            const uint32_t mmax = 3 * b;
-            // panels
-            DevArray<double> X(ctx, n * b), AX(ctx, n * b), MX(ctx, n * b), Xn(ctx, n * b), AXn(ctx, n * b), MXn(ctx, n * b);
-            DevArray<double> W(ctx, n * b), AW(ctx, n * b), MW(ctx, n * b), P(ctx, n * b), AP(ctx, n * b), MP(ctx, n * b);
-            DevArray<double> Pn(ctx, n * b), APn(ctx, n * b), MPn(ctx, n * b), R(ctx, n * b), Rw(ctx, n * b);
-            DevArray<double> gA(ctx, size_t(mmax) * mmax), gM(ctx, size_t(mmax) * mmax), gM0(ctx, size_t(mmax) * mmax), gA0(ctx, size_t(mmax) * mmax), App(ctx, size_t(b) * b), evals(ctx, mmax), ework(ctx, mmax);
-            const bool implicit_p = switches().implicit_p;
-            DevArray<double> Cp(ctx, size_t(mmax) * b), T1(ctx, size_t(mmax) * b), H(ctx, size_t(b) * b), H2(ctx, size_t(b) * b), G(ctx, size_t(b) * 2 * b), dscale(ctx, b);
-            DevArray<double> Linv(ctx, size_t(b) * b);
-            DevArray<double> theta_d(ctx, b), rn_d(ctx, b), mn_d(ctx, b), scratch, Ct(ctx, size_t(mmax) * 2 * b);
-            DevArray<uint32_t> idx_d(ctx, b);
-            DevArray<int> info(ctx, 2); // [1]: conditioning report of mh_potrf_small
-            const bool fp32_prec = switches().fp32_prec;
-            std::unique_ptr<Precond<float>> prec32;
-            std::unique_ptr<Precond<double>> prec64;
-            if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, b);
-            else prec64 = std::make_unique<Precond<double>>(sys, b);
-
-            // --- initial block: seed columns (warm start), then Gaussian noise; M-orthonormalise; Rayleigh-Ritz
-            k_random_panel<<<grid1(n * b), TB, 0, st>>>(X, n * b, 20260710ull);
-            KERNEL_CHECK();
-            const bool warm = seed_basis && seed_rows == n && seed_cols >= nev;
-            if (warm) {
-                const uint32_t ncols = std::min(seed_cols, b);
-                DevArray<float> seed(ctx, n * ncols);
-                seed.upload(seed_basis, n * ncols);
-                k_load_seed<<<grid1(n * ncols), TB, 0, st>>>(seed, sys->perm, sys->n_nodes, ncols, b, X);
-                KERNEL_CHECK();
-                HIP_CHECK(hipStreamSynchronize(st));
-            }
-            if (b >= 12) {
-                // A free body's six rigid-body modes are exact eigenvectors (lambda = 0): start from them -- also on a warm
-                // start, where they replace the six seeded (single-precision) copies: a rigid mode known only to 1e-7
-                // leaves A x = |sigma| M x as the difference of terms 12 orders larger, and its Ritz value is then noise.
-                auto hx = sys->node_xyz.to_host();
-                double c[3] = {0, 0, 0};
-                for (uint32_t i = 0; i < sys->n_nodes; ++i)
-                    for (int d = 0; d < 3; ++d) c[d] += hx[3 * size_t(i) + d];
-                for (double &v : c) v /= double(sys->n_nodes);
-                k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
-                KERNEL_CHECK();
-            }
-            bool w_implicit = false; // W itself left untransformed this iteration (see chol_orthonormalise)
-            int last_spread = 1 << 20; // 16 log2(max / min diagonal of the last Cholesky factor of a unit-diagonal Gram matrix)
-            bool p_needs_explicit = false; // the implicit projection against P was refused (ill-conditioned Gram matrix): caller redoes it explicitly
-            auto chol_orthonormalise = [&](double *V, double *MV, double *AV, uint32_t w, bool transform_images = true, bool allow_implicit = false,
-                                           const double *hp = nullptr, uint32_t hp_rows = 0) -> bool {
-                // hp (hp_rows x w, = P^T M V): V is to be taken as V - P hp without forming it: G -= hp^T hp (P is M-orthonormal).  Only
-                // valid together with the implicit treatment of V; when that is refused nothing is transformed and p_needs_explicit is set.
-                // allow_implicit: with a well-conditioned Gram matrix not even V is transformed (w_implicit is set): the caller works
-                // with V L^-T through L^-1 on the small matrices
-                // transform_images = false: M V is only read (for the Gram matrix); the caller keeps the images untransformed
-                // G = V^T M V, scaled to unit diagonal, Cholesky; V <- V L^-T (and the same for MV, AV)
-                gram(ctx, n, V, w, MV, w, G, w);
-                if (hp) {
-                    const double minus = -1, plus = 1;
-                    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(hp_rows), &minus, hp,
-                                                rocblas_int(hp_rows), hp, rocblas_int(hp_rows), &plus, G, rocblas_int(w)));
-                }
-                k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
-                KERNEL_CHECK();
-                double *Gs = G.get() + size_t(w) * w;
-                int hinfo = 0;
-                {
-                    last_spread = 1 << 20;
-                    if (w <= 128) {
-                        mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
-                        int both[2] = {0, 0};
-                        info.download(both, 2);
-                        hinfo = both[0];
-                        last_spread = both[1];
-                    } else {
-                        SolverLock solver_lock(g_rocsolver_mutex);
-                        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
-                        info.download(&hinfo, 1);
-                    }
-                }
-                p_needs_explicit = false;
-                if (hp && (hinfo != 0 || last_spread >= 16 * 8)) { // V - P hp is nearly dependent: project in the tall space instead
-                    p_needs_explicit = true;
-                    return true;
-                }
-                if (hinfo != 0) return false;
-                k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
-                KERNEL_CHECK();
-                const bool trsm_rocblas = switches().trsm_rocblas;
-                if (trsm_rocblas || w > 256) {
-                    panel_trsm(ctx, n, V, w, Gs, w);
-                    if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
-                    if (AV) panel_trsm(ctx, n, AV, w, Gs, w);
-                } else {
-                    // V <- V L^-T through the explicit small inverse and the MFMA basis-update kernel (in place: a workgroup
-                    // reads its rows before it writes them): L^-1 column-major IS the k-major coefficient matrix of V L^-T
-                    HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
-                    ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
-                    w_implicit = allow_implicit && !transform_images && last_spread < 16 * 8;
-                    if (!w_implicit) mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
-                    if (MV && transform_images) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);
-                    if (AV && transform_images) mh_combine(ctx, n, AV, w, nullptr, 0, nullptr, 0, Linv, w, AV, w, nullptr);
-                }
-                return true;
-            };
-            // A cold start begins from B M x for Gaussian noise x (one preconditioner application: the high-frequency content
-            // of the noise is damped before the first Rayleigh-Ritz step), with the exact rigid-body modes put back: one
-            // iteration fewer on every workload measured (18 -> 17 at S100k, 40 -> 39 on the ball, 17 -> 16 at S30k).
-            const int smooth_init = switches().smooth_init;
-            if (smooth_init && !warm) {
-                for (int rep = 0; rep < smooth_init; ++rep) {
-                    mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
-                    Timer tp(ctx);
-                    if (prec32) prec32->apply(MX, Xn, b);
-                    else prec64->apply(MX, Xn, b);
-                    precond_seconds += tp.stop();
-                    prof.op_applications += b;
-                    HIP_CHECK(hipMemcpyAsync(X, Xn.get(), n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
-                }
-                if (b >= 12) {
-                    auto hx = sys->node_xyz.to_host();
-                    double c[3] = {0, 0, 0};
-                    for (uint32_t i = 0; i < sys->n_nodes; ++i)
-                        for (int d = 0; d < 3; ++d) c[d] += hx[3 * size_t(i) + d];
-                    for (double &v : c) v /= double(sys->n_nodes);
-                    k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
-                    KERNEL_CHECK();
-                }
-            }
-            mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
-            if (!chol_orthonormalise(X, MX, nullptr, b)) mh_throw(MH_ENOTCONVERGED, "initial block is rank deficient");
-            mh_spmm(ctx, sys->L2, sys->L2.aval, X, AX, sys->L2.mval, MX, b);
-            std::vector<double> theta(b);
-            {
-                gram(ctx, n, X, b, AX, b, gA, b);
-                gram(ctx, n, X, b, MX, b, gM, b);
-                const int hinfo = rr_solve(ctx, gA, gM, b, evals, ework, info);
-                if (hinfo != 0) mh_throw(MH_ENOTCONVERGED, "initial Rayleigh-Ritz failed (info %d)", hinfo);
-                panel_mul(ctx, n, X, b, gA, b, Xn, b, 1.0, 0.0);
-                panel_mul(ctx, n, AX, b, gA, b, AXn, b, 1.0, 0.0);
-                panel_mul(ctx, n, MX, b, gA, b, MXn, b, 1.0, 0.0);
-                std::swap(X, Xn); std::swap(AX, AXn); std::swap(MX, MXn);
-                evals.download(theta.data(), b);
-            }
-            uint32_t wp = 0; // width of P
-            uint32_t iters = 0, nconv = 0;
-            std::vector<double> rn(b), mn(b), xn(b);
-            DevArray<double> norms_d(ctx, 3 * size_t(b));
-            std::vector<double> norms(3 * size_t(b));
-            double anorm = 0;
-            {
-                auto hd = sys->L2.dinv.to_host();
-                double dmin = 1e300;
-                for (double v : hd) dmin = std::min(dmin, v);
-                anorm = sys->L2.lmax / dmin; // lambda_max(A) <= lambda_max(D^-1 A) * max diag(A)
-            }
-            std::vector<uint32_t> act, order(b);
-            std::vector<uint8_t> locked(b, 0); // hard locking: a converged column leaves the Rayleigh-Ritz basis for good
-            std::vector<double> theta_act(b);
-            DevArray<double> theta_act_d(ctx, b);
-            bool converged = false;
-            std::vector<double> hist_worst;
-            std::vector<uint32_t> hist_nconv;
-            const bool implicit_w_env = switches().implicit_w_env;
-            const bool lazy_env = switches().lazy_env;
-            const bool fresh_env = switches().fresh_env;
-            const bool trsm_env = switches().trsm_env;
-            const bool lazy_images_ok = lazy_env && fresh_env && implicit_p && !trsm_env;
-            // W is orthogonalised against P in coefficient space (no M P panel, no tall projection against P): MH_IMPLICIT_PPROJ=0 disables
-            const bool pproj_env = switches().pproj_env;
-            const bool pproj_ok = pproj_env && lazy_images_ok && implicit_w_env && b <= 128;
-            DevArray<double> Hp(ctx, size_t(b) * b), Up(ctx, size_t(b) * b), Vp(ctx, size_t(b) * b), T1p(ctx, size_t(b) * b);
-            bool gm_identity = false; // this iteration's gM0 is exactly I (all blocks placed, none measured)
-            bool p_implicit = false; // this iteration: the basis is [X, (W - P Hp) L^-T, P] with W, P stored
-            bool lazy_images = false;
-            for (uint32_t it = 0; it <= max_iters; ++it) {
-                if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
-                if (g_concurrent) { // an exclusive holder synchronises the device itself: no need to drain our queue first
-                    iterating.release();
-                    iterating.acquire();
-                }
-                theta_d.upload(theta.data(), b);
-                {
-                    const uint32_t rpb = 256, nblk = div_up(n, rpb);
-                    if (scratch.count < size_t(nblk) * 3 * b) scratch.reset(ctx, size_t(nblk) * 3 * b);
-                    dim3 grid(nblk, div_up(b, 64));
-                    k_residual_norms<<<grid, 64, 0, st>>>(AX, MX, X, theta_d, 10.0 * std::abs(sigma), R, n, b, rpb, scratch);
-                    KERNEL_CHECK();
-                    k_colsumsq_final<<<3 * b, 256, 0, st>>>(scratch, nblk, 3 * b, norms_d); // partial rows are 3b wide
-                    KERNEL_CHECK();
-                    norms_d.download(norms.data(), 3 * size_t(b));
-                    std::copy(norms.begin(), norms.begin() + b, rn.begin());
-                    std::copy(norms.begin() + b, norms.begin() + 2 * b, mn.begin());
-                    std::copy(norms.begin() + 2 * b, norms.end(), xn.begin());
-                }
-                act.clear();
-                for (uint32_t i = 0; i < b; ++i) {
-                    // Converged: relative residual below tol, or at the rounding floor of forming A x (which is what
-                    // limits the rigid-body pairs: theta = |sigma| sits 10-12 orders below ||A||).
-                    const double rel = std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]));
-                    // The floor clause is for those pairs only (theta within 10x of |sigma|): an elastic pair of a stiff, sliver-heavy
-                    // mesh must not be accepted at a relative residual above the tolerance because ||A|| happens to be huge.
-                    const bool near_shift = std::abs(theta[i]) < 10.0 * std::abs(sigma);
-                    const bool ok = rel < residual_tol || (near_shift && std::sqrt(rn[i]) < 50 * 2.2e-16 * anorm * std::sqrt(xn[i]));
-                    if (ok) locked[i] = 1;
-                    if (!locked[i]) act.push_back(i);
-                }
-                // the nev smallest Ritz values must all belong to converged columns
-                std::iota(order.begin(), order.end(), 0u);
-                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return theta[a] < theta[c]; });
-                nconv = 0;
-                for (uint32_t k = 0; k < nev; ++k) nconv += locked[order[k]];
-                if (progress) *progress = 0.3f + 0.65f * float(nconv) / float(nev);
-                const bool verbose = switches().verbose;
-                if (verbose) {
-                    double worst = 0;
-                    for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
-                    fprintf(stderr, "[lobpcg] it %3u conv %3u/%u active %zu wp %u worst %.2e  floor-ratio[0..7]:", it, nconv, nev, act.size(), wp, worst);
-                    for (uint32_t i = 0; i < std::min(8u, b); ++i) fprintf(stderr, " %.1f", xn[i] > 0 ? std::sqrt(rn[i]) / (2.2e-16 * anorm * std::sqrt(xn[i])) : 0.0);
-                    fprintf(stderr, "  theta0 %.6e\n", theta[0]);
-                }
-                iters = it;
-                if (nconv >= nev || act.empty()) { converged = nconv >= nev; break; }
-                if (it == max_iters) break;
-                // Safety net of the single-precision smoothers: no newly converged pair and no 20 % drop of the worst
-                // residual over 6 iterations switches the cycle to double precision for the rest of the solve.
-                {
-                    double worst = 0;
-                    for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
-                    hist_worst.push_back(worst);
-                    hist_nconv.push_back(nconv);
-                    const size_t h = hist_worst.size();
-                    // against the state six iterations ago (the first iterations are not monotone: the residuals of a
-                    // random block first rise)
-                    if (prec32 && it >= 10 && h > 6 && hist_nconv[h - 7] == nconv && worst > 0.5 * hist_worst[h - 7]) {
-                        if (verbose) fprintf(stderr, "[lobpcg] it %3u stagnation: switching the preconditioner to double precision\n", it);
-                        prec32.reset();
-                        prec64 = std::make_unique<Precond<double>>(sys, b);
-                    }
-                }
-                const uint32_t w = uint32_t(act.size());
-                idx_d.upload(act.data(), w);
-                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
-                KERNEL_CHECK();
-                // The Rayleigh-Ritz basis is [X_active W P]; the active columns of X, A X, M X are addressed in place through
-                // the index list idx_d (column maps of the Gram and basis-update kernels), never copied out.
-                for (uint32_t k = 0; k < w; ++k) theta_act[k] = theta[act[k]];
-                theta_act_d.upload(theta_act.data(), w);
-                {
-                    Timer tp(ctx);
-                    if (prec32) prec32->apply(Rw, W, w);
-                    else prec64->apply(Rw, W, w);
-                    precond_seconds += tp.stop();
-                    prof.op_applications += w;
-                }
-                // W <- (I - X X^T M - P P^T M) W (the coefficients come from M X and M P: no M W needed yet), then A W and M W in
-                // one fused product, then M-orthonormalise W carrying both images along.  Against "M W first, project W and
-                // M W, orthonormalise, then A W" this is one basis-update launch and one pass over the matrix fewer per iteration.
-                bool ok = true;
-                // One projection + Cholesky-QR pass suffices: the Rayleigh-Ritz step solves the full pencil (gA, gM), so the
-                // basis only has to be well conditioned, not orthonormal to working precision.
-                const int ortho_passes = switches().ortho_passes;
-                const bool fused_images = switches().fused_images;
-                p_implicit = false;
-                if (fused_images && ortho_passes == 1 && pproj_ok && wp && w <= 128) {
-                    // project against X in the tall space, against P in coefficient space
-                    gram(ctx, n, MX, b, W, w, H, b); // b x w
-                    mh_pack_stacked(ctx, H, b, nullptr, 0, w, -1.0, Ct);
-                    mh_combine(ctx, n, X, b, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
-                    mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
-                    gram(ctx, n, P, wp, MW, w, Hp, wp); // Hp = P^T M W, wp x w
-                    lazy_images = true;
-                    w_implicit = false;
-                    ok = chol_orthonormalise(W, MW, AW, w, false, true, Hp, wp);
-                    if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-                    if (p_needs_explicit) { // rare: W - P Hp nearly dependent -> explicit projection, images again, ordinary Cholesky-QR
-                        mh_pack_stacked(ctx, Hp, wp, nullptr, 0, w, -1.0, Ct);
-                        mh_combine(ctx, n, P, wp, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
-                        mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
-                        lazy_images = lazy_images_ok && w <= 256;
-                        ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
-                        if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-                    } else {
-                        p_implicit = true;
-                    }
-                } else if (fused_images && ortho_passes == 1) {
-                    gram(ctx, n, MX, b, W, w, H, b); // b x w
-                    if (wp) {
-                        if (pproj_ok) mh_spmm(ctx, sys->L2, nullptr, P, nullptr, sys->L2.mval, MP, wp); // M P is not maintained in this mode: form it (wide block)
-                        gram(ctx, n, MP, wp, W, w, H2, wp);
-                    }
-                    mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
-                    mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
-                    mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
-                    // Only W itself is multiplied by L^-T.  Its images keep their pre-orthonormalisation form (A W L^T, M W L^T): the
-                    // Gram blocks that involve them are corrected on the small matrices (B <- B L^-T), the recombination of M P folds
-                    // L^-T into its coefficient rows, and A X, M X are recomputed from the new Ritz vectors anyway -- two tall
-                    // basis-update launches fewer per iteration.
-                    lazy_images = lazy_images_ok && w <= 256;
-                    w_implicit = false;
-                    ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
-                    if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-                } else {
-                    mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
-                    for (int pass = 0; pass < ortho_passes && ok; ++pass) {
-                        gram(ctx, n, MX, b, W, w, H, b); // b x w
-                        if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
-                        // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
-                        mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
-                        mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
-                        mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
-                        ok = chol_orthonormalise(W, MW, nullptr, w);
-                    }
-                    if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-                    mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
-                }
-                // Gram matrices of S = [X_active W P] (lower triangles), X block known: diag(theta) and I.  Locked columns are
-                // not part of the basis any more (W was projected against them above): the small problem has order
-                // 2w + wp instead of b + w + wp.
-                const uint32_t wa = w;
-                uint32_t m = wa + w + wp;
-                for (int attempt = 0; attempt < 2; ++attempt) {
-                    HIP_CHECK(hipMemsetAsync(gA, 0, size_t(m) * m * sizeof(double), st));
-                    HIP_CHECK(hipMemsetAsync(gM, 0, size_t(m) * m * sizeof(double), st));
-                    k_set_identity_blocks<<<grid1(wa), TB, 0, st>>>(gA, gM, theta_act_d, wa, m);
-                    KERNEL_CHECK();
-                    // W^T M X and P^T M W are zero by the projection that W just went through (measured 1e-14 .. 1e-12 in every run); they
-                    // are formed only on request (MH_VERIFY_CROSS=1).  W^T M W, which carries the Cholesky-QR's error, is always measured.
-                    const bool verify_cross = switches().verify_cross;
-                    const double unit_one = 1;
-                    auto left_corrected = [&](double *block, uint32_t cols) { // block (w x cols at leading dimension m) <- L^-1 block: W was not transformed
-                        if (w_implicit)
-                            ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(w),
-                                                        rocblas_int(cols), &unit_one, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
-                    };
-                    mh_gram(ctx, n, W, w, AX, wa, gA.get() + wa, m, b, idx_d);
-                    left_corrected(gA.get() + wa, wa);
-                    if (verify_cross) mh_gram(ctx, n, W, w, MX, wa, gM.get() + wa, m, b, idx_d);
-                    const double unit = 1;
-                    auto untransformed = [&](double *block, uint32_t rows) { // block (rows x w at leading dimension m) <- block L^-T
-                        if (lazy_images)
-                            ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, rocblas_int(rows),
-                                                        rocblas_int(w), &unit, Linv, rocblas_int(w), block, rocblas_int(m), block, rocblas_int(m)));
-                    };
-                    gram(ctx, n, W, w, AW, w, gA.get() + size_t(wa) * m + wa, m);
-                    if (p_implicit && wp) {
-                        // W' = W - P Hp:  P^T A W' = Bp - App Hp,  W'^T A W' = Bw - U - U^T + Hp^T App Hp with U = Hp^T Bp  (P^T A P = App, X^T A P = 0)
-                        const double plus = 1, nil = 0;
-                        double *bw = gA.get() + size_t(wa) * m + wa, *bp = gA.get() + size_t(wa) * m + wa + w;
-                        gram(ctx, n, P, wp, AW, w, bp, m);
-                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), bp,
-                                                    rocblas_int(m), &nil, Up, rocblas_int(w)));
-                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(wp), rocblas_int(w), rocblas_int(wp), &plus, App, rocblas_int(wp), Hp,
-                                                    rocblas_int(wp), &nil, T1p, rocblas_int(wp)));
-                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), T1p,
-                                                    rocblas_int(wp), &nil, Vp, rocblas_int(w)));
-                        k_sub_block<<<grid1(size_t(wp) * w), TB, 0, st>>>(bp, m, T1p, wp, wp, w); // Bp -= App Hp
-                        k_wblock_fix<<<grid1(size_t(w) * w), TB, 0, st>>>(bw, m, Up, Vp, w);
-                        KERNEL_CHECK();
-                    }
-                    untransformed(gA.get() + size_t(wa) * m + wa, w);
-                    left_corrected(gA.get() + size_t(wa) * m + wa, w);
-                    // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
-                    // says cond(G) < 2^16 (deviation ~1e-11)
-                    const bool w_block_trusted = !verify_cross && last_spread < 16 * 8 && !(p_implicit && wp == 0); // (a retry without P after an implicit P-projection: measure)
-                    gm_identity = w_block_trusted && implicit_p; // every block of gM was set, not measured: gM0 is the identity exactly
-                    if (w_block_trusted) {
-                        k_place_block<<<grid1(size_t(w) * w), TB, 0, st>>>(gM.get() + size_t(wa) * m + wa, m, nullptr, w);
-                        KERNEL_CHECK();
-                    } else {
-                        gram(ctx, n, W, w, MW, w, gM.get() + size_t(wa) * m + wa, m);
-                        untransformed(gM.get() + size_t(wa) * m + wa, w);
-                    }
-                    if (verbose) fprintf(stderr, "[lobpcg] it %3u Cholesky-QR diagonal spread 2^%.1f%s\n", it, last_spread / 16.0, w_block_trusted ? "" : " (W block measured)");
-                    if (wp) {
-                        if (!p_implicit) gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m); // (already formed and corrected above otherwise)
-                        untransformed(gA.get() + size_t(wa) * m + wa + w, wp);
-                        if (verify_cross || !implicit_p) {
-                            gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
-                            untransformed(gM.get() + size_t(wa) * m + wa + w, wp);
-                        }
-                        if (implicit_p) {
-                            // P = S_prev Cp with Cp gM-orthonormal and gM-orthogonal to the Ritz coefficients Cx, and
-                            // gA Cx = gM Cx Theta: hence P^T M P = I, P^T M X = P^T A X = 0 and P^T A P = Cp^T gA_prev Cp
-                            // (formed last iteration from the small matrices) -- four tall Gram products saved.
-                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gA.get() + size_t(wa + w) * m + wa + w, m, App, wp);
-                            k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(wa + w) * m + wa + w, m, nullptr, wp);
-                            KERNEL_CHECK();
-                        } else {
-                            mh_gram(ctx, n, P, wp, AX, wa, gA.get() + wa + w, m, b, idx_d);
-                            mh_gram(ctx, n, P, wp, MX, wa, gM.get() + wa + w, m, b, idx_d);
-                            gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(wa + w) * m + wa + w, m);
-                            gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(wa + w) * m + wa + w, m);
-                        }
-                    }
-                    k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, st>>>(gA, m, m);
-                    KERNEL_CHECK();
-                    HIP_CHECK(hipMemcpyAsync(gA0, gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
-                    HIP_CHECK(hipMemcpyAsync(gM0, gM, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
-                    const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info, wa);
-                    if (hinfo == 0) break;
-                    if (attempt == 1 || wp == 0) mh_throw(MH_ENOTCONVERGED, "Rayleigh-Ritz failed at iteration %u (info %d)", it, hinfo);
-                    wp = 0; // drop the previous directions and retry on [X W]
-                    m = wa + w;
-                }
-                evals.download(theta_act.data(), wa); // ascending Ritz values into the (ascending) active slots
-                for (uint32_t k = 0; k < wa; ++k) theta[act[k]] = theta_act[k];
-                // New directions in coefficient space: the [W P] part of the active Ritz vectors, made
-                // gM-orthonormal against the new X coefficients and among themselves.
-                const double one = 1, zero = 0, mone = -1;
-                uint32_t wp_new = w;
-                k_build_cp<<<grid1(size_t(m) * w), TB, 0, st>>>(gA, nullptr, wa, m, w, m, Cp, m);
-                KERNEL_CHECK();
-                // (gM0 Cp is Cp itself when gM0 is the identity by construction: the two symmetric products are skipped)
-                const double *mcp = gm_identity ? Cp.get() : T1.get();
-                if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, mcp, m, &zero, H, wa));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, wa, &mone, gA, m, H, wa, &one, Cp, m));
-                if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, mcp, m, &zero, G, w));
-                k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
-                KERNEL_CHECK();
-                {
-                    double *Gs = G.get() + size_t(w) * w;
-                    int hinfo = 0;
-                    {
-                        if (w <= 128) {
-                            mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
-                            info.download(&hinfo, 1);
-                        } else {
-                            SolverLock solver_lock(g_rocsolver_mutex);
-                            ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
-                            info.download(&hinfo, 1);
-                        }
-                    }
-                    if (hinfo != 0) {
-                        wp_new = 0;
-                    } else {
-                        k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
-                        KERNEL_CHECK();
-                        ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, w, &one, Gs, w, Cp, m));
-                    }
-                }
-                // No conjugate directions in the first iterations of a cold start, while the block is far from the invariant
-                // subspace: with residuals of order one the previous step carries no usable curvature information -- the iteration
-                // count is the same without it (18 and 18 at S100k) -- and an iteration on [X W] costs a third less
-                // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
-                const uint32_t skip_p = switches().skip_p;
-                if (!warm && it < skip_p && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
-                if (wp_new && implicit_p) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
-                    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m));
-                    ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
-                }
-                // X <- S Cx, P <- S Cp (and the A-, M-images): one fused MFMA launch per image
-                mh_pack_coefficients(ctx, gA, wa, Cp, wp_new, m, m, Ct);
-                // X_active <- S Cx (mapped columns of X), P <- S Cp.  One launch per image works in place (a workgroup reads its 64
-                // rows completely before writing them); more than 256 output columns take several launches over the same
-                // inputs, so those go through a contiguous copy and a scatter.
-                // Images of the new block.  A X and M X are formed from the new Ritz vectors by one fused product (written straight into
-                // the active columns) instead of being recombined from [A X, A W, A P] and [M X, M W, M P]: one pass over the matrix
-                // costs less than two passes over three tall panels each, the images carry no accumulated rounding, and A P is
-                // not needed at all (P^T A P comes from the small matrices, above).  M P, which the next projection needs, is
-                // still recombined -- before M X is overwritten.
-                const bool fresh_images = fresh_env;
-                const bool in_place = wa + wp_new <= 256;
-                if (fresh_images && implicit_p) {
-                    const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
-                    if (w_implicit) { // the basis holds W, not W L^-T: every coefficient row of the W part <- L^-T row (all columns)
-                        const double unit = 1;
-                        double *rows = Ct.get() + size_t(wa) * (wa + wp_new);
-                        ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wa + wp_new),
-                                                    rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
-                    }
-                    if (p_implicit && wp) { // ... and it holds W, not W - P Hp: the P rows take the difference, rows_P -= Hp rows_W (all columns)
-                        const double minus = -1, plus = 1;
-                        const rocblas_int pitchc = rocblas_int(wa + wp_new);
-                        double *rows_w = Ct.get() + size_t(wa) * (wa + wp_new), *rows_p = Ct.get() + size_t(wa + w) * (wa + wp_new);
-                        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, pitchc, rocblas_int(wp), rocblas_int(w), &minus, rows_w, pitchc, Hp,
-                                                    rocblas_int(wp), &plus, rows_p, pitchc));
-                    }
-                    mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
-                    if (wp_new && !pproj_ok) {
-                        if (lazy_images && !w_implicit) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
-                            const double unit = 1;
-                            double *rows = Ct.get() + size_t(wa) * (wa + wp_new) + wa;
-                            ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wp_new),
-                                                        rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
-                        }
-                        mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);
-                    }
-                    if (pitch == wa) k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), idx_d, X.get(), n, b, wa);
-                    else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
-                    KERNEL_CHECK();
-                    mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d);
-                } else {
-                const bool refresh = (it + 1) % 8 == 0; // images of the new Ritz vectors recomputed instead of recombined: A X and
-                                                        // M X otherwise inherit eight generations of rounding from the updates
-                auto update = [&](DevArray<double> &x_all, const double *wpanel, const double *ppanel, DevArray<double> &x_new, double *p_new, bool keep_contiguous) {
-                    if (in_place && !keep_contiguous) {
-                        mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_all, wa, p_new, false, b, idx_d, b, idx_d);
-                    } else {
-                        mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_new, wa, p_new, false, b, idx_d);
-                        if (!keep_contiguous) {
-                            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(x_new.get(), idx_d, x_all.get(), n, b, wa);
-                            KERNEL_CHECK();
-                        }
-                    }
-                };
-                update(X, W, P, Xn, Pn, refresh); // on a refresh Xn keeps the new vectors contiguously for the products below
-                update(AX, AW, AP, AXn, APn, refresh);
-                update(MX, MW, MP, MXn, MPn, refresh);
-                if (refresh) {
-                    mh_spmm(ctx, sys->L2, sys->L2.aval, Xn, AXn, sys->L2.mval, MXn, wa);
-                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
-                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
-                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
-                    KERNEL_CHECK();
-                }
-                }
-                std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
-                wp = wp_new;
-            }
-            prof.restarts = iters;
-            prof.op_solve = precond_seconds;
-            if (!converged) mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged in %u iterations", nconv, nev, iters);
-            for (uint32_t k = 0; k < nev; ++k) eigenvalues[k] = theta[order[k]] + sigma;
-            sys->evecs.reset(ctx, n * nev);
-            sys->evec_cols = nev;
-            idx_d.upload(order.data(), nev);
-            k_gather_cols<<<grid1(n * nev), TB, 0, st>>>(X, idx_d, sys->evecs, n, b, nev);
-            KERNEL_CHECK();
-            HIP_CHECK(hipStreamSynchronize(st));
-            prof.iterate = t_iter.stop();
-            sys->profile = prof;
-            if (profile) *profile = prof;
+            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
+            solver.run(eigenvalues);
         }
     }
 }
