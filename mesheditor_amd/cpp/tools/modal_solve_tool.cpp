@@ -204,8 +204,22 @@ int main(int argc, char **argv) {
     const auto input = ReadInput(cl);
     if (!input) {
         std::fprintf(stderr, "Usage: %s <mesh.obj> [--layers k] | <mesh.tet> | --kuhn lx ly lz nx ny nz [--origin x y z]  [--young E] [--poisson v] [--density rho] [--alpha a] [--beta b] "
-                             "[--min-freq f] [--max-freq f] [--modes n] [--gltf out.gltf]\n", cl.Program().data());
+                             "[--min-freq f] [--max-freq f] [--modes n] [--gltf out.gltf] [--write-tets out.tet [--tets-only]]\n", cl.Program().data());
         return 1;
+    }
+    // "--write-tets file": the tet mesh the solve would run on, in the tool's own plain format (counts, points, tets; doubles at
+    // full precision); with "--tets-only" nothing is solved and no device is touched
+    if (const char *tets_path = cl.Text("--write-tets")) {
+        std::FILE *f = std::fopen(tets_path, "w");
+        if (!f) {
+            std::fprintf(stderr, "Cannot write %s\n", tets_path);
+            return 1;
+        }
+        std::fprintf(f, "%zu %zu\n", input->Mesh.Points.size(), input->Mesh.Tets.size());
+        for (const auto &q : input->Mesh.Points) std::fprintf(f, "%.17g %.17g %.17g\n", q.x, q.y, q.z);
+        for (const auto &t : input->Mesh.Tets) std::fprintf(f, "%u %u %u %u\n", t[0], t[1], t[2], t[3]);
+        std::fclose(f);
+        if (cl.Find("--tets-only")) return 0;
     }
     // defaults as the reference tool: ceramic-like solid, the audible window, 30 kept modes out of 45 solved
     AcousticMaterialProperties material{};

@@ -617,3 +617,57 @@ def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
     [c.close() for c in ctxs + [busy_ctx]]
     assert not errs, errs
     assert not bad, bad
+
+
+def _rough_torus_tets(tmp_path, nu=40, nv=16, noise=0.16):
+    """An UNSTRUCTURED tet mesh: a rough torus surface (irregular triangles, genus 1) filled by the general tetrahedraliser through
+    the solve tool's --write-tets --tets-only (host code, no device)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "mesheditor_amd", "cpp", "bin", "modal_solve")
+    rng = np.random.default_rng(2024)
+    pts, tris = [], []
+    for i in range(nu):
+        for j in range(nv):
+            a, b = 2 * np.pi * i / nu, 2 * np.pi * j / nv
+            rr = 0.035 * (1 + noise * (rng.random() - 0.5))
+            pts.append((float((0.1 + rr * np.cos(b)) * np.cos(a)), float((0.1 + rr * np.cos(b)) * np.sin(a)), float(rr * np.sin(b))))
+    for i in range(nu):
+        for j in range(nv):
+            p, q, s, t = i * nv + j, ((i + 1) % nu) * nv + j, ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv
+            tris += [(p, q, s), (p, s, t)]
+    obj, out = tmp_path / "rough_torus.obj", tmp_path / "rough_torus.tet"
+    obj.write_text("".join(f"v {x!r} {y!r} {z!r}\n" for x, y, z in pts) + "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in tris))
+    r = subprocess.run([tool, str(obj), "--write-tets", str(out), "--tets-only"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    words = out.read_text().split()
+    npts, ntets = int(words[0]), int(words[1])
+    p = np.array(words[2:2 + 3 * npts], dtype=np.float64).reshape(npts, 3)
+    t = np.array(words[2 + 3 * npts:2 + 3 * npts + 4 * ntets], dtype=np.uint32).reshape(ntets, 4)
+    return p, t
+
+
+@pytest.mark.gpu
+def test_unstructured_mesh_from_the_tetrahedraliser(api, ctx, oracle, tmp_path):
+    """Every other mesh of this suite descends from a Kuhn grid (regular valences).  A rough torus filled by the general
+    tetrahedraliser has none of that regularity -- 4 to 30+ tets around a node, slivers, no interior points: the device
+    assembly must still match the oracle entry by entry (element numbering included), and the eigenvalues to 1e-6."""
+    pts, tets = _rough_torus_tets(tmp_path)
+    assert len(tets) > 1500
+    m = meshes.MATERIALS["Glass"]
+    mg, mo = _mats(api, oracle, m)
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
+    syso = oracle.System(pts, tets, mo)
+    assert sysg.n == syso.n and sysg.kept_tets == syso.kept_tets
+    assert np.array_equal(sysg.element_nodes(), syso.element_nodes())
+    K, M = sysg.to_scipy()
+    Ko, Mo = syso.full(0), syso.full(1)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert abs(M - Mo).max() <= 1e-13 * abs(Mo).max()
+    nev = 30
+    ev, _ = sysg.eigs(nev, SIGMA, 1e-6)
+    evo, _, _ = syso.eigs(nev)
+    elastic = evo > 1e-6 * evo[-1]
+    assert elastic.sum() == nev - 6
+    assert (np.abs(ev[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    assert np.abs(ev[~elastic]).max() < 1e-6 * evo[6]
