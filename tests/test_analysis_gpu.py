@@ -671,3 +671,39 @@ def test_unstructured_mesh_from_the_tetrahedraliser(api, ctx, oracle, tmp_path):
     assert elastic.sum() == nev - 6
     assert (np.abs(ev[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
     assert np.abs(ev[~elastic]).max() < 1e-6 * evo[6]
+
+
+@pytest.mark.gpu
+def test_a_node_shared_by_hundreds_of_tets(api, ctx, oracle):
+    """A fan of 320 tets around one centre point: the centre's diagonal node block collects 320 element contributions, more than
+    the assembly kernel stages in one round (256) -- its in-order sum must carry across rounds."""
+    t = (1 + 5 ** 0.5) / 2
+    v = [np.array(p, float) / np.linalg.norm(p) for p in [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9),
+         (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(2):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    pts = np.vstack([0.1 * np.array(v), [[0.0, 0.0, 0.0]]])
+    centre = len(pts) - 1
+    tets = np.array([(centre, a, b, c) for a, b, c in f], dtype=np.uint32)
+    assert len(tets) == 320
+    mg, mo = _mats(api, oracle, meshes.MATERIALS["Glass"])
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
+    syso = oracle.System(pts, tets, mo)
+    assert np.array_equal(sysg.element_nodes(), syso.element_nodes())
+    K, M = sysg.to_scipy()
+    Ko, Mo = syso.full(0), syso.full(1)
+    assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
+    assert abs(M - Mo).max() <= 1e-13 * abs(Mo).max()
