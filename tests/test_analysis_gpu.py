@@ -553,7 +553,7 @@ def test_elementwise_operator_matches_the_assembled_one(api, ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("m", [33, 96, 160, 222, 240, 256])
+@pytest.mark.parametrize("m", [33, 64, 65, 96, 127, 160, 222, 240, 255, 256])
 def test_small_tridiagonalisation_keeps_the_spectrum(ctx, variant, m):
     """The Rayleigh-Ritz step's Householder reduction (one workgroup / several workgroups exchanging tagged values):
     Q^T A Q = T must have A's eigenvalues, to rounding, and both variants must be reproducible run to run."""
