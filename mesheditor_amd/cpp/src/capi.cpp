@@ -3,10 +3,13 @@
 #include "modal/bank.hpp"
 #include "modal/contact.hpp"
 #include "modal/solver.hpp"
+#include "modal/tets.hpp"
 
 #include "modalhip.h"
 
 #include <cstring>
+#include <span>
+#include <vector>
 #include <type_traits>
 #include <exception>
 #include <string>
@@ -188,4 +191,30 @@ void mhx_inverse_inertia_tensor(const float diag[3], const float q[4], float out
 }
 double mhx_saturation_penetration(double curvature, double area) { return SaturationPenetration(curvature, area); }
 double mhx_punch_stiffness(double inv_modulus, double area) { return PunchStiffness(inv_modulus, area); }
+// ---- tet-generation front end (modal/tets.hpp): surface in, tet mesh out; host code only -----------------------------------
+struct mhx_tets {
+    tetra::Result Result;
+};
+mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner) {
+    auto *h = new mhx_tets;
+    try {
+        std::vector<dvec3> pts(n_points);
+        for (uint32_t i = 0; i < n_points; ++i) pts[i] = {points[3 * size_t(i)], points[3 * size_t(i) + 1], points[3 * size_t(i) + 2]};
+        tetra::Options options;
+        options.MaxSteinerPoints = size_t(max_steiner);
+        h->Result = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
+    } catch (const std::exception &e) { h->Result.Error = e.what(); }
+    return h;
+}
+const char *mhx_tets_error(const mhx_tets *h) { return h->Result.Error.c_str(); }
+uint32_t mhx_tets_num_points(const mhx_tets *h) { return uint32_t(h->Result.Mesh.Points.size()); }
+uint32_t mhx_tets_num_tets(const mhx_tets *h) { return uint32_t(h->Result.Mesh.Tets.size()); }
+uint32_t mhx_tets_boundary_steiner(const mhx_tets *h) { return h->Result.BoundarySteinerCount; }
+void mhx_tets_copy(const mhx_tets *h, double *points, uint32_t *tets) {
+    for (size_t i = 0; i < h->Result.Mesh.Points.size(); ++i)
+        for (int k = 0; k < 3; ++k) points[3 * i + k] = h->Result.Mesh.Points[i][k];
+    for (size_t t = 0; t < h->Result.Mesh.Tets.size(); ++t)
+        for (int k = 0; k < 4; ++k) tets[4 * t + k] = h->Result.Mesh.Tets[t][k];
+}
+void mhx_tets_free(mhx_tets *h) { delete h; }
 }

@@ -239,6 +239,16 @@ struct BsrLevel {
     double lmax{0}; // spectral radius estimate of D^-1 A
 };
 
+// Exact inverses of a level's operator on the nodes of badly shaped elements (mh_patch.hip): the patch part of the smoothers
+struct PatchSet {
+    uint32_t npe{0}, n_patches{0}, n_touched{0}; // nodes per element (10: P2 level, 4: P1 level)
+    DevArray<uint32_t> nodes;                      // n_patches x npe, the level's node ids
+    DevArray<double> inv64;                        // n_patches x (3 npe)^2, row-major (weighted)
+    DevArray<double> weight;                       // per patch: 1 / the largest number of patches sharing one of its nodes
+    DevArray<float> inv32;
+    DevArray<uint32_t> touched, t_ptr, t_patch, t_local; // nodes in some patch; per touched node its (patch, local node) entries, CSR
+};
+
 struct mh_system {
     mh_context *ctx;
     mh_material material{};
@@ -257,10 +267,15 @@ struct mh_system {
     DevArray<uint32_t> p1_corner; // P1 internal id -> internal P2 id of the same point
     DevArray<double> p1_xyz; // n_points x 3, P1 internal numbering
     BsrLevel L2, L1;
-    // level 0: rigid-body aggregates (runs of agg_size consecutive P1 nodes), dense Cholesky factor
-    uint32_t agg_size{32}, n_agg{0};
+    // level 0: rigid-body modes of aggregates of P1 nodes -- connected node sets grown on the P1 operator's graph (root +
+    // neighbours, then pairwise merging; mh_pipeline.hip), given as CSR lists -- with a dense, explicitly inverted operator
+    uint32_t agg_target{16}, n_agg{0}; // agg_target: merging goes on while the mean aggregate is well below it (MH_AGG)
+    DevArray<uint32_t> agg_of, agg_ptr, agg_nodes; // P1 node -> aggregate; aggregate -> its nodes (ascending), CSR
     DevArray<double> agg_t; // n_points x 18: the 3x6 tentative-prolongator block of each P1 node (row-major)
     DevArray<double> a0; // (6 n_agg)^2 column-major: the coarse operator, replaced by its explicit inverse at set-up
+    PatchSet patches2, patches1; // sliver patches of the two smoothed levels (empty on well-shaped meshes)
+    DevArray<uint32_t> elem_p1;  // kept_tets x 4, internal P1 numbering
+    float worst_quality{1.f};    // smallest element shape measure (1 = regular tetrahedron)
     double sigma_built{0};
     bool hierarchy_ready{false};
     // eigensolver result (internal numbering, row-major n x ncols)
@@ -298,6 +313,11 @@ struct MhSharedPhase {
 std::mutex &mh_solve_mutex(); // mh_eigs.hip: one eigensolve (or Gram benchmark) at a time per process, see there
 void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &mat, mh_system *sys); // mh_pipeline.hip
 void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
+void mh_select_patches(mh_system *sys, float threshold);                                  // mh_patch.hip: elements whose shape measure is below the threshold
+void mh_build_patch_inverses(mh_context *ctx, const BsrLevel &lvl, PatchSet &ps);         // mh_patch.hip: (A_ee)^-1 of every patch from lvl.aval
+// d += s, x += s (either may be null) or z (double, pitch wz) += s with s = coef * sum_e R_e^T (A_ee)^-1 R_e (in - minus); scratch: n_patches x 3 npe x w
+template<typename T>
+void mh_apply_patches(mh_context *ctx, const PatchSet &ps, const T *in, const T *minus, uint32_t w, T coef, T *d, T *x, double *z, uint32_t wz, T *scratch);
 // y (n x w row-major, ld = w) = A x with A given by 9-value blocks; optionally y2 = M x from the scalar blocks.
 // G (wa x wb, column-major, ld) = X^T Y for row-major panels (fp64 MFMA, deterministic two-stage reduction).  mh_dense.hip
 // Optional column map on Y: logical column j of Y is physical column ymap[j] of a panel of pitch ldy (0 = wb, no map).

@@ -722,7 +722,8 @@ __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *
 // (32 payload bits + a 32-bit tag = launch epoch and step), written by a write-through (sc0 sc1) store and polled with
 // cache-bypassing loads until both tags match -- no fence, no flag, no ordering needed (an aligned 8-byte granule is
 // written whole).  Slots alternate by step parity: a workgroup can only write step k + 2 after it has read
-// all of step k + 1, which exists only after every workgroup has finished reading step k.
+// all of step k + 1, which exists only after every workgroup that publishes at step k + 1 has finished reading step k; a
+// workgroup that leaves (no column left) publishes an acknowledgement at its last step instead, which the others collect.
 // Only workgroups with blockIdx % 8 == 0 take part (blocks b and b + 8 share an XCD and its L2 as the dispatcher is
 // observed to deal them; correctness does not depend on it).  Sums run in a fixed order for fixed G: bit-reproducible.
 // Every poll is bounded: a workgroup that gives up raises *gave_up and the result is garbage the caller must not use.
@@ -730,6 +731,8 @@ __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *
 #define MH_SYTRD_GROUPS 16
 #endif
 namespace {
+constexpr size_t SYTRD_XCH_WORDS = 2 * 2 * 256 * 2; // value slots [parity][kind][index][2 granules]; then 2 x 2 acknowledgement words, then the give-up flag
+constexpr size_t SYTRD_ACK_WORDS = 2 * 2;
 constexpr int SYTRD_LD = 272; // LDS column stride in doubles: the four 16-lane column groups of a wave start 32 banks apart
 typedef unsigned granule_pair __attribute__((ext_vector_type(4))); // {payload low, tag, payload high, tag}: two self-tagged 8-byte granules
 // One 16-byte write-through store per value (a scalar-sized sc1 store is a fabric write of its own: half as many this way).
@@ -764,6 +767,7 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
     __shared__ int s_fail;
     // exchange slots: [parity][kind: 0 = p, 1 = column][index][2 granules]
     auto slot = [&](int parity, int kind, int index) { return xch + ((size_t(parity) * 2 + kind) * 256 + index) * 2; };
+    auto ack_slot = [&](int parity) { return xch + SYTRD_XCH_WORDS + size_t(parity) * 2; }; // behind the value slots: one leaver per step
     const int jl = tid >> 4, t16 = tid & 15, cl = g + jl * G; // this thread's local column in the sweep
     const int last_col = g + G * ((m - 1 - g) / G);           // the last column this workgroup owns
     for (int j = 0; j < 16; ++j) {
@@ -805,10 +809,18 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
             // start, and only the collection proves that all of them are past that.
             if (mine && k > 0) A[size_t(k) * m + k + 1 + tid] = tid == 0 ? beta : vi;
         }
-        // A workgroup without a column beyond k is done: nobody waits for anything from it any more.  (Every workgroup that
-        // stays publishes at every step, so collecting a step's values proves that all the others have finished reading
-        // the step before -- which is what allows the slots to alternate.)
-        if (last_col <= k) return;
+        // A workgroup without a column beyond k is done -- but its departure must be SEEN.  Every workgroup that stays
+        // publishes at every step, so collecting a step's values proves that those have finished reading the step before,
+        // which is what allows the slots to alternate.  The owner of column k, when that is its last one (k >= m - G: exactly
+        // one workgroup leaves per step from there on), has nothing to publish at this step: it was still polling step
+        // k - 1's slots a moment ago, and nothing the others collect at step k would show that it has stopped, so they could
+        // reach step k + 1 and overwrite those slots under it.  It therefore publishes an acknowledgement (after its own
+        // collection of step k - 1, in program order behind barrier (1)), and the workgroups that stay collect it below.
+        const bool someone_leaves = k >= m - G;
+        if (last_col <= k) {
+            if (last_col == k && tid == 0) publish_tagged(ack_slot(parity), 1.0, tag);
+            return;
+        }
         __syncthreads(); // (2) reflector published inside the workgroup
         if (cl > k && cl < m) {
             const double vpc = vp[cl], wpc = wp[cl];
@@ -830,6 +842,9 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
             pr *= tau;
             prs[tid] = pr;
             pq[tid] = pr * vi;
+        } else if (someone_leaves && tid == 255) { // (l <= 255: this thread never collects a value) the leaver's acknowledgement
+            double a0, a1;
+            ok = collect_tagged2(ack_slot(parity), ack_slot(parity), tag, a0, a1);
         }
         if (!ok) s_fail = 1;
         __syncthreads(); // (3) p and its products with v published inside the workgroup
@@ -863,19 +878,23 @@ void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e
     // several workgroups from order 64 up (measured: 287 against 363 us at 96, 861 against 1 812 us at 222); MH_SYTRD_MULTI=0: always one
     static const bool multi_default = !(getenv("MH_SYTRD_MULTI") && atoi(getenv("MH_SYTRD_MULTI")) == 0);
     const bool multi = variant < 0 ? (multi_default && m >= 64) : variant == 1;
+    // the give-up flag belongs to THIS call: a timeout of an earlier launch (co-resident work stalling a workgroup) must not
+    // condemn every later reduction on the context (the one-workgroup kernels never raise it)
+    if (ctx->sytrd_flag) HIP_CHECK(hipMemsetAsync(ctx->sytrd_flag, 0, sizeof(int), ctx->stream));
     if (multi && m >= 32) {
         constexpr int G = MH_SYTRD_GROUPS;
-        constexpr size_t xch_words = 2 * 2 * 256 * 2;
+        constexpr size_t words = SYTRD_XCH_WORDS + SYTRD_ACK_WORDS;
         if (!ctx->sytrd_xch) {
-            ctx->sytrd_xch = static_cast<unsigned long long *>(ctx->pool.alloc(xch_words * sizeof(unsigned long long) + 64));
-            HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch, 0, xch_words * sizeof(unsigned long long) + 64, ctx->stream));
+            ctx->sytrd_xch = static_cast<unsigned long long *>(ctx->pool.alloc(words * sizeof(unsigned long long) + 64));
+            HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch, 0, words * sizeof(unsigned long long) + 64, ctx->stream));
         }
         if ((++ctx->sytrd_epoch & 0x7fffffu) == 0) { // the tag's epoch field wraps: clear the slots so that no old tag can match
             ctx->sytrd_epoch = 1;
-            HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch, 0, xch_words * sizeof(unsigned long long) + 64, ctx->stream));
+            HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch, 0, words * sizeof(unsigned long long) + 64, ctx->stream));
         }
-        k_sytrd_multi<G><<<8 * G, 256, 0, ctx->stream>>>(a, int(m), d, e, tau, ctx->sytrd_xch, ctx->sytrd_epoch, reinterpret_cast<int *>(ctx->sytrd_xch + xch_words));
-        ctx->sytrd_flag = reinterpret_cast<int *>(ctx->sytrd_xch + xch_words);
+        ctx->sytrd_flag = reinterpret_cast<int *>(ctx->sytrd_xch + words);
+        HIP_CHECK(hipMemsetAsync(ctx->sytrd_flag, 0, sizeof(int), ctx->stream));
+        k_sytrd_multi<G><<<8 * G, 256, 0, ctx->stream>>>(a, int(m), d, e, tau, ctx->sytrd_xch, ctx->sytrd_epoch, ctx->sytrd_flag);
     } else if (fused) k_sytrd_small_fused<<<1, MH_SYTRD_THREADS, 0, ctx->stream>>>(a, int(m), d, e, tau);
     else k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
     KERNEL_CHECK();

@@ -443,18 +443,20 @@ template<int NN> __global__ void __launch_bounds__(TB) k_assemble(const uint32_t
 }
 
 // ---- level 0: rigid-body aggregates ------------------------------------------------------------------------
-__global__ void k_aggregate_t(const double *__restrict__ p1_xyz, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ tmat) {
+__global__ void k_aggregate_t(const double *__restrict__ p1_xyz, const uint32_t *__restrict__ agg_ptr, const uint32_t *__restrict__ agg_nodes, uint32_t nagg,
+                              double *__restrict__ tmat) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nagg) return;
-    const uint32_t i0 = a * agg_size, i1 = (a == nagg - 1) ? npts : (a + 1) * agg_size;
+    const uint32_t l0 = agg_ptr[a], l1 = agg_ptr[a + 1];
     double c[3] = {0, 0, 0};
-    for (uint32_t i = i0; i < i1; ++i)
-        for (int d = 0; d < 3; ++d) c[d] += p1_xyz[3 * size_t(i) + d];
-    const double cnt = double(i1 - i0);
+    for (uint32_t l = l0; l < l1; ++l)
+        for (int d = 0; d < 3; ++d) c[d] += p1_xyz[3 * size_t(agg_nodes[l]) + d];
+    const double cnt = double(l1 - l0);
     for (int d = 0; d < 3; ++d) c[d] /= cnt;
     double rn[3] = {0, 0, 0}; // squared norms of the three rotation columns
-    for (uint32_t i = i0; i < i1; ++i) {
-        const double rx = p1_xyz[3 * size_t(i)] - c[0], ry = p1_xyz[3 * size_t(i) + 1] - c[1], rz = p1_xyz[3 * size_t(i) + 2] - c[2];
+    for (uint32_t l = l0; l < l1; ++l) {
+        const size_t i = agg_nodes[l];
+        const double rx = p1_xyz[3 * i] - c[0], ry = p1_xyz[3 * i + 1] - c[1], rz = p1_xyz[3 * i + 2] - c[2];
         rn[0] += ry * ry + rz * rz; // |e_x x r|^2
         rn[1] += rx * rx + rz * rz;
         rn[2] += rx * rx + ry * ry;
@@ -462,9 +464,10 @@ __global__ void k_aggregate_t(const double *__restrict__ p1_xyz, uint32_t npts, 
     const double st = 1.0 / sqrt(cnt);
     double sr[3];
     for (int q = 0; q < 3; ++q) sr[q] = rn[q] > 1e-300 ? 1.0 / sqrt(rn[q]) : 0.0;
-    for (uint32_t i = i0; i < i1; ++i) {
-        const double rx = p1_xyz[3 * size_t(i)] - c[0], ry = p1_xyz[3 * size_t(i) + 1] - c[1], rz = p1_xyz[3 * size_t(i) + 2] - c[2];
-        double *t = tmat + 18 * size_t(i); // row-major 3 x 6
+    for (uint32_t l = l0; l < l1; ++l) {
+        const size_t i = agg_nodes[l];
+        const double rx = p1_xyz[3 * i] - c[0], ry = p1_xyz[3 * i + 1] - c[1], rz = p1_xyz[3 * i + 2] - c[2];
+        double *t = tmat + 18 * i; // row-major 3 x 6
         for (int p = 0; p < 3; ++p)
             for (int q = 0; q < 3; ++q) t[6 * p + q] = p == q ? st : 0.0;
         // columns 3..5: e_q x r
@@ -472,6 +475,124 @@ __global__ void k_aggregate_t(const double *__restrict__ p1_xyz, uint32_t npts, 
         t[6 * 0 + 4] = rz * sr[1];   t[6 * 1 + 4] = 0;           t[6 * 2 + 4] = -rx * sr[1];
         t[6 * 0 + 5] = -ry * sr[2];  t[6 * 1 + 5] = rx * sr[2];  t[6 * 2 + 5] = 0;
     }
+}
+
+// Aggregates of P1 nodes for the rigid-body level, grown on the graph of the P1 operator (host index work at set-up, O(blocks)):
+//   1. every node, in internal (Morton) order, whose neighbours are all still free founds an aggregate with them;
+//   2. a leftover node joins the neighbouring aggregate it has the most connections to (as aggregates stood after step 1);
+//   3. what is still free founds aggregates with its free neighbours; aggregates of fewer than four nodes (their rigid-body
+//      columns would be dependent) are merged into their most connected neighbour;
+//   4. pairwise merging (each aggregate with the free neighbour it shares the most node connections with) while the mean
+//      size is well below `target` or the coarse order 6 n_agg exceeds `max_order`.
+// Every aggregate is a CONNECTED node set.  Runs of consecutive Morton nodes (rounds 1-2) are compact on a structured grid, but
+// on a scanned, thin-walled body they string together nodes from opposite faces and unrelated parts: the rigid-body modes of
+// such a set are no coarse space (measured: the cycle's condition number 128 against 39 on an 8k-tet skillet scan, and no
+// convergence in 300 iterations at 95k tets).  Deterministic: ties go to the lowest id.
+uint32_t graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col, uint32_t n, uint32_t target, uint32_t max_order,
+                          std::vector<uint32_t> &agg_of) {
+    constexpr uint32_t FREE = UINT32_MAX;
+    agg_of.assign(n, FREE);
+    uint32_t na = 0;
+    for (uint32_t i = 0; i < n; ++i) { // 1
+        if (agg_of[i] != FREE) continue;
+        bool all_free = row_ptr[i + 1] > row_ptr[i];
+        for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1] && all_free; ++p) all_free = agg_of[col[p]] == FREE;
+        if (!all_free) continue;
+        for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p) agg_of[col[p]] = na; // (the row holds i itself: the diagonal block)
+        agg_of[i] = na++;
+    }
+    { // 2
+        const std::vector<uint32_t> founded = agg_of;
+        std::vector<std::pair<uint32_t, uint32_t>> votes;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (founded[i] != FREE) continue;
+            votes.clear();
+            for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p)
+                if (founded[col[p]] != FREE) votes.emplace_back(founded[col[p]], 1u);
+            if (votes.empty()) continue;
+            std::sort(votes.begin(), votes.end());
+            uint32_t best = votes[0].first, best_count = 0;
+            for (size_t k = 0; k < votes.size();) {
+                size_t e = k;
+                while (e < votes.size() && votes[e].first == votes[k].first) ++e;
+                if (uint32_t(e - k) > best_count) best_count = uint32_t(e - k), best = votes[k].first;
+                k = e;
+            }
+            agg_of[i] = best;
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) { // 3
+        if (agg_of[i] != FREE) continue;
+        for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p)
+            if (agg_of[col[p]] == FREE) agg_of[col[p]] = na;
+        agg_of[i] = na++;
+    }
+    if (na == 0) return 0;
+    // aggregate graph: connection counts between aggregates
+    std::vector<uint32_t> size;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> links; // per aggregate: (neighbour aggregate, node connections), ascending
+    const auto rebuild = [&]() {
+        size.assign(na, 0);
+        for (uint32_t i = 0; i < n; ++i) ++size[agg_of[i]];
+        std::vector<uint64_t> pairs;
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p)
+                if (agg_of[col[p]] != agg_of[i]) pairs.push_back((uint64_t(agg_of[i]) << 32) | agg_of[col[p]]);
+        std::sort(pairs.begin(), pairs.end());
+        links.assign(na, {});
+        for (size_t k = 0; k < pairs.size();) {
+            size_t e = k;
+            while (e < pairs.size() && pairs[e] == pairs[k]) ++e;
+            links[pairs[k] >> 32].emplace_back(uint32_t(pairs[k]), uint32_t(e - k));
+            k = e;
+        }
+    };
+    const auto renumber = [&](std::vector<uint32_t> &into) { // into: aggregate -> merged aggregate (any labels) => dense ids in order of first use
+        std::vector<uint32_t> fresh(na, FREE);
+        uint32_t k = 0;
+        for (uint32_t a = 0; a < na; ++a)
+            if (fresh[into[a]] == FREE) fresh[into[a]] = k++;
+        for (uint32_t i = 0; i < n; ++i) agg_of[i] = fresh[into[agg_of[i]]];
+        na = k;
+    };
+    rebuild();
+    { // small aggregates join their most connected neighbour (one pass; a chain of tiny ones ends in a proper one or stays)
+        std::vector<uint32_t> into(na);
+        for (uint32_t a = 0; a < na; ++a) into[a] = a;
+        bool any = false;
+        for (uint32_t a = 0; a < na; ++a) {
+            if (size[a] >= 4 || links[a].empty()) continue;
+            uint32_t best = links[a][0].first, count = 0;
+            for (const auto &[nb, c] : links[a])
+                if (size[nb] >= 4 && c > count) count = c, best = nb;
+            if (count == 0) best = links[a][0].first;
+            into[a] = into[best];
+            any = true;
+        }
+        if (any) {
+            renumber(into);
+            rebuild();
+        }
+    }
+    for (int round = 0; round < 12; ++round) { // 4
+        const bool too_small = uint64_t(n) * 3 < uint64_t(na) * target * 2; // mean size < 2/3 target
+        const bool too_many = uint64_t(6) * na > max_order;
+        if (na <= 1 || !(too_small || too_many)) break;
+        std::vector<uint32_t> into(na, FREE);
+        for (uint32_t a = 0; a < na; ++a) {
+            if (into[a] != FREE) continue;
+            into[a] = a;
+            uint32_t best = FREE, count = 0;
+            for (const auto &[nb, c] : links[a])
+                if (into[nb] == FREE && c > count) count = c, best = nb;
+            if (best != FREE) into[best] = a;
+        }
+        const uint32_t before = na;
+        renumber(into);
+        if (na == before) break;
+        rebuild();
+    }
+    return na;
 }
 } // namespace
 
@@ -501,18 +622,19 @@ __global__ void k_diag_inverse(const uint32_t *__restrict__ row_ptr, const uint3
 // and walk the aggregate's node blocks in storage order, so every entry is summed in a fixed order by one thread: no
 // atomics, bit-reproducible.
 __global__ void __launch_bounds__(64) k_coarse_matrix(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ aval,
-                                                     const double *__restrict__ tmat, uint32_t npts, uint32_t agg_size, uint32_t nagg, double *__restrict__ a0) {
+                                                     const double *__restrict__ tmat, const uint32_t *__restrict__ agg_of, const uint32_t *__restrict__ agg_ptr,
+                                                     const uint32_t *__restrict__ agg_nodes, uint32_t nagg, double *__restrict__ a0) {
     const uint32_t ai = blockIdx.x, t = threadIdx.x;
     if (t >= 36) return;
     const uint32_t r = t / 6, c = t % 6;
     const size_t n0 = size_t(6) * nagg;
-    const uint32_t i0 = ai * agg_size, i1 = ai == nagg - 1 ? npts : (ai + 1) * agg_size;
-    for (uint32_t i = i0; i < i1; ++i) {
+    for (uint32_t l = agg_ptr[ai]; l < agg_ptr[ai + 1]; ++l) {
+        const uint32_t i = agg_nodes[l];
         const double *ti = tmat + 18 * size_t(i);
         const double t0 = ti[r], t1 = ti[6 + r], t2 = ti[12 + r];
         for (uint32_t p = row_ptr[i]; p < row_ptr[i + 1]; ++p) {
             const uint32_t j = col[p];
-            const uint32_t aj = min(j / agg_size, nagg - 1);
+            const uint32_t aj = agg_of[j];
             const double *a = aval + 9 * size_t(p);
             const double *tj = tmat + 18 * size_t(j);
             // (T_i^T A_ij T_j)[r][c] = sum_k T_i[k][r] * (A_ij T_j)[k][c]
@@ -731,7 +853,8 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
                                                      sys->parent_a, sys->parent_b, sys->p1_corner, sys->p1_xyz);
     KERNEL_CHECK();
     sys->elem_nodes.reset(ctx, size_t(nt) * 10);
-    DevArray<uint32_t> elem_p1(ctx, size_t(nt) * 4);
+    sys->elem_p1.reset(ctx, size_t(nt) * 4);
+    DevArray<uint32_t> &elem_p1 = sys->elem_p1;
     k_renumber_elements<<<div_up(size_t(nt) * 10, TB), TB, 0, st>>>(sys->elem_nodes_ref, sys->inv_perm, corner_incl, nt, sys->elem_nodes, elem_p1);
     KERNEL_CHECK();
     // transposed interpolation lists
@@ -764,20 +887,40 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
     build_level<10>(ctx, tmp, sys->elem_nodes, nt, nn, sys->elem_basis, tq_dev, sq_dev, mat, sys->L2);
     build_level<4>(ctx, tmp, elem_p1, nt, npts, sys->elem_basis, tl_dev, sl_dev, mat, sys->L1);
 
-    // --- rigid-body aggregates over runs of consecutive (Morton-ordered) P1 nodes
-    if (const char *e = getenv("MH_AGG")) sys->agg_size = std::max(2, atoi(e));
-    // The coarse operator is dense of order 6 n_agg and inverted explicitly (O(n0^2) memory, 2 n0^3 flops): with a fixed
-    // aggregate size it would grow with the mesh (33 k at a million tets: 9 GB and 7e13 flops per set-up).  Aggregates
-    // grow instead so that the order stays at or below MaxCoarseOrder (3 690 at the 100k-tet metric mesh is untouched);
-    // larger aggregates make a weaker coarse correction (more iterations), never a failure.
-    constexpr uint32_t MaxCoarseOrder = 6144;
-    if (uint64_t(6) * (npts / sys->agg_size) > MaxCoarseOrder) sys->agg_size = uint32_t((uint64_t(6) * npts + MaxCoarseOrder - 1) / MaxCoarseOrder);
-    sys->n_agg = std::max(1u, npts / sys->agg_size);
+    // --- rigid-body aggregates: connected node sets on the P1 operator's graph (graph_aggregates above)
+    if (const char *e = getenv("MH_AGG")) sys->agg_target = uint32_t(std::max(2, atoi(e)));
+    // The coarse operator is dense of order 6 n_agg and inverted explicitly (O(n0^2) memory, 2 n0^3 flops): aggregates are
+    // merged until the order is at or below MaxCoarseOrder; larger aggregates make a weaker coarse correction (more
+    // iterations), never a failure.
+    static const uint32_t MaxCoarseOrder = getenv("MH_COARSE_CAP") ? uint32_t(std::max(64, atoi(getenv("MH_COARSE_CAP")))) : 6144u;
+    {
+        std::vector<uint32_t> rp(size_t(npts) + 1), cl(sys->L1.n_blocks), agg_of;
+        HIP_CHECK(hipMemcpyAsync(rp.data(), sys->L1.row_ptr.get(), rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(cl.data(), sys->L1.col.get(), cl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        sys->n_agg = graph_aggregates(rp, cl, npts, sys->agg_target, MaxCoarseOrder, agg_of);
+        std::vector<uint32_t> ptr(size_t(sys->n_agg) + 1, 0), nodes(npts);
+        for (uint32_t i = 0; i < npts; ++i) ++ptr[agg_of[i] + 1];
+        for (uint32_t a = 0; a < sys->n_agg; ++a) ptr[a + 1] += ptr[a];
+        std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (uint32_t i = 0; i < npts; ++i) nodes[fill[agg_of[i]]++] = i;
+        sys->agg_of.reset(ctx, npts);
+        sys->agg_ptr.reset(ctx, ptr.size());
+        sys->agg_nodes.reset(ctx, npts);
+        sys->agg_of.upload(agg_of.data(), npts);
+        sys->agg_ptr.upload(ptr.data(), ptr.size());
+        sys->agg_nodes.upload(nodes.data(), npts);
+        HIP_CHECK(hipStreamSynchronize(st)); // (the staging vectors go out of scope)
+    }
     sys->agg_t.reset(ctx, size_t(npts) * 18);
-    k_aggregate_t<<<div_up(sys->n_agg, 64), 64, 0, st>>>(sys->p1_xyz, npts, sys->agg_size, sys->n_agg, sys->agg_t);
+    k_aggregate_t<<<div_up(sys->n_agg, 64), 64, 0, st>>>(sys->p1_xyz, sys->agg_ptr, sys->agg_nodes, sys->n_agg, sys->agg_t);
     KERNEL_CHECK();
     sys->points.reset(ctx, size_t(npts) * 3);
     HIP_CHECK(hipMemcpyAsync(sys->points.get(), mesh->points.get(), size_t(npts) * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st)); // host-side staging vectors (tables) must outlive their uploads
+    // --- sliver patches of the smoothers (mh_patch.hip): elements with a shape measure below 0.02 (a regular tetrahedron has 1,
+    //     a Kuhn tetrahedron 0.66; MH_PATCH_Q sets the threshold, 0 disables)
+    static const float patch_q = getenv("MH_PATCH_Q") ? float(atof(getenv("MH_PATCH_Q"))) : 0.02f;
+    mh_select_patches(sys, patch_q);
     sys->hierarchy_ready = false;
 }

@@ -86,4 +86,149 @@ def workload(name):
     if name == "skillet_s100k":  # BASELINE.json configs[2]: thin iron disc-like plate, 200 modes
         p, t = kuhn_box(93, 93, 2, 0.26, 0.26, 0.012)
         return p, t, MATERIALS["Iron"], {"num_modes": 200, "num_fem_modes": 215}
+    if name == "scan_s30k":  # RealImpact-like: scan surface -> general tetrahedraliser, ~30k tets (TetCorpusSnapshot.txt: 30 817)
+        p, t = skillet_scan_tets(0.011, 0.015)
+        return p, t, MATERIALS["Iron"], {"num_modes": 50, "num_fem_modes": 65}
+    if name == "scan_s100k":  # the same at the metric's size
+        p, t = skillet_scan_tets(0.006, 0.008)
+        return p, t, MATERIALS["Iron"], {"num_modes": 50, "num_fem_modes": 65}
     raise KeyError(name)
+
+
+# ---- scan-like surfaces (the RealImpact scans are absent) -------------------------------------------------
+def _skillet_sdf(p, thickness=0.008, noise_seed=7):
+    """Signed distance (negative inside) of a skillet-like solid: bottom disc + rim wall + handle bar, metres; a smooth
+    low-amplitude perturbation stands in for scan roughness."""
+    R, tb, tw, H = 0.13, thickness, thickness, 0.045
+    L, hw, hh = 0.15, 0.024, max(0.014, 1.5 * thickness)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    r = np.hypot(x, y)
+
+    def box(q, lo, hi):  # signed distance to an axis-aligned box
+        c, e = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        d = np.abs(q - c) - e
+        return np.linalg.norm(np.maximum(d, 0.0), axis=1) + np.minimum(d.max(1), 0.0)
+
+    rz = np.stack([r, z], 1)
+    disc = box(rz, np.array([-1.0, 0.0]), np.array([R, tb]))
+    wall = box(rz, np.array([R - tw, 0.0]), np.array([R, H]))
+    handle = box(p, np.array([R - 0.5 * tw, -0.5 * hw, H - hh]), np.array([R + L, 0.5 * hw, H]))
+    d = np.minimum(np.minimum(disc, wall), handle)
+    rng = np.random.Generator(np.random.MT19937(noise_seed))
+    k = rng.uniform(40.0, 120.0, (6, 3))
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    rough = sum(np.sin(p @ k[i] + ph[i]) for i in range(6)) * (0.0004 / 6)
+    return d + rough
+
+
+def marching_tets_surface(sdf, lo, hi, h, jitter=0.2, seed=11, clamp=0.3):
+    """Closed triangle surface {sdf = 0} by marching tetrahedra over a jittered Kuhn lattice of spacing h: a watertight
+    2-manifold with irregular triangles and valences.  Returns (points float64 [V,3], triangles uint32 [F,3])."""
+    n = np.maximum(1, np.ceil((np.asarray(hi) - np.asarray(lo)) / h).astype(int))
+    pts, tets = kuhn_box(int(n[0]), int(n[1]), int(n[2]), *(n * h), origin=tuple(lo))
+    rng = np.random.Generator(np.random.MT19937(seed))
+    pts = pts + rng.uniform(-jitter, jitter, pts.shape) * h
+    f = sdf(pts)
+    f = np.where(np.abs(f) < 1e-9, 1e-9, f)
+    inside = f < 0
+    cnt = inside[tets].sum(1)
+    tris = []  # triangles as triples of (a, b) lattice-vertex pairs, a inside, b outside
+    for k in (1, 3):  # one vertex on its own side: one triangle
+        sel = tets[cnt == k]
+        if len(sel) == 0:
+            continue
+        ins = inside[sel]
+        lone = (ins if k == 1 else ~ins).argmax(1)
+        order = np.array([[0, 1, 2, 3], [1, 0, 2, 3], [2, 0, 1, 3], [3, 0, 1, 2]])[lone]
+        t = np.take_along_axis(sel, order, 1)
+        e = [np.stack([t[:, 0], t[:, j]], 1) for j in (1, 2, 3)]
+        if k == 3:  # the lone vertex is outside: inside end first
+            e = [x[:, ::-1] for x in e]
+        tris.append(np.stack(e, 1))
+    sel = tets[cnt == 2]
+    if len(sel):
+        ins = inside[sel]
+        order = np.argsort(~ins, axis=1, kind="stable")  # inside vertices first
+        t = np.take_along_axis(sel, order, 1)
+        a0, a1, b0, b1 = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+        q = [np.stack([a0, b0], 1), np.stack([a0, b1], 1), np.stack([a1, b1], 1), np.stack([a1, b0], 1)]  # the quad, in cyclic order
+        tris.append(np.stack([q[0], q[1], q[2]], 1))
+        tris.append(np.stack([q[0], q[2], q[3]], 1))
+    tri_edges = np.concatenate(tris, 0)  # [F, 3, 2]
+    keys = tri_edges.reshape(-1, 2).astype(np.int64)
+    flat = keys[:, 0] * len(pts) + keys[:, 1]
+    uniq, inv = np.unique(flat, return_inverse=True)
+    a, b = uniq // len(pts), uniq % len(pts)
+    t = np.clip(f[a] / (f[a] - f[b]), clamp, 1.0 - clamp)
+    verts = pts[a] + t[:, None] * (pts[b] - pts[a])
+    faces = inv.reshape(-1, 3)
+    keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    return verts, np.ascontiguousarray(faces[keep], dtype=np.uint32)
+
+
+def taubin_smooth(verts, faces, iterations, lam=0.5, mu=-0.53):
+    """Taubin's lambda|mu smoothing over the surface's edge graph (no shrinkage to first order): takes the lattice noise out of a
+    marching-tetrahedra surface, whose raw facets meet at wedges no Delaunay refinement terminates on."""
+    f = faces.astype(np.int64)
+    i = np.concatenate([f[:, 0], f[:, 1], f[:, 2], f[:, 1], f[:, 2], f[:, 0]])
+    j = np.concatenate([f[:, 1], f[:, 2], f[:, 0], f[:, 0], f[:, 1], f[:, 2]])
+    pairs = np.unique(np.stack([i, j], 1), axis=0)  # every directed edge once
+    deg = np.bincount(pairs[:, 0], minlength=len(verts)).astype(np.float64)
+    v = verts.copy()
+    for _ in range(iterations):
+        for s in (lam, mu):
+            acc = np.zeros_like(v)
+            np.add.at(acc, pairs[:, 0], v[pairs[:, 1]])
+            v = v + s * (acc / deg[:, None] - v)
+    return v
+
+
+def largest_component(verts, faces):
+    """The largest connected piece of a triangle surface (the roughness term of the level set sheds a few stray bubbles: each
+    would be a free-floating body of its own with six more zero modes); unchanged arrays when there is only one piece."""
+    label = np.arange(len(verts))
+    f = faces.astype(np.int64)
+    while True:  # label propagation over the faces' vertices (a handful of sweeps on these surfaces)
+        m = np.minimum(np.minimum(label[f[:, 0]], label[f[:, 1]]), label[f[:, 2]])
+        new = label.copy()
+        for k in range(3):
+            np.minimum.at(new, f[:, k], m)
+        new = new[new]  # pointer jumping
+        if np.array_equal(new, label):
+            break
+        label = new
+    used = np.unique(f)
+    roots, counts = np.unique(label[used], return_counts=True)
+    if len(roots) == 1:
+        return verts, faces
+    keep_root = roots[np.argmax(counts)]
+    keep_face = label[f[:, 0]] == keep_root
+    kept = np.unique(f[keep_face])
+    remap = -np.ones(len(verts), np.int64)
+    remap[kept] = np.arange(len(kept))
+    return verts[kept], np.ascontiguousarray(remap[f[keep_face]], dtype=np.uint32)
+
+
+def skillet_scan_surface(h=0.006, thickness=0.008, smooth=8):
+    """The scan-like skillet surface at lattice spacing h (0.006 -> ~43k triangles)."""
+    lo, hi = np.array([-0.14, -0.14, -0.006]), np.array([0.29, 0.14, 0.053])
+    v, f = marching_tets_surface(lambda p: _skillet_sdf(p, thickness), lo - 0.5 * h, hi + 0.5 * h, h)
+    v, f = largest_component(v, f)
+    return taubin_smooth(v, f, smooth), f
+
+
+_SCAN_CACHE = {}
+
+
+def skillet_scan_tets(h, thickness):
+    """The skillet scan surface filled by the path's own general tetrahedraliser (tetra::Tetrahedralize, host C++): an
+    UNSTRUCTURED tet mesh -- no interior points, slivers, 2 to 70 tets around a node -- like the reference's scanned workloads
+    (tests/fixtures/TetCorpusSnapshot.txt: RealImpact meshes with 0-2 interior Steiner points)."""
+    key = (h, thickness)
+    if key not in _SCAN_CACHE:
+        from . import tets as tet_front_end
+        v, f = skillet_scan_surface(h, thickness)
+        p, t, _ = tet_front_end.tetrahedralize(v, f)
+        _SCAN_CACHE[key] = (p, t)
+    p, t = _SCAN_CACHE[key]
+    return p.copy(), t.copy()

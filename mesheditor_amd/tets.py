@@ -1,0 +1,38 @@
+"""Python binding of the tet-generation front end (modal/tets.hpp: tetra::Tetrahedralize, host C++ in libmodalhost.so)."""
+import ctypes as C
+
+import numpy as np
+
+
+def _lib():
+    from . import bank
+    L = bank.lib()
+    if not getattr(L, "_tets_bound", False):
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.mhx_tetrahedralize.restype, L.mhx_tetrahedralize.argtypes = vp, [vp, u32, vp, u32, C.c_uint64]
+        L.mhx_tets_error.restype, L.mhx_tets_error.argtypes = C.c_char_p, [vp]
+        for name in ("mhx_tets_num_points", "mhx_tets_num_tets", "mhx_tets_boundary_steiner"):
+            getattr(L, name).restype, getattr(L, name).argtypes = u32, [vp]
+        L.mhx_tets_copy.restype, L.mhx_tets_copy.argtypes = None, [vp, vp, vp]
+        L.mhx_tets_free.restype, L.mhx_tets_free.argtypes = None, [vp]
+        L._tets_bound = True
+    return L
+
+
+def tetrahedralize(points, triangles, max_steiner=0):
+    """(points float64 [V', 3], tets uint32 [T, 4], boundary_steiner_count): input vertex i keeps index i, added points follow.
+    Raises RuntimeError with the tetrahedraliser's message for open / self-intersecting / unrecoverable surfaces."""
+    L = _lib()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    tri = np.ascontiguousarray(triangles, dtype=np.uint32)
+    h = L.mhx_tetrahedralize(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner))
+    try:
+        err = L.mhx_tets_error(h).decode()
+        if err:
+            raise RuntimeError("Tetrahedralize: " + err)
+        out_p = np.zeros((L.mhx_tets_num_points(h), 3), np.float64)
+        out_t = np.zeros((L.mhx_tets_num_tets(h), 4), np.uint32)
+        L.mhx_tets_copy(h, out_p.ctypes.data_as(C.c_void_p), out_t.ctypes.data_as(C.c_void_p))
+        return out_p, out_t, int(L.mhx_tets_boundary_steiner(h))
+    finally:
+        L.mhx_tets_free(h)
