@@ -44,7 +44,7 @@ def pmc_traffic(family="spmm_family"):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes of this command (profiles/, made
     by tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 rule and checked on a kernel of known byte count) -- a
     separate profiled run, never this one; None when the summary is absent."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)[family]["hbm_bytes_per_launch"])
@@ -134,11 +134,85 @@ def cpu_baseline(workload="cube_s10k"):
     po.set_threads(1)
     best = runs[max(runs)]
     return {"value": best["eigenpairs_per_s"], "unit": "eigenpairs/s", "cores": best["threads"], "kind": "port", "host_cores": cores,
-            "sample": "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path (1/10 of the metric's mesh; the direct solve grows ~quadratically with size: "
-                      "the metric's own mesh took the oracle 431 s on 8 threads, profiles/r02_oracle_openmp_scaling.txt)" % (workload, len(tets), int(r.profile.get("dofs", 0)), best["eigenpairs"]),
+            "sample": "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path (1/10 of the metric's mesh, timed live on this box; the metric's own mesh: "
+                      "cpu_baseline_metric_mesh, a recorded run)" % (workload, len(tets), int(r.profile.get("dofs", 0)), best["eigenpairs"]),
             "single_thread": runs[1], "threaded": runs[max(runs)],
             "logical_cpus": os.cpu_count(),
             "note": "host_cores = CPUs this container may use (affinity and cgroup quota); threaded row: OpenMP team of min(host_cores, 16)"}
+
+
+def cpu_baseline_metric_mesh(workload="cube_s100k"):
+    """The oracle on the METRIC'S OWN mesh, from the committed record of that run (tests/golden/oracle_eigs_<workload>.json,
+    made in the build container by tests/golden/make_oracle_fixtures.py: the run takes minutes, the default bench may not) --
+    the same-input partner of `value`; the live `cpu_baseline` below stays the on-box sanity figure on the 10k-tet sample."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "oracle_eigs_%s.json" % workload)) as f:
+            d = json.load(f)
+        return {"value": d["eigenpairs_per_second"], "unit": "eigenpairs/s", "cores": d["host"]["threads"], "kind": "port", "workload": workload,
+                "seconds": d["seconds"], "eigenpairs": len(d["eigenvalues"]), "mesh": d["mesh"], "host": d["host"], "date": d["date"], "command": d["generator"],
+                "stages_s": {k: d["profile"][k] for k in ("mass_props", "quad_mesh", "assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract")},
+                "measured": "recorded run (build container), not this box", "record": "tests/golden/oracle_eigs_%s.json" % workload}
+    except (OSError, KeyError, ValueError) as e:
+        return {"error": str(e)[:200]}
+
+
+def edit_loop(api, ctx, pts, tets, m, ex, cfg, mesh):
+    """The reference bench's synthetic interactive-edit loop (tests/ModalSolverBench.cpp:346-411) on the metric's mesh: one cold
+    solve keeping the basis; a Poisson-ratio edit solved cold and warm-started from that basis (same kept-mode count and
+    fundamental within 0.05 Hz, the reference's criterion); a Young's-modulus-and-density edit solved cold against
+    RescaleModes of the first solve's summary (no eigensolve)."""
+    def timed(mat, **kw):
+        t0 = time.perf_counter()
+        r = api.mesh2modes(ctx, pts, tets, mat, ex, config=cfg, mesh=mesh, **kw)
+        ctx.synchronize()
+        return r, time.perf_counter() - t0
+    try:
+        initial, t_initial = timed(api.material(*m), keep_basis=True)
+        nu = (m[0], m[1], min(m[2] + 0.02, 0.49), m[3], m[4])
+        cold, t_cold = timed(api.material(*nu))
+        warm, t_warm = timed(api.material(*nu), seed_basis=initial.basis)
+        scaled = (m[0] * 0.8, m[1] * 1.5, m[2], m[3], m[4])
+        cold2, t_cold2 = timed(api.material(*scaled))
+        t0 = time.perf_counter()
+        resc = api.rescale_modes(initial.eigenvalues, initial.summary_shapes, api.material(*m), api.material(*scaled), cfg)
+        t_resc = time.perf_counter() - t0
+        f1 = lambda fr: float(fr[0]) if len(fr) else 0.0  # noqa: E731
+        return {"initial_cold_ms": 1e3 * t_initial,
+                "nu_edit": {"cold_ms": 1e3 * t_cold, "warm_ms": 1e3 * t_warm, "speedup": t_cold / t_warm, "cold_iterations": cold.profile.get("restarts"),
+                            "warm_iterations": warm.profile.get("restarts"), "modes": [len(cold.freqs), len(warm.freqs)], "f1_hz": [f1(cold.freqs), f1(warm.freqs)],
+                            "match": len(cold.freqs) == len(warm.freqs) and abs(f1(cold.freqs) - f1(warm.freqs)) < 0.05},
+                "e_rho_edit": {"cold_ms": 1e3 * t_cold2, "rescale_ms": 1e3 * t_resc, "speedup": t_cold2 / max(t_resc, 1e-9), "modes": [len(cold2.freqs), len(resc[0]) if resc else 0],
+                               "f1_hz": [f1(cold2.freqs), f1(resc[0]) if resc else 0.0],
+                               "match": resc is not None and len(cold2.freqs) == len(resc[0]) and abs(f1(cold2.freqs) - f1(resc[0])) < 0.05}}
+    except Exception as e:  # noqa: BLE001 -- the headline line must not depend on it
+        return {"error": repr(e)[:200]}
+
+
+def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k"), reps=2):
+    """Secondary rows: the scan-like unstructured meshes (marching-tetrahedra skillet surface through the path's own
+    tetrahedraliser: slivers, 2-60 tets per node, no interior points) beside the Kuhn grid of the same size -- iterations,
+    milliseconds and eigenpairs per second of the whole mesh2modes path, 65 pairs each."""
+    from mesheditor_amd import meshes
+    out = []
+    for name in names:
+        try:
+            pts, tets, m, kw = meshes.workload(name)
+            ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
+            cfg = api.default_config(**kw)
+            mesh = api.Mesh(ctx, pts, tets)
+            ts, r = [], None
+            for _ in range(reps + 1):
+                t0 = time.perf_counter()
+                r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=cfg, mesh=mesh)
+                ctx.synchronize()
+                ts.append(time.perf_counter() - t0)
+            mesh.close()
+            dt = float(np.median(ts[1:]))
+            out.append({"workload": name, "tets": int(len(tets)), "dof": int(r.profile.get("dofs", 0)), "eigenpairs": int(len(r.eigenvalues)),
+                        "lobpcg_iterations": int(r.profile.get("restarts", 0)), "ms": 1e3 * dt, "eigenpairs_per_s": len(r.eigenvalues) / dt if dt > 0 else 0.0})
+        except Exception as e:  # noqa: BLE001
+            out.append({"workload": name, "error": repr(e)[:200]})
+    return out
 
 
 def cpu_bank_baseline(blocks=2):
@@ -210,19 +284,35 @@ def main():
     share_gpu = bool(os.environ.get("BENCH_SHARE_GPU"))  # test mode: every rank on device 0, gloo instead of RCCL
     import torch
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path with one rank
+    # The data path's one collective -- the gather of the per-mesh records -- is ncclAllGather called from C++
+    # (modal::SolveBatch, mesheditor_amd/cpp/src/batch.cpp) whenever the ranks sit on different GPUs; torch.distributed (gloo)
+    # only launches the ranks' rendezvous: it ships the 128-byte communicator id and carries the timing barriers.
+    # BENCH_GATHER=torch keeps the records' gather in torch.distributed (RCCL through torch); BENCH_SHARE_GPU (all ranks on
+    # device 0, a test mode) always does, over gloo.
+    cpp_driver = (world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))) and not share_gpu and os.environ.get("BENCH_GATHER", "rccl") == "rccl"
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the distributed path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if share_gpu:
+        if share_gpu or cpp_driver:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = 0 if share_gpu or not torch.cuda.is_available() else local_rank
-    gather_device = "cpu" if share_gpu or dist is None else "cuda"
+    gather_device = "cpu" if share_gpu or dist is None or cpp_driver else "cuda"
 
     from mesheditor_amd import api, meshes, sharding
+    comm = None
+    if cpp_driver:
+        from mesheditor_amd import batch as batch_driver
+        box = [batch_driver.make_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            comm = batch_driver.BatchComm(world, rank, device, box[0])
+        except RuntimeError as e:  # no RCCL communicator: say so and gather through torch.distributed (gloo) instead
+            print("bench: %s -- falling back to the torch.distributed gather" % e, file=sys.stderr)
+            cpp_driver = False
 
     def sync(ctxs):
         for c in ctxs:
@@ -251,7 +341,10 @@ def main():
 
         def step():
             nonlocal records
-            records = sharding.solve_batch(items, solve, NEV_MAX, dist, gather_device, threads=len(ctxs), pos_max=POS_MAX)
+            if comm is not None:  # C++ driver: deal, solve (host threads per GPU), ncclAllGather of the records
+                records = batch_driver.solve_batch(comm, items, NEV_MAX, POS_MAX, threads=max(1, args.threads), excite=ex_of)
+            else:
+                records = sharding.solve_batch(items, solve, NEV_MAX, dist, gather_device, threads=len(ctxs), pos_max=POS_MAX)
             return records
     else:
         ctx = api.Context(device)
@@ -265,16 +358,34 @@ def main():
         ex = pts[:: len(pts) // 10][:10].astype(np.float32)  # P = 10 excitation positions, as the app and bench use
         mesh = api.Mesh(ctx, pts, tets)  # inputs resident in HBM before the timed region
         records = None
+        if comm is not None:  # every rank describes every rank's mesh (the same jitter rule): equal costs deal mesh r to rank r
+            rank_items, rank_ex = [], []
+            base = meshes.workload(args.workload)[0]
+            for r_ in range(world):
+                g = np.random.Generator(np.random.MT19937(1000 + r_))
+                p_ = base * g.uniform(0.9, 1.1, 3)[None, :] if world > 1 else base
+                rank_items.append((p_, tets, m, kw))
+                rank_ex.append(p_[:: len(p_) // 10][:10].astype(np.float32))
 
         def step():
             nonlocal records
+            if comm is not None:  # the C++ batch driver: this rank's mesh goes host -> HBM inside the step (+ ~1 ms at this size)
+                records = batch_driver.solve_batch(comm, rank_items, NEV_MAX, POS_MAX, threads=1, excite=rank_ex)
+                mine = records[rank]
+                return api.ModalResult(mine["freqs"], mine["t60s"], None, mine["positions"], mine["original_fundamental"], mine["eigenvalues"], mine["summary_shapes"],
+                                       mine["mass"], mine["center_of_mass"], mine["inertia_diagonal"], mine["inertia_orientation_wxyz"], mine["profile"], None)
             t0 = time.perf_counter()
             r = api.mesh2modes(ctx, pts, tets, mat, ex, config=cfg, mesh=mesh)
-            if len(r.eigenvalues) == 0:
-                raise RuntimeError("solve failed: %s" % r.profile)
+            failed = len(r.eigenvalues) == 0
             if dist is not None:  # the final gather: the whole fixed-size record of every rank's mesh, one collective
-                rec = sharding.pack_record(rank, r, NEV_MAX, POS_MAX, time.perf_counter() - t0)
+                # a rank whose solve failed still joins the collective (with a failed record): the others must not hang in it
+                rec = sharding.failed_record(rank, NEV_MAX, POS_MAX, time.perf_counter() - t0) if failed else sharding.pack_record(rank, r, NEV_MAX, POS_MAX, time.perf_counter() - t0)
                 records = [sharding.unpack_record(x, NEV_MAX, POS_MAX) for x in sharding.gather_records({rank: rec}, world, dist, gather_device)]
+                bad = [x["index"] for x in records if not x["ok"]]
+                if bad:
+                    raise RuntimeError("solve failed on rank(s) %s" % bad)
+            if failed:
+                raise RuntimeError("solve failed: %s" % r.profile)
             return r
 
     for _ in range(args.warmup):
@@ -307,8 +418,9 @@ def main():
     else:
         nev = len(last.eigenvalues)
         total_pairs, total_modes = nev * args.steps * world, len(last.freqs) * args.steps * world
-        config = {"workload": "%s: Kuhn mesh %d tets / %d DOF, NumModes=%d NumFemModes=%d, P=10 excitation points, one mesh per GPU"
-                              % (args.workload, len(tets), last.profile.get("dofs", 0), cfg.num_modes, cfg.num_fem_modes),
+        kind = "scan-like unstructured mesh (marching-tetrahedra skillet surface through the path's tetrahedraliser)" if args.workload.startswith("scan_") else "Kuhn mesh"
+        config = {"workload": "%s: %s %d tets / %d DOF, NumModes=%d NumFemModes=%d, P=10 excitation points, one mesh per GPU"
+                              % (args.workload, kind, len(tets), last.profile.get("dofs", 0), cfg.num_modes, cfg.num_fem_modes),
                   "eigenpairs_per_mesh": nev, "kept_modes_per_mesh": len(last.freqs), "lobpcg_iterations": last.profile.get("restarts"), "parallelism": "mesh-per-gpu x%d" % world}
         scaling = "weak"
     line = {
@@ -329,7 +441,8 @@ def main():
     }
     if dist is not None and records:
         line["gathered_records"] = {"count": len(records), "words_per_record": sharding.record_length(NEV_MAX, POS_MAX),
-                                    "fields": "eigenvalues, freqs, t60s, positions, shapes, mass properties, solve profile"}
+                                    "fields": "eigenvalues, freqs, t60s, positions, shapes, mass properties, solve profile",
+                                    "collective": "ncclAllGather from C++ (modal::SolveBatch)" if comm is not None else "torch.distributed all_gather (%s)" % ("gloo" if share_gpu else "nccl")}
     spmm, asm = stats
     if spmm["launches"]:
         achieved = spmm["total_bytes"] / (spmm["total_ms"] * 1e-3) / 1e9
@@ -352,7 +465,11 @@ def main():
             line["roofline"]["single_launch"] = operator_forms(api, ctxs[0], mesh, mat)
         if not batch:
             line["concurrent_solves"] = concurrent_throughput(api, device, pts, tets, mat, ex, cfg)
+        if not batch:
+            line["edit_loop"] = edit_loop(api, ctxs[0], pts, tets, m, ex, cfg, mesh)
+            line["scan_like"] = scan_like_rows(api, ctxs[0])
         line["cpu_baseline"] = cpu_baseline()
+        line["cpu_baseline_metric_mesh"] = cpu_baseline_metric_mesh("cube_s100k" if batch else args.workload)
         bank = bank_metric()
         line["resonator_bank"] = bank
         if isinstance(bank.get("all_live"), dict):
@@ -371,6 +488,8 @@ def main():
         mesh.close()
     for c in ctxs:
         c.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,221 @@
+// modal::SolveBatch: LPT deal, worker threads on this rank's GPU, one ncclAllGather of fixed-size records (modal/batch.hpp).
+#include "modal/batch.hpp"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <thread>
+
+namespace modal {
+namespace {
+constexpr size_t HeaderWords = 8, MassWords = 11, ProfileWords = 12;
+constexpr double StatusOk = 0.0, StatusFailed = 1.0;
+
+void Check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("SolveBatch: ") + what + ": " + hipGetErrorString(e));
+}
+void Check(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw std::runtime_error(std::string("SolveBatch: ") + what + ": " + ncclGetErrorString(r));
+}
+
+void Pack(double *rec, uint32_t index, const ModalResult &r, double seconds, const BatchOptions &o) {
+    const size_t E = o.MaxEigenpairs, P = o.MaxPositions;
+    const size_t nev = r.Summary.Eigenvalues.size(), kept = r.Modes.Freqs.size(), n_pos = r.Modes.Positions.size();
+    const bool fits = nev <= E && n_pos <= P && nev > 0;
+    rec[0] = index;
+    rec[1] = fits ? StatusOk : StatusFailed;
+    rec[5] = seconds;
+    if (!fits) return;
+    rec[2] = double(nev);
+    rec[3] = double(kept);
+    rec[4] = double(n_pos);
+    rec[6] = r.Modes.OriginalFundamentalFreq;
+    double *m = rec + HeaderWords;
+    m[0] = r.MassProps.Mass;
+    for (int i = 0; i < 3; ++i) m[1 + i] = r.MassProps.CenterOfMass[i], m[4 + i] = r.MassProps.InertiaDiagonal[i];
+    m[7] = r.MassProps.InertiaOrientation.w, m[8] = r.MassProps.InertiaOrientation.x, m[9] = r.MassProps.InertiaOrientation.y, m[10] = r.MassProps.InertiaOrientation.z;
+    double *p = m + MassWords;
+    const SolveProfile &pr = r.Profile;
+    const double prof[ProfileWords] = {pr.MassProps, pr.QuadMesh, pr.Assemble, pr.SampleExcite, pr.Factorize, pr.Iterate, pr.OpSolve, pr.Extract,
+                                       double(pr.Dofs), double(pr.StiffnessNonZeros), double(pr.OpApplications), double(pr.Restarts)};
+    std::copy(prof, prof + ProfileWords, p);
+    double *ev = p + ProfileWords;
+    std::copy(r.Summary.Eigenvalues.begin(), r.Summary.Eigenvalues.end(), ev);
+    for (size_t k = 0; k < kept; ++k) ev[E + k] = r.Modes.Freqs[k], ev[2 * E + k] = r.Modes.T60s[k];
+    double *pos = ev + 3 * E;
+    for (size_t q = 0; q < n_pos; ++q)
+        for (int i = 0; i < 3; ++i) pos[3 * q + i] = r.Modes.Positions[q][i];
+    double *sh = pos + 3 * P; // [position][eigenpair][3] at the record's full extents
+    for (size_t q = 0; q < std::min(n_pos, r.Summary.Shapes.size()); ++q)
+        for (size_t k = 0; k < std::min(nev, r.Summary.Shapes[q].size()); ++k)
+            for (int i = 0; i < 3; ++i) sh[(q * E + k) * 3 + i] = r.Summary.Shapes[q][k][i];
+}
+
+BatchRecord Unpack(const double *rec, const BatchOptions &o) {
+    const size_t E = o.MaxEigenpairs, P = o.MaxPositions;
+    BatchRecord out;
+    out.Index = uint32_t(rec[0]);
+    out.Ok = rec[1] == StatusOk;
+    out.Seconds = rec[5];
+    if (!out.Ok) return out;
+    const size_t nev = size_t(rec[2]), kept = size_t(rec[3]), n_pos = size_t(rec[4]);
+    ModalResult &r = out.Result;
+    r.Modes.OriginalFundamentalFreq = float(rec[6]);
+    const double *m = rec + HeaderWords;
+    r.MassProps.Mass = m[0];
+    for (int i = 0; i < 3; ++i) r.MassProps.CenterOfMass[i] = float(m[1 + i]), r.MassProps.InertiaDiagonal[i] = float(m[4 + i]);
+    r.MassProps.InertiaOrientation = {float(m[7]), float(m[8]), float(m[9]), float(m[10])};
+    const double *p = m + MassWords;
+    SolveProfile &pr = r.Profile;
+    pr.MassProps = p[0], pr.QuadMesh = p[1], pr.Assemble = p[2], pr.SampleExcite = p[3], pr.Factorize = p[4], pr.Iterate = p[5], pr.OpSolve = p[6], pr.Extract = p[7];
+    pr.Dofs = uint32_t(p[8]), pr.StiffnessNonZeros = uint32_t(p[9]), pr.OpApplications = uint32_t(p[10]), pr.Restarts = uint32_t(p[11]);
+    const double *ev = p + ProfileWords;
+    r.Summary.Eigenvalues.assign(ev, ev + nev);
+    r.Modes.Freqs.resize(kept);
+    r.Modes.T60s.resize(kept);
+    for (size_t k = 0; k < kept; ++k) r.Modes.Freqs[k] = float(ev[E + k]), r.Modes.T60s[k] = float(ev[2 * E + k]);
+    const double *pos = ev + 3 * E;
+    r.Modes.Positions.resize(n_pos);
+    for (size_t q = 0; q < n_pos; ++q) r.Modes.Positions[q] = {float(pos[3 * q]), float(pos[3 * q + 1]), float(pos[3 * q + 2])};
+    const double *sh = pos + 3 * P;
+    r.Summary.Shapes.assign(n_pos, std::vector<vec3>(nev));
+    for (size_t q = 0; q < n_pos; ++q)
+        for (size_t k = 0; k < nev; ++k) r.Summary.Shapes[q][k] = {float(sh[(q * E + k) * 3]), float(sh[(q * E + k) * 3 + 1]), float(sh[(q * E + k) * 3 + 2])};
+    return out;
+}
+} // namespace
+
+void BatchComm::MakeId(unsigned char (&id)[IdBytes]) {
+    static_assert(sizeof(ncclUniqueId) == IdBytes);
+    ncclUniqueId u;
+    Check(ncclGetUniqueId(&u), "ncclGetUniqueId");
+    std::memcpy(id, &u, IdBytes);
+}
+BatchComm::BatchComm(int world_size, int rank, int device, const unsigned char (&id)[IdBytes]) : World(world_size), Me(rank), Dev(device) {
+    Check(hipSetDevice(device), "hipSetDevice");
+    ncclUniqueId u;
+    std::memcpy(&u, id, IdBytes);
+    ncclComm_t c{};
+    Check(ncclCommInitRank(&c, world_size, u, rank), "ncclCommInitRank");
+    Comm = c;
+    hipStream_t s{};
+    Check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    Stream = s;
+}
+BatchComm::~BatchComm() {
+    if (Stream) (void)hipStreamDestroy(static_cast<hipStream_t>(Stream));
+    if (Comm) (void)ncclCommDestroy(static_cast<ncclComm_t>(Comm));
+}
+void BatchComm::AllGather(const double *send, double *recv, size_t count) {
+    Check(ncclAllGather(send, recv, count, ncclDouble, static_cast<ncclComm_t>(Comm), static_cast<hipStream_t>(Stream)), "ncclAllGather");
+}
+void BatchComm::Synchronize() { Check(hipStreamSynchronize(static_cast<hipStream_t>(Stream)), "hipStreamSynchronize"); }
+
+size_t BatchRecordLength(const BatchOptions &o) {
+    return HeaderWords + MassWords + ProfileWords + 3 * size_t(o.MaxEigenpairs) + 3 * size_t(o.MaxPositions) + 3 * size_t(o.MaxPositions) * o.MaxEigenpairs;
+}
+double MeshCost(size_t tets, uint32_t eigenpairs) { return double(tets) * double(eigenpairs); }
+
+std::vector<uint32_t> DealBatch(std::span<const double> costs, uint32_t bins) {
+    std::vector<uint32_t> order(costs.size()), bin(costs.size(), 0);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return costs[a] > costs[b]; }); // heaviest first, ties by index
+    std::vector<double> load(std::max(1u, bins), 0.0);
+    for (const uint32_t i : order) {
+        const size_t r = size_t(std::min_element(load.begin(), load.end()) - load.begin()); // least loaded, lowest bin on ties
+        load[r] += costs[i];
+        bin[i] = uint32_t(r);
+    }
+    return bin;
+}
+
+std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &comm, const BatchOptions &options) {
+    const size_t reclen = BatchRecordLength(options), n = items.size();
+    const int world = comm.WorldSize(), rank = comm.Rank();
+    std::vector<double> costs(n);
+    for (size_t i = 0; i < n; ++i) costs[i] = items[i].Mesh ? MeshCost(items[i].Mesh->Tets.size(), items[i].Config.NumFemModes) : 0.0;
+    const std::vector<uint32_t> bin = DealBatch(costs, uint32_t(world));
+    std::vector<uint32_t> mine;
+    std::vector<size_t> share(world, 0);
+    for (size_t i = 0; i < n; ++i) {
+        ++share[bin[i]];
+        if (int(bin[i]) == rank) mine.push_back(uint32_t(i)); // ascending within the rank
+    }
+    const size_t slots = *std::max_element(share.begin(), share.end()); // every rank sends the same count: the largest share
+    // [slot][1 + reclen]: word 0 says whether the slot is used
+    std::vector<double> send(slots * (reclen + 1), 0.0);
+    std::atomic<size_t> next{0};
+    const uint32_t workers = std::max<uint32_t>(1, std::min<uint32_t>(options.ThreadsPerDevice, uint32_t(std::max<size_t>(mine.size(), 1))));
+    const auto work = [&] {
+        SetDevice(comm.Device()); // this thread's modalhip context lives on the rank's GPU
+        for (size_t k = next.fetch_add(1); k < mine.size(); k = next.fetch_add(1)) {
+            const uint32_t i = mine[k];
+            double *slot = send.data() + k * (reclen + 1);
+            slot[0] = 1.0;
+            const auto t0 = std::chrono::steady_clock::now();
+            ModalResult r;
+            try {
+                const BatchItem &it = items[i];
+                if (it.Mesh) r = mesh2modes(*it.Mesh, it.Material, it.ExcitePositions, it.BakedScale, it.Config);
+            } catch (const std::exception &) { // (a failed factorisation throws, as the reference's does): the record says failed
+                r = ModalResult{};
+            }
+            Pack(slot + 1, i, r, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), options);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < workers; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    }
+    // the one collective: every rank's slots, on the device, over RCCL
+    Check(hipSetDevice(comm.Device()), "hipSetDevice");
+    const size_t count = slots * (reclen + 1);
+    std::vector<double> all(size_t(world) * count, 0.0);
+    if (count) {
+        double *d_send{}, *d_recv{};
+        Check(hipMalloc(reinterpret_cast<void **>(&d_send), count * sizeof(double)), "hipMalloc");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_recv), size_t(world) * count * sizeof(double)), "hipMalloc");
+        try {
+            Check(hipMemcpy(d_send, send.data(), count * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+            comm.AllGather(d_send, d_recv, count);
+            comm.Synchronize();
+            Check(hipMemcpy(all.data(), d_recv, all.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+        } catch (...) {
+            (void)hipFree(d_send);
+            (void)hipFree(d_recv);
+            throw;
+        }
+        (void)hipFree(d_send);
+        (void)hipFree(d_recv);
+    }
+    std::vector<double> out(n * reclen, 0.0);
+    std::vector<uint8_t> seen(n, 0);
+    for (size_t s = 0; s < size_t(world) * slots; ++s) {
+        const double *slot = all.data() + s * (reclen + 1);
+        if (slot[0] != 1.0) continue;
+        const size_t i = size_t(slot[1]);
+        if (i >= n) throw std::runtime_error("SolveBatch: a gathered record carries an index outside the batch");
+        std::copy(slot + 1, slot + 1 + reclen, out.begin() + i * reclen);
+        seen[i] = 1;
+    }
+    if (std::count(seen.begin(), seen.end(), uint8_t(1)) != std::ptrdiff_t(n)) throw std::runtime_error("SolveBatch: the gather did not return one record per mesh");
+    return out;
+}
+
+std::vector<BatchRecord> SolveBatch(std::span<const BatchItem> items, BatchComm &comm, const BatchOptions &options) {
+    const std::vector<double> raw = SolveBatchRaw(items, comm, options);
+    const size_t reclen = BatchRecordLength(options);
+    std::vector<BatchRecord> out;
+    out.reserve(items.size());
+    for (size_t i = 0; i < items.size(); ++i) out.push_back(Unpack(raw.data() + i * reclen, options));
+    return out;
+}
+} // namespace modal

@@ -25,7 +25,7 @@ def _run(name, timeout=600):
 
 def test_cpp_tests_compile_against_the_mirror():
     _build()
-    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test", "tets_test"):
+    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test", "tets_test", "batch_test"):
         assert os.path.exists(os.path.join(CPP, "bin", name))
 
 
@@ -205,3 +205,11 @@ def test_modal_render_properties_cpp():
 def test_modal_solver_closed_forms_cpp():
     _build()
     assert "0 failure(s)" in _run("modal_solver_test")
+
+
+@pytest.mark.gpu
+def test_solve_batch_cpp_with_rccl_on_one_rank():
+    """modal::SolveBatch (the C++ multi-GPU batch driver): one-rank RCCL communicator, one ncclAllGather per batch, records equal
+    to direct solves, a failing mesh travels as a failed record (tests/cpp/batch_test.cpp)."""
+    _build()
+    assert "0 failure(s)" in _run("batch_test")
