@@ -96,12 +96,13 @@ def operator_forms(api, ctx, mesh, mat, widths=(1, 16, 64, 80)):
     atomic scatter).  Fractions of the 8 TB/s roofline on two byte counts, both from SURVEY 8(d): the BSR bytes the kernel
     moves (76 B per node block + 4 B per row pointer + 16 B per panel entry; `roofline.frac` uses this one) and the canonical
     scalar-CSR count the 40 % target is quoted on (12 B per non-zero + 4 B per row pointer + 16 B per panel entry)."""
+    from tools import lab  # libmodalhip_lab.so: timing loops outside the path's ABI
     system = api.System(ctx, mesh, mat)
     n_nodes, n_blocks = system.node_count, system.node_blocks
     out = []
     for w in widths:
-        ms, by = system.bench_spmm(w, 10)
-        em = system.bench_elementwise(w, 10)
+        ms, by = lab.bench_spmm(system, w, 10)
+        em = lab.bench_elementwise(system, w, 10)
         csr = 12.0 * 9 * n_blocks + 4.0 * (3 * n_nodes + 1) + 16.0 * 3 * n_nodes * w
         out.append({"w": w, "algorithmic_bytes": by, "canonical_csr_bytes": csr, "bsr_us": 1e3 * ms, "bsr_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "bsr_frac_on_csr_bytes": csr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

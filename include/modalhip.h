@@ -104,28 +104,8 @@ int mh_system_export_blocks(const mh_system *, uint32_t *row_node, uint32_t *col
 /* y = K x (which = 0), M x (which = 1) or (K - sigma M) x at the reference's shift (which = 2) for `width` vectors, x and y column-major n x width in the reference's
  * DOF order (3*node + component).  The SpMM kernel of the eigensolver, exposed for parity and roofline measurement.
  * which = 3 / 4: the same shifted product as the preconditioner's smoothers form it -- single-precision values and panel
- * (3), double-precision values over a single-precision panel (4, width % 4 == 0) -- so those kernels can be checked too.
- * which = 5: the shifted operator applied element by element without the assembled matrix (measurement variant, scatter by
- * atomic adds: equal to which = 2 up to rounding, not bit-reproducible; the eigensolver does not use it). */
+ * (3), double-precision values over a single-precision panel (4, width % 4 == 0) -- so those kernels can be checked too. */
 int mh_system_matvec(mh_system *, int which, const double *x, double *y, uint32_t width);
-
-/* Measurement aid: average device time of `reps` back-to-back K x products over a resident n x width panel, and the
- * algorithmic bytes of one launch (76 B per node block + 4 B per row pointer + 16 B per panel entry). */
-int mh_system_bench_spmm(mh_system *, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes);
-
-/* The same measurement for the element-by-element product (which = 5 above), memset of y included. */
-int mh_system_bench_elementwise(mh_system *, uint32_t width, uint32_t reps, double *avg_ms);
-
-/* Measurement aid for the dense tall-skinny kernels of the eigensolver: kind 0 = Gram G = X^T Y (X n x wa, Y n x wb),
- * kind 1 = basis update Z = [X | W] C (n x wa and n x wb times (wa + wb) x wa).  Average device time of `reps` launches
- * over resident random panels. */
-int mh_context_bench_dense(mh_context *, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms);
-
-/* Test and measurement aid for the Rayleigh-Ritz step's Householder tridiagonalisation (what Eigen's
- * SelfAdjointEigenSolver does inside the reference's warm branch, mesh2modes.cpp:405-417, and Spectra inside the cold
- * one): a (m x m, symmetric, both triangles, m <= 256) -> diagonal d[m] and subdiagonal e[m - 1] of Q^T a Q.
- * variant 0 = one workgroup, 1 = several workgroups exchanging tagged values.  avg_ms (optional) = device time per run. */
-int mh_context_tridiagonalize(mh_context *, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms);
 
 /* The nearest tet point to each excitation position, first minimum wins (mesh2modes.cpp:626-636). */
 int mh_nearest_points(mh_context *, const mh_mesh *, uint32_t n, const float *positions_xyz, uint32_t *nearest);

@@ -41,8 +41,9 @@ class Impact(C.Structure):
 def build(force=False):
     """Compile libmodalhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(_HERE, "..", "include", "modalhip.h")]
-    if force or not os.path.exists(SO_PATH) or any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps):
+    lab_src, lab_so = os.path.join(src, "lab"), os.path.join(_HERE, "libmodalhip_lab.so")  # the lab bench (tools/lab.py) is built alongside
+    deps = [os.path.join(d, f) for d in (src, lab_src) for f in os.listdir(d) if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(_HERE, "..", "include", "modalhip.h")]
+    if force or not os.path.exists(SO_PATH) or not os.path.exists(lab_so) or any(os.path.getmtime(d) > min(os.path.getmtime(SO_PATH), os.path.getmtime(lab_so)) for d in deps):
         subprocess.check_call(["make", "-s", "-j4", "-C", src])
     return SO_PATH
 
@@ -64,10 +65,8 @@ def lib():
         "mh_assemble": (i32, [vp, vp, C.POINTER(Material), pp]), "mh_system_destroy": (None, [vp]),
         "mh_system_dims": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]),
         "mh_system_element_nodes": (i32, [vp, vp]), "mh_system_export_blocks": (i32, [vp, vp, vp, vp, vp]),
-        "mh_system_matvec": (i32, [vp, i32, vp, vp, u32]), "mh_system_bench_spmm": (i32, [vp, u32, u32, C.POINTER(f64), C.POINTER(f64)]),
-        "mh_system_bench_elementwise": (i32, [vp, u32, u32, C.POINTER(f64)]), "mh_nearest_points": (i32, [vp, vp, u32, vp, vp]),
-        "mh_context_bench_dense": (i32, [vp, i32, C.c_uint64, u32, u32, u32, C.POINTER(f64)]),
-        "mh_context_tridiagonalize": (i32, [vp, i32, u32, vp, vp, vp, u32, C.POINTER(f64)]),
+        "mh_system_matvec": (i32, [vp, i32, vp, vp, u32]),
+        "mh_nearest_points": (i32, [vp, vp, u32, vp, vp]),
         "mh_eigs": (i32, [vp, u32, f64, f64, u32, vp, u32, u32, vp, vp, vp, C.POINTER(Profile)]),
         "mh_system_gather_shapes": (i32, [vp, u32, vp, u32, vp]), "mh_system_basis": (i32, [vp, u32, vp]),
         "mh_system_eigenvectors": (i32, [vp, u32, vp]),

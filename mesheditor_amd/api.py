@@ -56,21 +56,6 @@ class Context:
     def time_kernels(self, enable=True):
         self.check(self.L.mh_context_time_kernels(self.h, int(enable)))
 
-    def bench_dense(self, kind, n, wa, wb, reps=10):
-        """Average ms of the Gram (kind 0) or basis-update (kind 1) kernel on resident n x wa / n x wb panels."""
-        ms = C.c_double(0)
-        self.check(self.L.mh_context_bench_dense(self.h, kind, n, wa, wb, reps, C.byref(ms)))
-        return ms.value
-
-    def tridiagonalize(self, a, variant=0, reps=1):
-        """(d, e, ms): the tridiagonal form of the symmetric matrix a (order <= 256) by the Rayleigh-Ritz step's kernel
-        (variant 0: one workgroup, 1: several), and the device time per run."""
-        a = np.asfortranarray(a, dtype=np.float64)
-        m = a.shape[0]
-        d, e, ms = np.zeros(m), np.zeros(max(m - 1, 1)), C.c_double(0)
-        self.check(self.L.mh_context_tridiagonalize(self.h, variant, m, _p(a), _p(d), _p(e), reps, C.byref(ms)))
-        return d, e[: m - 1], ms.value
-
     def kernel_stats(self, kernel_class=0):
         """Totals of a timed kernel class since time_kernels(True): 0 = operator products (bytes), 1 = assembly kernel (bytes),
         2 = resonator kernel (flops)."""
@@ -161,17 +146,6 @@ class System:
         y = np.zeros_like(x, order="F")
         self.ctx.check(self.ctx.L.mh_system_matvec(self.h, which, _p(x), _p(y), x.shape[1]))
         return y
-
-    def bench_spmm(self, width, reps=20):
-        ms, by = C.c_double(0), C.c_double(0)
-        self.ctx.check(self.ctx.L.mh_system_bench_spmm(self.h, width, reps, C.byref(ms), C.byref(by)))
-        return ms.value, by.value
-
-    def bench_elementwise(self, width, reps=20):
-        """Average ms of the element-by-element (matrix-free, atomic scatter) product over a resident n x width panel."""
-        ms = C.c_double(0)
-        self.ctx.check(self.ctx.L.mh_system_bench_elementwise(self.h, width, reps, C.byref(ms)))
-        return ms.value
 
     def eigs(self, nev, sigma=-(2 * np.pi * 20.0) ** 2, residual_tol=1e-6, max_iters=200, seed_basis=None):
         ev = np.zeros(nev)

@@ -1,7 +1,11 @@
 """Python binding of modal::SolveBatch (modal/batch.hpp, libmodalhost.so): a batch of independent meshes dealt over the
 ranks' GPUs by the LPT rule, solved by host threads per GPU, the fixed-size records gathered with ONE ncclAllGather -- the host
 side in C++, RCCL called directly.  The communicator's 128-byte id is made on rank 0 and shipped by the caller (bench.py: the
-launcher's TCP store); nothing else of the data path touches Python."""
+launcher's TCP store); nothing else of the data path touches Python.
+
+A process that has imported PyTorch carries a second copy of the ROCm runtime libraries (the wheel bundles its own), and which
+copy the system RCCL then binds to depends on load order: create the BatchComm before importing torch, or after torch has
+initialised the GPU (bench.py does the latter).  A C++ host has no such second runtime."""
 import ctypes as C
 
 import numpy as np

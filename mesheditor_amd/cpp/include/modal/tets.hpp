@@ -40,6 +40,11 @@ struct ObjSurface {
     std::vector<vec3> Positions;
     std::vector<uint32_t> TriangleIndices;
 };
+// The reference's SimplifySurface (src/mesh/Tets.h:8-10): quadric edge-collapse of the surface to `ratio` of its triangles, in
+// place, then unreferenced vertices are dropped; a no-op when ratio >= 1.  The surface stays a closed 2-manifold; a collapse that
+// would turn a triangle over or fold the surface through its own neighbourhood is refused and that neighbourhood keeps its
+// resolution (src/simplify.cpp).
+void SimplifySurface(std::vector<vec3> &positions, std::vector<uint32_t> &triangle_indices, float ratio);
 // The reference's GenerateTets (src/mesh/Tets.cpp:265): float surface in, tet mesh out -- the general fill.
 tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, const tetra::Options &options);
 // With a layer count: the layered fill when the surface is star-shaped about its centroid, the general fill otherwise.

@@ -99,6 +99,7 @@ void BatchComm::MakeId(unsigned char (&id)[IdBytes]) {
 }
 BatchComm::BatchComm(int world_size, int rank, int device, const unsigned char (&id)[IdBytes]) : World(world_size), Me(rank), Dev(device) {
     Check(hipSetDevice(device), "hipSetDevice");
+    (void)hipGetLastError(); // RCCL's set-up reads the thread's last HIP error: one left behind by unrelated earlier work is not its business
     ncclUniqueId u;
     std::memcpy(&u, id, IdBytes);
     ncclComm_t c{};

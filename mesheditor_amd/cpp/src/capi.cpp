@@ -271,4 +271,17 @@ int mhx_solve_batch(modal::BatchComm *comm, const mhx_batch_item *items, uint32_
         return 0;
     } catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
+// SimplifySurface (modal/tets.hpp): positions and triangles in, the coarsened surface out (counts through the pointers; the
+// arrays are overwritten in place, their leading parts valid).
+void mhx_simplify_surface(float *positions, uint32_t *n_positions, uint32_t *triangles, uint32_t *n_triangles, float ratio) {
+    std::vector<vec3> pos(*n_positions);
+    for (uint32_t i = 0; i < *n_positions; ++i) pos[i] = {positions[3 * size_t(i)], positions[3 * size_t(i) + 1], positions[3 * size_t(i) + 2]};
+    std::vector<uint32_t> tri(triangles, triangles + size_t(*n_triangles) * 3);
+    SimplifySurface(pos, tri, ratio);
+    for (size_t i = 0; i < pos.size(); ++i)
+        for (int k = 0; k < 3; ++k) positions[3 * i + k] = pos[i][k];
+    std::copy(tri.begin(), tri.end(), triangles);
+    *n_positions = uint32_t(pos.size());
+    *n_triangles = uint32_t(tri.size() / 3);
+}
 }

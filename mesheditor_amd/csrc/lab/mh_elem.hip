@@ -20,7 +20,7 @@
 //     bit-reproducible); it exists beside the BSR one for measurement.  A deterministic scatter needs element
 //     colouring (tens of launches with no locality: every gather and read-modify-write goes to HBM, ~5 GB at w = 64) or
 //     per-tile accumulators in LDS (a 1.5 KB row per node at w = 64: a hundred nodes per CU, i.e. no tile worth the name).
-#include "mh_common.h"
+#include "../mh_common.h"
 
 namespace {
 // midside node (4 .. 9) of the edge between corners a and b, edges in the reference's order 01 02 03 12 13 23

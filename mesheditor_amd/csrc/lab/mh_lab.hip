@@ -1,0 +1,172 @@
+// libmodalhip_lab.so: measurement and experiment entry points that are NOT part of the path's ABI (include/modalhip.h has
+// none of them): timing loops around the product's own kernels, the tridiagonalisation variants called directly, and the
+// matrix-free element-by-element operator (lab/mh_elem.hip: built, measured 2.1-2.6x slower than the BSR product, kept here for
+// the record).  Links libmodalhip.so and reaches its internals through mh_common.h; tests, tools/ and bench.py's secondary
+// figures load it explicitly (tools/lab.py), the product never does.
+#include "../mh_common.h"
+#include "modalhip_lab.h"
+
+#include <algorithm>
+
+void mh_elementwise_apply(mh_context *ctx, const mh_system *sys, double sigma, const double *x, double *y, uint32_t w); // lab/mh_elem.hip
+
+namespace {
+constexpr int TB = 256;
+// reference DOF order (column-major n x width) <-> internal row-major panel
+__global__ void k_lab_ref_to_panel(const double *__restrict__ x, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t width, double *__restrict__ panel) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nnodes) * 3 * width) return;
+    const uint32_t c = uint32_t(i % width), comp = uint32_t((i / width) % 3), node = uint32_t(i / (size_t(3) * width));
+    panel[i] = x[size_t(c) * (size_t(3) * nnodes) + size_t(3) * perm[node] + comp];
+}
+__global__ void k_lab_panel_to_ref(const double *__restrict__ panel, const uint32_t *__restrict__ perm, uint32_t nnodes, uint32_t width, double *__restrict__ y) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nnodes) * 3 * width) return;
+    const uint32_t c = uint32_t(i % width), comp = uint32_t((i / width) % 3), node = uint32_t(i / (size_t(3) * width));
+    y[size_t(c) * (size_t(3) * nnodes) + size_t(3) * perm[node] + comp] = panel[i];
+}
+} // namespace
+
+extern "C" {
+// y = (K - sigma M) x at the reference's shift, element by element without the assembled matrix (atomic scatter: equal to
+// mh_system_matvec(which = 2) up to rounding, not bit-reproducible).  x, y: column-major n x width, the reference's DOF order.
+int mhl_system_elementwise_matvec(mh_system *s, const double *x, double *y, uint32_t width) {
+    if (!s || !x || !y || width == 0) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * s->n_nodes;
+        DevArray<double> xr(ctx, n * width), xp(ctx, n * width), yp(ctx, n * width);
+        xr.upload(x, n * width);
+        k_lab_ref_to_panel<<<div_up(n * width, TB), TB, 0, ctx->stream>>>(xr, s->perm, s->n_nodes, width, xp);
+        KERNEL_CHECK();
+        mh_elementwise_apply(ctx, s, -15791.367041742974, xp, yp, width);
+        k_lab_panel_to_ref<<<div_up(n * width, TB), TB, 0, ctx->stream>>>(yp, s->perm, s->n_nodes, width, xr.get());
+        KERNEL_CHECK();
+        xr.download(y, n * width);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+int mhl_system_bench_spmm(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes) {
+    if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * s->n_nodes;
+        DevArray<double> x(ctx, n * width), y(ctx, n * width);
+        std::vector<double> hx(n * width);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        x.upload(hx.data(), hx.size());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int warm = 0; warm < 2; ++warm) mh_spmm(ctx, s->L2, s->L2.kval, x, y, nullptr, nullptr, width);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t r = 0; r < reps; ++r) mh_spmm(ctx, s->L2, s->L2.kval, x, y, nullptr, nullptr, width);
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
+        if (algorithmic_bytes) *algorithmic_bytes = 76.0 * double(s->L2.n_blocks) + 4.0 * (double(s->n_nodes) + 1) + 16.0 * double(n) * width;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+int mhl_system_bench_elementwise(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms) {
+    if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * s->n_nodes;
+        DevArray<double> x(ctx, n * width), y(ctx, n * width);
+        std::vector<double> hx(n * width);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        x.upload(hx.data(), hx.size());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int warm = 0; warm < 2; ++warm) mh_elementwise_apply(ctx, s, -15791.367041742974, x, y, width);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t r = 0; r < reps; ++r) mh_elementwise_apply(ctx, s, -15791.367041742974, x, y, width);
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+int mhl_context_bench_dense(mh_context *ctx, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms) {
+    if (!ctx || !avg_ms || n == 0 || wa == 0 || wb == 0 || reps == 0 || kind < 0 || kind > 1) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::lock_guard<std::mutex> lock(mh_solve_mutex());
+        DevArray<double> x(ctx, n * wa), y(ctx, n * wb), g(ctx, size_t(wa + wb) * (wa + wb)), z(ctx, n * wa);
+        std::vector<double> h(n * std::max(wa, wb));
+        for (size_t i = 0; i < h.size(); ++i) h[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        x.upload(h.data(), n * wa);
+        y.upload(h.data(), n * wb);
+        g.upload(h.data(), g.count);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        auto run = [&]() {
+            if (kind == 0) mh_gram(ctx, n, x, wa, y, wb, g, wa);
+            else mh_combine(ctx, n, x, wa, y, wb, nullptr, 0, g, wa, z, wa, nullptr);
+        };
+        run();
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t r = 0; r < reps; ++r) run();
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+int mhl_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms) {
+    if (!ctx || !a || !d || !e || m < 2 || m > 256 || variant < 0 || variant > 1) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        MhSharedPhase not_during_a_factorisation; // (no process-wide lock: calls on different contexts are meant to overlap)
+        DevArray<double> da(ctx, size_t(m) * m), work(ctx, size_t(m) * m), dd(ctx, m), de(ctx, m), dtau(ctx, m);
+        da.upload(a, size_t(m) * m);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float total = 0;
+        for (uint32_t r = 0; r < std::max(1u, reps); ++r) {
+            HIP_CHECK(hipMemcpyAsync(work, da, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_CHECK(hipEventRecord(e0, ctx->stream));
+            mh_sytrd_small(ctx, work, m, dd, de, dtau, variant);
+            HIP_CHECK(hipEventRecord(e1, ctx->stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        dd.download(d, m);
+        de.download(e, m - 1);
+        if (mh_sytrd_gave_up(ctx)) mh_throw(MH_EHIP, "tridiagonalisation: a workgroup timed out waiting for the others' values");
+        if (avg_ms) *avg_ms = total / std::max(1u, reps);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+}

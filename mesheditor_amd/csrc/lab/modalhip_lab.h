@@ -1,0 +1,21 @@
+/* Lab bench of libmodalhip: measurement and experiment entry points OUTSIDE the path's ABI (libmodalhip_lab.so).
+ * Nothing here replaces a reference interface; include/modalhip.h is the drop-in boundary. */
+#pragma once
+#include "../../../include/modalhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Average device time of `reps` back-to-back K x products over a resident n x width panel, and the algorithmic bytes of one
+ * launch (76 B per node block + 4 B per row pointer + 16 B per panel entry). */
+int mhl_system_bench_spmm(mh_system *, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes);
+/* The matrix-free element-by-element operator: one product in the reference's DOF order, and its timing loop. */
+int mhl_system_elementwise_matvec(mh_system *, const double *x, double *y, uint32_t width);
+int mhl_system_bench_elementwise(mh_system *, uint32_t width, uint32_t reps, double *avg_ms);
+/* kind 0 = Gram G = X^T Y (X n x wa, Y n x wb), kind 1 = basis update Z = [X | W] C: average device time of `reps` launches. */
+int mhl_context_bench_dense(mh_context *, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms);
+/* The Rayleigh-Ritz step's Householder tridiagonalisation called directly: a (m x m, symmetric, both triangles, m <= 256) ->
+ * d[m], e[m - 1]; variant 0 = one workgroup, 1 = several workgroups exchanging tagged values. */
+int mhl_context_tridiagonalize(mh_context *, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms);
+#ifdef __cplusplus
+}
+#endif

@@ -264,7 +264,7 @@ int mh_system_export_blocks(const mh_system *s, uint32_t *row_node, uint32_t *co
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32_t width) {
-    if (!s || !x || !y || width == 0) return MH_EINVAL;
+    if (!s || !x || !y || width == 0 || which < 0 || which > 4) return MH_EINVAL;
     mh_context *ctx = s->ctx;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
@@ -289,8 +289,6 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
                 mh_spmm_mixed(ctx, s->L2, xf, yp, width);
             }
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        } else if (which == 5) { // the same shifted operator applied element by element, no assembled matrix (mh_elem.hip)
-            mh_elementwise_apply(ctx, s, -15791.367041742974, xp, yp, width);
         } else { // which == 2: the shifted operator A = K - sigma M of the eigensolver at the reference's shift
             std::lock_guard<std::mutex> lock(mh_solve_mutex());
             mh_build_hierarchy(s, -15791.367041742974);
@@ -299,127 +297,6 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
         k_panel_to_ref<double><<<div_up(n * width, TB), TB, 0, ctx->stream>>>(yp, s->perm, s->n_nodes, width, width, xr.get());
         KERNEL_CHECK();
         xr.download(y, n * width);
-        return MH_OK;
-    } catch (const std::exception &e) { return mh_guard(ctx, e); }
-}
-
-int mh_system_bench_spmm(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms, double *algorithmic_bytes) {
-    if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
-    mh_context *ctx = s->ctx;
-    try {
-        HIP_CHECK(hipSetDevice(ctx->device));
-        const size_t n = size_t(3) * s->n_nodes;
-        DevArray<double> x(ctx, n * width), y(ctx, n * width);
-        std::vector<double> hx(n * width);
-        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
-        x.upload(hx.data(), hx.size());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (int warm = 0; warm < 2; ++warm) mh_spmm(ctx, s->L2, s->L2.kval, x, y, nullptr, nullptr, width);
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, ctx->stream));
-        for (uint32_t r = 0; r < reps; ++r) mh_spmm(ctx, s->L2, s->L2.kval, x, y, nullptr, nullptr, width);
-        HIP_CHECK(hipEventRecord(e1, ctx->stream));
-        HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *avg_ms = ms / reps;
-        if (algorithmic_bytes) *algorithmic_bytes = 76.0 * double(s->L2.n_blocks) + 4.0 * (double(s->n_nodes) + 1) + 16.0 * double(n) * width;
-        return MH_OK;
-    } catch (const std::exception &e) { return mh_guard(ctx, e); }
-}
-
-int mh_system_bench_elementwise(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms) {
-    if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
-    mh_context *ctx = s->ctx;
-    try {
-        HIP_CHECK(hipSetDevice(ctx->device));
-        const size_t n = size_t(3) * s->n_nodes;
-        DevArray<double> x(ctx, n * width), y(ctx, n * width);
-        std::vector<double> hx(n * width);
-        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
-        x.upload(hx.data(), hx.size());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (int warm = 0; warm < 2; ++warm) mh_elementwise_apply(ctx, s, -15791.367041742974, x, y, width);
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, ctx->stream));
-        for (uint32_t r = 0; r < reps; ++r) mh_elementwise_apply(ctx, s, -15791.367041742974, x, y, width);
-        HIP_CHECK(hipEventRecord(e1, ctx->stream));
-        HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *avg_ms = ms / reps;
-        return MH_OK;
-    } catch (const std::exception &e) { return mh_guard(ctx, e); }
-}
-
-int mh_context_bench_dense(mh_context *ctx, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms) {
-    if (!ctx || !avg_ms || n == 0 || wa == 0 || wb == 0 || reps == 0 || kind < 0 || kind > 1) return MH_EINVAL;
-    try {
-        HIP_CHECK(hipSetDevice(ctx->device));
-        std::lock_guard<std::mutex> lock(mh_solve_mutex());
-        DevArray<double> x(ctx, n * wa), y(ctx, n * wb), g(ctx, size_t(wa + wb) * (wa + wb)), z(ctx, n * wa);
-        std::vector<double> h(n * std::max(wa, wb));
-        for (size_t i = 0; i < h.size(); ++i) h[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
-        x.upload(h.data(), n * wa);
-        y.upload(h.data(), n * wb);
-        g.upload(h.data(), g.count);
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        auto run = [&]() {
-            if (kind == 0) mh_gram(ctx, n, x, wa, y, wb, g, wa);
-            else mh_combine(ctx, n, x, wa, y, wb, nullptr, 0, g, wa, z, wa, nullptr);
-        };
-        run();
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, ctx->stream));
-        for (uint32_t r = 0; r < reps; ++r) run();
-        HIP_CHECK(hipEventRecord(e1, ctx->stream));
-        HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *avg_ms = ms / reps;
-        return MH_OK;
-    } catch (const std::exception &e) { return mh_guard(ctx, e); }
-}
-
-int mh_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms) {
-    if (!ctx || !a || !d || !e || m < 2 || m > 256 || variant < 0 || variant > 1) return MH_EINVAL;
-    try {
-        HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation; // (no process-wide lock: calls on different contexts are meant to overlap)
-        DevArray<double> da(ctx, size_t(m) * m), work(ctx, size_t(m) * m), dd(ctx, m), de(ctx, m), dtau(ctx, m);
-        da.upload(a, size_t(m) * m);
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        float total = 0;
-        for (uint32_t r = 0; r < std::max(1u, reps); ++r) {
-            HIP_CHECK(hipMemcpyAsync(work, da, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_CHECK(hipEventRecord(e0, ctx->stream));
-            mh_sytrd_small(ctx, work, m, dd, de, dtau, variant);
-            HIP_CHECK(hipEventRecord(e1, ctx->stream));
-            HIP_CHECK(hipEventSynchronize(e1));
-            float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-            total += ms;
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        dd.download(d, m);
-        de.download(e, m - 1);
-        if (mh_sytrd_gave_up(ctx)) mh_throw(MH_EHIP, "tridiagonalisation: a workgroup timed out waiting for the others' values");
-        if (avg_ms) *avg_ms = total / std::max(1u, reps);
         return MH_OK;
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }

@@ -191,9 +191,9 @@ template<typename T> struct DevArray {
         ctx = c;
         count = n;
         ptr = n ? static_cast<T *>(c->pool.alloc(n * sizeof(T))) : nullptr;
-        // MH_POISON=1 (test mode): every fresh array starts as all-ones bits (NaN for floating point), so a read of
+        // MH_TEST=poison (test mode): every fresh array starts as all-ones bits (NaN for floating point), so a read of
         // memory the code never wrote shows up as a wrong result instead of depending on what the pool handed back
-        static const bool poison = getenv("MH_POISON") && atoi(getenv("MH_POISON")) != 0;
+        static const bool poison = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "poison");
         if (poison && ptr) (void)hipMemsetAsync(ptr, 0xff, n * sizeof(T), c->stream);
     }
     void free() {
@@ -343,5 +343,4 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
                            uint32_t w); // mh_spmm.hip: product + Chebyshev step in one launch
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w); // double A x of a float panel
-void mh_elementwise_apply(mh_context *ctx, const mh_system *sys, double sigma, const double *x, double *y, uint32_t w); // mh_elem.hip: (K - sigma M) x without the matrix (atomics)
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

@@ -302,7 +302,7 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
                 uint32_t ld) {
     const int ti_n = int((wa + 15) / 16), tj_n = int((wb + 15) / 16);
     // ~2 workgroups per CU; each stages KC rows per step and owns a contiguous row range
-    static const size_t nwg_cap = getenv("MH_GRAM_WGS") ? size_t(atoi(getenv("MH_GRAM_WGS"))) : 512;
+    constexpr size_t nwg_cap = 512;
     int nwg = int(std::min<size_t>(nwg_cap, (n + KC - 1) / KC));
     size_t rows_per_wg = ((n + nwg - 1) / nwg + KC - 1) / KC * KC;
     nwg = int((n + rows_per_wg - 1) / rows_per_wg);
@@ -406,7 +406,7 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     // on these tall-skinny shapes where our 256-column chunks stay at 36 (tools/probe/gemm_probe.py).  Row-major panels are
     // column-major transposes, so out^T (cols x n) = Ct^T-block (cols x k) * panel^T (k x n), one call per panel and output;
     // a column map on X becomes zero coefficient rows for the columns left out.
-    static const bool wide_blas = !(getenv("MH_COMBINE_BLAS") && atoi(getenv("MH_COMBINE_BLAS")) == 0);
+    constexpr bool wide_blas = true;
     const uint32_t m_total = wx + ww + wp;
     if (wide_blas && m_total >= 400 && col_count >= 128 && !caller_omap && out1 != x && out2 != x && n >= 65536) {
         const uint32_t px = ldx ? ldx : wx; // physical columns of the X panel
@@ -874,9 +874,9 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
 
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant) {
     if (m < 1 || m > 256) mh_throw(MH_EINVAL, "sytrd_small: order %u outside 1..256", m);
-    static const bool fused = !(getenv("MH_SYTRD_FUSED") && atoi(getenv("MH_SYTRD_FUSED")) == 0);
+    constexpr bool fused = true;
     // several workgroups from order 64 up (measured: 287 against 363 us at 96, 861 against 1 812 us at 222); MH_SYTRD_MULTI=0: always one
-    static const bool multi_default = !(getenv("MH_SYTRD_MULTI") && atoi(getenv("MH_SYTRD_MULTI")) == 0);
+    constexpr bool multi_default = true;
     const bool multi = variant < 0 ? (multi_default && m >= 64) : variant == 1;
     // the give-up flag belongs to THIS call: a timeout of an earlier launch (co-resident work stalling a workgroup) must not
     // condemn every later reduction on the context (the one-workgroup kernels never raise it)
@@ -1289,7 +1289,7 @@ bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32
     if (lds > 158 * 1024) return false;
     static PerDeviceOnce attr;
     attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tridiag_lowest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
-    static const bool spread = !(getenv("MH_TRIDIAG_SPREAD") && atoi(getenv("MH_TRIDIAG_SPREAD")) == 0);
+    constexpr bool spread = true;
     if (spread) {
         k_tridiag_values<<<k, 256, 0, ctx->stream>>>(d, e, int(m), lam_scratch);
         KERNEL_CHECK();
@@ -1498,7 +1498,7 @@ __global__ void __launch_bounds__(128 * 128 / NQ) k_spd_inverse_small(const doub
 
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "spd_inverse_small: order %u outside 1..128", w);
-    static const int nq = getenv("MH_GJ_NQ") ? atoi(getenv("MH_GJ_NQ")) : 16;
+    constexpr int nq = 16;
     if (nq == 16) k_spd_inverse_small<16><<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
     else if (nq == 32) k_spd_inverse_small<32><<<1, 512, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
     else k_spd_inverse_small<64><<<1, 256, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
@@ -1509,7 +1509,7 @@ void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "potrf_small: order %u outside 1..128", w);
     static PerDeviceOnce attr;
     attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });
-    static const bool panels = !(getenv("MH_POTRF_PANELS") && atoi(getenv("MH_POTRF_PANELS")) == 0);
+    constexpr bool panels = true;
     if (panels) {
         static PerDeviceOnce attr2;
         attr2.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_panels), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });

@@ -41,57 +41,41 @@ constexpr int TB = 256;
 //   * what still goes through a rocSOLVER factorisation -- the tiny-system dense eigensolve (sygvd), and the coarse
 //     operator under MH_COARSE_ROCSOLVER=1 -- takes the lock EXCLUSIVELY after a device-wide synchronisation: it runs alone.
 // 2.0x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
-// MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex); MH_ROCSOLVER_LOCK=1 additionally serialises the
-// rocSOLVER calls of the Rayleigh-Ritz step (not needed by any measurement).
+// MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex).
 std::mutex g_solve_mutex;
-std::mutex g_rocsolver_mutex;
-// Every environment switch of the solver, read ONCE per process (first use) into one immutable struct: the iteration code
-// below only looks at fields.  Defaults are the measured optimum; the alternatives are kept for comparison and as
-// fall-backs (DESIGN.md section 10 lists what each one does).
+// The solver's run-time switches, read ONCE per process (first use) into one immutable struct.  These are all there are
+// (DESIGN.md section 10 documents them); the alternatives that were measured and lost are gone from the code, the record of
+// each is in DESIGN.md and profiles/.
+//   MH_VERBOSE=1            per-iteration log on stderr
+//   MH_PRECOND_FP64=1       double-precision smoothers (default: single precision with double residuals between levels)
+//   MH_CYCLE=d2,d1,g,ratio  shape of the preconditioner cycle: Chebyshev degrees of the P2 and P1 smoothers, P1 cycles per
+//                           application, spectrum ratio lmax / lmin the smoothers target; 0 or missing keeps a built-in value
+//   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out)
+// and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
+// threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
 struct Switches {
-    bool always_reduce = getenv("MH_RR_REDUCE") && atoi(getenv("MH_RR_REDUCE")) != 0;
     bool verbose = getenv("MH_VERBOSE") != nullptr;
-    bool use_series = !(getenv("MH_RR_SERIES") && atoi(getenv("MH_RR_SERIES")) == 0);
-    bool own_sytrd = !(getenv("MH_RR_SYEVD") && atoi(getenv("MH_RR_SYEVD")) != 0);
-    bool own_tridiag = !(getenv("MH_RR_TRIDIAG") && atoi(getenv("MH_RR_TRIDIAG")) == 0);
-    bool own_ormtr = !(getenv("MH_RR_ORMTR") && atoi(getenv("MH_RR_ORMTR")) != 0);
-    bool fuse_steps = !(getenv("MH_CHEB_FUSED") && atoi(getenv("MH_CHEB_FUSED")) == 0);
-    int power_its = getenv("MH_LMAX_ITS") ? std::max(2, atoi(getenv("MH_LMAX_ITS"))) : 12;
-    bool coarse_rocsolver = getenv("MH_COARSE_ROCSOLVER") && atoi(getenv("MH_COARSE_ROCSOLVER")) != 0;
-    bool hierarchy_overlap = !(getenv("MH_HIERARCHY_OVERLAP") && atoi(getenv("MH_HIERARCHY_OVERLAP")) == 0);
-    bool check_coarse = getenv("MH_CHECK_COARSE") != nullptr;
-    int guard_pct = getenv("MH_GUARD_PCT") ? atoi(getenv("MH_GUARD_PCT")) : 10;
-    bool implicit_p = !(getenv("MH_IMPLICIT_P") && atoi(getenv("MH_IMPLICIT_P")) == 0);
     bool fp32_prec = !(getenv("MH_PRECOND_FP64") && atoi(getenv("MH_PRECOND_FP64")) != 0);
-    bool trsm_rocblas = getenv("MH_TRSM_ROCBLAS") && atoi(getenv("MH_TRSM_ROCBLAS")) != 0;
-    int smooth_init = getenv("MH_SMOOTH_INIT") ? atoi(getenv("MH_SMOOTH_INIT")) : 1;
-    bool implicit_w_env = !(getenv("MH_IMPLICIT_W") && atoi(getenv("MH_IMPLICIT_W")) == 0) && !(getenv("MH_VERIFY_CROSS") && atoi(getenv("MH_VERIFY_CROSS")) != 0);
-    bool lazy_env = !(getenv("MH_LAZY_IMAGES") && atoi(getenv("MH_LAZY_IMAGES")) == 0);
-    bool fresh_env = !(getenv("MH_FRESH_IMAGES") && atoi(getenv("MH_FRESH_IMAGES")) == 0);
-    bool trsm_env = getenv("MH_TRSM_ROCBLAS") && atoi(getenv("MH_TRSM_ROCBLAS")) != 0;
-    bool pproj_env = !(getenv("MH_IMPLICIT_PPROJ") && atoi(getenv("MH_IMPLICIT_PPROJ")) == 0);
-    int ortho_passes = getenv("MH_ORTHO_PASSES") ? std::max(1, atoi(getenv("MH_ORTHO_PASSES"))) : 1;
-    bool fused_images = !(getenv("MH_FUSED_IMAGES") && atoi(getenv("MH_FUSED_IMAGES")) == 0);
-    bool verify_cross = getenv("MH_VERIFY_CROSS") && atoi(getenv("MH_VERIFY_CROSS")) != 0;
-    uint32_t skip_p = getenv("MH_SKIP_P") ? uint32_t(atoi(getenv("MH_SKIP_P"))) : 4u;
-    int coarse_rocblas = getenv("MH_COARSE_ROCBLAS") ? atoi(getenv("MH_COARSE_ROCBLAS")) : -1; // -1: unset
-    int deg2 = getenv("MH_DEG2") ? std::max(1, atoi(getenv("MH_DEG2"))) : 0, deg1 = getenv("MH_DEG1") ? std::max(1, atoi(getenv("MH_DEG1"))) : 0; // 0: the built-in cycle shape
-    int gamma = getenv("MH_GAMMA") ? std::max(1, atoi(getenv("MH_GAMMA"))) : 0;
-    double cheb_ratio = getenv("MH_CHEB_RATIO") ? atof(getenv("MH_CHEB_RATIO")) : 0.0;
-    int guard_abs = getenv("MH_GUARD_ABS") ? std::max(1, atoi(getenv("MH_GUARD_ABS"))) : 0;
-    bool test_sytrd_giveup = getenv("MH_TEST_SYTRD_GIVEUP") && atoi(getenv("MH_TEST_SYTRD_GIVEUP")) != 0; // tests: treat every first attempt as timed out
+    int deg2 = 0, deg1 = 0, gamma = 0; // 0: the built-in cycle shape
+    double cheb_ratio = 0.0;
+    bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
+    Switches() {
+        if (const char *c = getenv("MH_CYCLE")) {
+            double v[4] = {0, 0, 0, 0};
+            sscanf(c, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]);
+            deg2 = std::max(0, int(v[0])), deg1 = std::max(0, int(v[1])), gamma = std::max(0, int(v[2]));
+            cheb_ratio = v[3];
+        }
+    }
 };
 const Switches &switches() {
     static const Switches s; // C++11 magic static: initialised once, thread-safe
     return s;
 }
-
-const bool g_rocsolver_serial = getenv("MH_ROCSOLVER_LOCK") && atoi(getenv("MH_ROCSOLVER_LOCK")) != 0;
-struct SolverLock { // rocSOLVER calls of different contexts one at a time (MH_ROCSOLVER_LOCK=0 lifts it)
-    std::unique_lock<std::mutex> l;
-    explicit SolverLock(std::mutex &m) : l(m, std::defer_lock) { if (g_rocsolver_serial) l.lock(); }
-    void unlock() { if (l.owns_lock()) l.unlock(); }
-};
+// Design constants (each was once a switch; the losing side of every comparison is recorded in DESIGN.md section 10)
+constexpr int kPowerIterations = 12; // spectral-bound estimate of the smoothers
+constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
+constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
 
 // readers-writer lock with writer priority (glibc's shared_mutex prefers readers: iterating solves would starve a factorisation)
 struct PhaseLock {
@@ -600,9 +584,8 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
     // The basis is built M-orthonormal (X and P by construction, W by projection + Cholesky-QR), so gM is the identity
     // up to the orthogonalisation error.  When that error is below 1e-11 the pencil is solved as a standard problem:
     // no Cholesky reduction (potrf + three trsm, ~1.2 ms of a ~4 ms solve at order 225).  Otherwise the full reduction.
-    const bool always_reduce = switches().always_reduce;
     bool identity = false, series = false;
-    if (!always_reduce) {
+    {
         static_assert(sizeof(unsigned long long) == sizeof(double), "defect word");
         unsigned long long *defect = reinterpret_cast<unsigned long long *>(ework);
         HIP_CHECK(hipMemsetAsync(defect, 0, sizeof(unsigned long long), ctx->stream));
@@ -619,8 +602,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         // A small defect (one Cholesky-QR pass of an ill-conditioned W leaves 1e-10 .. 1e-8) is absorbed by the series
         // S = (I + E)^(-1/2) = I - E/2 + 3/8 E^2 + O(E^3): S gA S z = theta z, c = S z.  Four order-m products instead of the
         // Cholesky reduction's factorisation and three triangular solves (~1.2 ms of single-workgroup kernels).
-        const bool use_series = switches().use_series;
-        series = use_series && !identity && d < 1e-7;
+        series = !identity && d < 1e-7;
     }
     DevArray<double> sroot, stmp;
     if (series) {
@@ -638,7 +620,6 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         KERNEL_CHECK();
         identity = true;
     }
-    SolverLock solver_lock(g_rocsolver_mutex);
     if (!identity) {
         ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, m, gM, m, info));
         info.download(&hinfo, 1);
@@ -646,13 +627,11 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
     }
-    const bool own_sytrd = switches().own_sytrd;
-    if (own_sytrd && m >= 8 && m <= 256) {
+    if (m >= 8 && m <= 256) {
         // syevd by parts: the tridiagonalisation (70 % of rocSOLVER's syevd at this order) in one workgroup of ours, then
         // rocSOLVER's divide and conquer on T and the back-transformation Z <- Q Z
         DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
-        const bool own_tridiag = switches().own_tridiag;
-        const bool partial = own_tridiag && nwant && nwant < m;
+        const bool partial = nwant && nwant < m;
         DevArray<double> zl(ctx, partial ? size_t(m) * nwant : 0); // the first attempt's vectors: z still holds the saved matrix then
         double *zres = z.get();
         uint32_t ncols = m;
@@ -701,9 +680,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
             }
             break;
         }
-        const bool own_ormtr = switches().own_ormtr;
-        if (own_ormtr) mh_apply_q(ctx, gA, tau, m, zres, m, ncols);
-        else ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, ncols, gA, m, tau, zres, m));
+        mh_apply_q(ctx, gA, tau, m, zres, m, ncols);
         HIP_CHECK(hipMemcpyAsync(gA, zres, size_t(m) * ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         // no synchronisation: the workspaces return to the context's pool, whose blocks are only ever used on this same stream
     } else {
@@ -711,7 +688,6 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         info.download(&hinfo, 1);
         if (hinfo != 0) return hinfo;
     }
-    solver_lock.unlock();
     if (series) { // c = S z
         ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, stmp, m));
         HIP_CHECK(hipMemcpyAsync(gA, stmp.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -745,7 +721,6 @@ template<typename T> struct Precond {
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
     DevArray<double> r0, x0, x0_partial;
     static constexpr uint32_t COARSE_SLICES = 8;
-    bool coarse_mfma{true};
     DevArray<double> t2d, r1d, t1d; // single-precision smoothers: the residuals handed down a level stay double
     DevArray<T> patch_y; // y_e = (A_ee)^-1 R_e v of the sliver patches (mh_patch.hip), both levels share it
     static constexpr bool kDouble = std::is_same<T, double>::value;
@@ -765,8 +740,7 @@ template<typename T> struct Precond {
         x0_partial.reset(ctx, n0 * w * COARSE_SLICES);
         patch_y.reset(ctx, std::max(size_t(s->patches2.n_patches) * 30, size_t(s->patches1.n_patches) * 12) * w);
         const Switches &sw = switches();
-        if (sw.coarse_rocblas >= 0) coarse_mfma = sw.coarse_rocblas == 0;
-        if (s->patches2.n_patches || getenv("MH_STRONG_CYCLE")) { // a mesh with slivers: the P1 space represents its smooth error poorly (measured two-grid bound, exact
+        if (s->patches2.n_patches) { // a mesh with slivers: the P1 space represents its smooth error poorly (measured two-grid bound, exact
             deg2 = 4;                // coarse solve, 30k-tet skillet scan: condition 34 with two steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax])
             ratio = 30.0;
         }
@@ -806,7 +780,7 @@ template<typename T> struct Precond {
         // followed by the patch part of the same residual (r holds it; the last step's is r - t, formed on the fly)
         const PatchSet &ps = patches_of(lvl);
         mh_apply_patches<T>(ctx, ps, r, nullptr, w, T(1.0 / theta), d, x, nullptr, 0, patch_y.get());
-        const bool fuse_steps = switches().fuse_steps;
+        constexpr bool fuse_steps = true; // the smoothing step as the epilogue of the product that forms A d (neutral in time, one panel pass less)
         T *cur = d, *alt = t; // the direction lives in `cur`; `alt` takes the product, or (fused step) the next direction
         for (int k = 1; k < deg; ++k) {
             const double rho_new = 1.0 / (2 * sig - rho);
@@ -845,7 +819,6 @@ template<typename T> struct Precond {
         const uint32_t w = pitch(w_in);
         const uint32_t nn = sys->n_nodes, np = sys->n_points, na = sys->n_agg;
         const size_t n2 = size_t(3) * nn, n1 = size_t(3) * np, n0 = size_t(6) * na;
-        const double one = 1, zero = 0;
         const T *r;
         if constexpr (kDouble) r = r_in;
         else r = rin.get(); // filled by the first smoothing step below
@@ -877,8 +850,7 @@ template<typename T> struct Precond {
             }
             KERNEL_CHECK();
             // r0 is (6 na) x w row-major = w x (6 na) column-major: x0 = r0 * A0^-1 (A0^-1 symmetric, explicit)
-            if (coarse_mfma) mh_short_product(ctx, n0, sys->a0, uint32_t(n0), r0, w, x0, x0_partial, COARSE_SLICES);
-            else ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, rocblas_int(n0), rocblas_int(n0), &one, r0, w, sys->a0, rocblas_int(n0), &zero, x0, w));
+            mh_short_product(ctx, n0, sys->a0, uint32_t(n0), r0, w, x0, x0_partial, COARSE_SLICES);
             k_prolong_agg<T><<<grid1(n1 * w), TB, 0, ctx->stream>>>(x0, sys->agg_t, x1.get(), sys->agg_of, np, w);
             KERNEL_CHECK();
             cheb(sys->L1, deg1, r1, x1, false, rr1, d1, t1, w);
@@ -899,7 +871,7 @@ double estimate_lmax(mh_context *ctx, BsrLevel &lvl, const PatchSet &ps) {
     colsumsq(ctx, v, rows, w, nrm, scratch);
     k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
     KERNEL_CHECK();
-    const int power_its = switches().power_its;
+    constexpr int power_its = kPowerIterations;
     for (int it = 0; it < power_its; ++it) {
         mh_spmm(ctx, lvl, lvl.aval, v, t, nullptr, nullptr, w);
         k_dinv_mul<<<grid1(rows * w), TB, 0, ctx->stream>>>(t, lvl.dinv, v, rows, w);
@@ -940,11 +912,9 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     KERNEL_CHECK();
     DevArray<int> info(ctx, 1);
     int hinfo = 0;
-    const bool coarse_rocsolver = switches().coarse_rocsolver;
     // The rest of the set-up -- the spectral bounds of both smoothers (power iterations: SpMMs that fill the GPU, with host
     // round trips) and the single-precision copies -- does not depend on the coarse inverse, whose elimination is a chain of
-    // one-workgroup kernels and small products: the two run side by side on two streams (MH_HIERARCHY_OVERLAP=0: one after the other).
-    const bool overlap = switches().hierarchy_overlap;
+    // one-workgroup kernels and small products: the two run side by side on two streams.
     auto smoother_setup = [&] {
         for (BsrLevel *lvl : {&sys->L2, &sys->L1}) {
             lvl->lmax = estimate_lmax(ctx, *lvl, lvl->id == 2 ? sys->patches2 : sys->patches1);
@@ -956,7 +926,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
             KERNEL_CHECK();
         }
     };
-    if (!coarse_rocsolver) {
+    {
         // Explicit inverse by block Gauss-Jordan elimination (no pivoting: the matrix is SPD), 128 columns per step:
         //   P = A_kk^-1 (one workgroup, in registers);  C = A(:, k);  R = P A(k, :);  A -= C R;  A(k, :) = R;  A(:, k) = -C P;  A_kk = P.
         // 2 n0^3 flops in n0 / 128 rank-128 updates of the whole matrix (rocBLAS dgemm) instead of potrf + potri's chains of
@@ -966,7 +936,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
         const uint32_t nb = 128;
         DevArray<double> cblk(ctx, n0 * nb), rblk(ctx, n0 * nb), pinv(ctx, size_t(nb) * nb);
         info.zero();
-        const bool side = overlap && ctx->aux_stream_ready();
+        const bool side = ctx->aux_stream_ready();
         struct StreamGuard { // whatever happens below, the context leaves on its own stream
             mh_context *c;
             hipStream_t s;
@@ -1012,28 +982,6 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
         }
         info.download(&hinfo, 1);
         if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
-        const bool check = switches().check_coarse;
-        if (check) { // symmetry of the computed inverse before it was symmetrised is gone by now: report its scale only
-            std::vector<double> h(n0 * n0);
-            sys->a0.download(h.data(), n0 * n0);
-            double amax = 0;
-            for (double v : h) amax = std::max(amax, std::abs(v));
-            fprintf(stderr, "[coarse] n0 %zu inverse, largest entry %.3e\n", n0, amax);
-        }
-    } else {
-        smoother_setup();
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        ExclusivePhase alone_on_the_device; // rocsolver_dpotrf must not run beside other streams' kernels (see the top of the file)
-        SolverLock solver_lock(g_rocsolver_mutex);
-        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
-        info.download(&hinfo, 1);
-        if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (potrf info %d): shift must be negative", hinfo);
-        ROCBLAS_CHECK(rocsolver_dpotri(ctx->blas, rocblas_fill_lower, rocblas_int(n0), sys->a0, rocblas_int(n0), info));
-        info.download(&hinfo, 1);
-        solver_lock.unlock();
-        if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse inverse failed (potri info %d)", hinfo);
-        k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
-        KERNEL_CHECK();
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     sys->sigma_built = sigma;
@@ -1057,7 +1005,6 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues)
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ExclusivePhase alone_on_the_device;
-    SolverLock solver_lock(g_rocsolver_mutex);
     ROCBLAS_CHECK(rocsolver_dsygvd(ctx->blas, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_lower, rocblas_int(n), a, rocblas_int(n), m, rocblas_int(n), d, e, info));
     int hinfo = 0;
     info.download(&hinfo, 1);
@@ -1095,19 +1042,21 @@ struct BlockLobpcg {
     Timer t_iter;
     double precond_seconds = 0;
     // ---- panels (n x b) and small matrices
-    DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, AP, MP, Pn, APn, MPn, R, Rw;
+    DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
     DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
     DevArray<uint32_t> idx_d;
     DevArray<int> info; // [1]: conditioning report of mh_potrf_small
     std::unique_ptr<Precond<float>> prec32;
     std::unique_ptr<Precond<double>> prec64;
     // ---- switches (read once) and what follows from them
-    const bool verbose = switches().verbose, implicit_p = switches().implicit_p, fp32_prec = switches().fp32_prec;
-    const bool implicit_w_env = switches().implicit_w_env, lazy_env = switches().lazy_env, fresh_env = switches().fresh_env, trsm_env = switches().trsm_env;
-    const bool lazy_images_ok = lazy_env && fresh_env && implicit_p && !trsm_env;
-    // W is orthogonalised against P in coefficient space (no M P panel, no tall projection against P): MH_IMPLICIT_PPROJ=0 disables
-    const bool pproj_env = switches().pproj_env;
+    const bool verbose = switches().verbose, fp32_prec = switches().fp32_prec;
+    // W is orthogonalised against P in coefficient space (no M P panel, no tall projection against P) for blocks of up to 128 columns
     const bool pproj_ok;
+    // A mesh with sliver elements (mh_patch.hip) measures its residuals in the Jacobi-scaled norm, ||r||_{D^-1} against
+    // theta ||M x||_{D^-1}: the same quantity on a uniform mesh, but the rounding noise of the assembled operator sits on the slivers'
+    // rows (entries up to 1e6 times their neighbours': eps ||A|| |x| there), where D is as large as the noise -- in the plain
+    // 2-norm that noise alone exceeds the tolerance (95k-tet skillet scan: floor 6e-3 against 1e-5) and nothing ever converges.
+    const bool scaled_norms;
     // ---- state across iterations
     bool warm = false;
     bool w_implicit = false;       // W itself left untransformed this iteration (see chol_orthonormalise)
@@ -1120,11 +1069,6 @@ struct BlockLobpcg {
     std::vector<uint32_t> act, order, hist_nconv;
     std::vector<uint8_t> locked; // hard locking: a converged column leaves the Rayleigh-Ritz basis for good
     bool converged = false;
-    // A mesh with sliver elements (mh_patch.hip) measures its residuals in the Jacobi-scaled norm, ||r||_{D^-1} against
-    // theta ||M x||_{D^-1}: the same quantity on a uniform mesh, but the rounding noise of the assembled operator sits on the slivers'
-    // rows (entries up to 1e6 times their neighbours': eps ||A|| |x| there), where D is as large as the noise -- in the plain
-    // 2-norm that noise alone exceeds the tolerance (95k-tet skillet scan: floor 6e-3 against 1e-5) and nothing ever converges.
-    const bool scaled_norms;
     bool gm_identity = false; // this iteration's gM0 is exactly I (all blocks placed, none measured)
     bool p_implicit = false;  // this iteration: the basis is [X, (W - P Hp) L^-T, P] with W, P stored
     bool lazy_images = false;
@@ -1135,9 +1079,11 @@ struct BlockLobpcg {
                 uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_)
         : sys(system), ctx(system->ctx), st(system->ctx->stream), n(size_t(3) * system->n_nodes), nev(nev_), b(block), mmax(3 * block), sigma(sigma_), residual_tol(residual_tol_),
           max_iters(max_iters_), seed_basis(seed_basis_), seed_rows(seed_rows_), seed_cols(seed_cols_), cancel(cancel_), progress(progress_), prof(prof_), profile(profile_),
-          t_iter(system->ctx), pproj_ok(pproj_env && lazy_images_ok && implicit_w_env && block <= 128), scaled_norms(getenv("MH_SCALED_NORMS") ? atoi(getenv("MH_SCALED_NORMS")) != 0 : system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
+          t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
           theta_act(block), order(block), locked(block, 0) {
-        for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &AP, &MP, &Pn, &APn, &MPn, &R, &Rw}) panel->reset(ctx, n * b);
+        for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &Pn, &R, &Rw}) panel->reset(ctx, n * b);
+        if (!pproj_ok) // M P is only kept for blocks wider than 128 columns (the narrower ones project against P in coefficient space)
+            for (DevArray<double> *panel : {&MP, &MPn}) panel->reset(ctx, n * b);
         for (DevArray<double> *small : {&gA, &gM, &gM0, &gA0}) small->reset(ctx, size_t(mmax) * mmax);
         for (DevArray<double> *small : {&App, &H, &H2, &Linv, &Hp, &Up, &Vp, &T1p}) small->reset(ctx, size_t(b) * b);
         for (DevArray<double> *small : {&Cp, &T1}) small->reset(ctx, size_t(mmax) * b);
@@ -1185,7 +1131,6 @@ struct BlockLobpcg {
                 hinfo = both[0];
                 last_spread = both[1];
             } else {
-                SolverLock solver_lock(g_rocsolver_mutex);
                 ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
                 info.download(&hinfo, 1);
             }
@@ -1198,8 +1143,7 @@ struct BlockLobpcg {
         if (hinfo != 0) return false;
         k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
         KERNEL_CHECK();
-        const bool trsm_rocblas = switches().trsm_rocblas;
-        if (trsm_rocblas || w > 256) {
+        if (w > 256) {
             panel_trsm(ctx, n, V, w, Gs, w);
             if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
             if (AV) panel_trsm(ctx, n, AV, w, Gs, w);
@@ -1245,9 +1189,8 @@ struct BlockLobpcg {
         // A cold start begins from B M x for Gaussian noise x (one preconditioner application: the high-frequency content
         // of the noise is damped before the first Rayleigh-Ritz step), with the exact rigid-body modes put back: one
         // iteration fewer on every workload measured (18 -> 17 at S100k, 40 -> 39 on the ball, 17 -> 16 at S30k).
-        const int smooth_init = switches().smooth_init;
-        if (smooth_init && !warm) {
-            for (int rep = 0; rep < smooth_init; ++rep) {
+        if (!warm) {
+            {
                 mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
                 Timer tp(ctx);
                 if (prec32) prec32->apply(MX, Xn, b);
@@ -1378,10 +1321,8 @@ struct BlockLobpcg {
         bool ok = true;
         // One projection + Cholesky-QR pass suffices: the Rayleigh-Ritz step solves the full pencil (gA, gM), so the
         // basis only has to be well conditioned, not orthonormal to working precision.
-        const int ortho_passes = switches().ortho_passes;
-        const bool fused_images = switches().fused_images;
         p_implicit = false;
-        if (fused_images && ortho_passes == 1 && pproj_ok && wp && w <= 128) {
+        if (pproj_ok && wp) {
             // project against X in the tall space, against P in coefficient space
             gram(ctx, n, MX, b, W, w, H, b); // b x w
             mh_pack_stacked(ctx, H, b, nullptr, 0, w, -1.0, Ct);
@@ -1396,18 +1337,15 @@ struct BlockLobpcg {
                 mh_pack_stacked(ctx, Hp, wp, nullptr, 0, w, -1.0, Ct);
                 mh_combine(ctx, n, P, wp, nullptr, 0, nullptr, 0, Ct, w, W, w, nullptr, true);
                 mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
-                lazy_images = lazy_images_ok && w <= 256;
-                ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
+                lazy_images = w <= 256;
+                ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images);
                 if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
             } else {
                 p_implicit = true;
             }
-        } else if (fused_images && ortho_passes == 1) {
+        } else { // no previous directions yet, or a block wider than 128 columns (M P is maintained there: update_basis)
             gram(ctx, n, MX, b, W, w, H, b); // b x w
-            if (wp) {
-                if (pproj_ok) mh_spmm(ctx, sys->L2, nullptr, P, nullptr, sys->L2.mval, MP, wp); // M P is not maintained in this mode: form it (wide block)
-                gram(ctx, n, MP, wp, W, w, H2, wp);
-            }
+            if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
             mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
             mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
             mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, sys->L2.mval, MW, w);
@@ -1415,23 +1353,10 @@ struct BlockLobpcg {
             // Gram blocks that involve them are corrected on the small matrices (B <- B L^-T), the recombination of M P folds
             // L^-T into its coefficient rows, and A X, M X are recomputed from the new Ritz vectors anyway -- two tall
             // basis-update launches fewer per iteration.
-            lazy_images = lazy_images_ok && w <= 256;
+            lazy_images = w <= 256;
             w_implicit = false;
-            ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images && implicit_w_env);
+            ok = chol_orthonormalise(W, MW, AW, w, !lazy_images, lazy_images);
             if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-        } else {
-            mh_spmm(ctx, sys->L2, nullptr, W, nullptr, sys->L2.mval, MW, w);
-            for (int pass = 0; pass < ortho_passes && ok; ++pass) {
-                gram(ctx, n, MX, b, W, w, H, b); // b x w
-                if (wp) gram(ctx, n, MP, wp, W, w, H2, wp);
-                // W -= [X P] [H; H2], M W likewise: two fused MFMA launches
-                mh_pack_stacked(ctx, H, b, H2, wp, w, -1.0, Ct);
-                mh_combine(ctx, n, X, b, P, wp, nullptr, 0, Ct, w, W, w, nullptr, true);
-                mh_combine(ctx, n, MX, b, MP, wp, nullptr, 0, Ct, w, MW, w, nullptr, true);
-                ok = chol_orthonormalise(W, MW, nullptr, w);
-            }
-            if (!ok) mh_throw(MH_ENOTCONVERGED, "search directions lost rank at iteration %u", it);
-            mh_spmm(ctx, sys->L2, sys->L2.aval, W, AW, nullptr, nullptr, w);
         }
     }
 
@@ -1447,9 +1372,8 @@ struct BlockLobpcg {
             HIP_CHECK(hipMemsetAsync(gM, 0, size_t(m) * m * sizeof(double), st));
             k_set_identity_blocks<<<grid1(wa), TB, 0, st>>>(gA, gM, theta_act_d, wa, m);
             KERNEL_CHECK();
-            // W^T M X and P^T M W are zero by the projection that W just went through (measured 1e-14 .. 1e-12 in every run); they
-            // are formed only on request (MH_VERIFY_CROSS=1).  W^T M W, which carries the Cholesky-QR's error, is always measured.
-            const bool verify_cross = switches().verify_cross;
+            // W^T M X and P^T M W are zero by the projection that W just went through (measured 1e-14 .. 1e-12 in every run): they
+            // are not formed.  W^T M W, which carries the Cholesky-QR's error, is measured unless the factor says it is tiny.
             const double unit_one = 1;
             auto left_corrected = [&](double *block, uint32_t cols) { // block (w x cols at leading dimension m) <- L^-1 block: W was not transformed
                 if (w_implicit)
@@ -1458,7 +1382,6 @@ struct BlockLobpcg {
             };
             mh_gram(ctx, n, W, w, AX, wa, gA.get() + wa, m, b, idx_d);
             left_corrected(gA.get() + wa, wa);
-            if (verify_cross) mh_gram(ctx, n, W, w, MX, wa, gM.get() + wa, m, b, idx_d);
             const double unit = 1;
             auto untransformed = [&](double *block, uint32_t rows) { // block (rows x w at leading dimension m) <- block L^-T
                 if (lazy_images)
@@ -1485,8 +1408,8 @@ struct BlockLobpcg {
             left_corrected(gA.get() + size_t(wa) * m + wa, w);
             // W^T M W after the Cholesky-QR deviates from I by about eps * cond(G); it is measured unless the factor's diagonal
             // says cond(G) < 2^16 (deviation ~1e-11)
-            const bool w_block_trusted = !verify_cross && last_spread < 16 * 8 && !(p_implicit && wp == 0); // (a retry without P after an implicit P-projection: measure)
-            gm_identity = w_block_trusted && implicit_p; // every block of gM was set, not measured: gM0 is the identity exactly
+            const bool w_block_trusted = last_spread < 16 * 8 && !(p_implicit && wp == 0); // (a retry without P after an implicit P-projection: measure)
+            gm_identity = w_block_trusted; // every block of gM was set, not measured: gM0 is the identity exactly
             if (w_block_trusted) {
                 k_place_block<<<grid1(size_t(w) * w), TB, 0, st>>>(gM.get() + size_t(wa) * m + wa, m, nullptr, w);
                 KERNEL_CHECK();
@@ -1498,22 +1421,13 @@ struct BlockLobpcg {
             if (wp) {
                 if (!p_implicit) gram(ctx, n, P, wp, AW, w, gA.get() + size_t(wa) * m + wa + w, m); // (already formed and corrected above otherwise)
                 untransformed(gA.get() + size_t(wa) * m + wa + w, wp);
-                if (verify_cross || !implicit_p) {
-                    gram(ctx, n, P, wp, MW, w, gM.get() + size_t(wa) * m + wa + w, m);
-                    untransformed(gM.get() + size_t(wa) * m + wa + w, wp);
-                }
-                if (implicit_p) {
+                {
                     // P = S_prev Cp with Cp gM-orthonormal and gM-orthogonal to the Ritz coefficients Cx, and
                     // gA Cx = gM Cx Theta: hence P^T M P = I, P^T M X = P^T A X = 0 and P^T A P = Cp^T gA_prev Cp
                     // (formed last iteration from the small matrices) -- four tall Gram products saved.
                     k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gA.get() + size_t(wa + w) * m + wa + w, m, App, wp);
                     k_place_block<<<grid1(size_t(wp) * wp), TB, 0, st>>>(gM.get() + size_t(wa + w) * m + wa + w, m, nullptr, wp);
                     KERNEL_CHECK();
-                } else {
-                    mh_gram(ctx, n, P, wp, AX, wa, gA.get() + wa + w, m, b, idx_d);
-                    mh_gram(ctx, n, P, wp, MX, wa, gM.get() + wa + w, m, b, idx_d);
-                    gram(ctx, n, P, wp, AP, wp, gA.get() + size_t(wa + w) * m + wa + w, m);
-                    gram(ctx, n, P, wp, MP, wp, gM.get() + size_t(wa + w) * m + wa + w, m);
                 }
             }
             k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, st>>>(gA, m, m);
@@ -1555,7 +1469,6 @@ struct BlockLobpcg {
                     mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
                     info.download(&hinfo, 1);
                 } else {
-                    SolverLock solver_lock(g_rocsolver_mutex);
                     ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
                     info.download(&hinfo, 1);
                 }
@@ -1572,9 +1485,8 @@ struct BlockLobpcg {
         // subspace: with residuals of order one the previous step carries no usable curvature information -- the iteration
         // count is the same without it (18 and 18 at S100k) -- and an iteration on [X W] costs a third less
         // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
-        const uint32_t skip_p = switches().skip_p;
-        if (!warm && it < skip_p && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
-        if (wp_new && implicit_p) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
+        if (!warm && it < kSkipP && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
+        if (wp_new) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m));
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
         }
@@ -1592,9 +1504,7 @@ struct BlockLobpcg {
         // costs less than two passes over three tall panels each, the images carry no accumulated rounding, and A P is
         // not needed at all (P^T A P comes from the small matrices, above).  M P, which the next projection needs, is
         // still recombined -- before M X is overwritten.
-        const bool fresh_images = fresh_env;
-        const bool in_place = wa + wp_new <= 256;
-        if (fresh_images && implicit_p) {
+        {
             const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
             if (w_implicit) { // the basis holds W, not W L^-T: every coefficient row of the W part <- L^-T row (all columns)
                 const double unit = 1;
@@ -1623,32 +1533,8 @@ struct BlockLobpcg {
             else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
             KERNEL_CHECK();
             mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d);
-        } else {
-        const bool refresh = (it + 1) % 8 == 0; // images of the new Ritz vectors recomputed instead of recombined: A X and
-                                                // M X otherwise inherit eight generations of rounding from the updates
-        auto update = [&](DevArray<double> &x_all, const double *wpanel, const double *ppanel, DevArray<double> &x_new, double *p_new, bool keep_contiguous) {
-            if (in_place && !keep_contiguous) {
-                mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_all, wa, p_new, false, b, idx_d, b, idx_d);
-            } else {
-                mh_combine(ctx, n, x_all, wa, wpanel, w, ppanel, wp, Ct, wa + wp_new, x_new, wa, p_new, false, b, idx_d);
-                if (!keep_contiguous) {
-                    k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(x_new.get(), idx_d, x_all.get(), n, b, wa);
-                    KERNEL_CHECK();
-                }
-            }
-        };
-        update(X, W, P, Xn, Pn, refresh); // on a refresh Xn keeps the new vectors contiguously for the products below
-        update(AX, AW, AP, AXn, APn, refresh);
-        update(MX, MW, MP, MXn, MPn, refresh);
-        if (refresh) {
-            mh_spmm(ctx, sys->L2, sys->L2.aval, Xn, AXn, sys->L2.mval, MXn, wa);
-            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn, idx_d, X, n, b, wa);
-            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(AXn, idx_d, AX, n, b, wa);
-            k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(MXn, idx_d, MX, n, b, wa);
-            KERNEL_CHECK();
         }
-        }
-        std::swap(P, Pn); std::swap(AP, APn); std::swap(MP, MPn);
+        std::swap(P, Pn); std::swap(MP, MPn);
         wp = wp_new;
     }
 
@@ -1695,11 +1581,9 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         // the reference counts the lower triangle of K (Eigen nonZeros of the lower-stored matrix, mesh2modes.cpp:615)
         prof.stiffness_nonzeros = uint32_t((sys->L2.n_blocks - sys->n_nodes) / 2 * 9 + uint64_t(6) * sys->n_nodes);
         if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
-        const int guard_pct = switches().guard_pct;
         // guard vectors: at least 15 (measured at S100k, nev = 65: 10 -> 23 iterations / 338 ms, 15 -> 19 / 317 ms,
         // 31 -> 15 / 338 ms), block rounded up to whole 16-column MFMA tiles
-        uint32_t b = (nev + std::max(15u, nev * guard_pct / 100) + 15u) / 16u * 16u;
-        if (switches().guard_abs > 0) b = nev + uint32_t(switches().guard_abs);
+        uint32_t b = (nev + std::max(15u, nev * kGuardPercent / 100) + 15u) / 16u * 16u;
         if (n <= 768 || n < size_t(5) * b) {
             Timer t(ctx);
             dense_eigs(sys, nev, sigma, eigenvalues);

@@ -689,7 +689,7 @@ void build_level(mh_context *ctx, CubTemp &tmp, const uint32_t *elem, uint32_t n
         // One lane per contribution (k_assemble_flat) against one thread per node block (k_assemble), S100k, tools/ab_assembly.sh:
         // DESIGN.md section 5 has the measured pair.  A third form (one wave per node row, LDS-staged element data) was built in
         // between and measured slower than either (426 us; profiles/r02_ab_assembly.txt); it is gone.
-        static const bool by_block = getenv("MH_ASSEMBLE_BY_BLOCK") && atoi(getenv("MH_ASSEMBLE_BY_BLOCK")) != 0;
+        constexpr bool by_block = false; // round 1's kernel, one thread per node block: 573 us against 171 us
         if (by_block) k_assemble<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
         else k_assemble_flat<NN><<<div_up(nb, TB), TB, 0, ctx->stream>>>(seg, pay_s, nb, basis, support_tables_dev, mat.density, lambda, mu, lvl.kval, lvl.mval);
     }
@@ -892,7 +892,7 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
     // The coarse operator is dense of order 6 n_agg and inverted explicitly (O(n0^2) memory, 2 n0^3 flops): aggregates are
     // merged until the order is at or below MaxCoarseOrder; larger aggregates make a weaker coarse correction (more
     // iterations), never a failure.
-    static const uint32_t MaxCoarseOrder = getenv("MH_COARSE_CAP") ? uint32_t(std::max(64, atoi(getenv("MH_COARSE_CAP")))) : 6144u;
+    constexpr uint32_t MaxCoarseOrder = 6144u;
     {
         std::vector<uint32_t> rp(size_t(npts) + 1), cl(sys->L1.n_blocks), agg_of;
         HIP_CHECK(hipMemcpyAsync(rp.data(), sys->L1.row_ptr.get(), rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -326,17 +326,17 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
 // a solve; the extra registers cost more occupancy than the overlapped round trips give back), the solve time is unchanged.
 // Off by default; MH_SPMM_SMALL=1 selects it.
 inline bool latency_bound_level(const BsrLevel &lvl) {
-    static const bool on = getenv("MH_SPMM_SMALL") && atoi(getenv("MH_SPMM_SMALL")) != 0;
+    constexpr bool on = false;
     return on && lvl.n_nodes < 32768;
 }
 
 template<typename TV, typename TX, typename TY, bool WITH_M, bool WITH_A>
 bool launch_spmm_wide(mh_context *ctx, const BsrLevel &lvl, const TV *vals9, const TX *x, TY *y, const TV *mscal, TY *y2, uint32_t w) {
     constexpr uint32_t VFULL = 16 / sizeof(TX);
-    static const bool legacy = getenv("MH_SPMM_LEGACY") && atoi(getenv("MH_SPMM_LEGACY")) != 0;
+    constexpr bool legacy = false;
     constexpr bool mixed = !std::is_same<TV, TX>::value || !std::is_same<TX, TY>::value;
     if (legacy && !mixed) return false;
-    static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+    constexpr int xcd = 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
     auto run = [&](auto v_tag) {
         constexpr int V = decltype(v_tag)::value;
@@ -370,7 +370,7 @@ void launch_spmm(mh_context *ctx, const BsrLevel &lvl, const T *vals9, const T *
     auto go = [&](auto cw_tag, auto nc_tag) {
         constexpr int CW = decltype(cw_tag)::value, NC = decltype(nc_tag)::value;
         constexpr int RPW = 64 / CW;
-        static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+        constexpr int xcd = 1;
         // grid.x padded to a multiple of 8 so the XCD remap is a bijection onto [0, 8*per)
         dim3 grid((div_up(n, (TB / 64) * RPW) + 7) / 8 * 8, div_up(w, CW * NC));
         k_spmm<T, CW, NC, WITH_M, WITH_A><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x, y, y2, n, w, xcd);
@@ -432,7 +432,7 @@ void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, c
                     uint32_t wreal, const uint32_t *omap) {
     if (w == 0 || wreal == 0) return;
     if (w % 2 || (reinterpret_cast<uintptr_t>(x) & 15)) mh_throw(MH_EINVAL, "mapped product needs an even pitch and an aligned panel (got %u)", w);
-    static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+    constexpr int xcd = 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
     // panels wider than the 128 columns one wave covers go in column ranges of the same pitch
     const uint32_t ranges = div_up(w, 128u), step = (div_up(w, ranges) + 1u) & ~1u;
@@ -461,7 +461,7 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
     if (w % 4 || w > 256 || !aligned16) return false;
     // algorithmic bytes: the product's (d read, no t written) plus the step's own passes: r and x read and written, d' written
     TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, w, 4, 4, 0, true, false) + 5.0 * 4.0 * 3.0 * double(lvl.n_nodes) * w);
-    static const int xcd = getenv("MH_SPMM_XCD") ? atoi(getenv("MH_SPMM_XCD")) : 1;
+    constexpr int xcd = 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
     ChebStep epi;
     epi.r = r; epi.dinv = dinv; epi.d_out = d_out; epi.x = x; epi.c1 = c1; epi.c2 = c2;

@@ -15,6 +15,7 @@ def _lib():
             getattr(L, name).restype, getattr(L, name).argtypes = u32, [vp]
         L.mhx_tets_copy.restype, L.mhx_tets_copy.argtypes = None, [vp, vp, vp]
         L.mhx_tets_free.restype, L.mhx_tets_free.argtypes = None, [vp]
+        L.mhx_simplify_surface.restype, L.mhx_simplify_surface.argtypes = None, [vp, C.POINTER(u32), vp, C.POINTER(u32), C.c_float]
         L._tets_bound = True
     return L
 
@@ -36,3 +37,14 @@ def tetrahedralize(points, triangles, max_steiner=0):
         return out_p, out_t, int(L.mhx_tets_boundary_steiner(h))
     finally:
         L.mhx_tets_free(h)
+
+
+def simplify_surface(positions, triangles, ratio):
+    """SimplifySurface of the reference (src/mesh/Tets.h:8): quadric edge-collapse to `ratio` of the triangles; returns the
+    coarsened (positions float32 [V', 3], triangles uint32 [F', 3])."""
+    L = _lib()
+    pos = np.array(positions, dtype=np.float32, order="C")
+    tri = np.array(triangles, dtype=np.uint32, order="C")
+    nv, nt = C.c_uint32(len(pos)), C.c_uint32(len(tri))
+    L.mhx_simplify_surface(pos.ctypes.data_as(C.c_void_p), C.byref(nv), tri.ctypes.data_as(C.c_void_p), C.byref(nt), float(ratio))
+    return pos[: nv.value].copy(), tri[: nt.value].copy()

@@ -361,6 +361,63 @@ CASE(degenerate_and_noisy_point_sets_fill) {
     }
 }
 
+CASE(simplify_surface_keeps_a_closed_manifold_and_its_shape) {
+    // the reference's SimplifySurface contract (src/mesh/Tets.h:8-10): `ratio` of the triangles, unreferenced vertices dropped, a
+    // no-op at ratio >= 1, no fold-overs -- checked on a rough sphere and a rough torus (genus 1): every edge keeps exactly two
+    // triangles, the Euler characteristic and (to a few per cent) the enclosed volume stay, and the result still fills
+    struct Named {
+        const char *Name;
+        Surface S;
+        int Euler;
+        bool Fill; // (a UV sphere's poles are fans of needle triangles, before and after: the Delaunay fill's documented limit)
+    };
+    const Named cases[]{{"rough sphere", Sphere(1.0, 40, 60, 0.01, 5), 2, false}, {"rough torus", Torus(1.0, 0.35, 80, 32, 0.02), 0, true}};
+    for (const auto &c : cases) {
+        std::vector<vec3> pos;
+        for (const auto &p : c.S.P) pos.push_back(vec3{float(p.x), float(p.y), float(p.z)});
+        std::vector<uint32_t> tri = c.S.T;
+        const auto volume = [](const std::vector<vec3> &p, const std::vector<uint32_t> &t) {
+            double v6 = 0;
+            for (size_t k = 0; k + 2 < t.size(); k += 3) v6 += Vol6(dvec3{0, 0, 0}, dvec3(p[t[k]]), dvec3(p[t[k + 1]]), dvec3(p[t[k + 2]]));
+            return v6 / 6;
+        };
+        const double v0 = volume(pos, tri);
+        const size_t nt0 = tri.size() / 3;
+        auto same_pos = pos;
+        auto same_tri = tri;
+        SimplifySurface(same_pos, same_tri, 1.0f);
+        EXPECT(same_pos == pos && same_tri == tri);
+        SimplifySurface(pos, tri, 0.25f);
+        const size_t nt = tri.size() / 3;
+        EXPECT_NOTE(nt <= nt0 / 4 + 2 && nt >= nt0 / 8, std::string(c.Name) + ": " + std::to_string(nt) + " of " + std::to_string(nt0));
+        std::map<std::pair<uint32_t, uint32_t>, int> edges;
+        std::set<uint32_t> used;
+        for (size_t k = 0; k < tri.size(); k += 3)
+            for (int e = 0; e < 3; ++e) {
+                const uint32_t a = tri[k + e], b = tri[k + (e + 1) % 3];
+                EXPECT(a != b && a < pos.size());
+                ++edges[{std::min(a, b), std::max(a, b)}];
+                used.insert(a);
+            }
+        bool closed = true;
+        for (const auto &[edge, count] : edges) closed = closed && count == 2;
+        EXPECT_NOTE(closed, c.Name);
+        EXPECT(used.size() == pos.size()); // unreferenced vertices were dropped
+        EXPECT(int(pos.size()) - int(edges.size()) + int(nt) == c.Euler);
+        EXPECT_NOTE(check::near(volume(pos, tri), v0, 0.03), c.Name);
+        Surface coarse;
+        for (const auto &p : pos) coarse.P.push_back(dvec3(p));
+        coarse.T = tri;
+        const auto r = c.Fill ? tetra::Tetrahedralize(coarse.P, coarse.T) : tetra::Result{};
+        if (c.Fill) EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        if (c.Fill && r) {
+            const auto defect = ValidateGeneral(coarse, r.Mesh, true);
+            EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
+        }
+        std::printf("%12s: %zu -> %zu triangles, volume %.4f -> %.4f\n", c.Name, nt0, nt, v0, volume(pos, tri));
+    }
+}
+
 CASE(the_general_fill_reports_unsuitable_surfaces) {
     auto open = BoxSurface(1, 1, 1, 2);
     open.T.resize(open.T.size() - 3);

@@ -29,6 +29,20 @@ def test_library_exports_every_declared_symbol(core):
     assert not missing, missing
     # the binding declares a signature for every exported function it uses
     assert set(L._declared) <= set(declared)
+    # the boundary holds path entry points only: measurement and experiment entries live in libmodalhip_lab.so
+    assert not [n for n in declared if "bench" in n or "tridiagonalize" in n or "elementwise" in n]
+
+
+def test_lab_library_is_separate_from_the_product(core):
+    """libmodalhip_lab.so (timing loops, kernel variants called directly, the matrix-free operator) exports what its own header
+    declares; the product library exports none of it."""
+    from tools import lab
+    L = lab.lib()
+    header = open(os.path.join(ROOT, "mesheditor_amd", "csrc", "lab", "modalhip_lab.h")).read()
+    declared = sorted(set(re.findall(r"\b(mhl_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) == 5 and all(hasattr(L, n) for n in declared)
+    P = core.lib()
+    assert not [n for n in declared if hasattr(P, n)] and not hasattr(P, "mh_system_bench_spmm")
 
 
 def test_no_gpu_fails_loudly(core):

@@ -1,13 +1,30 @@
 """modal::SolveBatch through its Python binding (mesheditor_amd/batch.py): a one-rank RCCL communicator, one ncclAllGather per
 batch; the records must equal direct solves through the C ABI, and a failing mesh must surface after the gather."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 from mesheditor_amd import meshes
 
 pytestmark = pytest.mark.gpu
+INNER = os.environ.get("MH_BATCH_TESTS_INNER") == "1"
+inner = pytest.mark.skipif(not INNER, reason="runs in the fresh interpreter started by test_batch_driver_in_a_fresh_interpreter")
 
 
+@pytest.mark.skipif(INNER, reason="the outer test")
+def test_batch_driver_in_a_fresh_interpreter():
+    """The tests below run in an interpreter of their own: earlier tests of a whole-suite run import PyTorch, whose wheel bundles
+    a second copy of the ROCm runtime, and the system RCCL must not be bound against that copy (mesheditor_amd/batch.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider"], capture_output=True, text=True,
+                       timeout=900, cwd=root, env=dict(os.environ, MH_BATCH_TESTS_INNER="1"))
+    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@inner
 def test_record_layouts_agree():
     from mesheditor_amd import batch, sharding
     L = batch._lib()
@@ -15,6 +32,7 @@ def test_record_layouts_agree():
         assert int(L.mhx_batch_record_length(nev, pos)) == sharding.record_length(nev, pos)
 
 
+@inner
 def test_solve_batch_world_one_matches_direct_solves():
     from mesheditor_amd import api, batch
     items = []
@@ -41,6 +59,7 @@ def test_solve_batch_world_one_matches_direct_solves():
     ctx.close()
 
 
+@inner
 def test_a_failing_mesh_is_reported_after_the_gather():
     from mesheditor_amd import batch
     p, t = meshes.kuhn_box(4, 4, 4, 0.1, 0.1, 0.1)

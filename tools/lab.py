@@ -1,0 +1,71 @@
+"""ctypes binding of libmodalhip_lab.so (mesheditor_amd/csrc/lab): measurement and experiment entry points that are NOT part of
+the path's ABI -- timing loops around the product's kernels, the tridiagonalisation variants called directly, the matrix-free
+element-by-element operator.  Used by tests, tools/ and bench.py's secondary figures; the product never loads it."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO_PATH = os.path.join(ROOT, "mesheditor_amd", "libmodalhip_lab.so")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        from mesheditor_amd import _lib as core
+        core.lib()  # the product library first (the lab bench links it)
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(SO_PATH)
+        vp, u32, i32, f64p = C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_double)
+        L.mhl_system_bench_spmm.restype, L.mhl_system_bench_spmm.argtypes = i32, [vp, u32, u32, f64p, f64p]
+        L.mhl_system_bench_elementwise.restype, L.mhl_system_bench_elementwise.argtypes = i32, [vp, u32, u32, f64p]
+        L.mhl_system_elementwise_matvec.restype, L.mhl_system_elementwise_matvec.argtypes = i32, [vp, vp, vp, u32]
+        L.mhl_context_bench_dense.restype, L.mhl_context_bench_dense.argtypes = i32, [vp, i32, C.c_uint64, u32, u32, u32, f64p]
+        L.mhl_context_tridiagonalize.restype, L.mhl_context_tridiagonalize.argtypes = i32, [vp, i32, u32, vp, vp, vp, u32, f64p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def bench_spmm(system, width, reps=20):
+    """(average ms, algorithmic bytes) of one fp64 K x product over an n x width panel."""
+    ms, by = C.c_double(0), C.c_double(0)
+    system.ctx.check(lib().mhl_system_bench_spmm(system.h, width, reps, C.byref(ms), C.byref(by)))
+    return ms.value, by.value
+
+
+def bench_elementwise(system, width, reps=20):
+    ms = C.c_double(0)
+    system.ctx.check(lib().mhl_system_bench_elementwise(system.h, width, reps, C.byref(ms)))
+    return ms.value
+
+
+def elementwise_matvec(system, x):
+    """(K - sigma M) x at the reference's shift, element by element without the assembled matrix."""
+    x = np.asfortranarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    y = np.zeros_like(x, order="F")
+    system.ctx.check(lib().mhl_system_elementwise_matvec(system.h, _p(x), _p(y), x.shape[1]))
+    return y
+
+
+def bench_dense(ctx, kind, n, wa, wb, reps=10):
+    ms = C.c_double(0)
+    ctx.check(lib().mhl_context_bench_dense(ctx.h, kind, n, wa, wb, reps, C.byref(ms)))
+    return ms.value
+
+
+def tridiagonalize(ctx, a, variant=0, reps=1):
+    """(d, e, average ms) of the Householder tridiagonalisation of a symmetric matrix (order <= 256)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    m = a.shape[0]
+    d, e, ms = np.zeros(m), np.zeros(m - 1), C.c_double(0)
+    ctx.check(lib().mhl_context_tridiagonalize(ctx.h, variant, m, _p(a), _p(d), _p(e), reps, C.byref(ms)))
+    return d, e, ms.value

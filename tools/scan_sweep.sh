@@ -1,21 +1,14 @@
 #!/bin/bash
-# Preconditioner variations on the scan-like 30k-tet mesh (iterations and ms per solve); output: gpurun_out/r03a/scan_sweep.txt
-out=${1:-gpurun_out/r03a/scan_sweep.txt}
-wl=${2:-scan_s30k}
+# Preconditioner-cycle and patch variations on named workloads (iterations and ms per solve), on the GPU box:
+#   bash tools/scan_sweep.sh gpurun_out/sweep.txt scan_s30k scan_s100k cube_s100k
+# MH_CYCLE = degree of the P2 smoother, degree of the P1 smoother, P1 cycles per application, spectrum ratio (0 = built-in).
+out=${1:-gpurun_out/scan_sweep.txt}; shift
+wls=${@:-"cube_s30k scan_s30k scan_s100k"}
 mkdir -p $(dirname $out); : > $out
-run() { echo "== $*" >> $out; env "$@" python tools/scan_probe.py $wl --reps 1 2>&1 | grep workload | python -c "import sys,json; [print({k:r[k] for k in ('iterations','ms','eigenpairs')}) for r in map(json.loads, sys.stdin)]" >> $out; }
-run X=0
-run MH_PRECOND_FP64=1
-run MH_DEG2=4
-run MH_DEG2=6
-run MH_DEG1=8
-run MH_DEG2=4 MH_DEG1=8
-run MH_CHEB_RATIO=30 MH_DEG2=6 MH_DEG1=8
-run MH_CHEB_RATIO=30 MH_DEG2=6 MH_DEG1=8 MH_PRECOND_FP64=1
-run MH_AGG=8
-run MH_AGG=16
-run MH_AGG=64
-run MH_GAMMA=1
-run MH_GAMMA=6
-run MH_GUARD_ABS=40
+for v in "X=0" "MH_CYCLE=2,0,0,8" "MH_CYCLE=3,0,0,16" "MH_CYCLE=6,0,0,30" "MH_CYCLE=0,6,0,0" "MH_CYCLE=0,0,2,0" "MH_PATCH_Q=0" "MH_PATCH_Q=0.05" "MH_AGG=32" "MH_PRECOND_FP64=1"; do
+  echo "== $v" >> $out
+  env $v timeout 900 python tools/scan_probe.py $wls --reps 2 2>&1 | grep workload | python -c "import sys,json
+for l in sys.stdin:
+    r=json.loads(l); print(r['workload'], {k:(round(r[k],2) if isinstance(r.get(k),float) else r.get(k)) for k in ('iterations','ms','factorize_ms','max_rel_err_vs_oracle')})" >> $out
+done
 cat $out
