@@ -350,21 +350,60 @@ __global__ void k_bank_mix(const Real *__restrict__ click, uint32_t n_impacts, c
 }
 
 // Host-pinned staging buffer mirrored by a device buffer: every small per-block array travels in ONE copy each way.
+// The block's results leave through a copy kernel that writes them into the pinned arena and then raises a sequence number the
+// host spins on: a blit + hipStreamSynchronize costs the copy engine's completion signal and a thread wake-up (~40 us of a
+// 0.34 ms block); the spin sees the results ~2 us after the last kernel.  16-byte granules, one workgroup (the region is a few KB).
+__global__ void __launch_bounds__(256) k_bank_download(const uint4 *__restrict__ src, uint4 *__restrict__ dst_host, uint32_t n16, volatile uint32_t *flag_host, uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < n16; i += 256) dst_host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *flag_host = seq;
+        __threadfence_system();
+    }
+}
+
 struct Arena {
-    char *host{nullptr}, *dev{nullptr};
+    char *host{nullptr}, *dev{nullptr}, *host_seen_by_device{nullptr};
+    uint32_t *flag{nullptr}, *flag_seen_by_device{nullptr}; // pinned word the download kernel raises
+    uint32_t seq{0};
     size_t cap{0}, used{0};
     void reserve(size_t n) {
         if (n <= cap) return;
         release();
         cap = n + n / 2 + 4096;
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), cap, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), cap, hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&host_seen_by_device), host, 0));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&flag), 64, hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&flag_seen_by_device), flag, 0));
+        *flag = 0;
+        seq = 0;
         HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), cap));
     }
     void release() {
         if (host) (void)hipHostFree(host);
+        if (flag) (void)hipHostFree(flag);
         if (dev) (void)hipFree(dev);
-        host = dev = nullptr;
+        host = dev = host_seen_by_device = nullptr;
+        flag = flag_seen_by_device = nullptr;
         cap = 0;
+    }
+    // device [begin, end) -> host arena, then wait for it: spin on the flag, with the stream's own synchronisation as the way out
+    // of a stall (and the place where an asynchronous error would surface)
+    void download_and_wait(hipStream_t st, size_t begin, size_t end) {
+        const size_t b16 = begin / 16, e16 = (end + 15) / 16; // (offsets are 64-byte aligned)
+        ++seq;
+        k_bank_download<<<1, 256, 0, st>>>(reinterpret_cast<const uint4 *>(dev) + b16, reinterpret_cast<uint4 *>(host_seen_by_device) + b16, uint32_t(e16 - b16), flag_seen_by_device, seq);
+        HIP_CHECK(hipGetLastError());
+        const volatile uint32_t *f = flag;
+        for (uint64_t spin = 0; *f != seq; ++spin) {
+            __builtin_ia32_pause();
+            if (spin > (1ull << 22)) { // ~10 ms: not a normal block any more
+                HIP_CHECK(hipStreamSynchronize(st));
+                break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     size_t take(size_t bytes) {
         const size_t o = used;
@@ -523,8 +562,13 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     k_bank_mix<Real><<<div_up(frames, 64), 64, 0, st>>>(B.click, clicks_in_mix, B.rout, n_renderers, frames, d_out);
     KERNEL_CHECK();
     // ---- one copy back ----
-    HIP_CHECK(hipMemcpyAsync(A.host + both_begin, A.dev + both_begin, (n_dealt ? total : both_end) - both_begin, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    static const bool blit = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "bank_blit"); // A/B hook: the copy engine + stream synchronisation
+    if (blit) {
+        HIP_CHECK(hipMemcpyAsync(A.host + both_begin, A.dev + both_begin, (n_dealt ? total : both_end) - both_begin, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    } else {
+        A.download_and_wait(st, both_begin, n_dealt ? total : both_end);
+    }
     std::copy(A.h<Real>(o_out), A.h<Real>(o_out) + frames, out);
     if (n_dealt) {
         std::copy(A.h<double>(o_energy), A.h<double>(o_energy) + n_dealt, object_energy);

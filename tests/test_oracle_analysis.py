@@ -110,6 +110,24 @@ def test_eigs_against_scipy_arpack(oracle):
     assert prof["op_applications"] > nev
 
 
+@pytest.mark.parametrize("name", ["cube_small", "bar_thin", "bar_square", "cube_s10k"])
+def test_eigs_against_committed_scipy_values(oracle, name):
+    """G8 as data: the oracle's Cholesky + Lanczos restatement against SciPy ARPACK's committed eigenvalues of the same
+    pencils (tests/golden/scipy_eigs.json, made by tests/golden/make_scipy_fixtures.py) -- the 1e-9 anchor of the 1e-6 parity bar."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scipy_eigs.json")) as f:
+        fx = json.load(f)["cases"][name]
+    pts, tets, mat, _ = meshes.workload(name)
+    s = oracle.System(pts, tets, oracle.material(*mat))
+    assert s.n == fx["dofs"]
+    ev, _, _ = s.eigs(fx["nev"], vectors=False)
+    ref = np.array(fx["eigenvalues"])
+    rel = np.abs(ev - ref) / np.maximum(np.abs(ref), abs(SIGMA))
+    # (the 46k-DOF case sits at the two solvers' own stopping tolerances: 1.1e-9 measured)
+    assert rel.max() < (5e-9 if name == "cube_s10k" else 1e-9), rel.max()
+
+
 def _solve_bar(oracle, name):
     pts, tets, mat, _ = meshes.workload(name)
     return oracle.mesh2modes(pts, tets, oracle.material(*mat), pts.astype(np.float32)), mat
