@@ -343,4 +343,5 @@ bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_
                            uint32_t w); // mh_spmm.hip: product + Chebyshev step in one launch
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip
 void mh_spmm_mixed(mh_context *ctx, const BsrLevel &lvl, const float *x, double *y, uint32_t w); // double A x of a float panel
+const uint32_t *mh_identity_map(mh_context *ctx); // 0, 1, 2, ... (1 024 entries) on the device
 void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w); // mh_spmm.hip

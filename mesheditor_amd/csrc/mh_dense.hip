@@ -384,6 +384,15 @@ __global__ void k_iota(uint32_t *p, uint32_t n) {
 } // namespace
 
 // out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct  (+= when accumulate)
+const uint32_t *mh_identity_map(mh_context *ctx) {
+    if (!ctx->iota) {
+        ctx->iota = static_cast<uint32_t *>(ctx->pool.alloc(1024 * sizeof(uint32_t)));
+        k_iota<<<4, 256, 0, ctx->stream>>>(ctx->iota, 1024);
+        KERNEL_CHECK();
+    }
+    return ctx->iota;
+}
+
 void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const double *w, uint32_t ww, const double *p, uint32_t wp, const double *ct, uint32_t nc,
                 double *out1, uint32_t n1, double *out2, bool accumulate, uint32_t ldx, const uint32_t *xmap, uint32_t ld1, const uint32_t *omap, uint32_t col_begin,
                 uint32_t col_count) {
@@ -394,13 +403,8 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     const bool mapped = xmap != nullptr;
     if (mapped && accumulate) mh_throw(MH_EINVAL, "combine: column maps are not supported with accumulate");
     if (mapped && !omap) { // the mapped kernel writes out1 through a map: identity when the caller has none
-        if (!ctx->iota) {
-            ctx->iota = static_cast<uint32_t *>(ctx->pool.alloc(1024 * sizeof(uint32_t)));
-            k_iota<<<4, 256, 0, ctx->stream>>>(ctx->iota, 1024);
-            KERNEL_CHECK();
-        }
         if (n1 > 1024) mh_throw(MH_EINVAL, "combine: %u mapped output columns exceed 1024", n1);
-        omap = ctx->iota;
+        omap = mh_identity_map(ctx);
     }
     // Wide blocks (the 200-mode configuration: several hundred basis and output columns): the vendor dgemm reaches 50-65 TF/s
     // on these tall-skinny shapes where our 256-column chunks stay at 36 (tools/probe/gemm_probe.py).  Row-major panels are

@@ -716,7 +716,7 @@ template<typename T> struct Precond {
     mh_system *sys;
     mh_context *ctx;
     uint32_t wmax;
-    int deg2{2}, deg1{4}, gamma{3}; // measured at S100k (tools/precond_scan.sh): deg1 3 -> 4 saves one to two iterations for 1 ms of P1-level work
+    int deg2{2}, deg1{5}, gamma{3}; // measured at S100k: deg1 3 -> 4 saves one to two iterations for 1 ms of P1-level work; 4 -> 5 (with the graph-grown aggregates) one more for 0.5 ms
     double ratio{8.0};
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
     DevArray<double> r0, x0, x0_partial;

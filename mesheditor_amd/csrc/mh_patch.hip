@@ -19,9 +19,11 @@
 namespace {
 constexpr int TB = 256;
 
-__global__ void k_element_quality(const double *__restrict__ pts, const uint32_t *__restrict__ elem_ref, uint32_t stride, uint32_t nt, float *__restrict__ q) {
-    const uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
-    if (el >= nt) return;
+__global__ void k_element_quality(const double *__restrict__ pts, const uint32_t *__restrict__ elem_ref, uint32_t stride, uint32_t nt, float *__restrict__ q, float threshold,
+                                  uint32_t *__restrict__ summary) {
+    const uint32_t el_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = el_raw < nt;
+    const uint32_t el = valid ? el_raw : nt - 1; // (idle lanes recompute the last element: the wave reductions below need every lane)
     double v[4][3];
     for (int a = 0; a < 4; ++a)
         for (int d = 0; d < 3; ++d) v[a][d] = pts[3 * size_t(elem_ref[size_t(el) * stride + a]) + d];
@@ -34,7 +36,17 @@ __global__ void k_element_quality(const double *__restrict__ pts, const uint32_t
         for (int b = a + 1; b < 4; ++b)
             for (int d = 0; d < 3; ++d) e2 += (v[a][d] - v[b][d]) * (v[a][d] - v[b][d]);
     const double rms = sqrt(e2 / 6);
-    q[el] = rms > 0 ? float(vol * 8.485281374238571 / (rms * rms * rms)) : 0.f; // 1 for the regular tetrahedron
+    const float shape = rms > 0 ? float(vol * 8.485281374238571 / (rms * rms * rms)) : 0.f; // 1 for the regular tetrahedron
+    if (valid) q[el] = shape;
+    uint32_t below = valid && shape < threshold ? 1u : 0u, lowest = __float_as_uint(shape);
+    for (int off = 32; off > 0; off >>= 1) {
+        below += __shfl_xor(below, off, 64);
+        lowest = min(lowest, uint32_t(__shfl_xor(lowest, off, 64)));
+    }
+    if ((threadIdx.x & 63) == 0) { // (integer atomics: the order of arrival does not change the result)
+        if (below) atomicAdd(summary, below);
+        atomicMin(summary + 1, lowest);
+    }
 }
 
 // One 64-thread workgroup per patch: gather the (3 NPE)^2 principal submatrix from the BSR rows (columns ascending: binary
@@ -146,14 +158,19 @@ void mh_select_patches(mh_system *sys, float threshold) {
     sys->patches1.npe = 4;
     if (!(threshold > 0) || nt == 0) return;
     DevArray<float> q(ctx, nt);
-    k_element_quality<<<div_up(nt, TB), TB, 0, st>>>(sys->points, sys->elem_nodes_ref, 10, nt, q);
+    DevArray<uint32_t> summary(ctx, 2); // [0]: elements below the threshold, [1]: the smallest shape measure (bits of a positive float order as integers)
+    const uint32_t init[2] = {0u, 0x7f7fffffu};
+    summary.upload(init, 2);
+    k_element_quality<<<div_up(nt, TB), TB, 0, st>>>(sys->points, sys->elem_nodes_ref, 10, nt, q, threshold, summary);
     KERNEL_CHECK();
+    uint32_t hs[2];
+    summary.download(hs, 2);
+    memcpy(&sys->worst_quality, &hs[1], sizeof(float));
+    if (hs[0] == 0) return; // a well-shaped mesh (every Kuhn workload): eight bytes came back, nothing else happens
     const std::vector<float> hq = q.to_host();
     std::vector<uint32_t> bad;
     for (uint32_t e = 0; e < nt; ++e)
         if (hq[e] < threshold) bad.push_back(e);
-    sys->worst_quality = nt ? *std::min_element(hq.begin(), hq.end()) : 1.f;
-    if (bad.empty()) return;
     // node lists of the bad elements, both levels (internal numbering)
     std::vector<uint32_t> en(size_t(nt) * 10), ep(size_t(nt) * 4);
     HIP_CHECK(hipMemcpyAsync(en.data(), sys->elem_nodes.get(), en.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

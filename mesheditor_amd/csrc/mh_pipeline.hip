@@ -555,8 +555,14 @@ uint32_t graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vecto
         for (uint32_t i = 0; i < n; ++i) agg_of[i] = fresh[into[agg_of[i]]];
         na = k;
     };
+    // (the aggregate graph costs a sort of every cross-aggregate connection: built only when something has to be merged)
+    size.assign(na, 0);
+    for (uint32_t i = 0; i < n; ++i) ++size[agg_of[i]];
+    const bool any_tiny = std::any_of(size.begin(), size.end(), [](uint32_t s) { return s < 4; });
+    const bool merging = uint64_t(n) * 3 < uint64_t(na) * target * 2 || uint64_t(6) * na > max_order;
+    if (!any_tiny && !merging) return na;
     rebuild();
-    { // small aggregates join their most connected neighbour (one pass; a chain of tiny ones ends in a proper one or stays)
+    if (any_tiny) { // small aggregates join their most connected neighbour (one pass; a chain of tiny ones ends in a proper one or stays)
         std::vector<uint32_t> into(na);
         for (uint32_t a = 0; a < na; ++a) into[a] = a;
         bool any = false;
