@@ -1,7 +1,15 @@
 // The tet-generation front end of the path, under the contract of the reference's
-// tetra::Tetrahedralize (src/mesh/Tetrahedralize.h:49-61): input vertex i keeps index i, every input triangle is on the
-// boundary, triangle winding is ignored, every tet is positively oriented, and an open or unrecoverable surface returns an
-// error string.  Two fills:
+// tetra::Tetrahedralize (src/mesh/Tetrahedralize.h:49-61): input vertex i keeps index i, triangle winding is ignored, every
+// tet is positively oriented, the tets fill exactly the enclosed volume, and an open or unrecoverable surface returns an error
+// string.  Where the general fill DEPARTS from that contract:
+//   * input triangles are not kept whole: missing edges and faces are recovered by points ON the surface, so the output's
+//     boundary refines the input triangulation (Result::BoundarySteinerCount says by how many points; 0 = the input surface
+//     appears exactly, which callers needing surface-to-tet vertex identity must check);
+//   * internal walls (an edge shared by an odd number of triangles) are rejected as "open", duplicate positions as
+//     "point coincides" -- the reference accepts non-manifold input;
+//   * no sliver repair, no quality refinement (the reference's Options::Quality / MaxVolume have no counterpart);
+//   * fans of needle triangles can exhaust the refinement budget: "did not converge" instead of a mesh.
+// Two fills:
 //   tetra::Tetrahedralize   any closed, non-self-intersecting surface -- non-convex, non-star-shaped, any genus, nested
 //                           cavities: a conforming Delaunay tetrahedralisation on exact predicates.  Surface triangles the
 //                           Delaunay mesh lacks are recovered by splitting them (points ON the surface, as the reference's
