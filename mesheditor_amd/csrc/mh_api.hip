@@ -132,8 +132,7 @@ int mh_context_create(int device, mh_context **out) {
         fprintf(stderr, "modalhip: %s\n", e.what());
         if (ctx->blas) rocblas_destroy_handle(ctx->blas);
         if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-        if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return code;
     }
