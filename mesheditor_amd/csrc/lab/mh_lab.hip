@@ -28,6 +28,15 @@ __global__ void k_lab_panel_to_ref(const double *__restrict__ panel, const uint3
 } // namespace
 
 extern "C" {
+// The rigid-body level's graph aggregation (host code, no device): CSR graph of a level's node blocks in, aggregate of every node
+// out; returns the aggregate count.
+uint32_t mhl_graph_aggregates(const uint32_t *row_ptr, const uint32_t *col, uint32_t n, uint32_t target, uint32_t max_order, uint32_t *agg_of) {
+    std::vector<uint32_t> rp(row_ptr, row_ptr + n + 1), cl(col, col + row_ptr[n]), out;
+    const uint32_t na = mh_graph_aggregates(rp, cl, n, target, max_order, out);
+    std::copy(out.begin(), out.end(), agg_of);
+    return na;
+}
+
 // y = (K - sigma M) x at the reference's shift, element by element without the assembled matrix (atomic scatter: equal to
 // mh_system_matvec(which = 2) up to rounding, not bit-reproducible).  x, y: column-major n x width, the reference's DOF order.
 int mhl_system_elementwise_matvec(mh_system *s, const double *x, double *y, uint32_t width) {

@@ -602,6 +602,11 @@ uint32_t graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vecto
 }
 } // namespace
 
+// (for the lab library and its CPU test: the aggregation is host code, checkable without a device)
+uint32_t mh_graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col, uint32_t n, uint32_t target, uint32_t max_order, std::vector<uint32_t> &agg_of) {
+    return graph_aggregates(row_ptr, col, n, target, max_order, agg_of);
+}
+
 __global__ void k_shift_values(const double *__restrict__ kval, const double *__restrict__ mval, size_t nblocks, double sigma, double *__restrict__ aval) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nblocks * 9) return;

@@ -40,7 +40,7 @@ def test_lab_library_is_separate_from_the_product(core):
     L = lab.lib()
     header = open(os.path.join(ROOT, "mesheditor_amd", "csrc", "lab", "modalhip_lab.h")).read()
     declared = sorted(set(re.findall(r"\b(mhl_[a-z0-9_]+)\s*\(", header)))
-    assert len(declared) == 5 and all(hasattr(L, n) for n in declared)
+    assert len(declared) == 6 and all(hasattr(L, n) for n in declared)
     P = core.lib()
     assert not [n for n in declared if hasattr(P, n)] and not hasattr(P, "mh_system_bench_spmm")
 
@@ -128,3 +128,42 @@ def test_host_mirror_contact_model(oracle):
     H.mhx_recoil_object_filter(0.05, 5e-4, 48000.0, p(fa))
     O.mo_recoil_object_filter(0.05, 5e-4, 48000.0, p(fb))
     assert np.array_equal(fa, fb) and fa[0] != 0
+
+
+def _p1_graph(tets, n_points):
+    import scipy.sparse as sp
+    t = tets.astype(np.int64)
+    i = np.repeat(t, 4, axis=1).ravel()
+    j = np.tile(t, (1, 4)).ravel()
+    g = sp.coo_matrix((np.ones(len(i)), (i, j)), shape=(n_points, n_points)).tocsr()
+    g.sort_indices()
+    return g
+
+
+@pytest.mark.parametrize("name", ["cube_s10k", "scan_s30k"])
+def test_graph_aggregates_are_connected_sets(core, name):
+    """The rigid-body level's aggregates (host code in libmodalhip, reached through the lab library): every P1 node in exactly one
+    aggregate, every aggregate a CONNECTED set of the P1 graph with at least four nodes, the coarse order within its cap, the
+    result deterministic -- on a Kuhn grid and on the scan-like mesh whose Morton-run aggregates were the round-2 solver's undoing."""
+    import scipy.sparse.csgraph as cg
+    from tools import lab
+    pts, tets, _, _ = meshes.workload(name)
+    g = _p1_graph(tets, len(pts))
+    agg, na = lab.graph_aggregates(g.indptr, g.indices)
+    agg2, na2 = lab.graph_aggregates(g.indptr, g.indices)
+    assert na == na2 and np.array_equal(agg, agg2)
+    assert agg.max() == na - 1 and 6 * na <= 6144
+    sizes = np.bincount(agg, minlength=na)
+    assert sizes.min() >= 4 and 8 <= sizes.mean() <= 64
+    same = agg[g.nonzero()[0]] == agg[g.nonzero()[1]]
+    inside = g.tocoo()
+    import scipy.sparse as sp
+    kept = sp.coo_matrix((np.ones(same.sum()), (inside.row[same], inside.col[same])), shape=g.shape)
+    ncomp, label = cg.connected_components(kept, directed=False)
+    assert ncomp == na, (ncomp, na)  # within-aggregate edges alone connect each aggregate
+    # a cap forces merging: still connected, fewer aggregates
+    agg3, na3 = lab.graph_aggregates(g.indptr, g.indices, target=16, max_order=6 * (na // 3))
+    assert na3 <= na // 3 and len(np.unique(agg3)) == na3
+    same3 = agg3[inside.row] == agg3[inside.col]
+    ncomp3, _ = cg.connected_components(sp.coo_matrix((np.ones(same3.sum()), (inside.row[same3], inside.col[same3])), shape=g.shape), directed=False)
+    assert ncomp3 == na3

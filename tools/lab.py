@@ -25,6 +25,7 @@ def lib():
         L.mhl_system_elementwise_matvec.restype, L.mhl_system_elementwise_matvec.argtypes = i32, [vp, vp, vp, u32]
         L.mhl_context_bench_dense.restype, L.mhl_context_bench_dense.argtypes = i32, [vp, i32, C.c_uint64, u32, u32, u32, f64p]
         L.mhl_context_tridiagonalize.restype, L.mhl_context_tridiagonalize.argtypes = i32, [vp, i32, u32, vp, vp, vp, u32, f64p]
+        L.mhl_graph_aggregates.restype, L.mhl_graph_aggregates.argtypes = u32, [vp, vp, u32, u32, u32, vp]
         _LIB = L
     return _LIB
 
@@ -69,3 +70,13 @@ def tridiagonalize(ctx, a, variant=0, reps=1):
     d, e, ms = np.zeros(m), np.zeros(m - 1), C.c_double(0)
     ctx.check(lib().mhl_context_tridiagonalize(ctx.h, variant, m, _p(a), _p(d), _p(e), reps, C.byref(ms)))
     return d, e, ms.value
+
+
+def graph_aggregates(row_ptr, col, target=16, max_order=6144):
+    """(aggregate of every node, aggregate count) for a CSR node graph with its diagonal entries (host code, no device)."""
+    rp = np.ascontiguousarray(row_ptr, np.uint32)
+    cl = np.ascontiguousarray(col, np.uint32)
+    n = len(rp) - 1
+    out = np.zeros(n, np.uint32)
+    na = lib().mhl_graph_aggregates(_p(rp), _p(cl), n, target, max_order, _p(out))
+    return out, int(na)
