@@ -339,7 +339,9 @@ void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, co
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);
 void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w, uint32_t ldy,
-                    uint32_t wreal, const uint32_t *omap); // mh_spmm.hip: results into mapped columns of wider panels
+                    uint32_t wreal, const uint32_t *omap, const double *res_theta = nullptr, double *res_out = nullptr, double *res_partial = nullptr,
+                    const double *res_dinv = nullptr); // mh_spmm.hip: results into mapped columns of wider panels; optional residual epilogue (w <= 128):
+                                                       // res_out (n x w) = A x - theta M x, res_partial (n_nodes x 2 x w) = per-node sums of r^2 and (M x)^2 (weighted by res_dinv)
 bool mh_spmm_f32_cheb_step(mh_context *ctx, const BsrLevel &lvl, const float *d_in, float *d_out, float *r, float *x, const float *dinv, float c1, float c2,
                            uint32_t w); // mh_spmm.hip: product + Chebyshev step in one launch
 void mh_spmm_f32(mh_context *ctx, const BsrLevel &lvl, const float *x, float *y, uint32_t w); // mh_spmm.hip

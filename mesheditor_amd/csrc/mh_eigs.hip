@@ -375,6 +375,15 @@ __global__ void k_colsumsq_partial(const double *__restrict__ x, size_t rows, ui
     }
     partial[size_t(blockIdx.x) * w + c] = s;
 }
+// Column sums (not of squares) of an n x w panel in row blocks: first stage for the per-node norm partials of the fused residual
+__global__ void k_colsum_partial(const double *__restrict__ x, size_t rows, uint32_t w, double *__restrict__ partial, uint32_t rows_per_block) {
+    const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= w) return;
+    const size_t r0 = size_t(blockIdx.x) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    double s = 0;
+    for (size_t r = r0; r < r1; ++r) s += x[r * w + c];
+    partial[size_t(blockIdx.x) * w + c] = s;
+}
 // one 256-thread block per column: strided partial sums, then a fixed binary tree in LDS
 __global__ void k_colsumsq_final(const double *__restrict__ partial, uint32_t nblocks, uint32_t w, double *__restrict__ out) {
     __shared__ double s[256];
@@ -1044,7 +1053,14 @@ struct BlockLobpcg {
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
     DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
-    DevArray<uint32_t> idx_d;
+    DevArray<uint32_t> idx_d, pos_d;
+    // The residuals of the active columns as the image product's epilogue leaves them (mh_spmm_mapped): compact panel of pitch
+    // res_pitch for the columns res_act, per-node norm partials, the reduced norms [2][res_pitch]
+    DevArray<double> Rr, res_partial, res_blocks, res_norms_d;
+    std::vector<uint32_t> res_act;
+    std::vector<double> res_norms;
+    uint32_t res_pitch = 0;
+    bool res_ready = false, rw_from_rr = false;
     DevArray<int> info; // [1]: conditioning report of mh_potrf_small
     std::unique_ptr<Precond<float>> prec32;
     std::unique_ptr<Precond<double>> prec64;
@@ -1093,6 +1109,15 @@ struct BlockLobpcg {
         Ct.reset(ctx, size_t(mmax) * 2 * b);
         norms_d.reset(ctx, 3 * size_t(b));
         idx_d.reset(ctx, b);
+        pos_d.reset(ctx, b);
+        if (b <= 128) { // (the epilogue covers panels of up to 128 columns; wider blocks keep the separate residual pass)
+            const uint32_t pmax = (b + 1u) & ~1u;
+            Rr.reset(ctx, n * pmax);
+            res_partial.reset(ctx, size_t(2) * sys->n_nodes * pmax);
+            res_blocks.reset(ctx, size_t(div_up(sys->n_nodes, 256)) * 2 * pmax);
+            res_norms_d.reset(ctx, size_t(2) * pmax);
+            res_norms.resize(size_t(2) * pmax);
+        }
         info.reset(ctx, 2);
         if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, b);
         else prec64 = std::make_unique<Precond<double>>(sys, b);
@@ -1234,6 +1259,18 @@ struct BlockLobpcg {
             iterating.release();
             iterating.acquire();
         }
+        bool fused = res_ready;
+        if (fused) // the rounding-floor clause needs ||x|| of the pairs near the shift: with one of them still active the separate pass runs
+            for (const uint32_t i : res_act) fused = fused && !(std::abs(theta[i]) < 10.0 * std::abs(sigma));
+        res_ready = false;
+        rw_from_rr = fused;
+        if (fused) {
+            res_norms_d.download(res_norms.data(), size_t(2) * res_pitch);
+            for (size_t k = 0; k < res_act.size(); ++k) {
+                rn[res_act[k]] = res_norms[k];
+                mn[res_act[k]] = res_norms[res_pitch + k];
+            }
+        } else {
         theta_d.upload(theta.data(), b);
         {
             const uint32_t rpb = 256, nblk = div_up(n, rpb);
@@ -1247,6 +1284,7 @@ struct BlockLobpcg {
             std::copy(norms.begin(), norms.begin() + b, rn.begin());
             std::copy(norms.begin() + b, norms.begin() + 2 * b, mn.begin());
             std::copy(norms.begin() + 2 * b, norms.end(), xn.begin());
+        }
         }
         act.clear();
         for (uint32_t i = 0; i < b; ++i) {
@@ -1302,16 +1340,34 @@ struct BlockLobpcg {
     void search_directions(uint32_t it) {
         w = uint32_t(act.size());
         idx_d.upload(act.data(), w);
-        k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
-        KERNEL_CHECK();
+        const double *residuals = Rw.get();
+        if (rw_from_rr) { // the epilogue's compact panel holds the previous active set; today's is a subset of it
+            if (act == res_act && res_pitch == w) {
+                residuals = Rr.get(); // nothing was locked and the pitch is the count: the panel is the input as it stands
+            } else {
+                std::vector<uint32_t> pos(w);
+                size_t q = 0;
+                for (uint32_t k = 0; k < w; ++k) {
+                    while (q < res_act.size() && res_act[q] != act[k]) ++q;
+                    if (q == res_act.size()) mh_throw(MH_EHIP, "active column %u was not active before", act[k]);
+                    pos[k] = uint32_t(q);
+                }
+                pos_d.upload(pos.data(), w);
+                k_gather_cols<<<grid1(n * w), TB, 0, st>>>(Rr, pos_d, Rw, n, res_pitch, w);
+                KERNEL_CHECK();
+            }
+        } else {
+            k_gather_cols<<<grid1(n * w), TB, 0, st>>>(R, idx_d, Rw, n, b, w);
+            KERNEL_CHECK();
+        }
         // The Rayleigh-Ritz basis is [X_active W P]; the active columns of X, A X, M X are addressed in place through
         // the index list idx_d (column maps of the Gram and basis-update kernels), never copied out.
         for (uint32_t k = 0; k < w; ++k) theta_act[k] = theta[act[k]];
         theta_act_d.upload(theta_act.data(), w);
         {
             Timer tp(ctx);
-            if (prec32) prec32->apply(Rw, W, w);
-            else prec64->apply(Rw, W, w);
+            if (prec32) prec32->apply(residuals, W, w);
+            else prec64->apply(residuals, W, w);
             precond_seconds += tp.stop();
             prof.op_applications += w;
         }
@@ -1532,7 +1588,21 @@ struct BlockLobpcg {
             if (pitch == wa) k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), idx_d, X.get(), n, b, wa);
             else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
             KERNEL_CHECK();
-            mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d);
+            if (Rr.count) {
+                // the new Ritz values sit in `evals` in the active slots' order: the residuals and their norms leave with the images
+                mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d, evals, Rr, res_partial, scaled_norms ? sys->L2.dinv.get() : nullptr);
+                const uint32_t rpb = 256, nblk = div_up(sys->n_nodes, rpb), w2 = 2 * pitch;
+                dim3 grid(nblk, div_up(w2, 64));
+                k_colsum_partial<<<grid, 64, 0, st>>>(res_partial, sys->n_nodes, w2, res_blocks, rpb); // rows of res_partial: [node][2][pitch]
+                KERNEL_CHECK();
+                k_colsumsq_final<<<w2, 256, 0, st>>>(res_blocks, nblk, w2, res_norms_d);
+                KERNEL_CHECK();
+                res_act = act;
+                res_pitch = pitch;
+                res_ready = true;
+            } else {
+                mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d);
+            }
         }
         std::swap(P, Pn); std::swap(MP, MPn);
         wp = wp_new;

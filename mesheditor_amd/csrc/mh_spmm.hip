@@ -129,6 +129,16 @@ struct ChebStep {
     float *x = nullptr;
     float c1 = 0.f, c2 = 0.f;
 };
+// MAPOUT with a residual epilogue: the rows of A x and M x are in registers when they are stored, and theta is known, so the
+// eigen-residual r = A x - theta M x of the row goes out beside them (compact panel of the launch's own pitch) together with
+// the row's contributions to ||r||^2 and ||M x||^2 per column (optionally in the Jacobi scaling): the separate residual pass over
+// A X, M X (three panel passes per iteration) and the column gather after it are not needed.  partial: [node][2][pitch].
+struct ResidualEpilogue {
+    const double *theta = nullptr; // per mapped column
+    double *r_out = nullptr;       // n x pitch
+    double *partial = nullptr;     // n_nodes x 2 x pitch
+    const double *dinv = nullptr;  // 3 n_nodes weights, or null
+};
 #ifdef MH_SPMM_WAVES
 #define MH_SPMM_OCC __attribute__((amdgpu_waves_per_eu(MH_SPMM_WAVES, 8)))
 #else
@@ -142,7 +152,7 @@ template<typename TV, typename TX, typename TY, int V, int CL, bool WITH_M, bool
 __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const TV *__restrict__ vals9,
                                                  const TV *__restrict__ mscal, const TX *__restrict__ x, TY *__restrict__ y, TY *__restrict__ y2, uint32_t nnodes,
                                                  uint32_t w, int xcd_remap, uint32_t ldy = 0, uint32_t wreal = 0, const uint32_t *__restrict__ omap = nullptr, ChebStep epi = ChebStep{},
-                                                 uint32_t xpitch = 0) { // xpitch (MAPOUT): row pitch of x when the launch covers a column range of a wider panel
+                                                 uint32_t xpitch = 0, ResidualEpilogue res = ResidualEpilogue{}) { // xpitch (MAPOUT): row pitch of x when the launch covers a column range of a wider panel
     constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = UR; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
@@ -302,6 +312,23 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
                 if (WITH_A) { y[o] = acc[0][e]; y[o + ldy] = acc[1][e]; y[o + 2 * size_t(ldy)] = acc[2][e]; }
                 if (WITH_M) { y2[o] = macc[0][e]; y2[o + ldy] = macc[1][e]; y2[o + 2 * size_t(ldy)] = macc[2][e]; }
             }
+            if constexpr (WITH_A && WITH_M && std::is_same<TY, double>::value && V == 2) {
+                if (res.r_out) { // (launches that cover the whole panel in one column range: pitch w = xpitch)
+                    Acc th, sr = Acc(0), sm = Acc(0);
+                    th[0] = res.theta[coff];
+                    th[1] = res.theta[coff + 1]; // (the pad column of an odd count reads one entry past the active ones: the array is longer)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const Acc r = acc[i] - th * macc[i];
+                        const TY wgt = res.dinv ? res.dinv[size_t(3) * row + i] : TY(1);
+                        *reinterpret_cast<Acc *>(res.r_out + (size_t(3) * row + i) * w + coff) = r;
+                        sr += wgt * (r * r);
+                        sm += wgt * (macc[i] * macc[i]);
+                    }
+                    *reinterpret_cast<Acc *>(res.partial + (size_t(2) * row) * w + coff) = sr;
+                    *reinterpret_cast<Acc *>(res.partial + (size_t(2) * row + 1) * w + coff) = sm;
+                }
+            }
         }
         return;
     }
@@ -429,8 +456,17 @@ void mh_spmm(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const do
 
 // A x and M x of an n x w panel (w even, 16-byte aligned) written to columns omap[c], c < wreal, of panels of pitch ldy.
 void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, const double *x, double *y, const double *mscal, double *y2, uint32_t w, uint32_t ldy,
-                    uint32_t wreal, const uint32_t *omap) {
+                    uint32_t wreal, const uint32_t *omap, const double *res_theta, double *res_out, double *res_partial, const double *res_dinv) {
     if (w == 0 || wreal == 0) return;
+    ResidualEpilogue res;
+    if (res_out && w <= 128) { // one column range covers the panel: the epilogue's compact pitch is the panel's
+        res.theta = res_theta;
+        res.r_out = res_out;
+        res.partial = res_partial;
+        res.dinv = res_dinv;
+    } else if (res_out) {
+        mh_throw(MH_EINVAL, "residual epilogue needs a panel of at most 128 columns (got %u)", w);
+    }
     if (w % 2 || (reinterpret_cast<uintptr_t>(x) & 15)) mh_throw(MH_EINVAL, "mapped product needs an even pitch and an aligned panel (got %u)", w);
     constexpr int xcd = 1;
     const unsigned grid = (div_up(lvl.n_nodes, TB / 64) + 7) / 8 * 8;
@@ -438,11 +474,12 @@ void mh_spmm_mapped(mh_context *ctx, const BsrLevel &lvl, const double *vals9, c
     const uint32_t ranges = div_up(w, 128u), step = (div_up(w, ranges) + 1u) & ~1u;
     for (uint32_t c0 = 0; c0 < wreal; c0 += step) {
         const uint32_t wc = std::min(step, w - c0), wr = std::min(wc, wreal - c0);
-        TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, wr, 8, 8, 8, true, true));
+        // (with the residual epilogue: one more panel written, and the two norm partials per node and column)
+        TimedLaunch timed(ctx, MH_KERNEL_SPMM, spmm_bytes(lvl, wr, 8, 8, 8, true, true) + (res.r_out ? 8.0 * double(wr) * (3.0 + 2.0) * double(lvl.n_nodes) : 0.0));
         auto go = [&](auto cl_tag) {
             constexpr int CL = decltype(cl_tag)::value;
             k_spmm_wide<double, double, double, 2, CL, true, true, true><<<grid, TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, vals9, mscal, x + c0, y, y2, lvl.n_nodes, wc, xcd, ldy, wr, omap + c0,
-                                                                                                  ChebStep{}, w);
+                                                                                                  ChebStep{}, w, res);
         };
         const uint32_t lanes = wc / 2;
         if (lanes <= 8) go(std::integral_constant<int, 8>{});
