@@ -1057,7 +1057,7 @@ struct BlockLobpcg {
     // The residuals of the active columns as the image product's epilogue leaves them (mh_spmm_mapped): compact panel of pitch
     // res_pitch for the columns res_act, per-node norm partials, the reduced norms [2][res_pitch]
     DevArray<double> Rr, res_partial, res_blocks, res_norms_d;
-    std::vector<uint32_t> res_act;
+    std::vector<uint32_t> res_act, res_pos; // (res_pos: a member so that its asynchronous upload never outlives it)
     std::vector<double> res_norms;
     uint32_t res_pitch = 0;
     bool res_ready = false, rw_from_rr = false;
@@ -1345,7 +1345,8 @@ struct BlockLobpcg {
             if (act == res_act && res_pitch == w) {
                 residuals = Rr.get(); // nothing was locked and the pitch is the count: the panel is the input as it stands
             } else {
-                std::vector<uint32_t> pos(w);
+                std::vector<uint32_t> &pos = res_pos;
+                pos.assign(w, 0);
                 size_t q = 0;
                 for (uint32_t k = 0; k < w; ++k) {
                     while (q < res_act.size() && res_act[q] != act[k]) ++q;
