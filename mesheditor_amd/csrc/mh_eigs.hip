@@ -1114,7 +1114,7 @@ struct BlockLobpcg {
             const uint32_t pmax = (b + 1u) & ~1u;
             Rr.reset(ctx, n * pmax);
             res_partial.reset(ctx, size_t(2) * sys->n_nodes * pmax);
-            res_blocks.reset(ctx, size_t(div_up(sys->n_nodes, 256)) * 2 * pmax);
+            res_blocks.reset(ctx, size_t(div_up(sys->n_nodes, 48)) * 2 * pmax);
             res_norms_d.reset(ctx, size_t(2) * pmax);
             res_norms.resize(size_t(2) * pmax);
         }
@@ -1592,7 +1592,7 @@ struct BlockLobpcg {
             if (Rr.count) {
                 // the new Ritz values sit in `evals` in the active slots' order: the residuals and their norms leave with the images
                 mh_spmm_mapped(ctx, sys->L2, sys->L2.aval, Xn, AX, sys->L2.mval, MX, pitch, b, wa, idx_d, evals, Rr, res_partial, scaled_norms ? sys->L2.dinv.get() : nullptr);
-                const uint32_t rpb = 256, nblk = div_up(sys->n_nodes, rpb), w2 = 2 * pitch;
+                const uint32_t rpb = 48, nblk = div_up(sys->n_nodes, rpb), w2 = 2 * pitch; // (short row blocks: ~9 k waves instead of ~2 k for the 190 MB of partials)
                 dim3 grid(nblk, div_up(w2, 64));
                 k_colsum_partial<<<grid, 64, 0, st>>>(res_partial, sys->n_nodes, w2, res_blocks, rpb); // rows of res_partial: [node][2][pitch]
                 KERNEL_CHECK();
