@@ -273,6 +273,11 @@ struct mh_system {
     DevArray<uint32_t> agg_of, agg_ptr, agg_nodes; // P1 node -> aggregate; aggregate -> its nodes (ascending), CSR
     DevArray<double> agg_t; // n_points x 18: the 3x6 tentative-prolongator block of each P1 node (row-major)
     DevArray<double> a0; // (6 n_agg)^2 column-major: the coarse operator, replaced by its explicit inverse at set-up
+    // Connected bodies of the mesh (components of the P1 graph): each is a free body with six rigid-body modes of its own.  A scan
+    // with stray fragments has several; the eigensolver seeds the exact modes of every one (mh_eigs.hip: start).
+    uint32_t n_components{1};
+    DevArray<uint32_t> node_component; // n_nodes (P2, internal numbering)
+    DevArray<double> component_centroid; // n_components x 3
     PatchSet patches2, patches1; // sliver patches of the two smoothed levels (empty on well-shaped meshes)
     DevArray<uint32_t> elem_p1;  // kept_tets x 4, internal P1 numbering
     float worst_quality{1.f};    // smallest element shape measure (1 = regular tetrahedron)

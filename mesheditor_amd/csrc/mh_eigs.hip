@@ -489,18 +489,24 @@ __global__ void k_load_seed(const float *__restrict__ seed, const uint32_t *__re
     const uint32_t c = uint32_t(i % ncols), comp = uint32_t((i / ncols) % 3), node = uint32_t(i / (size_t(3) * ncols));
     x[(size_t(3) * node + comp) * b + c] = double(seed[size_t(c) * (size_t(3) * nnodes) + size_t(3) * perm[node] + comp]);
 }
-// Exact rigid-body modes (three translations, three rotations about the centroid) into panel columns col0..col0+5
-__global__ void k_inject_rbm(const double *__restrict__ xyz, uint32_t nnodes, double3 c, double *__restrict__ x, uint32_t b, uint32_t col0) {
+// Exact rigid-body modes of every connected body (three translations, three rotations about the body's centroid) into panel
+// columns col0 + 6 c .. col0 + 6 c + 5 for body c: a node carries its own body's modes and zeros in the others' columns
+__global__ void k_inject_rbm(const double *__restrict__ xyz, const uint32_t *__restrict__ component, const double *__restrict__ centroid, uint32_t ncomp, uint32_t nnodes,
+                             double *__restrict__ x, uint32_t b, uint32_t col0) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnodes) return;
-    const double rx = xyz[3 * size_t(i)] - c.x, ry = xyz[3 * size_t(i) + 1] - c.y, rz = xyz[3 * size_t(i) + 2] - c.z;
-    double *r0 = x + (size_t(3) * i) * b + col0, *r1 = r0 + b, *r2 = r1 + b;
-    r0[0] = 1; r1[0] = 0; r2[0] = 0;
-    r0[1] = 0; r1[1] = 1; r2[1] = 0;
-    r0[2] = 0; r1[2] = 0; r2[2] = 1;
-    r0[3] = 0; r1[3] = -rz; r2[3] = ry; // e_x x r
-    r0[4] = rz; r1[4] = 0; r2[4] = -rx; // e_y x r
-    r0[5] = -ry; r1[5] = rx; r2[5] = 0; // e_z x r
+    const uint32_t mine = component[i];
+    const double rx = xyz[3 * size_t(i)] - centroid[3 * size_t(mine)], ry = xyz[3 * size_t(i) + 1] - centroid[3 * size_t(mine) + 1], rz = xyz[3 * size_t(i) + 2] - centroid[3 * size_t(mine) + 2];
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        double *r0 = x + (size_t(3) * i) * b + col0 + 6 * c, *r1 = r0 + b, *r2 = r1 + b;
+        const double on = c == mine ? 1.0 : 0.0;
+        r0[0] = on; r1[0] = 0; r2[0] = 0;
+        r0[1] = 0; r1[1] = on; r2[1] = 0;
+        r0[2] = 0; r1[2] = 0; r2[2] = on;
+        r0[3] = 0; r1[3] = -rz * on; r2[3] = ry * on; // e_x x r
+        r0[4] = rz * on; r1[4] = 0; r2[4] = -rx * on; // e_y x r
+        r0[5] = -ry * on; r1[5] = rx * on; r2[5] = 0; // e_z x r
+    }
 }
 __global__ void k_copy_cols(const double *__restrict__ src, uint32_t wsrc, double *__restrict__ dst, uint32_t wdst, size_t rows, uint32_t ncols) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1199,18 +1205,19 @@ struct BlockLobpcg {
             KERNEL_CHECK();
             HIP_CHECK(hipStreamSynchronize(st));
         }
-        if (b >= 12) {
-            // A free body's six rigid-body modes are exact eigenvectors (lambda = 0): start from them -- also on a warm
-            // start, where they replace the six seeded (single-precision) copies: a rigid mode known only to 1e-7
-            // leaves A x = |sigma| M x as the difference of terms 12 orders larger, and its Ritz value is then noise.
-            auto hx = sys->node_xyz.to_host();
-            double c[3] = {0, 0, 0};
-            for (uint32_t i = 0; i < sys->n_nodes; ++i)
-                for (int d = 0; d < 3; ++d) c[d] += hx[3 * size_t(i) + d];
-            for (double &v : c) v /= double(sys->n_nodes);
-            k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
+        // A free body's six rigid-body modes are exact eigenvectors (lambda = 0): start from them -- also on a warm start, where
+        // they replace the seeded (single-precision) copies: a rigid mode known only to 1e-7 leaves A x = |sigma| M x as the
+        // difference of terms 12 orders larger, and its Ritz value is then noise.  A mesh of several disconnected bodies (a scan
+        // with stray fragments) has six such modes per body; all of them are seeded.
+        const uint32_t n_rigid = 6 * sys->n_components;
+        const bool seed_rigid = b >= n_rigid + 6;
+        if (!seed_rigid && sys->n_components > 1)
+            mh_throw(MH_EINVAL, "the mesh consists of %u disconnected bodies (%u zero modes): more than a block of %u columns can seed", sys->n_components, n_rigid, b);
+        const auto inject_rigid_modes = [&] {
+            k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->node_component, sys->component_centroid, sys->n_components, sys->n_nodes, X, b, 0);
             KERNEL_CHECK();
-        }
+        };
+        if (seed_rigid) inject_rigid_modes();
         // A cold start begins from B M x for Gaussian noise x (one preconditioner application: the high-frequency content
         // of the noise is damped before the first Rayleigh-Ritz step), with the exact rigid-body modes put back: one
         // iteration fewer on every workload measured (18 -> 17 at S100k, 40 -> 39 on the ball, 17 -> 16 at S30k).
@@ -1224,15 +1231,7 @@ struct BlockLobpcg {
                 prof.op_applications += b;
                 HIP_CHECK(hipMemcpyAsync(X, Xn.get(), n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
-            if (b >= 12) {
-                auto hx = sys->node_xyz.to_host();
-                double c[3] = {0, 0, 0};
-                for (uint32_t i = 0; i < sys->n_nodes; ++i)
-                    for (int d = 0; d < 3; ++d) c[d] += hx[3 * size_t(i) + d];
-                for (double &v : c) v /= double(sys->n_nodes);
-                k_inject_rbm<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, double3{c[0], c[1], c[2]}, X, b, 0);
-                KERNEL_CHECK();
-            }
+            if (seed_rigid) inject_rigid_modes();
         }
         mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
         if (!chol_orthonormalise(X, MX, nullptr, b)) mh_throw(MH_ENOTCONVERGED, "initial block is rank deficient");
@@ -1654,7 +1653,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         if (cancel && *cancel) mh_throw(MH_ECANCELLED, "cancelled");
         // guard vectors: at least 15 (measured at S100k, nev = 65: 10 -> 23 iterations / 338 ms, 15 -> 19 / 317 ms,
         // 31 -> 15 / 338 ms), block rounded up to whole 16-column MFMA tiles
-        uint32_t b = (nev + std::max(15u, nev * kGuardPercent / 100) + 15u) / 16u * 16u;
+        // (every further disconnected body brings six more zero modes: the block grows by as many columns)
+        uint32_t b = (nev + std::max(15u, nev * kGuardPercent / 100) + 6u * (sys->n_components - 1u) + 15u) / 16u * 16u;
         if (n <= 768 || n < size_t(5) * b) {
             Timer t(ctx);
             dense_eigs(sys, nev, sigma, eigenvalues);

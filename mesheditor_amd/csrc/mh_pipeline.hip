@@ -915,6 +915,42 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
         for (uint32_t a = 0; a < sys->n_agg; ++a) ptr[a + 1] += ptr[a];
         std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
         for (uint32_t i = 0; i < npts; ++i) nodes[fill[agg_of[i]]++] = i;
+        // connected bodies: components of the same graph (nodes no element touches stay with component 0)
+        {
+            std::vector<uint32_t> comp(npts, UINT32_MAX), stack;
+            uint32_t nc = 0;
+            for (uint32_t seed = 0; seed < npts; ++seed) {
+                if (comp[seed] != UINT32_MAX || rp[seed + 1] == rp[seed]) continue;
+                comp[seed] = nc;
+                stack.assign(1, seed);
+                while (!stack.empty()) {
+                    const uint32_t v = stack.back();
+                    stack.pop_back();
+                    for (uint32_t p = rp[v]; p < rp[v + 1]; ++p)
+                        if (comp[cl[p]] == UINT32_MAX) comp[cl[p]] = nc, stack.push_back(cl[p]);
+                }
+                ++nc;
+            }
+            sys->n_components = std::max(1u, nc);
+            std::vector<uint32_t> pa(nn), node_comp(nn);
+            std::vector<double> xyz(size_t(nn) * 3), cent(size_t(sys->n_components) * 3, 0.0), count(sys->n_components, 0.0);
+            HIP_CHECK(hipMemcpyAsync(pa.data(), sys->parent_a.get(), size_t(nn) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(xyz.data(), sys->node_xyz.get(), xyz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            for (uint32_t i = 0; i < nn; ++i) {
+                const uint32_t c = pa[i] < npts && comp[pa[i]] != UINT32_MAX ? comp[pa[i]] : 0u;
+                node_comp[i] = c;
+                count[c] += 1.0;
+                for (int d = 0; d < 3; ++d) cent[size_t(3) * c + d] += xyz[size_t(3) * i + d];
+            }
+            for (uint32_t c = 0; c < sys->n_components; ++c)
+                for (int d = 0; d < 3; ++d) cent[size_t(3) * c + d] /= std::max(count[c], 1.0);
+            sys->node_component.reset(ctx, nn);
+            sys->component_centroid.reset(ctx, cent.size());
+            sys->node_component.upload(node_comp.data(), nn);
+            sys->component_centroid.upload(cent.data(), cent.size());
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         sys->agg_of.reset(ctx, npts);
         sys->agg_ptr.reset(ctx, ptr.size());
         sys->agg_nodes.reset(ctx, npts);

@@ -720,3 +720,28 @@ def test_a_node_shared_by_hundreds_of_tets(api, ctx, oracle):
     Ko, Mo = syso.full(0), syso.full(1)
     assert abs(K - Ko).max() <= 1e-12 * abs(Ko).max()
     assert abs(M - Mo).max() <= 1e-13 * abs(Mo).max()
+
+
+@pytest.mark.gpu
+def test_a_mesh_of_several_disconnected_bodies(api, ctx, oracle):
+    """A scan with stray fragments is several free bodies in one mesh: six zero modes each.  The reference's direct solver takes
+    that in its stride; the device solver seeds the exact rigid-body modes of every connected body (components of the P1 graph)
+    and must return the same spectrum: two unequal boxes and a small third one -> 18 zero modes, then the union of the elastic
+    spectra."""
+    parts = [meshes.kuhn_box(5, 4, 3, 0.2, 0.15, 0.1), meshes.kuhn_box(4, 4, 4, 0.12, 0.12, 0.12, origin=(0.5, 0.0, 0.0)), meshes.kuhn_box(2, 2, 2, 0.03, 0.03, 0.03, origin=(0.0, 0.4, 0.0))]
+    pts = np.vstack([p for p, _ in parts])
+    off = np.cumsum([0] + [len(p) for p, _ in parts[:-1]])
+    tets = np.vstack([t + o for (_, t), o in zip(parts, off)]).astype(np.uint32)
+    m = meshes.MATERIALS["Glass"]
+    mg, mo = _mats(api, oracle, m)
+    sysg = api.System(ctx, api.Mesh(ctx, pts, tets), mg)
+    syso = oracle.System(pts, tets, mo)
+    nev = 50
+    ev, prof = sysg.eigs(nev, SIGMA, 1e-6)
+    evo, _, _ = syso.eigs(nev, ncv=90)
+    evo = np.sort(evo)
+    elastic = evo > 1e-6 * evo[-1]
+    assert (~elastic).sum() == 18 and np.all(~elastic[:18])
+    assert np.abs(ev[:18]).max() < 1e-6 * evo[18]
+    assert (np.abs(ev[18:] - evo[18:]) / evo[18:]).max() < 1e-6
+    sysg.close()
