@@ -276,6 +276,7 @@ struct mh_system {
     // Connected bodies of the mesh (components of the P1 graph): each is a free body with six rigid-body modes of its own.  A scan
     // with stray fragments has several; the eigensolver seeds the exact modes of every one (mh_eigs.hip: start).
     uint32_t n_components{1};
+    uint32_t unreferenced_points{0}; // mesh points no kept tetrahedron uses: their rows of K and M are empty, the shifted operator is singular
     DevArray<uint32_t> node_component; // n_nodes (P2, internal numbering)
     DevArray<double> component_centroid; // n_components x 3
     PatchSet patches2, patches1; // sliver patches of the two smoothed levels (empty on well-shaped meshes)

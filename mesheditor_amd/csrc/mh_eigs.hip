@@ -1646,6 +1646,9 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         const size_t n = size_t(3) * sys->n_nodes;
         if (nev >= n) mh_throw(MH_EINVAL, "nev %u must be below the %zu unknowns", nev, n);
         if (!(sigma < 0)) mh_throw(MH_EFACTOR, "shift must be negative for a positive-definite shifted operator");
+        // A mesh point that no kept tetrahedron uses has empty rows in K and M: K - sigma M is singular there and the reference's
+        // Cholesky factorisation fails ("Modal shift-invert factorization failed.", CholeskyShiftInvert.cpp:44) -- so does this solve.
+        if (sys->unreferenced_points) mh_throw(MH_EFACTOR, "%u mesh point(s) belong to no tetrahedron: the shifted operator is singular", sys->unreferenced_points);
         mh_profile prof = sys->profile;
         prof.dofs = uint32_t(n);
         // the reference counts the lower triangle of K (Eigen nonZeros of the lower-stored matrix, mesh2modes.cpp:615)

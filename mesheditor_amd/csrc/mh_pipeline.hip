@@ -932,6 +932,8 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
                 ++nc;
             }
             sys->n_components = std::max(1u, nc);
+            sys->unreferenced_points = 0;
+            for (uint32_t i = 0; i < npts; ++i) sys->unreferenced_points += rp[i + 1] == rp[i] ? 1u : 0u;
             std::vector<uint32_t> pa(nn), node_comp(nn);
             std::vector<double> xyz(size_t(nn) * 3), cent(size_t(sys->n_components) * 3, 0.0), count(sys->n_components, 0.0);
             HIP_CHECK(hipMemcpyAsync(pa.data(), sys->parent_a.get(), size_t(nn) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -745,3 +745,20 @@ def test_a_mesh_of_several_disconnected_bodies(api, ctx, oracle):
     assert np.abs(ev[:18]).max() < 1e-6 * evo[18]
     assert (np.abs(ev[18:] - evo[18:]) / evo[18:]).max() < 1e-6
     sysg.close()
+
+
+@pytest.mark.gpu
+def test_points_no_tetrahedron_uses_fail_like_the_reference(api, ctx, oracle):
+    """A mesh point outside every tetrahedron leaves empty rows in K and M: the reference's Cholesky factorisation of K - sigma M
+    fails (CholeskyShiftInvert.cpp:44, std::runtime_error) and its mesh2modes has no result -- the oracle returns an empty one, the
+    device path raises the reference's message."""
+    pts, tets = meshes.kuhn_box(4, 4, 4, 0.1, 0.1, 0.1)
+    pts2 = np.vstack([pts, [[5.0, 5.0, 5.0]]])
+    m = meshes.MATERIALS["Glass"]
+    ex = pts[::13].astype(np.float32)
+    ro = oracle.mesh2modes(pts2, tets, oracle.material(*m), ex, config=oracle.default_config(num_modes=10, num_fem_modes=20, max_mode_freq=1e6))
+    assert len(ro.eigenvalues) == 0
+    with pytest.raises(RuntimeError, match="factorization failed"):
+        api.mesh2modes(ctx, pts2, tets, api.material(*m), ex, config=api.default_config(num_modes=10, num_fem_modes=20, max_mode_freq=1e6))
+    ok = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(num_modes=10, num_fem_modes=20, max_mode_freq=1e6))
+    assert len(ok.eigenvalues) == 20
