@@ -33,7 +33,7 @@ struct Result {
     explicit operator bool() const { return Error.empty(); }
 };
 struct Options {
-    size_t MaxSteinerPoints{0}; // boundary-recovery budget; 0 = 8 x the input vertices + 4096
+    size_t MaxSteinerPoints{0}; // boundary-recovery budget; 0 = 2 x the input vertices + 4096
 };
 Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options = {});
 // `layers` shells between the surface and the centroid (0: a plain fan of one tet per triangle).  Each layer is a copy of

@@ -18,7 +18,7 @@
 //      edges are again not Delaunay.  Cut points are the EXACT midpoints (coordinates kept as floating-point expansions), so
 //      the pieces of an edge stay exactly collinear and the pieces of a triangle exactly coplanar.
 //      Limits: fans of needle triangles (apex angles of a few degrees) on a rough surface can refine without end; a cap on
-//      the added points (8 x the input vertices + 4096) turns that into an error string.  Scan-like surfaces with reasonably
+//      the added points (2 x the input vertices + 4096) turns that into an error string.  Scan-like surfaces with reasonably
 //      shaped triangles (20 k triangles: ~10 % added points, well under a second), boxes with rectangular cells, brackets,
 //      tori, bowls and nested cavities go through.
 //   3. Inside / outside by parity: a flood from the enclosing tetrahedron that flips each time it crosses a surface face;
@@ -287,7 +287,7 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
 
     // 2. boundary recovery by refinement, one split at a time: a split can knock neighbouring constraints out of the mesh (and
     //    make queued ones present again), so everything near the new point is re-examined before anything else is cut
-    const size_t steiner_cap = options.MaxSteinerPoints ? options.MaxSteinerPoints : 8 * size_t(n_input) + 4096;
+    const size_t steiner_cap = options.MaxSteinerPoints ? options.MaxSteinerPoints : 2 * size_t(n_input) + 4096; // (surfaces that fill at all needed at most 0.4 x their vertices; a run-away refinement is cut short: seconds instead of a minute)
     const auto length2 = [&](uint32_t a, uint32_t b) {
         const dvec3 d = dt.Points[a] - dt.Points[b];
         return d.x * d.x + d.y * d.y + d.z * d.z;
