@@ -72,7 +72,9 @@ int mh_context_synchronize(mh_context *);
 /* The context's hipStream_t, for callers that time with HIP events. */
 void *mh_context_stream(mh_context *);
 void mh_default_config(mh_solver_config *);
-/* Measurement aid (no reference counterpart): when enabled, every launch of the path's named kernels is bracketed by
+/* Kernel timing of the path itself (no reference counterpart; the one instrumentation hook that has to live in the product,
+ * because it brackets the product's own launches in place -- bench.py's roofline objects read it; timing loops and experiments
+ * are in libmodalhip_lab.so): when enabled, every launch of the path's named kernels is bracketed by
  * HIP events on the context's stream.  Kernel classes and their algorithmic work unit:
  *   MH_KERNEL_SPMM     the operator products y = (K - sigma M) x over n x w panels (both levels, all precisions);
  *                      bytes: (9 values + 1 index) per node block + 4 B per row pointer + every panel pass
