@@ -144,6 +144,9 @@ def test_solve_tool_fills_a_surface_that_is_not_star_shaped(tmp_path):
         out = json.loads(p.stdout)
         assert abs(out["mass"] / (2700 * 3 * unit ** 3) - 1) < 1e-6
         assert len(out["positions"]) >= len(pts) and np.allclose(np.array(out["positions"][: len(pts)]), np.array(pts, dtype=np.float32), atol=1e-7)
+        # the tetrahedraliser refines this surface (points on it), yet the model's surface is the caller's: the sample points are
+        # the input vertices under their own indices and `indices` are the input triangles (reference tests/ModalSolveTool.cpp:84-94)
+        assert np.array_equal(np.array(out["indices"]).reshape(-1, 3), np.array(tris))
         runs.append(np.array(out["frequencies"]))
     small, large = runs
     assert len(small) == len(large) == 6 and small[0] > 1000
