@@ -119,6 +119,7 @@ int mh_context_create(int device, mh_context **out) {
         if (count <= 0) mh_throw(MH_EHIP, "no HIP device: libmodalhip has no CPU fallback");
         if (device < 0 || device >= count) mh_throw(MH_EINVAL, "device %d out of range (%d visible)", device, count);
         ctx->device = device;
+        if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->cu_count <= 0) ctx->cu_count = 256;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ROCBLAS_CHECK(rocblas_create_handle(&ctx->blas));

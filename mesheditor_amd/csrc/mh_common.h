@@ -110,6 +110,7 @@ struct DevicePool {
 
 struct mh_context {
     int device{0};
+    int cu_count{256}; // compute units of the device (persistent grids are sized by it)
     hipStream_t stream{nullptr};
     hipStream_t aux_stream{nullptr}; // second stream of the context: the coarse elimination beside the smoothers' set-up (created on first use)
     bool aux_stream_ready() {

@@ -8,6 +8,8 @@
 //   result is bit-reproducible.  Roofline: max(8 n (wa + wb) bytes / HBM, 2 n wa wb flops / fp64 MFMA peak).
 #include "mh_common.h"
 
+#include <map>
+
 // hipFuncSetAttribute once per (kernel, device): function attributes are per device, and first calls may race between the host
 // threads of concurrent solves -- a per-call-site table of once-flags indexed by the context's device.
 struct PerDeviceOnce {
@@ -191,15 +193,23 @@ __global__ void __launch_bounds__(1024) k_gram_reduce(const double *__restrict__
 // directions from the same basis) and reads the basis once.  A workgroup owns 64 rows (16 per wave) and all nc <= 256
 // output columns; the basis rows and the matching coefficient rows are staged through LDS in K-chunks of 32 and
 // multiplied with v_mfma_f64_16x16x4_f64.  Bound: 2 n m nc flops on fp64 MFMA vs 8 n (m + nc) bytes of HBM.
+typedef __attribute__((address_space(1))) double GlobalDouble; // an address built from integers is a global one (a generic load would also count as an LDS access)
 constexpr int CK = 16; // K chunk (32 measured slower: 475 vs 427 us at 75 + 75 -> 75)
+// What shapes this kernel (in-kernel cycle stamps, profiles/r03_combine_phases.txt): beside the fp64 matrix instructions of the
+// workgroup it shares the SIMDs with, a wave's ordinary vector instructions wait for a gap between two of them -- ~45 address /
+// select instructions per chunk took 2 100 cycles, most of a 2 560-cycle matrix phase, and 120 of them around the output stores
+// 11 000.  So the loop carries almost none: addresses come from a table in LDS (one multiply-add per staged basis element), from
+// scalar bases with constant per-thread offsets (coefficients, outputs), and from compile-time LDS offsets (the chunk loop is
+// unrolled over its two stage buffers).  Workgroups are persistent (row tiles dealt round-robin), so the table and the launch
+// are paid once.
 template<int NT, bool ACCUMULATE, bool MAPPED> // 16-column output tiles per wave (nc <= 16 * NT); ACCUMULATE: out += instead of out =; MAPPED: column maps on X / out1
 __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, int wx, int ldx, const uint32_t *__restrict__ xmap, const double *__restrict__ W, int ww,
                                                 const double *__restrict__ P, int wp,
                                                 const double *__restrict__ Ct, int ldc, int c0, int nc, size_t n, double *__restrict__ out1, int n1,
                                                 double *__restrict__ out2, size_t split_stride, int ld1, const uint32_t *__restrict__ omap) {
     // X's logical column k lives at physical column xmap[k] of a panel of pitch ldx (xmap null: identity); out1's logical
-    // column c goes to physical column omap[c] of a panel of pitch ld1 (in place over X is safe: a workgroup reads all of its
-    // 64 rows before it writes them)
+    // column c goes to physical column omap[c] of a panel of pitch ld1 (in place over X is safe: a workgroup reads all of a
+    // tile's 64 rows before it writes them)
     // this launch owns output columns c0 .. c0 + nc of the ldc the coefficient matrix has; with gridDim.y > 1 the K range
     // is cut into gridDim.y slices and slice s writes its partial product to out1 + s * split_stride
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -209,82 +219,121 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
     if (gridDim.y > 1) out1 += size_t(blockIdx.y) * split_stride;
     constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16; // = 16 (mod 32): conflict-free B reads
     constexpr int SP = CK + 2; // A-tile pitch: rows 2 doubles apart mod 32 -> conflict-free ds_read_b64
-    double *Ss = smem; // 64 rows x SP
-    double *Cs = smem + 64 * SP; // CK x CP (all NT column strips staged; missing ones as zeros)
-    int *xm = reinterpret_cast<int *>(Cs + CK * CP); // MAPPED: physical column of each logical X column
-    if (MAPPED) {
-        for (int k = threadIdx.x; k < wx; k += 256) xm[k] = int(xmap[k]);
-        __syncthreads();
+    // two stage buffers: chunk c + 1 is written while chunk c is multiplied, one barrier per chunk
+    constexpr int STAGE = 64 * SP + CK * CP; // 64 rows x SP of the basis, then CK x CP of the coefficients (all NT column strips)
+    // Where basis column k lives: the address of its row-0 element and its panel's row pitch in bytes, for the columns of this
+    // K slice (CK entries past the end repeat the last column).
+    unsigned long long *kaddr = reinterpret_cast<unsigned long long *>(smem + 2 * STAGE);
+    uint32_t *kpitch = reinterpret_cast<uint32_t *>(kaddr + (ke - kb + CK));
+    for (int i = threadIdx.x; i < ke - kb + CK; i += 256) {
+        const int k = min(kb + i, m - 1);
+        const double *base = X;
+        int col = MAPPED ? (k < wx ? int(xmap[k]) : 0) : k, pitch = ldx;
+        if (k >= wx + ww) base = P, col = k - wx - ww, pitch = wp;
+        else if (k >= wx) base = W, col = k - wx, pitch = ww;
+        kaddr[i] = reinterpret_cast<unsigned long long>(base + col);
+        kpitch[i] = uint32_t(pitch) * 8u;
     }
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t r0 = size_t(blockIdx.x) * 64;
-    double4_t acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = double4_t{0, 0, 0, 0};
-    // staging maps: S tile: thread -> (row = tid / 4, 4 consecutive k); C tile: NT strips of 16 columns per k row
-    constexpr int SJ = CK / 4, CPASS = CK / 16; // S: thread -> (row = tid / 4, SJ consecutive k); C: 16 k rows per pass
+    // staging maps: S tile: thread -> (row = tid / 4, 4 consecutive k); C tile: thread -> (k row = tid / 16, NT columns 16 apart)
+    static_assert(CK == 16, "one pass of 16 coefficient rows per chunk");
+    constexpr int SJ = CK / 4;
     const int srow = tid >> 2, sk = (tid & 3) * SJ;
-    const int ck = tid >> 4, cc = tid & 15; // 16 k rows x 16 threads, each thread NT columns (stride 16)
-    double ps[SJ], pc[CPASS][NT];
-    // Branch-free staging: every load goes to a clamped, always-valid address (the panel is picked by pointer
-    // selects), and entries outside the operands are zeroed when the registers are written to LDS.
-    const size_t rs = min(r0 + srow, n - 1);
-    const bool row_ok = r0 + srow < n;
-    const double *xrow = X + rs * ldx, *wrow = W ? W + rs * ww : X, *prow = P ? P + rs * wp : X;
-    auto fetch = [&](int k0) {
+    const int ck = tid >> 4, cc = tid & 15;
+    // Every load goes to a clamped, always-valid address and nothing is zeroed on the way to LDS except the basis columns past
+    // the end of the K slice (last chunk only): rows past n and output columns past nc compute values that are never stored,
+    // from finite data, and a zero basis entry silences whatever coefficient row it meets.
+    // coefficient tile: a uniform base per chunk (scalar registers) plus per-thread byte offsets that never change; only the last
+    // two column strips can pass nc, and only the last chunk can pass row m - 1
+    const char *cbytes = reinterpret_cast<const char *>(Ct + c0);
+    const uint32_t row_bytes = uint32_t(ldc) * 8u;
+    const uint32_t coff = uint32_t(ck) * row_bytes + uint32_t(cc) * 8u;
+    const uint32_t ctail0 = uint32_t(ck) * row_bytes + uint32_t(min(cc + 16 * (NT - 2), nc - 1)) * 8u, ctail1 = uint32_t(ck) * row_bytes + uint32_t(min(cc + 16 * (NT - 1), nc - 1)) * 8u;
+    // outputs (C/D layout: column = lane & 15 of strip t, row = (lane >> 4) + 4 * reg): a strip lies in out1, in out2, or -- one at
+    // most -- across the two; byte offsets of this lane's column within a row of either
+    const int col_l = lane & 15, row_l = lane >> 4;
+    const int pitch2 = ldc - n1;
+    uint32_t ocol[MAPPED ? NT : 1]; // MAPPED: out1 columns through the map
+    if (MAPPED) {
 #pragma unroll
-        for (int j = 0; j < SJ; ++j) {
-            const int k = min(k0 + sk + j, m - 1);
-            const double *src = k < wx ? xrow + (MAPPED ? xm[k] : k) : (k < wx + ww ? wrow + (k - wx) : prow + (k - wx - ww));
-            ps[j] = *src;
-        }
-#pragma unroll
-        for (int q = 0; q < CPASS; ++q) {
-            const double *crow = Ct + size_t(min(k0 + ck + 16 * q, m - 1)) * ldc + c0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) pc[q][t] = crow[min(cc + 16 * t, nc - 1)];
-        }
-    };
-    auto commit = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < SJ; ++j) Ss[srow * SP + sk + j] = (row_ok && k0 + sk + j < ke) ? ps[j] : 0.0;
-#pragma unroll
-        for (int q = 0; q < CPASS; ++q) {
-            const bool kok = k0 + ck + 16 * q < ke;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) Cs[(ck + 16 * q) * CP + cc + 16 * t] = (kok && cc + 16 * t < nc) ? pc[q][t] : 0.0;
-        }
-    };
-    fetch(kb);
-    for (int k0 = kb; k0 < ke; k0 += CK) {
-        commit(k0);
-        __syncthreads();
-        if (k0 + CK < ke) fetch(k0 + CK); // in flight under the MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < CK; kk += 4) {
-            const double a = Ss[(wave * 16 + (lane & 15)) * SP + kk + (lane >> 4)];
-            const double *brow = Cs + (kk + (lane >> 4)) * CP + (lane & 15);
-            double bf[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) bf[t] = brow[t * 16];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[t], acc[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        for (int t = 0; t < NT; ++t) ocol[t] = omap[min(c0 + 16 * t + col_l, max(n1, 1) - 1)] * 8u;
     }
-    // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double ps[SJ], pc[NT];
+    const size_t tiles = (n + 63) / 64;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t r0 = tile * 64;
+        const uint32_t rs = uint32_t(min(r0 + srow, n - 1));
+        double4_t acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t * 16 + (lane & 15) >= nc) continue;
-        const int c = c0 + t * 16 + (lane & 15);
+        for (int t = 0; t < NT; ++t) acc[t] = double4_t{0, 0, 0, 0};
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int j = 0; j < SJ; ++j) {
+                const int i = k0 - kb + sk + j;
+                ps[j] = *reinterpret_cast<const GlobalDouble *>(kaddr[i] + (unsigned long long)(rs) * kpitch[i]);
+            }
+            const char *cchunk = cbytes + size_t(k0) * row_bytes;
+            uint32_t o = coff, o0 = ctail0, o1 = ctail1;
+            if (k0 + CK > m) { // rows past m - 1 read row m - 1
+                const uint32_t back = uint32_t(ck - min(ck, m - 1 - k0)) * row_bytes;
+                o -= back, o0 -= back, o1 -= back;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pc[t] = *reinterpret_cast<const double *>(cchunk + (t < NT - 2 ? size_t(o) + 128 * t : size_t(t == NT - 2 ? o0 : o1)));
+        };
+        auto commit = [&](int k0, double *stage) {
+            double *Ss = stage + srow * SP + sk, *Cs = stage + 64 * SP + ck * CP + cc;
+            if (k0 + CK <= ke) {
+#pragma unroll
+                for (int j = 0; j < SJ; ++j) Ss[j] = ps[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < SJ; ++j) Ss[j] = k0 + sk + j < ke ? ps[j] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Cs[16 * t] = pc[t];
+        };
+        // one chunk: the next one's loads go out first and land in the other buffer after this one's products
+        auto chunk = [&](int k0, int B) {
+            const bool more = k0 + CK < ke;
+            if (more) fetch(k0 + CK);
+            const double *Ss = smem + B * STAGE, *Cs = Ss + 64 * SP;
+#pragma unroll
+            for (int kk = 0; kk < CK; kk += 4) {
+                const double a = Ss[(wave * 16 + col_l) * SP + kk + row_l];
+                const double *brow = Cs + (kk + row_l) * CP + col_l;
+                double bf[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bf[t] = brow[t * 16];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[t], acc[t], 0, 0, 0);
+            }
+            if (more) commit(k0 + CK, smem + (B ^ 1) * STAGE); // its readers passed the last barrier
+            __syncthreads();
+        };
+        fetch(kb);
+        commit(kb, smem); // (the previous tile's last chunk ended with a barrier)
+        __syncthreads();
+        for (int k0 = kb, buf = 0; k0 < ke; k0 += CK, buf ^= 1) chunk(k0, buf);
+        // stores: per accumulator row one 64-bit row address for each output (scalar base + row offset), strips at constant
+        // byte offsets from it
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const size_t r = r0 + wave * 16 + (lane >> 4) + 4 * reg;
+            const size_t r = r0 + wave * 16 + row_l + 4 * reg;
             if (r >= n) continue;
-            double *dst = c < n1 ? out1 + r * ld1 + (MAPPED ? int(omap[c]) : c) : out2 + r * (ldc - n1) + (c - n1);
-            *dst = ACCUMULATE ? *dst + acc[t][reg] : acc[t][reg];
+            char *row1 = reinterpret_cast<char *>(out1 + r * size_t(ld1)) + (MAPPED ? 0 : (c0 + col_l) * 8);
+            char *row2 = reinterpret_cast<char *>(out2 + r * size_t(pitch2)) + (c0 + col_l - n1) * 8;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t >= NT - 2 && t * 16 + col_l >= nc) continue; // only the last two strips can pass nc
+                const int s0 = c0 + 16 * t; // first column of the strip (uniform)
+                double *dst;
+                if (s0 + 16 <= n1) dst = reinterpret_cast<double *>(row1 + (MAPPED ? size_t(ocol[t]) : size_t(128 * t)));
+                else if (s0 >= n1) dst = reinterpret_cast<double *>(row2 + 128 * t);
+                else dst = s0 + col_l < n1 ? reinterpret_cast<double *>(row1 + (MAPPED ? size_t(ocol[t]) : size_t(128 * t))) : reinterpret_cast<double *>(row2 + 128 * t);
+                *dst = ACCUMULATE ? *dst + acc[t][reg] : acc[t][reg];
+            }
         }
     }
 }
@@ -383,6 +432,24 @@ __global__ void k_iota(uint32_t *p, uint32_t n) {
 }
 } // namespace
 
+namespace {
+// Workgroups of an instantiation that fit a CU with `lds` bytes of dynamic LDS each (its two stage buffers may exceed the 64 KB
+// a launch may ask for by default: the limit is raised once per device); asked once per (device, 4 KB LDS class).
+template<int NT, bool ACCUMULATE, bool MAPPED> int combine_residency(mh_context *ctx, size_t lds) {
+    static PerDeviceOnce attr;
+    attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_combine<NT, ACCUMULATE, MAPPED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    static std::mutex guard;
+    static std::map<std::pair<int, size_t>, int> known;
+    std::lock_guard<std::mutex> lock(guard);
+    auto [it, fresh] = known.try_emplace({ctx->device, lds >> 12}, 1);
+    if (fresh) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_combine<NT, ACCUMULATE, MAPPED>), 256, ((lds >> 12) + 1) << 12) == hipSuccess && nb > 0) it->second = std::min(nb, 8);
+    }
+    return it->second;
+}
+} // namespace
+
 // out1 (n x n1), out2 (n x (nc - n1)) = [X | W | P] * Ct  (+= when accumulate)
 const uint32_t *mh_identity_map(mh_context *ctx) {
     if (!ctx->iota) {
@@ -442,7 +509,6 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
         if (mapped) HIP_CHECK(hipStreamSynchronize(ctx->stream)); // ct_full returns to the pool
         return;
     }
-    const unsigned grid = div_up(n, 64);
     // more than 256 output columns: column chunks, each a launch over the same basis
     const uint32_t chunks = div_up(col_count, 256), step = (div_up(col_count, chunks) + 15) / 16 * 16;
     for (uint32_t c0 = col_begin; c0 < col_begin + col_count; c0 += step) {
@@ -450,8 +516,10 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
         auto go = [&](auto nt_tag) {
             constexpr int NT = decltype(nt_tag)::value;
             constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
-            const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
-            const size_t lds_m = lds + (mapped ? size_t(wx) * sizeof(int) : 0);
+            const size_t lds = 2 * (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double) + size_t(m_total + CK) * 12;
+            const size_t lds_m = lds;
+            const int per_cu = accumulate ? combine_residency<NT, true, false>(ctx, lds) : mapped ? combine_residency<NT, false, true>(ctx, lds) : combine_residency<NT, false, false>(ctx, lds);
+            const unsigned grid = unsigned(std::min<size_t>(div_up(n, 64), size_t(per_cu) * ctx->cu_count));
 #define MH_COMBINE_ARGS x, int(wx), int(ldx ? ldx : wx), xmap, w, int(ww), p, int(wp), ct, int(nc), int(c0), int(ncc), n, out1, int(n1), out2, 0, int(ld1 ? ld1 : n1), omap
             if (accumulate) k_combine<NT, true, false><<<grid, 256, lds, ctx->stream>>>(MH_COMBINE_ARGS);
             else if (mapped) k_combine<NT, false, true><<<grid, 256, lds_m, ctx->stream>>>(MH_COMBINE_ARGS);
@@ -489,12 +557,14 @@ __global__ void k_sum_slices(const double *__restrict__ partial, int slices, siz
 void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices) {
     if (!nc || !n) return;
     if (nc > 256) mh_throw(MH_EINVAL, "short product: %u columns exceed 256", nc);
-    const dim3 grid(div_up(n, 64), slices);
     const size_t stride = n * nc;
     auto go = [&](auto nt_tag) {
         constexpr int NT = decltype(nt_tag)::value;
         constexpr int CP = (NT * 16) % 32 == 16 ? NT * 16 : NT * 16 + 16;
-        const size_t lds = (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double);
+        const uint32_t kslice = (div_up(m, slices) + CK - 1) / CK * CK; // as the kernel cuts the K range
+        const size_t lds = 2 * (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double) + size_t(std::min(kslice, m) + CK) * 12;
+        if (lds > 160 * 1024) mh_throw(MH_EINVAL, "short product: %u basis columns per slice exceed the staging table", kslice);
+        const dim3 grid(unsigned(std::min<size_t>(div_up(n, 64), size_t(std::max(1u, combine_residency<NT, false, false>(ctx, lds) * unsigned(ctx->cu_count) / slices)))), slices);
         k_combine<NT, false, false><<<grid, 256, lds, ctx->stream>>>(a, int(m), int(m), nullptr, nullptr, 0, nullptr, 0, ct, int(nc), 0, int(nc), n, slices > 1 ? partial : out, int(nc), nullptr, stride,
                                                              int(nc), nullptr);
     };
@@ -1521,3 +1591,4 @@ void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
     } else k_potrf_small<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
     KERNEL_CHECK();
 }
+
