@@ -22,6 +22,11 @@ template<typename Real> struct ImpactDev {
     Real jx, jy, jz, phase_re, phase_im, rot_re, rot_im, gamma, accel_amp, b0, a1, a2, z1, z2;
 };
 
+template<typename Real> struct ImpactBack { // an impact's state after the block, as the host reads it back
+    uint32_t samples_left;
+    Real phase_re, phase_im, z1, z2;
+};
+
 struct WaveDesc {
     uint32_t dealt; // index into the flattened deal
     uint32_t first_mode; // first mode of this wave inside the object (multiple of 64)
@@ -30,7 +35,7 @@ struct WaveDesc {
 // Force curve + click filter per impact (ModalAudio.cpp:504-538).  force/click: [impact][frames].
 template<typename Real>
 __global__ void k_bank_forces(ImpactDev<Real> *__restrict__ impacts, uint32_t n_impacts, const Real *__restrict__ listener_gain, Real click_gain,
-                              uint32_t frames, Real *__restrict__ force, Real *__restrict__ click) {
+                              uint32_t frames, Real *__restrict__ force, Real *__restrict__ click, ImpactBack<Real> *__restrict__ back) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_impacts) return;
     ImpactDev<Real> im = impacts[i];
@@ -40,7 +45,7 @@ __global__ void k_bank_forces(ImpactDev<Real> *__restrict__ impacts, uint32_t n_
     Real z1 = im.z1, z2 = im.z2;
     uint32_t left = im.samples_left;
     Real *f = force + size_t(i) * frames, *ck = click + size_t(i) * frames;
-    for (uint32_t s = 0; s < frames; ++s) {
+    auto sample = [&](Real &force_out, Real &click_out) {
         Real cur = 0;
         if (left > 0) {
             const Real re = phase_re * rot_re - phase_im * rot_im;
@@ -49,19 +54,34 @@ __global__ void k_bank_forces(ImpactDev<Real> *__restrict__ impacts, uint32_t n_
             cur = gamma * Real(0.5) * (Real(1) - phase_re);
             --left;
         }
-        f[s] = cur;
+        force_out = cur;
         const Real u = amp * cur;
         const Real y = b0 * u + z1;
         z1 = -a1 * y + z2;
         z2 = -b0 * u - a2 * y;
-        ck[s] = y * impact_click_gain;
+        click_out = y * impact_click_gain;
+    };
+    // every thread writes its own two rows: four samples per store (a wave's store touches 64 rows either way, and the loop was
+    // bound by issuing those stores, not by its recurrences)
+    typedef Real Quad __attribute__((ext_vector_type(4)));
+    uint32_t s = 0;
+    if ((frames & 3u) == 0) {
+        for (; s < frames; s += 4) {
+            Real fv[4], cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sample(fv[u], cv[u]);
+            *reinterpret_cast<Quad *>(f + s) = Quad{fv[0], fv[1], fv[2], fv[3]};
+            *reinterpret_cast<Quad *>(ck + s) = Quad{cv[0], cv[1], cv[2], cv[3]};
+        }
     }
+    for (; s < frames; ++s) sample(f[s], ck[s]);
     im.phase_re = phase_re;
     im.phase_im = phase_im;
     im.samples_left = left;
     im.z1 = z1;
     im.z2 = z2;
     impacts[i] = im;
+    back[i] = {left, phase_re, phase_im, z1, z2}; // what the host takes back, written where it reads it (pinned memory)
 }
 
 template<typename Real> struct BankCols {
@@ -220,14 +240,29 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
 
 // Per dealt object (one wave each): energy, audible prefix, whole-object silence (ModalAudio.cpp:132-146).  Loads are
 // lane-parallel; every sum runs in the reference's order through wave-uniform lane broadcasts.
-template<typename Real>
-__global__ void __launch_bounds__(WAVE) k_bank_objects(BankCols<Real> b, const uint32_t *__restrict__ deal_objects, const uint32_t *__restrict__ render_count,
-                                                      const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ imp_ptr, const Real *__restrict__ out_gain,
-                                                      const Real *__restrict__ chunk_energy, uint32_t n_dealt, double *__restrict__ energy_out,
-                                                      uint32_t *__restrict__ live_out, uint8_t *__restrict__ silenced, const uint32_t *__restrict__ tuned_count,
-                                                      double *__restrict__ modal_energy) {
-    const uint32_t d = blockIdx.x, lane = threadIdx.x;
-    if (d >= n_dealt) return;
+struct PerDeviceOnceBank { // hipFuncSetAttribute once per (kernel, device)
+    std::once_flag flag[64];
+    template<typename F> void run(int device, F &&f) { std::call_once(flag[device >= 0 && device < 64 ? device : 0], std::forward<F>(f)); }
+};
+template<typename Real> struct ObjectPassArgs {
+    BankCols<Real> b;
+    const uint32_t *deal_objects, *render_count, *chunk_base, *imp_ptr;
+    const Real *out_gain, *chunk_energy;
+    uint32_t n_dealt;
+    double *energy_out;
+    uint32_t *live_out;
+    uint8_t *silenced;
+    const uint32_t *tuned_count;
+    double *modal_energy;
+};
+template<typename Real> __device__ void bank_object_pass(const ObjectPassArgs<Real> &a, uint32_t d, uint32_t lane) {
+    const BankCols<Real> &b = a.b;
+    const uint32_t *deal_objects = a.deal_objects, *render_count = a.render_count, *chunk_base = a.chunk_base, *imp_ptr = a.imp_ptr, *tuned_count = a.tuned_count;
+    const Real *out_gain = a.out_gain, *chunk_energy = a.chunk_energy;
+    double *energy_out = a.energy_out, *modal_energy = a.modal_energy;
+    uint32_t *live_out = a.live_out;
+    uint8_t *silenced = a.silenced;
+    if (d >= a.n_dealt) return;
     const uint32_t o = deal_objects[d], count = render_count[d];
     const Real og = out_gain[o];
     Real energy = 0;
@@ -281,80 +316,114 @@ __global__ void __launch_bounds__(WAVE) k_bank_objects(BankCols<Real> b, const u
 // adds per sample is sequential by contract, so the work is a latency problem: one 1024-thread workgroup per
 // (SW-sample strip, renderer) streams tiles of RPT*1024/SW chunk rows through LDS with all 16 waves loading (next tile
 // in registers while the current one is consumed) and its first wave runs the ordered chain out of LDS.
+// The passes after the resonators depend on them (or on the forces) but not on one another, and each is a latency chain that
+// fills a few CUs: ONE launch runs them side by side, told apart by blockIdx.y --
+//   y < n_renderers                 renderer y's ordered chunk sum
+//   y == n_renderers (click_rows)   the impacts' click rows added, in impact order, to what the caller left in the block
+//                                   (click_inout: a workgroup reads its own strip's start values before it writes them)
+//   above                           the per-object pass, one wave per dealt object
 template<typename Real, int SW>
-__global__ void __launch_bounds__(1024) k_bank_renderer_sum(const Real *__restrict__ partial, const uint32_t *__restrict__ renderer_chunk_ptr, uint32_t frames,
-                                                           Real *__restrict__ rout, const Real *__restrict__ start = nullptr, uint32_t only_begin = 0, uint32_t only_end = 0) {
-    // renderer_chunk_ptr == nullptr: ONE chain over rows only_begin .. only_end - 1, continuing from start[s] (may alias rout:
-    // a workgroup reads its own strip's start values before it writes them) -- the impacts' click rows added to the block
-    constexpr int RPT = 8, ROUND = 1024 / SW, TILE = RPT * ROUND;
-    __shared__ Real xs[TILE * SW];
+__global__ void __launch_bounds__(1024) k_bank_post(const Real *__restrict__ partial, const uint32_t *__restrict__ renderer_chunk_ptr, uint32_t n_renderers, uint32_t frames,
+                                                   Real *__restrict__ rout, const Real *__restrict__ click, uint32_t click_rows, Real *__restrict__ click_inout,
+                                                   ObjectPassArgs<Real> objects) {
+    // An ordered sum: the adds of one sample are a dependent chain (8 192 rows per renderer with every mode live), run by wave 0
+    // out of LDS; the block's 16 waves stream tiles of rows in, transposed, so that a chain lane reads four consecutive rows with
+    // one 16-byte LDS read.  Two tile buffers, one barrier per tile: the next tile lands while this one is added.
+    constexpr int RPT = 32 / sizeof(Real), ROUND = 1024 / SW, TILE = RPT * ROUND, PITCH = TILE + 16 / sizeof(Real);
+    extern __shared__ __attribute__((aligned(16))) unsigned char post_lds[];
+    Real *xs = reinterpret_cast<Real *>(post_lds); // [2][SW][PITCH]
     const uint32_t tid = threadIdx.x, col = tid % SW, rr = tid / SW;
-    const uint32_t s = blockIdx.x * SW + col, r = blockIdx.y;
-    const uint32_t c_begin = renderer_chunk_ptr ? renderer_chunk_ptr[r] : only_begin, c_end = renderer_chunk_ptr ? renderer_chunk_ptr[r + 1] : only_end;
+    const uint32_t sum_slices = n_renderers + (click_rows ? 1u : 0u);
+    if (blockIdx.y >= sum_slices) {
+        bank_object_pass<Real>(objects, ((blockIdx.y - sum_slices) * gridDim.x + blockIdx.x) * (1024 / WAVE) + tid / WAVE, tid % WAVE);
+        return;
+    }
+    const uint32_t r = blockIdx.y;
+    const bool clicks = r >= n_renderers;
+    if (clicks) partial = click;
+    const Real *start = clicks ? click_inout : nullptr;
+    const uint32_t c_begin = clicks ? 0u : renderer_chunk_ptr[r], c_end = clicks ? click_rows : renderer_chunk_ptr[r + 1];
+    const uint32_t s = blockIdx.x * SW + col;
     const bool in_range = s < frames;
+    const uint32_t sc = in_range ? s : frames - 1; // loads of a strip's missing samples read the last one (never stored)
+    // wave 0 runs the chain, a pure latency problem; the others (and whatever else shares the CU in this launch) only feed it: it
+    // goes first whenever it can issue
+    if (tid < WAVE) __builtin_amdgcn_s_setprio(3);
     Real pre[RPT];
+    // rows past the end read the last row: the chain stops at the row count, nothing is zero-filled
     auto fetch = [&](uint32_t base) {
+        if (base + TILE <= c_end) {
+            const Real *p = partial + size_t(base + rr) * frames + sc;
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const uint32_t c = base + j * ROUND + rr;
-            pre[j] = (c < c_end && in_range) ? partial[size_t(c) * frames + s] : Real(0);
+            for (int j = 0; j < RPT; ++j) pre[j] = p[size_t(j) * ROUND * frames];
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) pre[j] = partial[size_t(min(base + j * ROUND + rr, c_end - 1)) * frames + sc];
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        Real *dst = xs + (size_t(buf) * SW + col) * PITCH + rr;
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) xs[(j * ROUND + rr) * SW + col] = pre[j];
+        for (int j = 0; j < RPT; ++j) dst[j * ROUND] = pre[j];
     };
     Real acc = (start && tid < SW && in_range) ? start[s] : Real(0);
+    // (this load must have landed on every path into the tile loop: left pending on one of them, the compiler guards the chain's
+    // first add with a wait for ALL outstanding loads -- which inside the loop are the next tile's, so the chain would start only
+    // after its own prefetch had returned)
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     if (c_begin < c_end) {
         fetch(c_begin);
-        commit();
+        commit(0);
     }
     __syncthreads();
-    for (uint32_t base = c_begin; base < c_end; base += TILE) {
+    typedef Real Quad __attribute__((ext_vector_type(4)));
+    int buf = 0;
+    for (uint32_t base = c_begin; base < c_end; base += TILE, buf ^= 1) {
         const bool more = base + TILE < c_end;
         if (more) fetch(base + TILE);
         if (tid < SW) {
             const uint32_t cnt = min(uint32_t(TILE), c_end - base);
+            const Real *row = xs + (size_t(buf) * SW + col) * PITCH;
+            // the adds are one dependent chain; the LDS reads are not: the next sixteen rows are on their way while these sixteen are
+            // added (a read's latency is about sixteen dependent adds)
             uint32_t q = 0;
-            for (; q + 8 <= cnt; q += 8) {
-                Real v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = xs[(q + u) * SW + col];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+            auto quad = [&](uint32_t at) { return *reinterpret_cast<const Quad *>(row + at); };
+            auto add4 = [&](const Quad &v) { acc += v.x, acc += v.y, acc += v.z, acc += v.w; };
+            if (cnt >= 16) {
+                Quad a0 = quad(0), a1 = quad(4), a2 = quad(8), a3 = quad(12), b0, b1, b2, b3;
+                for (; q + 48 <= cnt; q += 32) {
+                    b0 = quad(q + 16), b1 = quad(q + 20), b2 = quad(q + 24), b3 = quad(q + 28);
+                    add4(a0), add4(a1), add4(a2), add4(a3);
+                    a0 = quad(q + 32), a1 = quad(q + 36), a2 = quad(q + 40), a3 = quad(q + 44);
+                    add4(b0), add4(b1), add4(b2), add4(b3);
+                }
+                add4(a0), add4(a1), add4(a2), add4(a3);
+                q += 16;
             }
-            for (; q < cnt; ++q) acc += xs[q * SW + col];
+            for (; q < cnt; ++q) acc += row[q];
         }
-        __syncthreads();
-        if (more) commit();
+        if (more) commit(buf ^ 1); // the other buffer: its chain ended before the last barrier
         __syncthreads();
     }
-    if (tid < SW && in_range) rout[size_t(r) * frames + s] = acc;
+    if (tid < SW && in_range) (clicks ? click_inout[s] : rout[size_t(r) * frames + s]) = acc;
 }
+template<typename Real, int SW> size_t bank_post_lds() { return size_t(2) * SW * ((32 / sizeof(Real)) * (1024 / SW) + 16 / sizeof(Real)) * sizeof(Real); }
+// Host-pinned staging buffer mirrored by a device buffer: every small per-block array travels to the device in ONE copy.  Nothing
+// is copied back: the kernels that produce what the host reads (impact states, per-object energies, the block's samples) write it
+// into the pinned arena themselves, and the block's last kernel then raises a sequence number the host spins on -- a blit +
+// hipStreamSynchronize cost the copy engine's completion signal and a thread wake-up (~40 us of a 0.34 ms block), a copy kernel for
+// the ~120 KB region 15 us at the end of the chain; the spin sees the results ~2 us after the last kernel.
+// That last kernel is the mix: out[s] += clicks in impact order (when they did not go through the streaming sum), then the
+// renderers' buffers in renderer order (ModalAudio.cpp:531,553-555).
 template<typename Real>
-void launch_renderer_sum(hipStream_t st, const Real *partial, const uint32_t *renderer_chunk_ptr, uint32_t frames, uint32_t n_renderers, Real *rout) {
-    constexpr int SW = 16;
-    dim3 grid(div_up(frames, SW), n_renderers);
-    k_bank_renderer_sum<Real, SW><<<grid, 1024, 0, st>>>(partial, renderer_chunk_ptr, frames, rout);
-    KERNEL_CHECK();
-}
-// out[s] += clicks in impact order, then the renderers' buffers in renderer order (ModalAudio.cpp:531,553-555).
-template<typename Real>
-__global__ void k_bank_mix(const Real *__restrict__ click, uint32_t n_impacts, const Real *__restrict__ rout, uint32_t n_renderers, uint32_t frames, Real *__restrict__ out) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= frames) return;
-    Real acc = out[s];
-    for (uint32_t i = 0; i < n_impacts; ++i) acc += click[size_t(i) * frames + s];
-    for (uint32_t r = 0; r < n_renderers; ++r) acc += rout[size_t(r) * frames + s];
-    out[s] = acc;
-}
-
-// Host-pinned staging buffer mirrored by a device buffer: every small per-block array travels in ONE copy each way.
-// The block's results leave through a copy kernel that writes them into the pinned arena and then raises a sequence number the
-// host spins on: a blit + hipStreamSynchronize costs the copy engine's completion signal and a thread wake-up (~40 us of a
-// 0.34 ms block); the spin sees the results ~2 us after the last kernel.  16-byte granules, one workgroup (the region is a few KB).
-__global__ void __launch_bounds__(256) k_bank_download(const uint4 *__restrict__ src, uint4 *__restrict__ dst_host, uint32_t n16, volatile uint32_t *flag_host, uint32_t seq) {
-    for (uint32_t i = threadIdx.x; i < n16; i += 256) dst_host[i] = src[i];
+__global__ void __launch_bounds__(256) k_bank_mix(const Real *__restrict__ click, uint32_t n_impacts, const Real *__restrict__ rout, uint32_t n_renderers, uint32_t frames,
+                                                  const Real *__restrict__ out_dev, Real *__restrict__ out_host, volatile uint32_t *flag_host, uint32_t seq) {
+    for (uint32_t s = threadIdx.x; s < frames; s += 256) {
+        Real acc = out_dev[s];
+        for (uint32_t i = 0; i < n_impacts; ++i) acc += click[size_t(i) * frames + s];
+        for (uint32_t r = 0; r < n_renderers; ++r) acc += rout[size_t(r) * frames + s];
+        out_host[s] = acc;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -388,12 +457,12 @@ struct Arena {
         flag = flag_seen_by_device = nullptr;
         cap = 0;
     }
-    // device [begin, end) -> host arena, then wait for it: spin on the flag, with the stream's own synchronisation as the way out
-    // of a stall (and the place where an asynchronous error would surface)
-    void download_and_wait(hipStream_t st, size_t begin, size_t end) {
-        const size_t b16 = begin / 16, e16 = (end + 15) / 16; // (offsets are 64-byte aligned)
+    // the block's mix into the pinned arena, then wait for it: spin on the flag, with the stream's own synchronisation as the way
+    // out of a stall (and the place where an asynchronous error would surface)
+    template<typename Real>
+    void mix_and_wait(hipStream_t st, const Real *click, uint32_t n_impacts, const Real *rout, uint32_t n_renderers, uint32_t frames, size_t out_off) {
         ++seq;
-        k_bank_download<<<1, 256, 0, st>>>(reinterpret_cast<const uint4 *>(dev) + b16, reinterpret_cast<uint4 *>(host_seen_by_device) + b16, uint32_t(e16 - b16), flag_seen_by_device, seq);
+        k_bank_mix<Real><<<1, 256, 0, st>>>(click, n_impacts, rout, n_renderers, frames, d<Real>(out_off), hd<Real>(out_off), flag_seen_by_device, seq);
         HIP_CHECK(hipGetLastError());
         const volatile uint32_t *f = flag;
         for (uint64_t spin = 0; *f != seq; ++spin) {
@@ -412,6 +481,7 @@ struct Arena {
     }
     template<typename T> T *h(size_t off) const { return reinterpret_cast<T *>(host + off); }
     template<typename T> T *d(size_t off) const { return reinterpret_cast<T *>(dev + off); }
+    template<typename T> T *hd(size_t off) const { return reinterpret_cast<T *>(host_seen_by_device + off); } // the pinned arena as kernels address it
     ~Arena() { release(); }
 };
 
@@ -460,10 +530,12 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     const size_t o_waves = A.take((n_waves + 1) * sizeof(WaveDesc)), o_deal = A.take((n_dealt + 1) * 4), o_count = A.take((n_dealt + 1) * 4);
     const size_t o_tuned = A.take((n_dealt + 1) * 4), o_chunk_base = A.take((n_dealt + 1) * 4), o_imp_ptr = A.take((n_dealt + 1) * 4);
     const size_t o_imp_idx = A.take((n_impacts + 1) * 4), o_rcp = A.take((n_renderers + 1) * 4);
-    const size_t both_begin = A.used;
     const size_t o_out = A.take(frames * sizeof(Real)), o_impacts = A.take((n_impacts + 1) * sizeof(ImpactDev<Real>));
     const size_t both_end = A.used;
+    // (written by the kernels straight into the pinned arena -- no copy back: the host sees them once the block's last kernel has
+    // raised the sequence number)
     const size_t o_energy = A.take((n_dealt + 1) * 8), o_modal = A.take((n_dealt + 1) * 8), o_live = A.take((n_dealt + 1) * 4), o_silenced = A.take(n_dealt + 1);
+    const size_t o_back = A.take((n_impacts + 1) * sizeof(ImpactBack<Real>));
     const size_t total = A.used;
     if (total > A.cap) {
         HIP_CHECK(hipStreamSynchronize(st));
@@ -525,7 +597,7 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     ensure(ctx, B.force, size_t(std::max<uint32_t>(n_impacts, 1)) * frames);
     ensure(ctx, B.click, size_t(std::max<uint32_t>(n_impacts, 1)) * frames);
     if (n_impacts) {
-        k_bank_forces<Real><<<div_up(n_impacts, 64), 64, 0, st>>>(d_impacts, n_impacts, d_listener, Real(click_gain), frames, B.force, B.click);
+        k_bank_forces<Real><<<div_up(n_impacts, 64), 64, 0, st>>>(d_impacts, n_impacts, d_listener, Real(click_gain), frames, B.force, B.click, A.hd<ImpactBack<Real>>(o_back));
         KERNEL_CHECK();
     }
     ensure(ctx, B.rout, size_t(std::max<uint32_t>(n_renderers, 1)) * frames);
@@ -542,33 +614,29 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
                                                          B.force, d_out_gain, d_listener, frames, B.partial, B.chunk_energy, B.gain_scratch, max_imp);
             KERNEL_CHECK();
         }
-        k_bank_objects<Real><<<n_dealt, WAVE, 0, st>>>(B.cols(), d_deal, d_count, d_chunk_base, d_imp_ptr, d_out_gain, B.chunk_energy, n_dealt, A.d<double>(o_energy),
-                                                        A.d<uint32_t>(o_live), A.d<uint8_t>(o_silenced), A.d<uint32_t>(o_tuned), A.d<double>(o_modal));
-        KERNEL_CHECK();
-        launch_renderer_sum<Real>(st, B.partial, A.d<uint32_t>(o_rcp), frames, n_renderers, B.rout);
     } else if (n_renderers) {
         HIP_CHECK(hipMemsetAsync(B.rout.get(), 0, size_t(n_renderers) * frames * sizeof(Real), st));
     }
     // out[s] += clicks in impact order, then the renderers in order.  With many impacts in flight the click chain is the
     // same latency problem as a renderer's chunks (1 024 impacts: 100 us as a per-sample loop): it goes through the streaming
-    // kernel, continuing from what the caller left in the block, and the mix then starts from its result.
-    uint32_t clicks_in_mix = n_impacts;
-    if (n_impacts > 64) {
+    // sum, continuing from what the caller left in the block, and the mix then starts from its result.  That sum, the renderers'
+    // sums and the per-object pass are one launch (k_bank_post).
+    const uint32_t streamed_clicks = n_impacts > 64 ? n_impacts : 0;
+    if (n_dealt || streamed_clicks) {
         constexpr int SW = 16;
-        k_bank_renderer_sum<Real, SW><<<dim3(div_up(frames, SW), 1), 1024, 0, st>>>(B.click, nullptr, frames, d_out, d_out, 0u, n_impacts);
+        const uint32_t strips = div_up(frames, SW), sum_slices = (n_dealt ? n_renderers : 0) + (streamed_clicks ? 1 : 0);
+        const uint32_t object_slices = n_dealt ? div_up(n_dealt, strips * (1024 / WAVE)) : 0;
+        ObjectPassArgs<Real> objects{B.cols(), A.d<uint32_t>(o_deal), A.d<uint32_t>(o_count), A.d<uint32_t>(o_chunk_base), A.d<uint32_t>(o_imp_ptr), d_out_gain, B.chunk_energy, n_dealt,
+                                     A.hd<double>(o_energy), A.hd<uint32_t>(o_live), A.hd<uint8_t>(o_silenced), A.d<uint32_t>(o_tuned), A.hd<double>(o_modal)};
+        static PerDeviceOnceBank attr;
+        attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bank_post<Real, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+        k_bank_post<Real, SW><<<dim3(strips, sum_slices + object_slices), 1024, bank_post_lds<Real, SW>(), st>>>(B.partial, A.d<uint32_t>(o_rcp), n_dealt ? n_renderers : 0, frames, B.rout, B.click, streamed_clicks,
+                                                                                        d_out, objects);
         KERNEL_CHECK();
-        clicks_in_mix = 0;
     }
-    k_bank_mix<Real><<<div_up(frames, 64), 64, 0, st>>>(B.click, clicks_in_mix, B.rout, n_renderers, frames, d_out);
-    KERNEL_CHECK();
-    // ---- one copy back ----
-    static const bool blit = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "bank_blit"); // A/B hook: the copy engine + stream synchronisation
-    if (blit) {
-        HIP_CHECK(hipMemcpyAsync(A.host + both_begin, A.dev + both_begin, (n_dealt ? total : both_end) - both_begin, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-    } else {
-        A.download_and_wait(st, both_begin, n_dealt ? total : both_end);
-    }
+    const uint32_t clicks_in_mix = streamed_clicks ? 0 : n_impacts;
+    // ---- the mix, written to the host with the sequence number the host waits for ----
+    A.template mix_and_wait<Real>(st, B.click, clicks_in_mix, B.rout, n_renderers, frames, o_out);
     std::copy(A.h<Real>(o_out), A.h<Real>(o_out) + frames, out);
     if (n_dealt) {
         std::copy(A.h<double>(o_energy), A.h<double>(o_energy) + n_dealt, object_energy);
@@ -576,13 +644,14 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
         std::copy(A.h<uint8_t>(o_silenced), A.h<uint8_t>(o_silenced) + n_dealt, object_silenced);
         if (object_modal_energy) std::copy(A.h<double>(o_modal), A.h<double>(o_modal) + n_dealt, object_modal_energy);
     }
+    const ImpactBack<Real> *back = A.h<ImpactBack<Real>>(o_back);
     for (uint32_t i = 0; i < n_impacts; ++i) {
         mh_impact &m = impacts[i];
-        m.samples_left = himp[i].samples_left;
-        m.phase_re = double(himp[i].phase_re);
-        m.phase_im = double(himp[i].phase_im);
-        m.click_z1 = double(himp[i].z1);
-        m.click_z2 = double(himp[i].z2);
+        m.samples_left = back[i].samples_left;
+        m.phase_re = double(back[i].phase_re);
+        m.phase_im = double(back[i].phase_im);
+        m.click_z1 = double(back[i].z1);
+        m.click_z2 = double(back[i].z2);
     }
 }
 } // namespace

@@ -55,51 +55,70 @@ __global__ void __launch_bounds__(GI * GJ * KS * 64) __attribute__((amdgpu_waves
     const size_t r_begin = size_t(blockIdx.x) * rows_per_wg;
     const size_t r_end = min(n, r_begin + rows_per_wg);
     const int kk_lane = lane >> 4, c_lane = lane & 15;
-    // staging map: 16 threads per row, NTH/16 rows per pass.  The hot loop has no branch: loads go to clamped
-    // addresses and out-of-range entries are zeroed by a 0/1 factor (a select would be turned back into a branch with
-    // a wait per load).
+    // staging map: 16 threads per row, NTH/16 rows per pass.  The hot loop carries no address arithmetic and no selects (beside
+    // the fp64 matrix instructions of the CU's other workgroup every ordinary vector instruction waits for a gap between two of
+    // them -- profiles/r03_combine_phases.txt): loads go to a scalar base that moves with the step plus per-thread byte offsets
+    // fixed at kernel start, columns past the panels read a real column (their products land in outputs nobody stores), and only
+    // a workgroup's last, partial step clamps its rows and writes zeros for the missing ones.
     constexpr int RPP = NTH / 16;
     static_assert(KC % RPP == 0 || RPP > KC, "staging passes");
     constexpr int PASSES = RPP >= KC ? 1 : KC / RPP;
     const int srow = tid >> 4, scol = tid & 15;
     const bool stager = srow < KC; // RPP > KC: the extra threads carry nothing
-    int xcol[CA], ycol[CB];
-    uint32_t xbits = 0, ybits = 0; // strips of this thread's column that exist in the panels
+    const uint32_t xpitch = uint32_t(ldx) * 8u, ypitch = uint32_t(ldy) * 8u;
+    uint32_t xoff[CA], yoff[CB]; // byte offset of this thread's column of each strip within a row
 #pragma unroll
-    for (int c = 0; c < CA; ++c) {
-        const int col = scol + 16 * c;
-        xcol[c] = min(col, wa - 1);
-        xbits |= (col < wa ? 1u : 0u) << c;
-    }
+    for (int c = 0; c < CA; ++c) xoff[c] = uint32_t(min(scol + 16 * c, wa - 1)) * 8u;
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
-        const int col = scol + 16 * c;
-        ycol[c] = ymap ? int(ymap[min(col, wb - 1)]) : min(col, wb - 1); // optional column map: Y's logical column -> physical column
-        ybits |= (col < wb ? 1u : 0u) << c;
+        const int col = min(scol + 16 * c, wb - 1);
+        yoff[c] = (ymap ? ymap[col] : uint32_t(col)) * 8u; // optional column map: Y's logical column -> physical column
     }
     double px[PASSES][CA], py[PASSES][CB];
-    auto fetch = [&](size_t r0) { // raw loads from clamped addresses
+    auto fetch = [&](size_t r0) {
+        const char *xb = reinterpret_cast<const char *>(X + r0 * size_t(ldx)), *yb = reinterpret_cast<const char *>(Y + r0 * size_t(ldy)); // uniform
+        if (r0 + KC <= r_end) {
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const size_t r = r0 + ps * RPP + srow;
-            const size_t rc = (r < r_end && stager) ? r : r_begin;
-            const double *xr = X + rc * ldx, *yr = Y + rc * ldy;
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const uint32_t xr = uint32_t(stager ? ps * RPP + srow : 0) * xpitch, yr = uint32_t(stager ? ps * RPP + srow : 0) * ypitch;
 #pragma unroll
-            for (int c = 0; c < CA; ++c) px[ps][c] = xr[xcol[c]];
+                for (int c = 0; c < CA; ++c) px[ps][c] = *reinterpret_cast<const double *>(xb + size_t(xr + xoff[c]));
 #pragma unroll
-            for (int c = 0; c < CB; ++c) py[ps][c] = yr[ycol[c]];
+                for (int c = 0; c < CB; ++c) py[ps][c] = *reinterpret_cast<const double *>(yb + size_t(yr + yoff[c]));
+            }
+        } else { // rows past the end read the step's first row
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int k = ps * RPP + srow;
+                const uint32_t row = (stager && r0 + k < r_end) ? uint32_t(k) : 0u;
+#pragma unroll
+                for (int c = 0; c < CA; ++c) px[ps][c] = *reinterpret_cast<const double *>(xb + size_t(row * xpitch + xoff[c]));
+#pragma unroll
+                for (int c = 0; c < CB; ++c) py[ps][c] = *reinterpret_cast<const double *>(yb + size_t(row * ypitch + yoff[c]));
+            }
         }
     };
-    auto commit = [&](size_t r0) { // registers -> LDS, entries outside the panels as zeros
+    auto commit = [&](size_t r0) { // registers -> LDS
         if (!stager) return;
+        if (r0 + KC <= r_end) {
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int k = ps * RPP + srow;
-            const bool rok = r0 + k < r_end;
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int k = ps * RPP + srow;
 #pragma unroll
-            for (int c = 0; c < CA; ++c) Xs[k * PA + scol + 16 * c] = (rok && ((xbits >> c) & 1u)) ? px[ps][c] : 0.0;
+                for (int c = 0; c < CA; ++c) Xs[k * PA + scol + 16 * c] = px[ps][c];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) Ys[k * PB + scol + 16 * c] = (rok && ((ybits >> c) & 1u)) ? py[ps][c] : 0.0;
+                for (int c = 0; c < CB; ++c) Ys[k * PB + scol + 16 * c] = py[ps][c];
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int k = ps * RPP + srow;
+                const bool rok = r0 + k < r_end;
+#pragma unroll
+                for (int c = 0; c < CA; ++c) Xs[k * PA + scol + 16 * c] = rok ? px[ps][c] : 0.0;
+#pragma unroll
+                for (int c = 0; c < CB; ++c) Ys[k * PB + scol + 16 * c] = rok ? py[ps][c] : 0.0;
+            }
         }
     };
     if (r_begin < r_end) fetch(r_begin);
@@ -312,8 +331,10 @@ __global__ void __launch_bounds__(256) k_combine(const double *__restrict__ X, i
             if (more) commit(k0 + CK, smem + (B ^ 1) * STAGE); // its readers passed the last barrier
             __syncthreads();
         };
-        fetch(kb);
-        commit(kb, smem); // (the previous tile's last chunk ended with a barrier)
+        if (kb < ke) { // (an empty K slice -- more slices than chunks -- still stores its zeros)
+            fetch(kb);
+            commit(kb, smem); // (the previous tile's last chunk ended with a barrier)
+        }
         __syncthreads();
         for (int k0 = kb, buf = 0; k0 < ke; k0 += CK, buf ^= 1) chunk(k0, buf);
         // stores: per accumulator row one 64-bit row address for each output (scalar base + row offset), strips at constant
