@@ -15,7 +15,6 @@
 namespace {
 constexpr int LANES = 8; // ModalAudio.h:169
 constexpr int WAVE = 64;
-constexpr int CHUNKS_PER_WAVE = WAVE / LANES;
 
 template<typename Real> struct ImpactDev {
     uint32_t object, ex_pos, samples_left, pad;
@@ -29,7 +28,7 @@ template<typename Real> struct ImpactBack { // an impact's state after the block
 
 struct WaveDesc {
     uint32_t dealt; // index into the flattened deal
-    uint32_t first_mode; // first mode of this wave inside the object (multiple of 64)
+    uint32_t first_mode; // first mode of this wave inside the object (multiple of MODES_PER_WAVE)
 };
 
 // Force curve + click filter per impact (ModalAudio.cpp:504-538).  force/click: [impact][frames].
@@ -119,11 +118,14 @@ template<typename Real> __device__ __forceinline__ Real chunk_sum_in_order(Real 
     return acc;
 }
 
-// One wave = 64 consecutive modes of one dealt object = 8 chunks.  partial: [global chunk][frames].
-// Samples run in tiles of TS: during a tile every lane (= mode) advances its resonator sample by sample and drops its
-// output term into an LDS tile [sample][mode]; after the tile the wave turns around -- lane = (chunk group, sample) --
-// and adds each chunk's 8 terms in lane order 0..7, which is the reference's summation order at two LDS reads per
-// mode-sample instead of a cross-lane chain per sample, and makes the partial-signal stores contiguous in the sample.
+// One wave = 128 consecutive modes of one dealt object = 16 chunks, two adjacent modes per lane: the resonator arithmetic is
+// issue bound (every operation its own instruction -- no contraction, the reference's expression tree), and on a pair of fp32
+// values one packed instruction does the work of two (the fp64 bank runs the same code unpacked).  partial: [global chunk][frames].
+// Samples run in tiles of TS: during a tile every lane advances its two resonators sample by sample and drops their output terms
+// into an LDS tile [sample][mode]; after the tile the wave turns around -- lane = (chunk group, sample) -- and adds each chunk's 8
+// terms in mode order 0..7, which is the reference's summation order at two LDS reads per mode-sample instead of a cross-lane
+// chain per sample, and makes the partial-signal stores contiguous in the sample.
+constexpr int MODES_PER_WAVE = 2 * WAVE;
 template<typename Real>
 __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const WaveDesc *__restrict__ waves, const uint32_t *__restrict__ deal_objects,
                                                     const uint32_t *__restrict__ render_count, const uint32_t *__restrict__ chunk_base,
@@ -131,43 +133,48 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
                                                     const ImpactDev<Real> *__restrict__ impacts, const Real *__restrict__ force,
                                                     const Real *__restrict__ out_gain, const Real *__restrict__ listener_gain, uint32_t frames,
                                                     Real *__restrict__ partial, Real *__restrict__ chunk_energy, Real *__restrict__ gain_scratch, uint32_t max_imp) {
-    constexpr uint32_t TS = 32, PITCH = WAVE + 1;
-    __shared__ Real s_term[TS * PITCH];
+    typedef Real Pair __attribute__((ext_vector_type(2)));
+    constexpr uint32_t TS = 32, PITCH = MODES_PER_WAVE + 2, CHUNKS = MODES_PER_WAVE / LANES;
+    __shared__ __attribute__((aligned(16))) Real s_term[TS * PITCH];
     const WaveDesc wd = waves[blockIdx.x];
     const uint32_t lane = threadIdx.x;
     const uint32_t o = deal_objects[wd.dealt];
     const uint32_t count = render_count[wd.dealt];
     const uint32_t k0 = b.mode_offset[o], stride = b.mode_count[o], shape0 = b.shape_offset[o];
-    const uint32_t k = wd.first_mode + lane;
-    const bool live = k < count;
+    const uint32_t k = wd.first_mode + 2 * lane; // this lane's modes: k, k + 1
+    const bool live[2] = {k < count, k + 1 < count};
     const uint32_t chunk0 = chunk_base[wd.dealt] + wd.first_mode / LANES; // global index of this wave's first chunk
-    const uint32_t chunks_here = min(uint32_t(CHUNKS_PER_WAVE), (count - wd.first_mode + LANES - 1) / LANES);
-    Real z_re = 0, z_im = 0, c_re = 0, c_im = 0, p_re = 0, p_im = 0;
-    if (live) {
-        z_re = b.state_re[k0 + k]; z_im = b.state_im[k0 + k];
-        c_re = b.coeff_re[k0 + k]; c_im = b.coeff_im[k0 + k];
-        p_im = b.phase_im[k0 + k]; p_re = b.phase_re[k0 + k];
-    }
+    const uint32_t chunks_here = min(CHUNKS, (count - wd.first_mode + LANES - 1) / LANES);
+    Pair z_re = {0, 0}, z_im = {0, 0}, c_re = {0, 0}, c_im = {0, 0}, p_re = {0, 0}, p_im = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (live[h]) {
+            z_re[h] = b.state_re[k0 + k + h]; z_im[h] = b.state_im[k0 + k + h];
+            c_re[h] = b.coeff_re[k0 + k + h]; c_im[h] = b.coeff_im[k0 + k + h];
+            p_im[h] = b.phase_im[k0 + k + h]; p_re[h] = b.phase_re[k0 + k + h];
+        }
     const uint32_t i0 = imp_ptr[wd.dealt], n_imp = imp_ptr[wd.dealt + 1] - i0;
-    // Hoisted impact gains (ImpactGainRow, ModalAudio.h:182-188); zero on padded lanes.  The first IMP_REG impacts of
+    // Hoisted impact gains (ImpactGainRow, ModalAudio.h:182-188); zero on padded modes.  The first IMP_REG impacts of
     // the object live in registers, further ones (rare) in a scratch row.
     constexpr uint32_t IMP_REG = 2;
-    Real g_reg[IMP_REG] = {};
+    Pair g_reg[IMP_REG] = {};
     uint32_t f_row[IMP_REG] = {};
-    Real *g_mem = gain_scratch + size_t(blockIdx.x) * max_imp * WAVE;
+    Real *g_mem = gain_scratch + size_t(blockIdx.x) * max_imp * MODES_PER_WAVE;
     for (uint32_t t = 0; t < n_imp; ++t) {
-        Real g = 0;
+        Pair g = {0, 0};
         const uint32_t ii = imp_idx[i0 + t];
-        if (live) {
-            const ImpactDev<Real> &im = impacts[ii];
-            const uint32_t base = shape0 + im.ex_pos * stride + k;
-            g = b.rad_gain[k0 + k] * (b.shape_x[base] * im.jx + b.shape_y[base] * im.jy + b.shape_z[base] * im.jz);
-        }
+        const ImpactDev<Real> &im = impacts[ii];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (live[h]) {
+                const uint32_t base = shape0 + im.ex_pos * stride + k + h;
+                g[h] = b.rad_gain[k0 + k + h] * (b.shape_x[base] * im.jx + b.shape_y[base] * im.jy + b.shape_z[base] * im.jz);
+            }
         if (t < IMP_REG) { g_reg[t] = g; f_row[t] = ii; }
-        else g_mem[size_t(t) * WAVE + lane] = g;
+        else *reinterpret_cast<Pair *>(g_mem + size_t(t) * MODES_PER_WAVE + 2 * lane) = g;
     }
     const Real mix_gain = out_gain[o] * listener_gain[o];
-    const uint32_t half = lane / TS, ts = lane % TS; // turn-around mapping: chunks 4*half .. 4*half+3 of sample ts
+    const uint32_t half = lane / TS, ts = lane % TS; // turn-around mapping: chunks 8*half .. 8*half+7 of sample ts
 
     // NR = impacts held in registers (0, 1 or 2); EXTRA = the object has more than IMP_REG impacts.
     auto run = [&](auto nr_tag, auto extra_tag) {
@@ -180,25 +187,26 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
             for (uint32_t t = 0; t < NR; ++t)
                 if (lane < sn) f_tile[t] = force[size_t(f_row[t]) * frames + s0 + lane];
             auto sample = [&](uint32_t ds) {
-                Real excite = 0;
+                Pair excite = {0, 0};
 #pragma unroll
                 for (uint32_t t = 0; t < NR; ++t) {
-                    // a zero force sample is skipped by the reference; adding +0 instead is the same bits
+                    // a zero force sample is skipped by the reference; adding its product instead is the same bits: the product is a
+                    // zero of either sign (the gains are finite), and excite -- never a negative zero, it starts at +0 -- is unchanged
+                    // by one (a select here was two more vector instructions per impact and sample in an issue-bound loop)
                     const Real f = lane_bcast(f_tile[t], ds);
-                    const Real fg = f * g_reg[t];
-                    excite += f != Real(0) ? fg : Real(0);
+                    excite += f * g_reg[t];
                 }
                 if (EXTRA) {
                     for (uint32_t t = IMP_REG; t < n_imp; ++t) {
                         const Real f = force[size_t(imp_idx[i0 + t]) * frames + s0 + ds];
                         if (f == Real(0)) continue;
-                        excite += f * g_mem[size_t(t) * WAVE + lane];
+                        excite += f * *reinterpret_cast<const Pair *>(g_mem + size_t(t) * MODES_PER_WAVE + 2 * lane);
                     }
                 }
-                const Real re = z_re * c_re - z_im * c_im + excite;
+                const Pair re = z_re * c_re - z_im * c_im + excite;
                 z_im = z_re * c_im + z_im * c_re;
                 z_re = re;
-                s_term[ds * PITCH + lane] = p_im * z_im + p_re * re;
+                *reinterpret_cast<Pair *>(s_term + ds * PITCH + 2 * lane) = p_im * z_im + p_re * re;
             };
             if (sn == TS && !EXTRA) {
 #pragma unroll
@@ -208,13 +216,17 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
             }
             __syncthreads();
             if (ts < sn) {
-                const Real *row = s_term + ts * PITCH + half * (4 * LANES);
+                const Real *row = s_term + ts * PITCH + half * (CHUNKS / 2 * LANES);
 #pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
+                for (uint32_t c = 0; c < CHUNKS / 2; ++c) {
                     Real acc = 0;
 #pragma unroll
-                    for (uint32_t l = 0; l < LANES; ++l) acc += row[c * LANES + l];
-                    const uint32_t chunk = 4 * half + c;
+                    for (uint32_t l = 0; l < LANES; l += 2) {
+                        const Pair v = *reinterpret_cast<const Pair *>(row + c * LANES + l);
+                        acc += v.x;
+                        acc += v.y;
+                    }
+                    const uint32_t chunk = CHUNKS / 2 * half + c;
                     if (chunk < chunks_here) partial[size_t(chunk0 + chunk) * frames + s0 + ts] = acc * mix_gain;
                 }
             }
@@ -228,14 +240,24 @@ __global__ void __launch_bounds__(WAVE) k_bank_modes(BankCols<Real> b, const Wav
     else if (n_imp == 1) run(T1{}, std::false_type{});
     else if (n_imp == 2) run(T2{}, std::false_type{});
     else run(T2{}, std::true_type{});
-    if (live) {
-        b.state_re[k0 + k] = z_re;
-        b.state_im[k0 + k] = z_im;
-    }
-    // chunk energy: sum over the chunk's valid lanes in order (padded lanes hold zero state)
-    const Real e = z_re * z_re + z_im * z_im;
-    const Real chunk = chunk_sum_in_order(live ? e : Real(0));
-    if ((lane & (LANES - 1)) == 0 && lane / LANES < chunks_here) chunk_energy[chunk0 + lane / LANES] = chunk;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (live[h]) {
+            b.state_re[k0 + k + h] = z_re[h];
+            b.state_im[k0 + k + h] = z_im[h];
+        }
+    // chunk energy: sum over the chunk's valid modes in order (padded modes hold zero state); a chunk is four lanes' pairs
+    const Pair e = z_re * z_re + z_im * z_im;
+    const Real e0 = live[0] ? e.x : Real(0), e1 = live[1] ? e.y : Real(0);
+    Real chunk = Real(0) + e0;
+    chunk += e1;
+    chunk += row_shl<1>(e0);
+    chunk += row_shl<1>(e1);
+    chunk += row_shl<2>(e0);
+    chunk += row_shl<2>(e1);
+    chunk += row_shl<3>(e0);
+    chunk += row_shl<3>(e1);
+    if ((lane & (LANES / 2 - 1)) == 0 && lane / (LANES / 2) < chunks_here) chunk_energy[chunk0 + lane / (LANES / 2)] = chunk;
 }
 
 // Per dealt object (one wave each): energy, audible prefix, whole-object silence (ModalAudio.cpp:132-146).  Loads are
@@ -522,7 +544,7 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     Real *out = static_cast<Real *>(out_v);
     const uint32_t n_dealt = n_renderers ? deal_offset[n_renderers] : 0;
     uint32_t n_waves = 0;
-    for (uint32_t d = 0; d < n_dealt; ++d) n_waves += (render_count[d] + WAVE - 1) / WAVE;
+    for (uint32_t d = 0; d < n_dealt; ++d) n_waves += (render_count[d] + MODES_PER_WAVE - 1) / MODES_PER_WAVE;
     // ---- arena layout: [upload only | both ways | download only] ----
     Arena &A = B.arena;
     A.used = 0;
@@ -551,7 +573,7 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
         for (uint32_t d = 0; d < n_dealt; ++d) {
             const uint32_t count = render_count[d];
             chunk_base[d + 1] = chunk_base[d] + (count + LANES - 1) / LANES;
-            for (uint32_t k = 0; k < count; k += WAVE) waves[wv++] = {d, k};
+            for (uint32_t k = 0; k < count; k += MODES_PER_WAVE) waves[wv++] = {d, k};
             if (deal_objects[d] < B.n_objects) B.dealt_of_object[deal_objects[d]] = int32_t(d);
             imp_ptr[d + 1] = 0;
         }
@@ -604,7 +626,7 @@ void render_impl(BankImpl<Real> &B, uint32_t frames, float click_gain, uint32_t 
     if (n_dealt) {
         ensure(ctx, B.partial, size_t(n_chunks + 1) * frames);
         ensure(ctx, B.chunk_energy, n_chunks + 1);
-        ensure(ctx, B.gain_scratch, size_t(n_waves + 1) * max_imp * WAVE);
+        ensure(ctx, B.gain_scratch, size_t(n_waves + 1) * max_imp * MODES_PER_WAVE);
         const uint32_t *d_deal = A.d<uint32_t>(o_deal), *d_count = A.d<uint32_t>(o_count), *d_chunk_base = A.d<uint32_t>(o_chunk_base), *d_imp_ptr = A.d<uint32_t>(o_imp_ptr);
         if (n_waves) {
             uint64_t rendered_modes = 0;
