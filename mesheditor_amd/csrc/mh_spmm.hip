@@ -156,9 +156,12 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
     constexpr int G = 64 / CL, STRIP = 64, VP = sizeof(TV) == 4 ? 12 : 10, U = UR; // V = panel entries per lane (16 bytes; 1 for odd pitches)
     typedef TX Vec __attribute__((ext_vector_type(V)));
     typedef TY Acc __attribute__((ext_vector_type(V)));
-    __shared__ __attribute__((aligned(16))) TV sv[TB / 64][WITH_A ? STRIP * VP : 1];
-    __shared__ TV sm[TB / 64][WITH_M ? STRIP : 1];
-    __shared__ uint32_t sc[TB / 64][STRIP];
+    // (one slot more than a strip holds: the slot after a strip's last block is a ZERO block on a valid column, and a lane group
+    // without a block in the last round takes it -- no per-value selects in the loop, which the compiler had turned into nine
+    // exec-masked LDS reads with their scalar bookkeeping, more instructions than the products themselves)
+    __shared__ __attribute__((aligned(16))) TV sv[TB / 64][WITH_A ? (STRIP + 1) * VP : 1];
+    __shared__ TV sm[TB / 64][WITH_M ? STRIP + 1 : 1];
+    __shared__ uint32_t sc[TB / 64][STRIP + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = lane % CL, g = lane / CL; // CL need not divide 64 (20 lanes x 3 groups for 80 floats): lanes past G * CL idle
     const uint32_t nb_grid = gridDim.x, per = (nb_grid + 7) / 8;
@@ -208,6 +211,11 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
             }
         }
         if (WITH_M) smw[lane] = uint32_t(lane) < nb ? mscal[base + lane] : TV(0);
+        if (lane == 0) { // the zero block
+            scw[nb] = row;
+            if (WITH_M) smw[nb] = TV(0);
+        }
+        if (WITH_A && lane < VP) svw[nb * VP + lane] = TV(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // round t: lane group g takes block t*G + g of the strip
         const uint32_t rounds = (nb + G - 1) / G;
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < rounds) { // wave-uniform
-                    bi[u] = min((t0 + u) * G + g, nb - 1);
+                    bi[u] = min((t0 + u) * G + g, nb);
                     const uint32_t xp = MAPOUT ? xpitch : w;
                     const TX *xr = x + size_t(3) * scw[bi[u]] * xp + coff;
                     xv[u][0] = *reinterpret_cast<const Vec *>(xr);
@@ -228,19 +236,18 @@ __global__ void __launch_bounds__(TB) MH_SPMM_OCC k_spmm_wide(const uint32_t *__
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < rounds) {
-                    const bool ok = (t0 + u) * G + g < nb && (G * CL == 64 || g < G);
                     const Acc x0 = __builtin_convertvector(xv[u][0], Acc), x1 = __builtin_convertvector(xv[u][1], Acc), x2 = __builtin_convertvector(xv[u][2], Acc);
                     if (WITH_A) {
                         TY v[9];
 #pragma unroll
-                        for (int e = 0; e < 9; ++e) v[e] = ok ? TY(svw[bi[u] * VP + e]) : TY(0);
+                        for (int e = 0; e < 9; ++e) v[e] = TY(svw[bi[u] * VP + e]);
                         // one fused multiply-add per term (a sum of three products first costs a fourth instruction)
                         acc[0] += v[0] * x0; acc[0] += v[1] * x1; acc[0] += v[2] * x2;
                         acc[1] += v[3] * x0; acc[1] += v[4] * x1; acc[1] += v[5] * x2;
                         acc[2] += v[6] * x0; acc[2] += v[7] * x1; acc[2] += v[8] * x2;
                     }
                     if (WITH_M) {
-                        const TY m = ok ? TY(smw[bi[u]]) : TY(0);
+                        const TY m = TY(smw[bi[u]]);
                         macc[0] += m * x0;
                         macc[1] += m * x1;
                         macc[2] += m * x2;
