@@ -1534,27 +1534,38 @@ __global__ void __launch_bounds__(256) k_potrf_panels(double *__restrict__ A, in
 // leading dimension ldo): in-place Gauss-Jordan without pivoting in registers, one workgroup.  Every pivot of an SPD matrix is
 // positive; a pivot that is not sets *info = its index + 1 (info is only ever raised: clear it before a sequence of calls).
 namespace {
-template<int NQ> // columns per thread: 128 * 128 / NQ threads
-__global__ void __launch_bounds__(128 * 128 / NQ) k_spd_inverse_small(const double *__restrict__ A, int lda, int w, double *__restrict__ out, int ldo, int *__restrict__ info) {
-    // Thread t owns row i = t & 127 and the NQ columns j = (t >> 7) + NG q of the (padded) 128 x 128 block, in registers for the
-    // whole elimination.  Step p needs row p and column p of the current matrix.  Between a processed and an unprocessed index
-    // the in-place Gauss-Jordan iterate is antisymmetric (rows were scaled by +1/pivot, columns by -1/pivot) and symmetric
-    // otherwise, so column p is row p with the sign of the processed entries flipped: only the NG owners of row p publish
-    // it (LDS, two alternating buffers), one barrier per step.
-    __shared__ double rowbuf[2][128];
-    const int tid = threadIdx.x, i = tid & 127, jg = tid >> 7;
-    constexpr int NG = 128 / NQ; // column groups
-    double val[NQ];
+// Explicit inverse of an SPD block of order <= 128 by in-place Gauss-Jordan elimination, one workgroup of 1 024 threads, the
+// (padded) 128 x 128 iterate in registers for the whole elimination: thread (tr, tc) = (tid & 31, tid >> 5) owns the 4 x 4 entries
+// (tr + 32 a, tc + 32 b).  Step p needs row p and column p of the current matrix.  Between a processed and an unprocessed index
+// the iterate is antisymmetric (rows were scaled by +1/pivot, columns by -1/pivot) and symmetric otherwise, so column p is row p
+// with the sign of the processed entries flipped: only the 32 owners of row p publish it (LDS, two alternating buffers), one
+// barrier per step.  A 4 x 4 tile reads 4 + 4 + 1 published values per step for its 16 updates; the 1 x 16 strips this kernel
+// used first read 18, and the LDS pipe -- 16 waves x 18 reads x 4 cycles against 512 cycles of fp64 arithmetic per step --
+// was what bound it: 179 -> ~75 us at order 128 with the same operations per entry, bit for bit.
+__global__ void __launch_bounds__(1024) k_spd_inverse_small(const double *__restrict__ A, int lda, int w, double *__restrict__ out, int ldo, int *__restrict__ info) {
+    __shared__ double rowbuf[2][128 + 1]; // row p, and 1 / pivot (one division, by the pivot's owner, instead of 1 024 of them per step)
+    const int tid = threadIdx.x, tr = tid & 31, tc = tid >> 5;
+    double val[4][4];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int j = jg + NG * q;
-        val[q] = (i < w && j < w) ? A[size_t(j) * lda + i] : (i == j ? 1.0 : 0.0); // identity padding: inert
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = tr + 32 * a, j = tc + 32 * b;
+            val[a][b] = (i < w && j < w) ? A[size_t(j) * lda + i] : (i == j ? 1.0 : 0.0); // identity padding: inert
+        }
     for (int p = 0; p < w; ++p) {
         double *rb = rowbuf[p & 1];
-        if (i == p) {
+        const int ap = p >> 5, lp = p & 31; // row / column p inside its owners' tiles (uniform)
+        if (tr == lp) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rb[jg + NG * q] = val[q];
+            for (int a = 0; a < 4; ++a)
+                if (a == ap) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        rb[tc + 32 * b] = val[a][b];
+                        if (tc == lp && b == ap) rb[128] = 1.0 / val[a][b];
+                    }
+                }
         }
         __syncthreads();
         const double piv = rb[p];
@@ -1562,41 +1573,54 @@ __global__ void __launch_bounds__(128 * 128 / NQ) k_spd_inverse_small(const doub
             if (tid == 0) atomicMax(info, p + 1);
             break;
         }
-        const double inv = 1.0 / piv;
-        const double f = i < p ? -rb[i] : rb[i]; // element (i, p)
-        // generic entries first, without selects (the fp64 ALU work of the step is what bounds it) ...
+        const double inv = rb[128];
+        double f[4], r[4];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const double t = f * rb[jg + NG * q];
-            val[q] = fma(-t, inv, val[q]);
+        for (int a = 0; a < 4; ++a) {
+            const int i = tr + 32 * a;
+            f[a] = i < p ? -rb[i] : rb[i]; // element (i, p)
         }
-        // ... then row p (its owners' waves only) and column p (one register per owner, selected by a uniform switch)
-        if (i == p) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) val[q] = rb[jg + NG * q] * inv;
+        for (int b = 0; b < 4; ++b) r[b] = rb[tc + 32 * b];
+        // generic entries first, without selects (the fp64 ALU work of the step is what should bound it) ...
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double t = f[a] * r[b];
+                val[a][b] = fma(-t, inv, val[a][b]);
+            }
+        // ... then row p (its owners only) and column p (one register per tile row of its owners), picked by uniform compares
+        if (tr == lp) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a == ap) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) val[a][b] = r[b] * inv;
+                }
         }
-        const int qp = p / NG;
-        const double cp = (i == p) ? inv : -f * inv; // element (i, p) of the result
-        if (jg == p % NG) {
+        if (tc == lp) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (q == qp) val[q] = cp; // qp is uniform: a scalar compare per q, no per-lane select chains
+            for (int b = 0; b < 4; ++b)
+                if (b == ap) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) val[a][b] = (tr + 32 * a == p) ? inv : -f[a] * inv; // element (i, p) of the result
+                }
         }
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int j = jg + NG * q;
-        if (i < w && j < w) out[size_t(j) * ldo + i] = val[q];
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = tr + 32 * a, j = tc + 32 * b;
+            if (i < w && j < w) out[size_t(j) * ldo + i] = val[a][b];
+        }
 }
 } // namespace
 
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "spd_inverse_small: order %u outside 1..128", w);
-    constexpr int nq = 16;
-    if (nq == 16) k_spd_inverse_small<16><<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
-    else if (nq == 32) k_spd_inverse_small<32><<<1, 512, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
-    else k_spd_inverse_small<64><<<1, 256, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
+    k_spd_inverse_small<<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
     KERNEL_CHECK();
 }
 
