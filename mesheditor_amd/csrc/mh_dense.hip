@@ -585,7 +585,8 @@ void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, co
         const uint32_t kslice = (div_up(m, slices) + CK - 1) / CK * CK; // as the kernel cuts the K range
         const size_t lds = 2 * (size_t(64) * (CK + 2) + size_t(CK) * CP) * sizeof(double) + size_t(std::min(kslice, m) + CK) * 12;
         if (lds > 160 * 1024) mh_throw(MH_EINVAL, "short product: %u basis columns per slice exceed the staging table", kslice);
-        const dim3 grid(unsigned(std::min<size_t>(div_up(n, 64), size_t(std::max(1u, combine_residency<NT, false, false>(ctx, lds) * unsigned(ctx->cu_count) / slices)))), slices);
+        (void)combine_residency<NT, false, false>(ctx, lds); // (raises the kernel's LDS limit on first use)
+        const dim3 grid(div_up(n, 64), slices); // one 64-row tile per workgroup: a few hundred workgroups in all, about one round of the device
         k_combine<NT, false, false><<<grid, 256, lds, ctx->stream>>>(a, int(m), int(m), nullptr, nullptr, 0, nullptr, 0, ct, int(nc), 0, int(nc), n, slices > 1 ? partial : out, int(nc), nullptr, stride,
                                                              int(nc), nullptr);
     };
