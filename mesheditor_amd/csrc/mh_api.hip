@@ -132,6 +132,8 @@ int mh_context_create(int device, mh_context **out) {
         const int code = mh_guard(ctx, e);
         fprintf(stderr, "modalhip: %s\n", e.what());
         if (ctx->blas) rocblas_destroy_handle(ctx->blas);
+    if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
+        if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
         if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -143,6 +145,7 @@ void mh_context_destroy(mh_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->blas) rocblas_destroy_handle(ctx->blas);
+    if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -115,9 +115,17 @@ struct mh_context {
     hipStream_t aux_stream{nullptr}; // second stream of the context: the coarse elimination beside the smoothers' set-up (created on first use)
     bool aux_stream_ready() {
         if (!aux_stream && hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) aux_stream = nullptr;
-        return aux_stream != nullptr;
+        if (aux_stream && !blas_aux) {
+            if (rocblas_create_handle(&blas_aux) != rocblas_status_success) blas_aux = nullptr;
+            else if (rocblas_set_stream(blas_aux, aux_stream) != rocblas_status_success) {
+                (void)rocblas_destroy_handle(blas_aux);
+                blas_aux = nullptr;
+            }
+        }
+        return aux_stream != nullptr && blas_aux != nullptr;
     }
     rocblas_handle blas{nullptr};
+    rocblas_handle blas_aux{nullptr}; // the second stream's own handle (a handle's workspace must not serve two streams at once), created with the stream
     DevicePool pool;
     std::string last_error;
     hipEvent_t ev0{nullptr}, ev1{nullptr};
@@ -285,6 +293,18 @@ struct mh_system {
     float worst_quality{1.f};    // smallest element shape measure (1 = regular tetrahedron)
     double sigma_built{0};
     bool hierarchy_ready{false};
+    // The coarse inverse's elimination runs on the context's second stream and may still be running when mh_build_hierarchy
+    // returns (defer = true): its workspaces live here until mh_finish_hierarchy has made the main stream wait for it -- which
+    // the first application of the preconditioner does -- so the eigensolver's start-up (first block, its images, the first
+    // Rayleigh-Ritz step) runs beside the elimination's one-workgroup kernels.
+    hipEvent_t coarse_done{nullptr};
+    bool coarse_pending{false};
+    DevArray<double> coarse_ws[3];
+    DevArray<int> coarse_info;
+    ~mh_system() {
+        if (coarse_pending && coarse_done) (void)hipEventSynchronize(coarse_done);
+        if (coarse_done) (void)hipEventDestroy(coarse_done);
+    }
     // eigensolver result (internal numbering, row-major n x ncols)
     DevArray<double> evecs;
     uint32_t evec_cols{0};
@@ -319,7 +339,8 @@ struct MhSharedPhase {
 };
 std::mutex &mh_solve_mutex(); // mh_eigs.hip: one eigensolve (or Gram benchmark) at a time per process, see there
 void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &mat, mh_system *sys); // mh_pipeline.hip
-void mh_build_hierarchy(mh_system *sys, double sigma); // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
+void mh_build_hierarchy(mh_system *sys, double sigma, bool defer = false);
+void mh_finish_hierarchy(mh_system *sys); // no-op unless a deferred elimination is pending // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
 uint32_t mh_graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col, uint32_t n, uint32_t target, uint32_t max_order, std::vector<uint32_t> &agg_of); // mh_pipeline.hip
 void mh_select_patches(mh_system *sys, float threshold);                                  // mh_patch.hip: elements whose shape measure is below the threshold
 void mh_build_patch_inverses(mh_context *ctx, const BsrLevel &lvl, PatchSet &ps);         // mh_patch.hip: (A_ee)^-1 of every patch from lvl.aval

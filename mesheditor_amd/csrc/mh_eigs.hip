@@ -831,6 +831,7 @@ template<typename T> struct Precond {
     }
     // z = B r for an n2 x w panel
     void apply(const double *r_in, double *z_out, uint32_t w_in) {
+        mh_finish_hierarchy(sys);
         const uint32_t w = pitch(w_in);
         const uint32_t nn = sys->n_nodes, np = sys->n_points, na = sys->n_agg;
         const size_t n2 = size_t(3) * nn, n1 = size_t(3) * np, n0 = size_t(6) * na;
@@ -905,9 +906,27 @@ double estimate_lmax(mh_context *ctx, BsrLevel &lvl, const PatchSet &ps) {
 }
 } // namespace
 
-void mh_build_hierarchy(mh_system *sys, double sigma) {
+void mh_finish_hierarchy(mh_system *sys) {
+    if (!sys->coarse_pending) return;
     mh_context *ctx = sys->ctx;
-    if (sys->hierarchy_ready && sys->sigma_built == sigma) return;
+    sys->coarse_pending = false;
+    HIP_CHECK(hipStreamWaitEvent(ctx->stream, sys->coarse_done, 0));
+    int hinfo = 0;
+    sys->coarse_info.download(&hinfo, 1); // (on the main stream, i.e. after the elimination)
+    for (auto &ws : sys->coarse_ws) ws.reset(ctx, 0);
+    if (hinfo != 0) {
+        sys->hierarchy_ready = false;
+        mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
+    }
+}
+
+void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
+    mh_context *ctx = sys->ctx;
+    if (sys->hierarchy_ready && sys->sigma_built == sigma) {
+        if (!defer) mh_finish_hierarchy(sys);
+        return;
+    }
+    mh_finish_hierarchy(sys); // (a rebuild at another shift while the last elimination was never waited for)
     hipStream_t main_stream = ctx->stream;
     for (BsrLevel *lvl : {&sys->L2, &sys->L1}) {
         lvl->aval.reset(ctx, lvl->n_blocks * 9);
@@ -925,8 +944,8 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
     KERNEL_CHECK();
     k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), 1e-12);
     KERNEL_CHECK();
-    DevArray<int> info(ctx, 1);
-    int hinfo = 0;
+    DevArray<int> &info = sys->coarse_info;
+    info.reset(ctx, 1);
     // The rest of the set-up -- the spectral bounds of both smoothers (power iterations: SpMMs that fill the GPU, with host
     // round trips) and the single-precision copies -- does not depend on the coarse inverse, whose elimination is a chain of
     // one-workgroup kernels and small products: the two run side by side on two streams.
@@ -949,7 +968,10 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
         // solve needs no exclusive phase on the device.  The coarse solve becomes one dense product per application (2.5x
         // faster than two triangular solves at these sizes, and free of their O(n0 / 128) dependent launches).
         const uint32_t nb = 128;
-        DevArray<double> cblk(ctx, n0 * nb), rblk(ctx, n0 * nb), pinv(ctx, size_t(nb) * nb);
+        DevArray<double> &cblk = sys->coarse_ws[0], &rblk = sys->coarse_ws[1], &pinv = sys->coarse_ws[2];
+        cblk.reset(ctx, n0 * nb);
+        rblk.reset(ctx, n0 * nb);
+        pinv.reset(ctx, size_t(nb) * nb);
         info.zero();
         const bool side = ctx->aux_stream_ready();
         struct StreamGuard { // whatever happens below, the context leaves on its own stream
@@ -958,7 +980,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
             ~StreamGuard() {
                 if (c->stream != s) {
                     c->stream = s;
-                    (void)rocblas_set_stream(c->blas, s);
+                    std::swap(c->blas, c->blas_aux);
                     (void)hipStreamSynchronize(c->aux_stream);
                 }
             }
@@ -969,7 +991,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
             HIP_CHECK(hipEventRecord(forked, main_stream));
             HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, forked, 0));
             ctx->stream = ctx->aux_stream;
-            ROCBLAS_CHECK(rocblas_set_stream(ctx->blas, ctx->aux_stream));
+            std::swap(ctx->blas, ctx->blas_aux); // the second stream's own handle
         }
         const double one = 1, zero = 0, mone = -1;
         const rocblas_int ld = rocblas_int(n0);
@@ -988,19 +1010,21 @@ void mh_build_hierarchy(mh_system *sys, double sigma) {
         KERNEL_CHECK();
         if (side) { // back to the main stream for the smoothers' set-up while the elimination runs
             ctx->stream = main_stream;
-            ROCBLAS_CHECK(rocblas_set_stream(ctx->blas, main_stream));
+            std::swap(ctx->blas, ctx->blas_aux);
         }
+        // the elimination's end, as the main stream will wait for it (without a second stream it ran on the main one)
+        if (!sys->coarse_done) HIP_CHECK(hipEventCreateWithFlags(&sys->coarse_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(sys->coarse_done, side ? ctx->aux_stream : main_stream));
+        sys->coarse_pending = true;
         smoother_setup();
-        if (side) {
-            HIP_CHECK(hipStreamSynchronize(ctx->aux_stream)); // (the workspaces above live until here)
-            (void)hipEventDestroy(forked);
-        }
-        info.download(&hinfo, 1);
-        if (hinfo != 0) mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
+        if (side) (void)hipEventDestroy(forked);
     }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
     sys->sigma_built = sigma;
     sys->hierarchy_ready = true;
+    if (!defer) {
+        mh_finish_hierarchy(sys);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
 }
 
 namespace {
@@ -1668,7 +1692,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         } else {
             {
                 Timer t(ctx);
-                mh_build_hierarchy(sys, sigma);
+                mh_build_hierarchy(sys, sigma, true); // (the coarse elimination may still run: the first preconditioner application waits for it)
                 prof.factorize = t.stop();
             }
             if (progress) *progress = 0.3f;
