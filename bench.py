@@ -189,7 +189,7 @@ def edit_loop(api, ctx, pts, tets, m, ex, cfg, mesh):
         return {"error": repr(e)[:200]}
 
 
-def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k"), reps=2):
+def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior"), reps=2):
     """Secondary rows: the scan-like unstructured meshes (marching-tetrahedra skillet surface through the path's own
     tetrahedraliser: slivers, 2-60 tets per node, no interior points) beside the Kuhn grid of the same size -- iterations,
     milliseconds and eigenpairs per second of the whole mesh2modes path, 65 pairs each."""

@@ -1,10 +1,12 @@
 // The tet-generation front end of the path, under the contract of the reference's
 // tetra::Tetrahedralize (src/mesh/Tetrahedralize.h:49-61): input vertex i keeps index i, triangle winding is ignored, every
 // tet is positively oriented, the tets fill exactly the enclosed volume, and an open or unrecoverable surface returns an error
-// string.  Where the general fill DEPARTS from that contract:
-//   * input triangles are not kept whole: missing edges and faces are recovered by points ON the surface, so the output's
-//     boundary refines the input triangulation (Result::BoundarySteinerCount says by how many points; 0 = the input surface
-//     appears exactly, which callers needing surface-to-tet vertex identity must check);
+// string.  "Every input triangle is a boundary face, and added (Steiner) points lie strictly inside" (Tetrahedralize.h:59) holds
+// when Result::BoundarySteinerCount is 0 -- the usual outcome: the recovery first adds points ON the surface (edge bisections),
+// and a second pass (Options::InteriorSteiner, on by default) takes them off it again, last one first, by moving each inside and
+// filling the two thin wedges that open under its restored triangles with a tetrahedron each (src/tetrahedralize.cpp,
+// LiftBoundaryPoints).  A point for which no valid inner position exists stays on the surface and is counted.
+// Where the general fill still DEPARTS from the reference's contract:
 //   * internal walls (an edge shared by an odd number of triangles) are rejected as "open", duplicate positions as
 //     "point coincides" -- the reference accepts non-manifold input;
 //   * no sliver repair, no quality refinement (the reference's Options::Quality / MaxVolume have no counterpart);
@@ -12,8 +14,7 @@
 // Two fills:
 //   tetra::Tetrahedralize   any closed, non-self-intersecting surface -- non-convex, non-star-shaped, any genus, nested
 //                           cavities: a conforming Delaunay tetrahedralisation on exact predicates.  Surface triangles the
-//                           Delaunay mesh lacks are recovered by splitting them (points ON the surface, as the reference's
-//                           own boundary Steiner points; its validator accepts refined faces).
+//                           Delaunay mesh lacks are recovered by bisecting their edges; the added points then move inside.
 //   tetra::FillStarShaped   surfaces star-shaped about their centroid: layered shells, no point on the surface is added,
 //                           well-shaped elements (the Delaunay fill of a bare surface has long interior tets).
 #pragma once
@@ -29,11 +30,12 @@ namespace tetra {
 struct Result {
     TetMesh Mesh;
     std::string Error; // empty on success
-    uint32_t BoundarySteinerCount{0}; // points added ON the surface (refined input triangles); always 0 for FillStarShaped
+    uint32_t BoundarySteinerCount{0}; // added points left ON the surface (input triangles they refine are not boundary faces); 0 = the input triangulation is the boundary
     explicit operator bool() const { return Error.empty(); }
 };
 struct Options {
     size_t MaxSteinerPoints{0}; // boundary-recovery budget; 0 = 2 x the input vertices + 4096
+    bool InteriorSteiner{true}; // after the fill, move the recovery's points off the surface (every input triangle a boundary face again)
 };
 Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options = {});
 // `layers` shells between the surface and the centroid (0: a plain fan of one tet per triangle).  Each layer is a copy of

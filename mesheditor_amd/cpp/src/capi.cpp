@@ -196,13 +196,14 @@ double mhx_punch_stiffness(double inv_modulus, double area) { return PunchStiffn
 struct mhx_tets {
     tetra::Result Result;
 };
-mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner) {
+mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner, int interior_steiner) {
     auto *h = new mhx_tets;
     try {
         std::vector<dvec3> pts(n_points);
         for (uint32_t i = 0; i < n_points; ++i) pts[i] = {points[3 * size_t(i)], points[3 * size_t(i) + 1], points[3 * size_t(i) + 2]};
         tetra::Options options;
         options.MaxSteinerPoints = size_t(max_steiner);
+        options.InteriorSteiner = interior_steiner != 0;
         h->Result = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
     } catch (const std::exception &e) { h->Result.Error = e.what(); }
     return h;

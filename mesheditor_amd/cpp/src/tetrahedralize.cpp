@@ -233,6 +233,140 @@ struct SurfaceEdgeUse {
 };
 } // namespace
 
+// The recovery above leaves its points ON the surface: the boundary of the mesh refines the input triangulation.  The reference's
+// contract (src/mesh/Tetrahedralize.h:59) wants every input triangle a boundary face and added points strictly inside, so the
+// points are taken off the surface again, last one first.  The last point m bisected a surface edge (a, b) with the apexes c, d
+// of its two triangles, and nothing later touched its four boundary triangles (a, m, c), (m, b, c), (a, m, d), (m, b, d): moving
+// m to a position m' strictly inside and adding the tetrahedra (a, b, c, m') and (a, b, d, m') fills exactly the two thin
+// wedges that open between the old faces and the restored triangles (a, b, c), (a, b, d).  With m gone from the surface the
+// point before it is in the same situation, and so on.  m' is taken along the bisector of the two triangles' inward normals or
+// towards the centroid of m's tetrahedra, as far in as keeps every tetrahedron at m positively oriented (exact predicates) and
+// gives the best worst-volume among them and the two new ones.  Returns how many points had to stay on the surface.
+static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::vector<std::array<uint32_t, 2>> &split_edge) {
+    auto &P = mesh.Points;
+    auto &T = mesh.Tets;
+    const auto face_key = [](uint32_t a, uint32_t b, uint32_t c) {
+        if (a > b) std::swap(a, b);
+        if (b > c) std::swap(b, c);
+        if (a > b) std::swap(a, b);
+        return (uint64_t(a) << 42) | (uint64_t(b) << 21) | uint64_t(c); // (< 2^21 points: checked by the caller of this pass)
+    };
+    if (P.size() >= (size_t(1) << 21)) return uint32_t(P.size() - n_input);
+    // faces of the mesh: how many tetrahedra share each, and one of them (a boundary face has exactly one)
+    std::unordered_map<uint64_t, std::pair<uint32_t, uint32_t>> faces; // key -> (count, a tet)
+    faces.reserve(T.size() * 2);
+    std::vector<std::vector<uint32_t>> star(P.size() - n_input); // tets of every added point
+    const auto add_tet = [&](uint32_t t) {
+        const auto &v = T[t];
+        for (int i = 0; i < 4; ++i) {
+            auto &f = faces[face_key(v[(i + 1) & 3], v[(i + 2) & 3], v[(i + 3) & 3])];
+            ++f.first;
+            f.second = t;
+            if (v[i] >= n_input) star[v[i] - n_input].push_back(t);
+        }
+    };
+    for (uint32_t t = 0; t < T.size(); ++t) add_tet(t);
+    const auto orient = [&](const dvec3 &a, const dvec3 &b, const dvec3 &c, const dvec3 &d) { return exact::Orient3D(a, b, c, d); };
+    const auto volume6 = [](const dvec3 &a, const dvec3 &b, const dvec3 &c, const dvec3 &d) {
+        const dvec3 u = b - a, v = c - a, w = d - a;
+        return u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x);
+    };
+    uint32_t stuck = 0;
+    for (size_t k = split_edge.size(); k-- > 0;) {
+        const uint32_t m = n_input + uint32_t(k), a = split_edge[k][0], b = split_edge[k][1];
+        // the boundary triangles at m: exactly (a, m, c), (m, b, c), (a, m, d), (m, b, d)
+        uint32_t apex[2] = {0, 0};
+        int n_apex = 0, n_boundary = 0;
+        bool pattern = true;
+        for (const uint32_t t : star[k]) {
+            const auto &v = T[t];
+            for (int i = 0; i < 4 && pattern; ++i) {
+                if (v[i] == m) continue; // the face opposite v[i] contains m
+                const uint32_t f[3] = {v[(i + 1) & 3], v[(i + 2) & 3], v[(i + 3) & 3]};
+                if (faces[face_key(f[0], f[1], f[2])].first != 1) continue;
+                ++n_boundary;
+                uint32_t others[2];
+                int no = 0;
+                for (const uint32_t x : f)
+                    if (x != m) others[no++] = x;
+                const bool has_a = others[0] == a || others[1] == a, has_b = others[0] == b || others[1] == b;
+                if (has_a == has_b) { pattern = false; break; } // each boundary triangle at m holds exactly one end of the edge
+                const uint32_t w = (others[0] == a || others[0] == b) ? others[1] : others[0];
+                if (n_apex < 2 && (n_apex == 0 || apex[0] != w) && (n_apex < 2 || apex[1] != w)) {
+                    if (n_apex == 0 || apex[0] != w) apex[n_apex++] = w;
+                } else if (!(apex[0] == w || (n_apex == 2 && apex[1] == w))) pattern = false;
+            }
+        }
+        if (!pattern || n_boundary != 4 || n_apex != 2) { ++stuck; continue; }
+        const uint32_t c = apex[0], d = apex[1];
+        for (const auto key : {face_key(a, m, c), face_key(m, b, c), face_key(a, m, d), face_key(m, b, d)})
+            if (!faces.count(key) || faces[key].first != 1) pattern = false;
+        if (!pattern) { ++stuck; continue; }
+        // which side of the restored triangles is inside: the side of the fourth vertex of the tet on (a, m, c) / (a, m, d)
+        const auto fourth = [&](uint32_t t, uint32_t x, uint32_t y, uint32_t z) {
+            for (const uint32_t v : T[t])
+                if (v != x && v != y && v != z) return v;
+            return x;
+        };
+        const uint32_t ec = fourth(faces[face_key(a, m, c)].second, a, m, c), ed = fourth(faces[face_key(a, m, d)].second, a, m, d);
+        const int in_c = orient(P[a], P[m], P[c], P[ec]), in_d = orient(P[a], P[m], P[d], P[ed]);
+        if (in_c == 0 || in_d == 0) { ++stuck; continue; }
+        const auto cross = [](const dvec3 &u, const dvec3 &v) { return dvec3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; };
+        const auto unit = [](dvec3 v) {
+            const double l = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+            return l > 0 ? dvec3{v.x / l, v.y / l, v.z / l} : v;
+        };
+        dvec3 nc = unit(cross(P[b] - P[a], P[c] - P[a])), nd = unit(cross(P[b] - P[a], P[d] - P[a]));
+        if (volume6(P[a], P[b], P[c], P[ec]) < 0) nc = dvec3{-nc.x, -nc.y, -nc.z};
+        if (volume6(P[a], P[b], P[d], P[ed]) < 0) nd = dvec3{-nd.x, -nd.y, -nd.z};
+        dvec3 centroid{0, 0, 0};
+        for (const uint32_t t : star[k])
+            for (const uint32_t v : T[t]) centroid = centroid + P[v] * (0.25 / double(star[k].size()));
+        const dvec3 old = P[m];
+        const dvec3 ab = P[b] - P[a];
+        const double h = 0.5 * std::sqrt(ab.x * ab.x + ab.y * ab.y + ab.z * ab.z);
+        const dvec3 towards = centroid - old;
+        const double reach = std::sqrt(towards.x * towards.x + towards.y * towards.y + towards.z * towards.z);
+        const dvec3 dir_n = unit(nc + nd), dir_c = unit(towards), dir_mix = unit(dir_n + dir_c);
+        const auto valid_quality = [&](const dvec3 &x, double &worst) { // every tet at m stays positive, the two new ones fit
+            worst = 1e300;
+            for (const uint32_t t : star[k]) {
+                dvec3 q[4];
+                for (int i = 0; i < 4; ++i) q[i] = T[t][i] == m ? x : P[T[t][i]];
+                if (orient(q[0], q[1], q[2], q[3]) <= 0) return false;
+                worst = std::min(worst, volume6(q[0], q[1], q[2], q[3]));
+            }
+            // (a, b, c, x): x on the inner side of the restored triangle, b beyond the face (a, x, c) as seen from inside, a beyond (x, b, c)
+            if (orient(P[a], P[b], P[c], x) != in_c || orient(P[a], P[b], P[d], x) != in_d) return false;
+            if (orient(P[a], x, P[c], P[b]) != -in_c || orient(x, P[b], P[c], P[a]) != -orient(P[m], P[b], P[c], P[fourth(faces[face_key(m, b, c)].second, m, b, c)])) return false;
+            if (orient(P[a], x, P[d], P[b]) != -in_d || orient(x, P[b], P[d], P[a]) != -orient(P[m], P[b], P[d], P[fourth(faces[face_key(m, b, d)].second, m, b, d)])) return false;
+            const int sc = orient(P[a], P[b], x, P[c]), sd = orient(P[a], P[b], x, P[d]);
+            if (sc == 0 || sc != -sd) return false; // c and d on opposite sides of the face the two new tets share
+            worst = std::min({worst, std::fabs(volume6(P[a], P[b], P[c], x)), std::fabs(volume6(P[a], P[b], P[d], x))});
+            return true;
+        };
+        dvec3 best = old;
+        double best_q = 0;
+        for (const dvec3 &dir : {dir_n, dir_c, dir_mix})
+            for (const double step : {1.0, 0.8, 0.6, 0.4, 0.25, 0.15, 0.08, 0.04, 0.02, 0.01, 0.003}) { // (shallow moves cost the eigensolver iterations: 39 at <= 0.6, 56 at <= 0.08, 79 at <= 0.02 on the 30k-tet scan)
+                const double len = step * std::min(h, reach > 0 ? 2 * reach : h);
+                const dvec3 x = old + dir * len;
+                double q;
+                if (valid_quality(x, q) && q > best_q) best_q = q, best = x;
+            }
+        if (!(best_q > 0)) { ++stuck; continue; }
+        // apply: m moves; the four old boundary faces become interior, two tetrahedra restore (a, b, c) and (a, b, d)
+        P[m] = best;
+        for (const uint32_t w : {c, d}) {
+            std::array<uint32_t, 4> tet{a, b, w, m};
+            if (orient(P[tet[0]], P[tet[1]], P[tet[2]], P[tet[3]]) < 0) std::swap(tet[0], tet[1]);
+            T.push_back(tet);
+            add_tet(uint32_t(T.size() - 1));
+        }
+    }
+    return stuck;
+}
+
 Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options) {
     Result out;
     const uint32_t n_input = uint32_t(points.size());
@@ -313,8 +447,10 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
                 if (alive[t] && !queued[t]) queued[t] = 1, pending.push_back(t);
         }
     };
+    std::vector<std::array<uint32_t, 2>> split_edge; // per Steiner point, in insertion order: the surface edge it bisected
     const auto split = [&](uint32_t u, uint32_t v) -> bool {
         const uint32_t m = dt.AddMidpoint(u, v); // exactly on the segment (exact coordinates), rounded only for output
+        split_edge.push_back({u, v});
         const uint64_t key = EdgeKey(u, v);
         const std::vector<uint32_t> hit = on_edge[key];
         on_edge.erase(key);
@@ -439,6 +575,10 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         out.Mesh.Tets.push_back({final_id(cell.V[0]), final_id(cell.V[1]), final_id(cell.V[2]), final_id(cell.V[3])});
     }
     if (out.Mesh.Tets.empty()) return out.Error = "surface encloses no volume", out;
+    if (options.InteriorSteiner && out.BoundarySteinerCount) {
+        for (auto &e : split_edge) e = {final_id(e[0]), final_id(e[1])};
+        out.BoundarySteinerCount = LiftBoundaryPoints(out.Mesh, n_input, split_edge);
+    }
     return out;
 }
 } // namespace tetra

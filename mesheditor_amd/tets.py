@@ -9,7 +9,7 @@ def _lib():
     L = bank.lib()
     if not getattr(L, "_tets_bound", False):
         vp, u32 = C.c_void_p, C.c_uint32
-        L.mhx_tetrahedralize.restype, L.mhx_tetrahedralize.argtypes = vp, [vp, u32, vp, u32, C.c_uint64]
+        L.mhx_tetrahedralize.restype, L.mhx_tetrahedralize.argtypes = vp, [vp, u32, vp, u32, C.c_uint64, C.c_int]
         L.mhx_tets_error.restype, L.mhx_tets_error.argtypes = C.c_char_p, [vp]
         for name in ("mhx_tets_num_points", "mhx_tets_num_tets", "mhx_tets_boundary_steiner"):
             getattr(L, name).restype, getattr(L, name).argtypes = u32, [vp]
@@ -20,13 +20,15 @@ def _lib():
     return L
 
 
-def tetrahedralize(points, triangles, max_steiner=0):
+def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True):
     """(points float64 [V', 3], tets uint32 [T, 4], boundary_steiner_count): input vertex i keeps index i, added points follow.
+    interior_steiner (tetra::Options::InteriorSteiner): the recovery's points are moved off the surface afterwards, so that every
+    input triangle is a boundary face (the count returned is what had to stay on it; 0 = the reference's contract holds).
     Raises RuntimeError with the tetrahedraliser's message for open / self-intersecting / unrecoverable surfaces."""
     L = _lib()
     pts = np.ascontiguousarray(points, dtype=np.float64)
     tri = np.ascontiguousarray(triangles, dtype=np.uint32)
-    h = L.mhx_tetrahedralize(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner))
+    h = L.mhx_tetrahedralize(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner), int(bool(interior_steiner)))
     try:
         err = L.mhx_tets_error(h).decode()
         if err:

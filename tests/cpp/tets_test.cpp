@@ -207,6 +207,29 @@ std::string ValidateGeneral(const Surface &s, const TetMesh &mesh, bool oriented
     }
     return {};
 }
+// The reference's contract in full (src/mesh/Tetrahedralize.h:59): "every input triangle is a boundary face, and added
+// (Steiner) points lie strictly inside" -- the boundary faces of the mesh are the input triangles, no more, no fewer.
+std::string InputSurfaceIsTheBoundary(const Surface &s, const TetMesh &mesh) {
+    std::map<std::array<uint32_t, 3>, int> faces;
+    static constexpr int F[4][3]{{1, 3, 2}, {0, 2, 3}, {0, 3, 1}, {0, 1, 2}};
+    for (const auto &t : mesh.Tets)
+        for (const auto &f : F) ++faces[Sorted(t[f[0]], t[f[1]], t[f[2]])];
+    std::set<std::array<uint32_t, 3>> input;
+    for (size_t i = 0; i < s.T.size(); i += 3) {
+        const auto key = Sorted(s.T[i], s.T[i + 1], s.T[i + 2]);
+        if (!input.insert(key).second) input.erase(key); // (a triangle given twice is a flap: it bounds nothing)
+    }
+    size_t boundary = 0;
+    for (const auto &[f, count] : faces) {
+        if (count != 1) continue;
+        ++boundary;
+        if (!input.count(f)) return "a boundary face is not an input triangle";
+        for (const uint32_t v : f)
+            if (v >= s.P.size()) return "an added point lies on the boundary";
+    }
+    if (boundary != input.size()) return "an input triangle is not a boundary face";
+    return {};
+}
 // a parametric quad grid closed in both directions (torus) or with poles welded (sphere); consistently wound
 Surface Torus(double R, double r, int nu, int nv, double noise = 0.0, double flatten = 1.0, unsigned seed = 3) {
     Surface s;
@@ -296,6 +319,38 @@ Surface Bowl(double outer, double inner, int rings, int segments) {
     band(in[0], out[0], false); // the rim
     return s;
 }
+// an icosahedron subdivided `level` times and projected onto the sphere (20 * 4^level well-shaped triangles, outward winding),
+// radii varied point by point
+Surface IcoSphere(int level, double noise, unsigned seed) {
+    Surface s;
+    const double t = (1 + std::sqrt(5.0)) / 2;
+    for (const auto &p : std::vector<dvec3>{{-1, t, 0}, {1, t, 0}, {-1, -t, 0}, {1, -t, 0}, {0, -1, t}, {0, 1, t}, {0, -1, -t}, {0, 1, -t}, {t, 0, -1}, {t, 0, 1}, {-t, 0, -1}, {-t, 0, 1}}) s.P.push_back(p);
+    s.T = {0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11, 1, 5, 9, 5, 11, 4, 11, 10, 2, 10, 7, 6, 7, 1, 8,
+           3, 9, 4, 3, 4, 2, 3, 2, 6, 3, 6, 8, 3, 8, 9, 4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7, 9, 8, 1};
+    for (int l = 0; l < level; ++l) {
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> mid;
+        const auto midpoint = [&](uint32_t a, uint32_t b) {
+            const auto key = std::minmax(a, b);
+            const auto it = mid.find(key);
+            if (it != mid.end()) return it->second;
+            s.P.push_back({(s.P[a].x + s.P[b].x) / 2, (s.P[a].y + s.P[b].y) / 2, (s.P[a].z + s.P[b].z) / 2});
+            return mid[key] = uint32_t(s.P.size() - 1);
+        };
+        std::vector<uint32_t> next;
+        for (size_t i = 0; i < s.T.size(); i += 3) {
+            const uint32_t a = s.T[i], b = s.T[i + 1], c = s.T[i + 2], ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+            next.insert(next.end(), {a, ab, ca, b, bc, ab, c, ca, bc, ab, bc, ca});
+        }
+        s.T.swap(next);
+    }
+    unsigned state = seed * 2654435761u + 1u;
+    for (auto &p : s.P) {
+        state = state * 1664525u + 1013904223u;
+        const double r = (1.0 + noise * (double(state >> 8) / double(1u << 24) - 0.5)) / std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+        p = {p.x * r, p.y * r, p.z * r};
+    }
+    return s;
+}
 void Append(Surface &to, const Surface &from) {
     const uint32_t base = uint32_t(to.P.size());
     to.P.insert(to.P.end(), from.P.begin(), from.P.end());
@@ -322,7 +377,15 @@ CASE(non_star_shaped_and_higher_genus_surfaces_fill) {
         if (!r) continue;
         const auto defect = ValidateGeneral(c.S, r.Mesh);
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
-        std::printf("%12s: %zu surface triangles -> %zu tets, %u boundary Steiner points\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(), r.BoundarySteinerCount);
+        // the recovery's points were taken off the surface again: the boundary IS the input triangulation
+        EXPECT_NOTE(r.BoundarySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
+        const auto contract = InputSurfaceIsTheBoundary(c.S, r.Mesh);
+        EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
+        tetra::Options on_surface;
+        on_surface.InteriorSteiner = false;
+        const auto refined = tetra::Tetrahedralize(c.S.P, c.S.T, on_surface);
+        std::printf("%12s: %zu surface triangles -> %zu tets, %zu added points (%u of them on the surface before they were moved inside)\n", c.Name, c.S.T.size() / 3,
+                    r.Mesh.Tets.size(), r.Mesh.Points.size() - c.S.P.size(), refined ? refined.BoundarySteinerCount : 0u);
     }
     // the star-shaped filler refuses the bracket, the layered front end falls through to the general fill
     const Surface bent = LPrism();
@@ -342,7 +405,8 @@ CASE(degenerate_and_noisy_point_sets_fill) {
         bool Oriented;
     };
     const Named cases[]{{"cube", BoxSurface(1, 1, 1, 1), false}, {"grid box 4", BoxSurface(1, 1, 1, 4), false}, {"grid box 7", BoxSurface(2, 1, 0.5, 7), false},
-                        {"sphere", Sphere(1.0, 8, 12, 0, 0), true}, {"noisy sphere", Sphere(1.0, 8, 12, 0.05, 7), true}};
+                        {"sphere", Sphere(1.0, 8, 12, 0, 0), true}, {"noisy sphere", Sphere(1.0, 8, 12, 0.05, 7), true},
+                        {"20k sphere", IcoSphere(5, 0.01, 11), true}};
     for (const auto &c : cases) {
         const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
         EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
@@ -357,7 +421,13 @@ CASE(degenerate_and_noisy_point_sets_fill) {
                 for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], p[d]), hi[d] = std::max(hi[d], p[d]);
             EXPECT(check::near(v6 / 6, (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]), 1e-12));
         }
-        std::printf("%12s: %zu surface triangles -> %zu tets, %u boundary Steiner points\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(), r.BoundarySteinerCount);
+        EXPECT_NOTE(r.BoundarySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
+        if (c.Oriented) { // (the boxes' test surfaces wind every other quad the wrong way; their triangles are checked all the same)
+            const auto contract = InputSurfaceIsTheBoundary(c.S, r.Mesh);
+            EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
+        }
+        std::printf("%12s: %zu surface triangles -> %zu tets, %zu added points, %u left on the surface\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(),
+                    r.Mesh.Points.size() - c.S.P.size(), r.BoundarySteinerCount);
     }
 }
 
