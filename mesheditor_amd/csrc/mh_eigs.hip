@@ -756,9 +756,9 @@ template<typename T> struct Precond {
         patch_y.reset(ctx, std::max(size_t(s->patches2.n_patches) * 30, size_t(s->patches1.n_patches) * 12) * w);
         const Switches &sw = switches();
         if (s->patches2.n_patches) { // a mesh with slivers: the P1 space represents its smooth error poorly (measured two-grid bound, exact
-            deg2 = 4;                // coarse solve, 30k-tet skillet scan: condition 34 with two steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax])
-            ratio = 30.0;
-        }
+            deg2 = 5;                // coarse solve, 30k-tet skillet scan: condition 34 with two steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax]).
+            ratio = 60.0;            // With the patches scaled by their overlap (mh_patch.hip) five steps over [lmax/60, lmax] are the measured best on the
+        }                            // four scan workloads: 24 / 26 / 40 / 40 iterations (4 over lmax/30: 26 / 33 / 44 / 48)
         if (sw.deg2 > 0) deg2 = sw.deg2;
         if (sw.deg1 > 0) deg1 = sw.deg1;
         if (sw.gamma > 0) gamma = sw.gamma;

@@ -176,7 +176,12 @@ void mh_select_patches(mh_system *sys, float threshold) {
     HIP_CHECK(hipMemcpyAsync(en.data(), sys->elem_nodes.get(), en.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(ep.data(), sys->elem_p1.get(), ep.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    constexpr bool weighted = false; // measured: 46 iterations unweighted against 55 weighted at 95k tets with q < 0.02 (the weights make the threshold uncritical; the default threshold makes them unnecessary)
+    // Overlapping patches add up: where c of them share a node the sum overshoots c-fold and drags the smoother's spectral bound
+    // along (lmax 21 against 8 on the 30k-tet scan filled with interior points, whose slivers come in clusters).  Each patch is
+    // scaled by (the largest number of patches at any of its nodes)^-0.35: still symmetric positive definite.  Measured on the four
+    // scan workloads (iterations, surface-refined / interior fills at 30k and 95k tets): unscaled 27 / 39 / 44 / 54; exponent -1
+    // 26 / 40 / 54 / 57; -0.5 26 / 34 / 45 / 50; -0.35 26 / 33 / 44 / 48; a greedy independent set of patches instead 29 / 45 / 77 / 76.
+    constexpr double overlap_exponent = -0.35;
     const auto fill = [&](PatchSet &ps, const std::vector<uint32_t> &elem, uint32_t npe) {
         const uint32_t np = uint32_t(bad.size());
         std::vector<uint32_t> nodes(size_t(np) * npe);
@@ -197,17 +202,14 @@ void mh_select_patches(mh_system *sys, float threshold) {
             tl.push_back(inc[k].second % npe);
         }
         ptr.push_back(uint32_t(inc.size()));
-        // Overlapping patches add up: where c of them share a node the sum overshoots c-fold and drags the smoother's spectral bound
-        // along (measured: lmax 20 against 8 with the patches unweighted).  Each patch is weighted by 1 / (the largest number of
-        // patches at any of its nodes): still symmetric positive definite, and the sum is bounded by the single-patch scale.
         std::vector<double> weight(np, 1.0);
-        if (weighted) {
+        {
             std::vector<uint32_t> cover(touched.size(), 0);
             for (size_t t = 0; t + 1 < ptr.size(); ++t) cover[t] = ptr[t + 1] - ptr[t];
             std::vector<uint32_t> worst(np, 1);
             for (size_t t = 0; t + 1 < ptr.size(); ++t)
                 for (uint32_t l = ptr[t]; l < ptr[t + 1]; ++l) worst[tp[l]] = std::max(worst[tp[l]], cover[t]);
-            for (uint32_t p = 0; p < np; ++p) weight[p] = 1.0 / double(worst[p]);
+            for (uint32_t p = 0; p < np; ++p) weight[p] = std::pow(double(worst[p]), overlap_exponent);
         }
         ps.weight.reset(ctx, np);
         ps.weight.upload(weight.data(), np);
