@@ -167,3 +167,28 @@ def test_graph_aggregates_are_connected_sets(core, name):
     same3 = agg3[inside.row] == agg3[inside.col]
     ncomp3, _ = cg.connected_components(sp.coo_matrix((np.ones(same3.sum()), (inside.row[same3], inside.col[same3])), shape=g.shape), directed=False)
     assert ncomp3 == na3
+
+
+def test_tet_front_end_keeps_the_input_triangulation_as_the_boundary():
+    """SURVEY 8f row N3 through the Python binding (host C++, no GPU): the scan-like skillet surface filled with the tetrahedraliser's
+    default options -- the boundary recovery's points moved inside afterwards -- has exactly the input triangles as boundary faces and
+    no added point on one (reference contract, src/mesh/Tetrahedralize.h:59); with interior_steiner=False the same surface comes
+    back refined (points left on it), which is what the count reports."""
+    from mesheditor_amd import meshes, tets
+    v, f = meshes.skillet_scan_surface(0.02, 0.02)
+    for interior in (True, False):
+        p, t, on_surface = tets.tetrahedralize(v, f, interior_steiner=interior)
+        assert np.array_equal(p[: len(v)], v)
+        a, b, c, d = (p[t[:, i]] for i in range(4))
+        assert (np.einsum("ij,ij->i", np.cross(b - a, c - a), d - a) > 0).all()
+        faces = np.sort(np.concatenate([t[:, [1, 2, 3]], t[:, [0, 2, 3]], t[:, [0, 1, 3]], t[:, [0, 1, 2]]]), axis=1)
+        uniq, counts = np.unique(faces, axis=0, return_counts=True)
+        assert counts.max() <= 2
+        boundary = {tuple(r) for r in uniq[counts == 1]}
+        given = {tuple(sorted(r)) for r in f.tolist()}
+        if interior:
+            assert on_surface == 0 and len(p) > len(v)  # points were added, none is left on the surface
+            assert boundary == given
+        else:
+            assert on_surface == len(p) - len(v) > 0
+            assert boundary != given and all(max(face) < len(v) for face in boundary & given)
