@@ -1,4 +1,5 @@
-"""Python binding of modal::SolveBatch (modal/batch.hpp, libmodalhost.so): a batch of independent meshes dealt over the
+"""Python binding of modal::SolveBatch (modal/batch.hpp, libmodalbatch.so -- the one host library that links RCCL and the HIP
+runtime directly; libmodalhost.so, which everything else binds, does not): a batch of independent meshes dealt over the
 ranks' GPUs by the LPT rule, solved by host threads per GPU, the fixed-size records gathered with ONE ncclAllGather -- the host
 side in C++, RCCL called directly.  The communicator's 128-byte id is made on rank 0 and shipped by the caller (bench.py: the
 launcher's TCP store); nothing else of the data path touches Python.
@@ -18,11 +19,23 @@ class _Item(C.Structure):
                 ("excite", C.c_void_p), ("n_excite", C.c_uint32), ("num_modes", C.c_uint32), ("num_fem_modes", C.c_uint32)]
 
 
+_LIB = None
+
+
 def _lib():
-    from . import bank
-    L = bank.lib()
+    global _LIB
+    if _LIB is None:
+        import os
+        from . import bank
+        bank.lib()  # libmodalhost.so (and libmodalhip.so under it) first: libmodalbatch.so depends on both
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmodalbatch.so")
+        if not os.path.exists(so):
+            raise RuntimeError("libmodalbatch.so is missing: run `make -C mesheditor_amd/cpp` (or __graft_entry__.build())")
+        _LIB = C.CDLL(so)
+    L = _LIB
     if not getattr(L, "_batch_bound", False):
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        L.mhx_batch_last_error.restype, L.mhx_batch_last_error.argtypes = C.c_char_p, []
         L.mhx_batch_make_id.restype, L.mhx_batch_make_id.argtypes = None, [vp]
         L.mhx_batch_comm_create.restype, L.mhx_batch_comm_create.argtypes = vp, [i32, i32, i32, vp]
         L.mhx_batch_comm_destroy.restype, L.mhx_batch_comm_destroy.argtypes = None, [vp]
@@ -38,7 +51,7 @@ def make_id():
     _lib().mhx_batch_make_id(buf)
     raw = bytes(buf)
     if not any(raw):
-        raise RuntimeError("ncclGetUniqueId failed: " + _lib().mhx_last_error().decode())
+        raise RuntimeError("ncclGetUniqueId failed: " + _lib().mhx_batch_last_error().decode())
     return raw
 
 
@@ -51,7 +64,7 @@ class BatchComm:
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         self.h = self.L.mhx_batch_comm_create(world, rank, device, buf)
         if not self.h:
-            raise RuntimeError("SolveBatch communicator: " + self.L.mhx_last_error().decode())
+            raise RuntimeError("SolveBatch communicator: " + self.L.mhx_batch_last_error().decode())
 
     def close(self):
         if getattr(self, "h", None):
@@ -82,7 +95,7 @@ def solve_batch(comm, meshes, nev_max=256, pos_max=16, threads=3, excite=None):
     assert reclen == sharding.record_length(nev_max, pos_max), "record layouts of batch.cpp and sharding.py differ"
     out = np.zeros((len(meshes), reclen))
     if L.mhx_solve_batch(comm.h, items, len(meshes), threads, nev_max, pos_max, out.ctypes.data_as(C.c_void_p)) != 0:
-        raise RuntimeError("SolveBatch: " + L.mhx_last_error().decode())
+        raise RuntimeError("SolveBatch: " + L.mhx_batch_last_error().decode())
     records = [sharding.unpack_record(out[i], nev_max, pos_max) for i in range(len(meshes))]
     failed = [r["index"] for r in records if not r["ok"]]
     if failed:

@@ -39,7 +39,9 @@ public:
     int Device() const { return Dev; }
     // every rank contributes `count` doubles from `send` (device memory) and receives world x count into `recv`
     void AllGather(const double *send, double *recv, size_t count);
-    void Synchronize();
+    // waits for the gather; RCCL's asynchronous error state or `timeout_seconds` without completion abort the communicator and throw
+    void Synchronize(double timeout_seconds = 600.0);
+    void Abort(); // ncclCommAbort: the other ranks' pending collective fails instead of waiting for this one
 
 private:
     int World{1}, Me{0}, Dev{0};
@@ -50,6 +52,7 @@ private:
 struct BatchOptions {
     uint32_t ThreadsPerDevice{3}; // solves in flight per GPU
     uint32_t MaxEigenpairs{256}, MaxPositions{16}; // record capacity
+    double GatherTimeoutSeconds{600.0}; // watchdog of the one collective (a rank that never joins must not hang the others)
 };
 
 struct BatchRecord { // what ModalResult carries per mesh, minus the optional basis

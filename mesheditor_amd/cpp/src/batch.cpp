@@ -114,9 +114,36 @@ BatchComm::~BatchComm() {
     if (Comm) (void)ncclCommDestroy(static_cast<ncclComm_t>(Comm));
 }
 void BatchComm::AllGather(const double *send, double *recv, size_t count) {
+    if (!Comm) throw std::runtime_error("SolveBatch: the communicator was aborted");
     Check(ncclAllGather(send, recv, count, ncclDouble, static_cast<ncclComm_t>(Comm), static_cast<hipStream_t>(Stream)), "ncclAllGather");
 }
-void BatchComm::Synchronize() { Check(hipStreamSynchronize(static_cast<hipStream_t>(Stream)), "hipStreamSynchronize"); }
+// Waits for the collective with a watchdog: a rank that died before joining would otherwise leave the others in the all-gather
+// for ever.  The stream is polled; RCCL's asynchronous error state or the timeout abort the communicator and throw.
+void BatchComm::Synchronize(double timeout_seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(Stream));
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) {
+            Abort();
+            Check(q, "hipStreamQuery");
+        }
+        ncclResult_t async = ncclSuccess;
+        if (Comm && ncclCommGetAsyncError(static_cast<ncclComm_t>(Comm), &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+            Abort();
+            Check(async, "ncclAllGather (asynchronous error)");
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds) {
+            Abort();
+            throw std::runtime_error("SolveBatch: the gather did not complete within " + std::to_string(int(timeout_seconds)) + " s (a rank never joined); communicator aborted");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+void BatchComm::Abort() {
+    if (Comm) (void)ncclCommAbort(static_cast<ncclComm_t>(Comm));
+    Comm = nullptr;
+}
 
 size_t BatchRecordLength(const BatchOptions &o) {
     return HeaderWords + MassWords + ProfileWords + 3 * size_t(o.MaxEigenpairs) + 3 * size_t(o.MaxPositions) + 3 * size_t(o.MaxPositions) * o.MaxEigenpairs;
@@ -153,21 +180,31 @@ std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &c
     std::vector<double> send(slots * (reclen + 1), 0.0);
     std::atomic<size_t> next{0};
     const uint32_t workers = std::max<uint32_t>(1, std::min<uint32_t>(options.ThreadsPerDevice, uint32_t(std::max<size_t>(mine.size(), 1))));
+    // Nothing a worker does may keep this rank from the collective: whatever is thrown (by the device selection, a solve, the
+    // packing -- std::exception or not) turns into failed records for the slots concerned, and the rank joins the gather.
     const auto work = [&] {
-        SetDevice(comm.Device()); // this thread's modalhip context lives on the rank's GPU
+        bool device_ok = true;
+        try {
+            SetDevice(comm.Device()); // this thread's modalhip context lives on the rank's GPU
+        } catch (...) { device_ok = false; }
         for (size_t k = next.fetch_add(1); k < mine.size(); k = next.fetch_add(1)) {
             const uint32_t i = mine[k];
             double *slot = send.data() + k * (reclen + 1);
-            slot[0] = 1.0;
             const auto t0 = std::chrono::steady_clock::now();
             ModalResult r;
             try {
                 const BatchItem &it = items[i];
-                if (it.Mesh) r = mesh2modes(*it.Mesh, it.Material, it.ExcitePositions, it.BakedScale, it.Config);
-            } catch (const std::exception &) { // (a failed factorisation throws, as the reference's does): the record says failed
+                if (device_ok && it.Mesh) r = mesh2modes(*it.Mesh, it.Material, it.ExcitePositions, it.BakedScale, it.Config);
+            } catch (...) { // (a failed factorisation throws, as the reference's does): the record says failed
                 r = ModalResult{};
             }
-            Pack(slot + 1, i, r, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), options);
+            try {
+                Pack(slot + 1, i, r, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), options);
+            } catch (...) {
+                std::fill(slot + 1, slot + 1 + reclen, 0.0);
+                Pack(slot + 1, i, ModalResult{}, 0.0, options); // (an empty result packs without allocating)
+            }
+            slot[0] = 1.0;
         }
     };
     {
@@ -176,18 +213,26 @@ std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &c
         work();
         for (auto &t : pool) t.join();
     }
-    // the one collective: every rank's slots, on the device, over RCCL
-    Check(hipSetDevice(comm.Device()), "hipSetDevice");
+    // the one collective: every rank's slots, on the device, over RCCL.  A rank that cannot stage its records (no memory, a
+    // failed copy) cannot join; it aborts the communicator so that the others' watchdogs fire at once instead of after the timeout.
     const size_t count = slots * (reclen + 1);
     std::vector<double> all(size_t(world) * count, 0.0);
     if (count) {
         double *d_send{}, *d_recv{};
-        Check(hipMalloc(reinterpret_cast<void **>(&d_send), count * sizeof(double)), "hipMalloc");
-        Check(hipMalloc(reinterpret_cast<void **>(&d_recv), size_t(world) * count * sizeof(double)), "hipMalloc");
         try {
+            Check(hipSetDevice(comm.Device()), "hipSetDevice");
+            Check(hipMalloc(reinterpret_cast<void **>(&d_send), count * sizeof(double)), "hipMalloc");
+            Check(hipMalloc(reinterpret_cast<void **>(&d_recv), size_t(world) * count * sizeof(double)), "hipMalloc");
             Check(hipMemcpy(d_send, send.data(), count * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+        } catch (...) {
+            comm.Abort();
+            if (d_send) (void)hipFree(d_send);
+            if (d_recv) (void)hipFree(d_recv);
+            throw;
+        }
+        try {
             comm.AllGather(d_send, d_recv, count);
-            comm.Synchronize();
+            comm.Synchronize(options.GatherTimeoutSeconds);
             Check(hipMemcpy(all.data(), d_recv, all.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
         } catch (...) {
             (void)hipFree(d_send);

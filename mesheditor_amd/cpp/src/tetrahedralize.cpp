@@ -173,9 +173,309 @@ public:
         return true;
     }
 
+    // Brings the missing edge {c, d} into the mesh WITHOUT adding a point, when the mesh can stay Delaunay: on degenerate
+    // input (grid boxes: the corners of every cell cospherical, the corners of every surface quad concyclic) the Delaunay
+    // tetrahedralisation is not unique, and the insertion order picked the other diagonal {a, b} of the planar quad
+    // (a, c, b, d).  The cells around {a, b}, together with every cell that shares a circumsphere with one of them (the
+    // whole degenerate Delaunay cells: a grid cell on the inside, the cells towards the enclosing tetrahedron outside a hull
+    // face), are one region whose boundary faces stay; the region is tetrahedralised anew on its own vertices by a
+    // backtracking advancing front over the tetrahedra with empty circumspheres, and the first tiling that holds {c, d}
+    // and every face / edge for which `keep_face` / `keep_edge` answer true replaces the old cells -- if it is locally
+    // Delaunay against the cells outside as well (exact), so later Bowyer-Watson insertions still see a Delaunay mesh.
+    // (A set of positively oriented tetrahedra whose faces pair up and whose outer faces are the region's boundary is a
+    // tiling of the region: the map has degree one.)  Returns false, mesh untouched, when {c, d} does not cross exactly one
+    // edge in that manner, the region is too large to search, or no such tiling exists.
+    template <class KeepEdge, class KeepFace> bool FlipIn(uint32_t c, uint32_t d, const KeepEdge &keep_edge, const KeepFace &keep_face) {
+        // the edge {a, b} that {c, d} crosses, among the faces opposite c in the cells around c
+        uint32_t a = 0, b = 0;
+        int32_t first = -1;
+        ForStar(c, [&](int32_t id) {
+            const Cell &t = Cells[size_t(id)];
+            uint32_t o[3];
+            int n = 0;
+            for (const uint32_t v : t.V)
+                if (v != c) o[n++] = v;
+            for (int k = 0; k < 3 && first < 0; ++k) {
+                const uint32_t x = o[k], y = o[(k + 1) % 3], z = o[(k + 2) % 3];
+                if (x == d || y == d) continue;
+                if (exact::Orient3D(At(c), At(d), At(x), At(y)) != 0) continue; // c, d, x, y in one plane; z is off it
+                const int sx = exact::Orient3D(At(c), At(d), At(z), At(x)), sy = exact::Orient3D(At(c), At(d), At(z), At(y));
+                if (sx == 0 || sx != -sy) continue; // x and y strictly on opposite sides of the line c d
+                const int sc = exact::Orient3D(At(x), At(y), At(z), At(c)), sd = exact::Orient3D(At(x), At(y), At(z), At(d));
+                if (sc == 0 || sc != -sd) continue; // c and d strictly on opposite sides of the line x y
+                a = x, b = y, first = id;
+            }
+            return first < 0;
+        });
+        if (first < 0 || keep_edge(a, b)) return false;
+        // the cells around {a, b} ...
+        constexpr size_t MaxRegionCells = 24, MaxRegionVertices = 14; // two grid cells and the cells outside a hull face: 16 cells, 14 vertices
+        std::vector<int32_t> region;
+        ++Epoch;
+        {
+            int32_t cell = first;
+            uint32_t from = c;
+            for (size_t guard = 0; guard < MaxRegionCells; ++guard) {
+                const Cell &t = Cells[size_t(cell)];
+                uint32_t to = UINT32_MAX;
+                int i_from = -1;
+                for (int i = 0; i < 4; ++i) {
+                    if (t.V[i] == from) i_from = i;
+                    else if (t.V[i] != a && t.V[i] != b) to = t.V[i];
+                }
+                if (i_from < 0 || to == UINT32_MAX) return false;
+                region.push_back(cell);
+                Cells[size_t(cell)].Stamp = Epoch;
+                cell = t.N[i_from]; // across the face (a, b, to)
+                from = to;
+                if (cell < 0) return false; // (only at the enclosing tetrahedron: never for an edge of real vertices)
+                if (cell == first) break;
+            }
+            if (cell != first) return false;
+        }
+        // ... and everything cospherical with them
+        const auto flood = [&](std::vector<int32_t> &cells, size_t at) {
+            for (; at < cells.size(); ++at) {
+                const Cell t = Cells[size_t(cells[at])];
+                for (int i = 0; i < 4; ++i) {
+                    const int32_t n = t.N[i];
+                    if (n < 0 || Cells[size_t(n)].Stamp == Epoch) continue;
+                    const Cell &o = Cells[size_t(n)];
+                    uint32_t facing = 0;
+                    for (int j = 0; j < 4; ++j)
+                        if (o.N[j] == cells[at]) facing = o.V[j];
+                    if (exact::InSphere(At(t.V[0]), At(t.V[1]), At(t.V[2]), At(t.V[3]), At(facing)) != 0) continue;
+                    if (cells.size() >= MaxRegionCells) return false;
+                    Cells[size_t(n)].Stamp = Epoch;
+                    cells.push_back(n);
+                }
+            }
+            return true;
+        };
+        if (!flood(region, 0)) return false;
+        size_t budget = 0; // search steps left in an attempt (the attempts that succeed on grid bodies take tens to a few thousand)
+        const auto attempt = [&](const std::vector<int32_t> &region) -> bool {
+            budget = 8000;
+        std::vector<uint32_t> verts;
+        for (const int32_t id : region)
+            for (const uint32_t v : Cells[size_t(id)].V)
+                if (std::find(verts.begin(), verts.end(), v) == verts.end()) verts.push_back(v);
+        if (verts.size() > MaxRegionVertices) return false;
+        std::sort(verts.begin(), verts.end());
+        // faces: which of the two sides already has its tetrahedron (bit 0: the negative side of the sorted triple, bit 1: the positive one)
+        const auto side_bit = [&](const Tri &f, uint32_t v) { return exact::Orient3D(At(f[0]), At(f[1]), At(f[2]), At(v)) > 0 ? 2 : 1; };
+        std::map<Tri, int> used;
+        std::vector<Tri> kept_faces; // faces and edges inside the region that the new tiling must hold
+        std::vector<std::array<uint32_t, 2>> kept_edges{{c, d}};
+        for (const int32_t id : region) {
+            const Cell &t = Cells[size_t(id)];
+            for (int i = 0; i < 4; ++i) {
+                const Tri f = Sorted(t.V[FaceOf[i][0]], t.V[FaceOf[i][1]], t.V[FaceOf[i][2]]);
+                if (t.N[i] < 0 || Cells[size_t(t.N[i])].Stamp != Epoch) used[f] |= 3 ^ side_bit(f, t.V[i]); // boundary: the outside is taken
+                else if (keep_face(f[0], f[1], f[2])) kept_faces.push_back(f);
+            }
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j)
+                    if (keep_edge(t.V[i], t.V[j])) kept_edges.push_back({t.V[i], t.V[j]});
+        }
+        std::map<std::array<uint32_t, 4>, bool> empty_ball; // candidate tetrahedron (sorted) -> no region vertex strictly inside its circumsphere
+        const auto delaunay = [&](const Tri &f, uint32_t v) {
+            std::array<uint32_t, 4> key{f[0], f[1], f[2], v};
+            std::sort(key.begin(), key.end());
+            const auto it = empty_ball.find(key);
+            if (it != empty_ball.end()) return it->second;
+            std::array<uint32_t, 4> t = key;
+            if (exact::Orient3D(At(t[0]), At(t[1]), At(t[2]), At(t[3])) < 0) std::swap(t[0], t[1]);
+            bool ok = true;
+            for (const uint32_t w : verts)
+                if (ok && w != t[0] && w != t[1] && w != t[2] && w != t[3] && exact::InSphere(At(t[0]), At(t[1]), At(t[2]), At(t[3]), At(w)) > 0) ok = false;
+            return empty_ball[key] = ok;
+        };
+        std::vector<std::array<uint32_t, 4>> tiling;
+        const auto complete = [&] {
+            for (const auto &e : kept_edges) {
+                bool held = false;
+                for (const auto &t : tiling)
+                    held = held || (std::find(t.begin(), t.end(), e[0]) != t.end() && std::find(t.begin(), t.end(), e[1]) != t.end());
+                if (!held) return false;
+            }
+            for (const Tri &f : kept_faces) {
+                bool held = false;
+                for (const auto &t : tiling)
+                    held = held || (std::find(t.begin(), t.end(), f[0]) != t.end() && std::find(t.begin(), t.end(), f[1]) != t.end() && std::find(t.begin(), t.end(), f[2]) != t.end());
+                if (!held) return false;
+            }
+            return true;
+        };
+        const auto advance = [&](auto &&self) -> bool {
+            const auto open = std::find_if(used.begin(), used.end(), [](const auto &e) { return e.second == 1 || e.second == 2; });
+            if (open == used.end()) return complete();
+            if (budget == 0) return false;
+            --budget;
+            const Tri f = open->first;
+            const int want = 3 ^ open->second;
+            for (const uint32_t v : verts) {
+                if (v == f[0] || v == f[1] || v == f[2]) continue;
+                if (exact::Orient3D(At(f[0]), At(f[1]), At(f[2]), At(v)) == 0 || side_bit(f, v) != want || !delaunay(f, v)) continue;
+                const std::array<uint32_t, 4> t{f[0], f[1], f[2], v};
+                std::array<std::pair<Tri, int>, 4> marks;
+                bool fits = true;
+                for (int i = 0; i < 4 && fits; ++i) {
+                    const Tri g = Sorted(t[(i + 1) & 3], t[(i + 2) & 3], t[(i + 3) & 3]);
+                    marks[size_t(i)] = {g, side_bit(g, t[size_t(i)])};
+                    const auto it = used.find(g);
+                    fits = it == used.end() || !(it->second & marks[size_t(i)].second);
+                }
+                if (!fits) continue;
+                for (const auto &[g, bit] : marks) used[g] |= bit;
+                tiling.push_back(t);
+                if (self(self)) return true;
+                tiling.pop_back();
+                for (const auto &[g, bit] : marks) {
+                    const auto it = used.find(g);
+                    it->second &= ~bit;
+                    if (it->second == 0) used.erase(it);
+                }
+            }
+            return false;
+        };
+        if (!advance(advance)) return false;
+        std::vector<Cell> fresh;
+        for (const auto &t : tiling) {
+            Cell cell{{t[0], t[1], t[2], t[3]}, {-1, -1, -1, -1}};
+            if (exact::Orient3D(At(cell.V[0]), At(cell.V[1]), At(cell.V[2]), At(cell.V[3])) < 0) std::swap(cell.V[0], cell.V[1]);
+            fresh.push_back(cell);
+        }
+        return Exchange(region, fresh);
+        };
+        if (attempt(region)) return true;
+        // no tiling with the region's own boundary: the faces it shares with neighbouring degenerate cells may be what stands in
+        // the way (a grid cell's side faces were triangulated for the neighbours' convenience).  The neighbours join, one at a
+        // time first, then two at a time.
+        std::vector<std::vector<int32_t>> families;
+        for (size_t at = 0; at < region.size(); ++at) {
+            const Cell t = Cells[size_t(region[at])];
+            for (int i = 0; i < 4; ++i) {
+                const int32_t n = t.N[i];
+                if (n < 0 || Cells[size_t(n)].Stamp == Epoch) continue;
+                if (keep_face(t.V[FaceOf[i][0]], t.V[FaceOf[i][1]], t.V[FaceOf[i][2]])) continue;
+                bool known = false;
+                for (const auto &f : families) known = known || std::find(f.begin(), f.end(), n) != f.end();
+                if (known) continue;
+                std::vector<int32_t> family{n};
+                Cells[size_t(n)].Stamp = Epoch;
+                const bool whole = flood(family, 0);
+                for (const int32_t id : family) Cells[size_t(id)].Stamp = 0;
+                if (whole) families.push_back(std::move(family));
+            }
+        }
+        const auto with = [&](std::initializer_list<size_t> chosen) {
+            std::vector<int32_t> wider = region;
+            for (const size_t f : chosen) wider.insert(wider.end(), families[f].begin(), families[f].end());
+            if (wider.size() > MaxRegionCells) return false;
+            const uint32_t epoch = Epoch; // (a successful attempt ends in Exchange, which moves the epoch on)
+            for (size_t k = region.size(); k < wider.size(); ++k) Cells[size_t(wider[k])].Stamp = epoch;
+            if (attempt(wider)) return true;
+            for (size_t k = region.size(); k < wider.size(); ++k) Cells[size_t(wider[k])].Stamp = 0;
+            return false;
+        };
+        for (size_t f = 0; f < families.size(); ++f)
+            if (with({f})) return true;
+        for (size_t f = 0; f < families.size(); ++f)
+            for (size_t g = f + 1; g < families.size(); ++g)
+                if (with({f, g})) return true;
+        return false;
+    }
+
 private:
     int32_t Last{0};
     uint32_t Epoch{0};
+
+    // Calls visit(cell id) for the live cells around vertex u until it returns false.
+    template <class Visit> void ForStar(uint32_t u, const Visit &visit) const {
+        if (u >= CellOf.size() || CellOf[u] < 0) return;
+        if (StarSeen.size() < Cells.size()) StarSeen.resize(Cells.size(), 0);
+        ++StarEpoch;
+        StarStack.assign(1, CellOf[u]);
+        StarSeen[size_t(CellOf[u])] = StarEpoch;
+        while (!StarStack.empty()) {
+            const int32_t id = StarStack.back();
+            StarStack.pop_back();
+            const Cell c = Cells[size_t(id)];
+            for (int i = 0; i < 4; ++i) {
+                if (c.V[i] == u || c.N[i] < 0) continue;
+                if (StarSeen[size_t(c.N[i])] == StarEpoch) continue;
+                StarSeen[size_t(c.N[i])] = StarEpoch;
+                StarStack.push_back(c.N[i]);
+            }
+            if (!visit(id)) return;
+        }
+    }
+
+    // Replaces the cells `old` by `fresh` (same region, positively oriented, adjacency not yet set) if every fresh cell is
+    // locally Delaunay; false and nothing changed otherwise.
+    bool Exchange(const std::vector<int32_t> &old, std::vector<Cell> &fresh) {
+        enum class Kind { Unmatched, Hull, Outside, Fresh };
+        struct Side {
+            Kind What{Kind::Unmatched};
+            int32_t Cell{-1}, Face{-1}; // Outside: a live cell beyond the region and its face looking at it; Fresh: index into `fresh`
+        };
+        std::map<Tri, Side> open;
+        ++Epoch;
+        for (const int32_t c : old) Cells[size_t(c)].Stamp = Epoch;
+        for (const int32_t c : old)
+            for (int i = 0; i < 4; ++i) {
+                const Cell &t = Cells[size_t(c)];
+                const int32_t outside = t.N[i];
+                if (outside >= 0 && Cells[size_t(outside)].Stamp == Epoch) continue;
+                Side side{outside >= 0 ? Kind::Outside : Kind::Hull, outside, -1};
+                if (outside >= 0)
+                    for (int j = 0; j < 4; ++j)
+                        if (Cells[size_t(outside)].N[j] == c) side.Face = j;
+                open[Sorted(t.V[FaceOf[i][0]], t.V[FaceOf[i][1]], t.V[FaceOf[i][2]])] = side;
+            }
+        std::vector<std::array<Side, 4>> across(fresh.size());
+        for (size_t f = 0; f < fresh.size(); ++f)
+            for (int i = 0; i < 4; ++i) {
+                const Tri key = Sorted(fresh[f].V[FaceOf[i][0]], fresh[f].V[FaceOf[i][1]], fresh[f].V[FaceOf[i][2]]);
+                const auto it = open.find(key);
+                if (it == open.end()) {
+                    open[key] = Side{Kind::Fresh, int32_t(f), i};
+                    continue;
+                }
+                across[f][size_t(i)] = it->second;
+                if (it->second.What == Kind::Fresh) across[size_t(it->second.Cell)][size_t(it->second.Face)] = Side{Kind::Fresh, int32_t(f), i};
+                open.erase(it);
+            }
+        if (!open.empty()) return false; // the fresh cells do not tile the region
+        for (size_t f = 0; f < fresh.size(); ++f)
+            for (int i = 0; i < 4; ++i) {
+                const Side &s = across[f][size_t(i)];
+                if (s.What == Kind::Unmatched) return false;
+                if (s.What == Kind::Hull) continue;
+                const uint32_t facing = s.What == Kind::Outside ? Cells[size_t(s.Cell)].V[s.Face] : fresh[size_t(s.Cell)].V[s.Face];
+                if (exact::InSphere(At(fresh[f].V[0]), At(fresh[f].V[1]), At(fresh[f].V[2]), At(fresh[f].V[3]), At(facing)) > 0) return false;
+            }
+        const int32_t base = int32_t(Cells.size());
+        Touched.clear();
+        for (size_t f = 0; f < fresh.size(); ++f)
+            for (int i = 0; i < 4; ++i) {
+                const Side &s = across[f][size_t(i)];
+                if (s.What == Kind::Outside) {
+                    fresh[f].N[i] = s.Cell;
+                    Cells[size_t(s.Cell)].N[s.Face] = base + int32_t(f);
+                } else if (s.What == Kind::Fresh) {
+                    fresh[f].N[i] = base + s.Cell;
+                }
+            }
+        for (const int32_t c : old) Cells[size_t(c)].Alive = false;
+        for (size_t f = 0; f < fresh.size(); ++f) {
+            Cells.push_back(fresh[f]);
+            for (const uint32_t v : fresh[f].V) CellOf[v] = base + int32_t(f), Touched.push_back(v);
+        }
+        Last = base;
+        return true;
+    }
     mutable std::vector<int32_t> StarStack;
     mutable std::vector<uint32_t> StarSeen;
     mutable uint32_t StarEpoch{0};
@@ -478,6 +778,17 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         requeue_near(dt.Touched);
         return true;
     };
+    const auto is_surface_edge = [&](uint32_t a, uint32_t b) {
+        const auto it = on_edge.find(EdgeKey(a, b));
+        return it != on_edge.end() && !it->second.empty();
+    };
+    const auto is_surface_face = [&](uint32_t a, uint32_t b, uint32_t c) {
+        const auto it = on_edge.find(EdgeKey(a, b));
+        if (it == on_edge.end()) return false;
+        for (const uint32_t t : it->second)
+            if (alive[t] && (surface[t][0] == c || surface[t][1] == c || surface[t][2] == c)) return true;
+        return false;
+    };
     while (!pending.empty()) {
         const uint32_t t = pending.front();
         pending.pop_front();
@@ -485,8 +796,18 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         if (!alive[t]) continue;
         const Tri tri = surface[t];
         int cut = -1;
-        for (int e = 0; e < 3 && cut < 0; ++e)
-            if (!dt.HasEdge(tri[e], tri[(e + 1) % 3])) cut = e;
+        bool flipped = false;
+        for (int e = 0; e < 3 && cut < 0 && !flipped; ++e)
+            if (!dt.HasEdge(tri[e], tri[(e + 1) % 3])) {
+                // first without a point: on degenerate input another Delaunay tetrahedralisation may hold the edge
+                if (dt.FlipIn(tri[e], tri[(e + 1) % 3], is_surface_edge, is_surface_face)) flipped = true;
+                else cut = e;
+            }
+        if (flipped) { // look at the triangle again, and at everything around the exchanged cells
+            requeue_near(dt.Touched);
+            if (!queued[t]) queued[t] = 1, pending.push_back(t);
+            continue;
+        }
         if (cut < 0 && !dt.HasFace(tri[0], tri[1], tri[2])) { // edges present, face absent: cut the longest edge
             cut = 0;
             for (int e = 1; e < 3; ++e)

@@ -96,6 +96,14 @@ def workload(name):
     if name in ("scan_s100k", "scan_s100k_interior"):
         p, t = skillet_scan_tets(0.006, 0.008, interior_steiner=name.endswith("_interior"))
         return p, t, MATERIALS["Iron"], {"num_modes": 50, "num_fem_modes": 65}
+    # BASELINE.json configs[2] as written -- "scanned mesh ~100k tets, 200 modes" -- and its RealImpact-true size
+    # (tests/fixtures/TetCorpusSnapshot.txt:9-10: IronSkillet 30 817 tets): the scan-like solids above with NumModes = 200.
+    if name == "config3_s30k":
+        p, t = skillet_scan_tets(0.011, 0.015, interior_steiner=False)
+        return p, t, MATERIALS["Iron"], {"num_modes": 200, "num_fem_modes": 215}
+    if name == "config3_s100k":
+        p, t = skillet_scan_tets(0.006, 0.008, interior_steiner=False)
+        return p, t, MATERIALS["Iron"], {"num_modes": 200, "num_fem_modes": 215}
     raise KeyError(name)
 
 

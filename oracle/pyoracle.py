@@ -72,6 +72,9 @@ def lib():
         so = os.path.join(_HERE, "libmodal_oracle.so")
         if not os.path.exists(so):
             so = build()
+        # idle team members sleep instead of spinning: on a host that is busy with anything else, spinning OpenMP teams turn a
+        # 0.1 s solve into 13 s (measured here with one other single-threaded job running); read by libgomp when it first loads
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(so)
         vp, u32, f32p, f64p, u32p = C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint32)
         L.mo_mesh2modes.restype = vp

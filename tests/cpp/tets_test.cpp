@@ -396,6 +396,59 @@ CASE(non_star_shaped_and_higher_genus_surfaces_fill) {
     EXPECT(ValidateGeneral(bent, r.Mesh).empty());
 }
 
+// A surface gridded like the reference's sample generator does it (glTF_PhysicalAudio/samples/generate.py:254-272: every quad split
+// along its (0,0)-(1,1) diagonal), one cell thick: every point is a surface vertex and every cell's corners are cospherical, so
+// the Delaunay tetrahedralisation is not unique and the one the insertion order gives carries the wrong diagonal on a third of
+// the surface quads.  The recovery must re-tile the degenerate cells instead of adding points (the reference adds none: its
+// golden models list exactly the surface vertices), and the input triangles must be the boundary faces.
+Surface SlabSurface(int nx, int ny, int nz, double hx, double hy, double hz) {
+    Surface s;
+    std::map<std::array<int, 3>, uint32_t> ids;
+    const auto v = [&](int i, int j, int k) {
+        const auto [it, fresh] = ids.try_emplace({i, j, k}, uint32_t(s.P.size()));
+        if (fresh) s.P.push_back({2 * hx * i / nx - hx, 2 * hy * j / ny - hy, 2 * hz * k / nz - hz});
+        return it->second;
+    };
+    const auto quad = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { s.T.insert(s.T.end(), {a, b, c, a, c, d}); };
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < ny; ++j) {
+            quad(v(i, j, 0), v(i, j + 1, 0), v(i + 1, j + 1, 0), v(i + 1, j, 0));
+            quad(v(i, j, nz), v(i + 1, j, nz), v(i + 1, j + 1, nz), v(i, j + 1, nz));
+        }
+    for (int i = 0; i < nx; ++i)
+        for (int k = 0; k < nz; ++k) {
+            quad(v(i, 0, k), v(i + 1, 0, k), v(i + 1, 0, k + 1), v(i, 0, k + 1));
+            quad(v(i, ny, k), v(i, ny, k + 1), v(i + 1, ny, k + 1), v(i + 1, ny, k));
+        }
+    for (int j = 0; j < ny; ++j)
+        for (int k = 0; k < nz; ++k) {
+            quad(v(0, j, k), v(0, j, k + 1), v(0, j + 1, k + 1), v(0, j + 1, k));
+            quad(v(nx, j, k), v(nx, j + 1, k), v(nx, j + 1, k + 1), v(nx, j, k + 1));
+        }
+    return s;
+}
+
+CASE(one_cell_thick_grid_bodies_fill_without_any_added_point) {
+    struct Named {
+        const char *Name;
+        Surface S;
+        size_t Cells;
+    };
+    const Named cases[]{{"box 12x3x1", SlabSurface(12, 3, 1, 0.12, 0.03, 0.01), 36}, {"platform 12x1x12", SlabSurface(12, 1, 12, 0.3, 0.03, 0.3), 144}, {"rod 1x1x9", SlabSurface(1, 1, 9, 0.01, 0.01, 0.2), 9}};
+    for (const auto &c : cases) {
+        const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
+        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        if (!r) continue;
+        EXPECT_NOTE(r.Mesh.Points.size() == c.S.P.size(), std::string(c.Name) + ": points were added");
+        EXPECT(r.Mesh.Tets.size() == 6 * c.Cells); // (parallel diagonals on opposite faces rule the five-tet tiling out)
+        const auto defect = ValidateGeneral(c.S, r.Mesh, true);
+        EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
+        const auto contract = InputSurfaceIsTheBoundary(c.S, r.Mesh);
+        EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
+        std::printf("%18s: %zu surface triangles -> %zu tets, %zu added points\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(), r.Mesh.Points.size() - c.S.P.size());
+    }
+}
+
 CASE(degenerate_and_noisy_point_sets_fill) {
     // the reference's own synthetic cases (tests/ModalSolverTest.cpp:266-272): exact coordinates put every predicate on its
     // degenerate case -- coplanar faces, cospherical corners, collinear edges; noise moves them to near-degenerate instead

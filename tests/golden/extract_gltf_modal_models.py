@@ -13,6 +13,8 @@ import os
 import struct
 import sys
 
+import numpy as np
+
 ROOT = "/root/reference/glTF_PhysicalAudio/samples"
 FILES = ["test/StrikeOne/a_ThreeInstances.gltf", "Pile.gltf", "test/AccelerationNoise/a_SteelBead.gltf"]
 FIXTURE = "/root/reference/tests/fixtures/KHR_audio_rigid_bodies.gltf"
@@ -63,7 +65,18 @@ def extract(path, rel):
         if m.get("name") == "Solved box":
             rec["positions"] = pos
         out.append(rec)
+        # the full record -- surface (positions + triangles: the solve tool's INPUT mesh, tests/ModalSolveTool.cpp:84-93) and every
+        # mode shape -- goes to the binary companion file
+        key = "%s|%s" % (rel, m.get("name", ""))
+        FULL[key + "|positions"] = np.array(pos, np.float32).reshape(-1, 3)
+        FULL[key + "|indices"] = np.array(idx, np.uint32).reshape(-1, 3)
+        FULL[key + "|shapes"] = np.array(shapes, np.float32).reshape(len(freqs), npos, 3)  # mode-major
+        FULL[key + "|frequencies"] = np.array(freqs, np.float32)
+        FULL[key + "|decayRates"] = np.array(decay, np.float32)
     return out
+
+
+FULL = {}
 
 
 def main():
@@ -82,6 +95,9 @@ def main():
         return x
     json.dump({"source": "khiner/MeshEditor glTF_PhysicalAudio/samples (decoded accessors)", "models": r9(models)}, open(dst, "w"), separators=(",", ":"))
     print("wrote", dst, len(models), "models", os.path.getsize(dst), "bytes")
+    full = os.path.join(os.path.dirname(dst), "gltf_modal_models_full.npz")
+    np.savez_compressed(full, **FULL)
+    print("wrote", full, os.path.getsize(full), "bytes")
     for m in models:
         print(" ", m["file"], repr(m["name"]), len(m["frequencies"]), "modes", m["numPositions"], "pts", m["frequencies"][:4])
 
