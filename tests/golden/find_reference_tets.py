@@ -311,7 +311,6 @@ MODELS = {
 def main(names):
     full = np.load(os.path.join(HERE, "gltf_modal_models_full.npz"))
     dst = os.path.join(HERE, "reference_tets.npz")
-    found = dict(np.load(dst)) if os.path.exists(dst) else {}
     for name in names:
         key, material, max_freq, mesh_name = MODELS[name]
         grid = Grid(full[key + "|positions"], full[key + "|indices"])
@@ -324,6 +323,7 @@ def main(names):
         j, df, es = mismatch(grid.tets(bits, sel), detail=True)
         print("%s: cells %s, %d inner faces, mismatch %.3e in %.0f s; max |df/f| %.2e, max shape error %.2e" % (name, grid.n, len(grid.free), j, time.time() - t0, np.abs(df).max(), es.max()))
         if np.abs(df).max() < 2e-7:
+            found = dict(np.load(dst)) if os.path.exists(dst) else {}  # (read now: another run may have added a mesh meanwhile)
             found[mesh_name] = grid.tets(bits, sel)
             np.savez_compressed(dst, **found)
             print("  -> %s[%s]" % (dst, mesh_name))
