@@ -40,11 +40,17 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
-def pmc_traffic(family="spmm_family"):
+PMC_WORKLOAD = "cube_s100k"  # the workload the committed --pmc passes ran (the default command line of this file)
+
+
+def pmc_traffic(family="spmm_family", workload=PMC_WORKLOAD):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes of this command (profiles/, made
     by tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 rule and checked on a kernel of known byte count) -- a
-    separate profiled run, never this one; None when the summary is absent."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    separate profiled run, never this one; None when the summary is absent, and None for any workload other than the one
+    those passes measured (a per-launch figure of the cube says nothing about a batch of 30k-tet meshes)."""
+    if workload != PMC_WORKLOAD:
+        return None
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)[family]["hbm_bytes_per_launch"])
@@ -142,10 +148,52 @@ def cpu_baseline(workload="cube_s10k"):
             "note": "host_cores = CPUs this container may use (affinity and cgroup quota); threaded row: OpenMP team of min(host_cores, 16)"}
 
 
+def cpu_baseline_metric_mesh_live(workload="cube_s100k"):
+    """`--cpu-baseline-metric-mesh`: the oracle on the METRIC'S OWN mesh, timed on THIS box's host cores (about ten minutes on
+    the 16 cores the GPU box grants).  Opt-in; the record it prints is committed as profiles/r04_cpu_baseline_metric_mesh.json
+    and the default line cites it."""
+    import datetime
+    import platform
+    from oracle import pyoracle as po
+    from mesheditor_amd import meshes
+    pts, tets, m, kw = meshes.workload(workload)
+    cores = po.available_cores()
+    team = min(cores, 16)
+    po.set_threads(team)
+    cfg = po.default_config(num_modes=kw["num_modes"], num_fem_modes=kw["num_fem_modes"])
+    ex = pts[:: len(pts) // 10][:10].astype(np.float32)
+    t0 = time.perf_counter()
+    r = po.mesh2modes(pts, tets, po.material(*m), ex, config=cfg)
+    dt = time.perf_counter() - t0
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": len(r.eigenvalues) / dt, "unit": "eigenpairs/s", "cores": team, "kind": "port", "workload": workload, "seconds": dt,
+            "eigenpairs": int(len(r.eigenvalues)), "mesh": {"tets": int(len(tets)), "dof": int(r.profile["dofs"])},
+            "host": {"cpu": cpu or platform.processor(), "cores_available": cores, "logical_cpus": os.cpu_count(), "threads": team, "node": platform.node()},
+            "date": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d"), "command": "python bench.py --cpu-baseline-metric-mesh",
+            "stages_s": {k: r.profile[k] for k in ("mass_props", "quad_mesh", "assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract")},
+            "first_eigenvalues": [float(v) for v in r.eigenvalues[6:12]],
+            "measured": "live on the GPU box's host cores (oracle = restated reference algorithm, OpenMP team of min(host cores, 16))"}
+
+
 def cpu_baseline_metric_mesh(workload="cube_s100k"):
-    """The oracle on the METRIC'S OWN mesh, from the committed record of that run (tests/golden/oracle_eigs_<workload>.json,
-    made in the build container by tests/golden/make_oracle_fixtures.py: the run takes minutes, the default bench may not) --
-    the same-input partner of `value`; the live `cpu_baseline` below stays the on-box sanity figure on the 10k-tet sample."""
+    """The oracle on the METRIC'S OWN mesh -- the same-input partner of `value`.  The run takes ten minutes, the default bench
+    may not, so this reads a committed record: profiles/r04_cpu_baseline_metric_mesh.json (timed on a GPU box's host cores by
+    `bench.py --cpu-baseline-metric-mesh` through gpurun) when it describes this workload, else the build container's record in
+    tests/golden/oracle_eigs_<workload>.json.  The live `cpu_baseline` stays the on-this-box figure on the 10k-tet sample."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_cpu_baseline_metric_mesh.json")) as f:
+            d = json.load(f)
+        if d.get("workload") == workload:
+            d["measured"] = "recorded run on a GPU box of this pool (same host type as this run), not timed in this invocation"
+            d["record"] = "profiles/r04_cpu_baseline_metric_mesh.json"
+            return d
+    except (OSError, ValueError):
+        pass
     try:
         with open(os.path.join(ROOT, "tests", "golden", "oracle_eigs_%s.json" % workload)) as f:
             d = json.load(f)
@@ -216,6 +264,38 @@ def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k", "sca
     return out
 
 
+def config3_rows(api, ctx):
+    """BASELINE config 3 as written -- a scanned ~100k-tet mesh, 200 modes (215 pairs) -- at the metric's size and at the
+    RealImpact-true size, beside the Kuhn plate that stood in for it in rounds 1-3: iterations, ms, eigenpairs per second."""
+    return scan_like_rows(api, ctx, names=("config3_s30k", "config3_s100k", "skillet_s100k"), reps=1)
+
+
+def batch64_pass(api, device, threads=3):
+    """BASELINE config 4 on the GPU(s) of this run's first rank: the 64 jittered 29k-tet boxes solved by `threads` host threads
+    (one context each), one pass after a warm-up solve; N = 1 here -- the multi-GPU form is `--workload batch64 --gpus N`."""
+    from mesheditor_amd import sharding
+    try:
+        items = batch_meshes()
+        ctxs = [api.Context(device) for _ in range(threads)]
+        ex_of = [m[0][:: len(m[0]) // 10][:10].astype(np.float32) for m in items]
+
+        def solve(i, m, worker=0):
+            return api.mesh2modes(ctxs[worker], m[0], m[1], api.material(*m[2]), ex_of[i], config=api.default_config(**m[3]))
+        solve(0, items[0])
+        [c.synchronize() for c in ctxs]
+        t0 = time.perf_counter()
+        recs = sharding.solve_batch(items, solve, NEV_MAX, None, "cpu", threads=threads, pos_max=POS_MAX)
+        [c.synchronize() for c in ctxs]
+        dt = time.perf_counter() - t0
+        [c.close() for c in ctxs]
+        pairs = sum(len(r["eigenvalues"]) for r in recs)
+        return {"workload": "64 jittered Kuhn boxes of %d tets, 7 materials cycled, 45 eigenpairs each, mesh upload included" % len(items[0][1]), "n_gpus": 1,
+                "threads_per_gpu": threads, "seconds": dt, "eigenpairs_per_s": pairs / dt, "meshes_per_s": len(items) / dt,
+                "iterations_mean": float(np.mean([r["iterations"] for r in recs]))}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+
+
 def cpu_bank_baseline(blocks=2):
     """The oracle's bank (the reference's RenderObjectFast loop, fp32) on config 5 with every mode live: seconds per
     512-frame block and RenderShare (= seconds x SR / frames; > 1 underruns) at 1 and 4 renderers (the reference's
@@ -274,7 +354,11 @@ def main():
     ap.add_argument("--workload", default="cube_s100k", help="a meshes.workload name (one mesh per rank per step) or batch64 (BASELINE config 4)")
     ap.add_argument("--threads", type=int, default=3, help="batch64: solves in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-metric-mesh", action="store_true", help="only time the CPU oracle on the metric's own mesh on this box (~10 min) and print that record")
     args = ap.parse_args()
+    if args.cpu_baseline_metric_mesh:  # no GPU work at all
+        print(json.dumps(cpu_baseline_metric_mesh_live(args.workload)), flush=True)
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))  # before anything here touches the GPU
@@ -460,14 +544,14 @@ def main():
         line["roofline"] = {"bound": "hbm",
                             "kernel": "k_spmm_wide / k_spmm: BSR 3x3 SpMM of the P2 and P1 operators over n-by-w panels "
                                       "(every launch of the solve: fp32 smoother products, mixed fp64-A x fp32-panel residuals, fp64 operator products)",
-                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("spmm_family", args.workload),
                             "launches": spmm["launches"], "avg_launch_us": 1e3 * spmm["total_ms"] / spmm["launches"],
                             "algorithmic_bytes_per_launch": spmm["total_bytes"] / spmm["launches"],
                             "measured_in": "%d further steps after the timed region, HIP events around every launch (%.1f ms per step with them)" % (args.steps, 1e3 * dt_instrumented / args.steps)}
     if asm["launches"]:
         achieved = asm["total_bytes"] / (asm["total_ms"] * 1e-3) / 1e9
         line["roofline_assembly"] = {"bound": "hbm", "kernel": "K/M assembly of the quadratic level (SURVEY 8d bytes: 152 B read per tet, 80 B written per node block)",
-                                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("assembly"),
+                                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("assembly", args.workload),
                                      "launches": asm["launches"], "avg_launch_us": 1e3 * asm["total_ms"] / asm["launches"],
                                      "algorithmic_bytes_per_launch": asm["total_bytes"] / asm["launches"]}
     if not batch:
@@ -480,6 +564,8 @@ def main():
         if not batch:
             line["edit_loop"] = edit_loop(api, ctxs[0], pts, tets, m, ex, cfg, mesh)
             line["scan_like"] = scan_like_rows(api, ctxs[0])
+            line["config3"] = config3_rows(api, ctxs[0])
+            line["batch64"] = batch64_pass(api, device)
         line["cpu_baseline"] = cpu_baseline()
         line["cpu_baseline_metric_mesh"] = cpu_baseline_metric_mesh("cube_s100k" if batch else args.workload)
         bank = bank_metric()

@@ -9,7 +9,8 @@
 // Where the general fill still DEPARTS from the reference's contract:
 //   * internal walls (an edge shared by an odd number of triangles) are rejected as "open", duplicate positions as
 //     "point coincides" -- the reference accepts non-manifold input;
-//   * no sliver repair, no quality refinement (the reference's Options::Quality / MaxVolume have no counterpart);
+//   * sliver repair changes connectivity only (edge removal, 2-3 flips: Options::RepairSlivers); no vertex smoothing, no quality
+//     refinement (the reference's Options::Quality / MaxVolume have no counterpart);
 //   * fans of needle triangles can exhaust the refinement budget: "did not converge" instead of a mesh.
 // Two fills:
 //   tetra::Tetrahedralize   any closed, non-self-intersecting surface -- non-convex, non-star-shaped, any genus, nested
@@ -31,11 +32,14 @@ struct Result {
     TetMesh Mesh;
     std::string Error; // empty on success
     uint32_t BoundarySteinerCount{0}; // added points left ON the surface (input triangles they refine are not boundary faces); 0 = the input triangulation is the boundary
+    uint32_t SliverExchanges{0}; // edge removals and 2-3 flips the sliver repair made
     explicit operator bool() const { return Error.empty(); }
 };
 struct Options {
     size_t MaxSteinerPoints{0}; // boundary-recovery budget; 0 = 2 x the input vertices + 4096
     bool InteriorSteiner{true}; // after the fill, move the recovery's points off the surface (every input triangle a boundary face again)
+    bool RepairSlivers{true}; // connectivity-only sliver repair afterwards (the reference repairs slivers whatever its options: Tetrahedralize.h:20)
+    double SliverTarget{0.25}; // tetrahedra with a shape measure below this are worked on (1 = regular, 0 = flat)
 };
 Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options = {});
 // `layers` shells between the surface and the centroid (0: a plain fan of one tet per triangle).  Each layer is a copy of

@@ -202,7 +202,8 @@ mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint
         for (uint32_t i = 0; i < n_points; ++i) pts[i] = {points[3 * size_t(i)], points[3 * size_t(i) + 1], points[3 * size_t(i) + 2]};
         tetra::Options options;
         options.MaxSteinerPoints = size_t(max_steiner);
-        options.InteriorSteiner = interior_steiner != 0;
+        options.InteriorSteiner = (interior_steiner & 1) != 0; // bit 0: points moved off the surface, bit 1: sliver repair
+        options.RepairSlivers = (interior_steiner & 2) != 0;
         h->Result = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
     } catch (const std::exception &e) { h->Result.Error = e.what(); }
     return h;

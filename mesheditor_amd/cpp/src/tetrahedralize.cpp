@@ -667,6 +667,276 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
     return stuck;
 }
 
+// Sliver repair (the reference's tetrahedraliser repairs slivers whatever its options say: src/mesh/Tetrahedralize.h:20).  A
+// Delaunay fill of a bare surface leaves flat tetrahedra -- four points of one latitude ring of a UV sphere, the wedges under a
+// recovered edge -- whose stiffness entries dwarf their neighbours' and stall iterative eigensolvers (shape 2e-8 on the reference's
+// sample sphere: ||A|| / theta ~ 1e13).  This pass changes the CONNECTIVITY only, by hill climbing on the worst shape measure of
+// the tetrahedra involved (shape = 6 sqrt 2 V / l_rms^3: 1 for the regular tetrahedron, 0 for a flat one):
+//   * edge removal: the n <= 7 tetrahedra around an interior edge {u, v} are replaced by the best triangulation of their link
+//     polygon coned to u and to v (Klincsek's dynamic programme over the polygon: n = 3 is the 3-2 flip, n = 4 the 4-4 flip);
+//   * the 2-3 flip of an interior face.
+// Boundary faces are untouched (an edge on the boundary has an open ring and is skipped), no point is added or moved, every new
+// tetrahedron is positively oriented (exact), and an exchange is made only if the worst shape among the new tetrahedra exceeds
+// the worst among the old ones -- so the pass terminates and can only improve the mesh's worst elements.
+static uint32_t RepairSlivers(TetMesh &mesh, double target) {
+    auto &P = mesh.Points;
+    auto &T = mesh.Tets;
+    struct FaceHash {
+        size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
+    };
+    std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> faces; // sorted face -> the (at most two) live tets on it
+    faces.reserve(T.size() * 2);
+    std::vector<uint8_t> alive(T.size(), 1);
+    const auto link = [&](int32_t t, bool add) {
+        const auto &v = T[size_t(t)];
+        for (int i = 0; i < 4; ++i) {
+            const Tri key = Sorted(v[(i + 1) & 3], v[(i + 2) & 3], v[(i + 3) & 3]);
+            if (add) {
+                auto [it, fresh] = faces.try_emplace(key, std::array<int32_t, 2>{t, -1});
+                if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
+            } else {
+                auto it = faces.find(key);
+                if (it->second[0] == t) it->second[0] = it->second[1];
+                it->second[1] = -1;
+                if (it->second[0] < 0) faces.erase(it);
+            }
+        }
+    };
+    for (size_t t = 0; t < T.size(); ++t) link(int32_t(t), true);
+    const auto across = [&](int32_t t, uint32_t a, uint32_t b, uint32_t c) -> int32_t { // the other tet on face {a, b, c}, or -1
+        const auto it = faces.find(Sorted(a, b, c));
+        if (it == faces.end()) return -1;
+        return it->second[0] == t ? it->second[1] : it->second[0];
+    };
+    const auto shape_of = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        const dvec3 &pa = P[a], &pb = P[b], &pc = P[c], &pd = P[d];
+        const dvec3 u = pb - pa, v = pc - pa, w = pd - pa;
+        const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+        double l2 = 0;
+        const dvec3 *q[4] = {&pa, &pb, &pc, &pd};
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                const dvec3 e = *q[i] - *q[j];
+                l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+            }
+        const double lrms = std::sqrt(l2 / 6);
+        return lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0;
+    };
+    const auto shape = [&](int32_t t) { return shape_of(T[size_t(t)][0], T[size_t(t)][1], T[size_t(t)][2], T[size_t(t)][3]); };
+    const auto positive = [&](std::array<uint32_t, 4> t) {
+        if (exact::Orient3D(P[t[0]], P[t[1]], P[t[2]], P[t[3]]) < 0) std::swap(t[0], t[1]);
+        return t;
+    };
+    struct Plan {
+        double Worst{0};
+        std::vector<int32_t> Old;
+        std::vector<std::array<uint32_t, 4>> Fresh;
+    };
+    constexpr int MaxRing = 7;
+    // best re-tiling of the tets around the edge {u, v} of tet t; Worst = 0 when there is none
+    const auto remove_edge = [&](int32_t t, uint32_t u, uint32_t v) {
+        Plan plan;
+        uint32_t ring_v[MaxRing];
+        int32_t ring_t[MaxRing];
+        int n = 0;
+        uint32_t from = UINT32_MAX, to = UINT32_MAX;
+        for (const uint32_t x : T[size_t(t)])
+            if (x != u && x != v) (from == UINT32_MAX ? from : to) = x;
+        int32_t cell = t;
+        double old_worst = 1e300;
+        for (;;) {
+            if (n == MaxRing) return plan;
+            ring_v[n] = from, ring_t[n] = cell, ++n;
+            old_worst = std::min(old_worst, shape(cell));
+            const int32_t next = across(cell, u, v, to);
+            if (next < 0) return plan; // the edge lies on the boundary
+            uint32_t beyond = UINT32_MAX;
+            for (const uint32_t x : T[size_t(next)])
+                if (x != u && x != v && x != to) beyond = x;
+            from = to, to = beyond, cell = next;
+            if (cell == t) break;
+        }
+        if (n < 3) return plan;
+        const int turn = exact::Orient3D(P[ring_v[0]], P[ring_v[1]], P[v], P[u]);
+        if (turn == 0) return plan;
+        double best[MaxRing][MaxRing];
+        int apex[MaxRing][MaxRing];
+        for (int len = 1; len < n; ++len)
+            for (int i = 0; i + len < n; ++i) {
+                const int j = i + len;
+                if (len == 1) { best[i][j] = 1e300; continue; }
+                best[i][j] = -1, apex[i][j] = -1;
+                for (int k = i + 1; k < j; ++k) {
+                    if (best[i][k] <= old_worst || best[k][j] <= old_worst) continue;
+                    const uint32_t a = ring_v[i], b = ring_v[k], c = ring_v[j];
+                    if (exact::Orient3D(P[a], P[b], P[c], P[u]) != turn || exact::Orient3D(P[a], P[b], P[c], P[v]) != -turn) continue;
+                    const double q = std::min({best[i][k], best[k][j], shape_of(a, b, c, u), shape_of(a, b, c, v)});
+                    if (q > best[i][j]) best[i][j] = q, apex[i][j] = k;
+                }
+            }
+        if (!(best[0][n - 1] > old_worst * 1.001 + 1e-14)) return plan;
+        plan.Worst = best[0][n - 1];
+        plan.Old.assign(ring_t, ring_t + n);
+        const auto emit = [&](auto &&self, int i, int j) -> void {
+            if (j == i + 1) return;
+            const int k = apex[i][j];
+            plan.Fresh.push_back(positive({ring_v[i], ring_v[k], ring_v[j], u}));
+            plan.Fresh.push_back(positive({ring_v[i], ring_v[k], ring_v[j], v}));
+            self(self, i, k);
+            self(self, k, j);
+        };
+        emit(emit, 0, n - 1);
+        return plan;
+    };
+    // the 2-3 flip of the face of t opposite its vertex `at`
+    const auto flip_face = [&](int32_t t, int at) {
+        Plan plan;
+        const auto &v = T[size_t(t)];
+        const uint32_t a = v[size_t(at)], p = v[size_t(at + 1) & 3], q = v[size_t(at + 2) & 3], r = v[size_t(at + 3) & 3];
+        const int32_t o = across(t, p, q, r);
+        if (o < 0) return plan;
+        uint32_t b = UINT32_MAX;
+        for (const uint32_t x : T[size_t(o)])
+            if (x != p && x != q && x != r) b = x;
+        // a and b on opposite sides of (p, q, r) already; the segment a b must pass through the triangle's interior
+        const int s0 = exact::Orient3D(P[a], P[b], P[p], P[q]), s1 = exact::Orient3D(P[a], P[b], P[q], P[r]), s2 = exact::Orient3D(P[a], P[b], P[r], P[p]);
+        if (s0 == 0 || s0 != s1 || s1 != s2) return plan;
+        const double old_worst = std::min(shape(t), shape(o));
+        const double fresh_worst = std::min({shape_of(a, b, p, q), shape_of(a, b, q, r), shape_of(a, b, r, p)});
+        if (!(fresh_worst > old_worst * 1.001 + 1e-14)) return plan;
+        plan.Worst = fresh_worst;
+        plan.Old = {t, o};
+        plan.Fresh = {positive({a, b, p, q}), positive({a, b, q, r}), positive({a, b, r, p})};
+        return plan;
+    };
+    std::vector<int32_t> work;
+    for (size_t t = 0; t < T.size(); ++t)
+        if (shape(int32_t(t)) < target) work.push_back(int32_t(t));
+    uint32_t exchanges = 0;
+    for (int pass = 0; pass < 8 && !work.empty(); ++pass) {
+        std::sort(work.begin(), work.end(), [&](int32_t x, int32_t y) { return shape(x) < shape(y); });
+        std::vector<int32_t> next;
+        for (const int32_t t : work) {
+            if (!alive[size_t(t)]) continue;
+            Plan best;
+            const auto v = T[size_t(t)];
+            for (int i = 0; i < 4; ++i) {
+                for (int j = i + 1; j < 4; ++j) {
+                    Plan plan = remove_edge(t, v[size_t(i)], v[size_t(j)]);
+                    if (plan.Worst > best.Worst) best = std::move(plan);
+                }
+                Plan plan = flip_face(t, i);
+                if (plan.Worst > best.Worst) best = std::move(plan);
+            }
+            if (best.Fresh.empty()) continue;
+            for (const int32_t o : best.Old) link(o, false), alive[size_t(o)] = 0;
+            for (const auto &f : best.Fresh) {
+                T.push_back(f);
+                alive.push_back(1);
+                link(int32_t(T.size() - 1), true);
+                if (shape(int32_t(T.size() - 1)) < target) next.push_back(int32_t(T.size() - 1));
+            }
+            ++exchanges;
+        }
+        work.swap(next);
+    }
+    std::vector<std::array<uint32_t, 4>> kept;
+    kept.reserve(T.size());
+    for (size_t t = 0; t < T.size(); ++t)
+        if (alive[t]) kept.push_back(T[t]);
+    T.swap(kept);
+    return exchanges;
+}
+
+// Vertex smoothing of the ADDED points (the reference's "vertex optimisation" runs with its sliver repair: Tetrahedralize.h:20):
+// an interior point moves towards the centroid of the vertices it is connected to, as far (1, 1/2, 1/4 of the way) as raises the
+// worst shape measure of its tetrahedra while every one of them stays positively oriented (exact).  Input vertices never move;
+// neither does an added point that is still on the boundary.  Returns the number of points moved.
+static uint32_t SmoothAddedPoints(TetMesh &mesh, uint32_t n_input) {
+    auto &P = mesh.Points;
+    const auto &T = mesh.Tets;
+    if (P.size() <= n_input) return 0;
+    std::vector<std::vector<uint32_t>> star(P.size() - n_input);
+    std::map<Tri, int> face_count;
+    for (uint32_t t = 0; t < T.size(); ++t)
+        for (int i = 0; i < 4; ++i) {
+            if (T[t][size_t(i)] >= n_input) star[T[t][size_t(i)] - n_input].push_back(t);
+        }
+    // added points on the boundary: a face with one tet only
+    std::vector<uint8_t> on_boundary(P.size() - n_input, 0);
+    {
+        std::unordered_map<uint64_t, uint32_t> count; // (only faces that hold an added point matter)
+        const auto key = [](uint32_t a, uint32_t b, uint32_t c) {
+            if (a > b) std::swap(a, b);
+            if (b > c) std::swap(b, c);
+            if (a > b) std::swap(a, b);
+            return (uint64_t(a) << 42) | (uint64_t(b) << 21) | uint64_t(c);
+        };
+        if (P.size() >= (size_t(1) << 21)) return 0;
+        for (const auto &v : T)
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t a = v[size_t(i + 1) & 3], b = v[size_t(i + 2) & 3], c = v[size_t(i + 3) & 3];
+                if (a >= n_input || b >= n_input || c >= n_input) ++count[key(a, b, c)];
+            }
+        for (const auto &v : T)
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t f[3] = {v[size_t(i + 1) & 3], v[size_t(i + 2) & 3], v[size_t(i + 3) & 3]};
+                if ((f[0] >= n_input || f[1] >= n_input || f[2] >= n_input) && count[key(f[0], f[1], f[2])] == 1)
+                    for (const uint32_t x : f)
+                        if (x >= n_input) on_boundary[x - n_input] = 1;
+            }
+    }
+    const auto shape_at = [&](const std::array<uint32_t, 4> &t, uint32_t moved, const dvec3 &x) {
+        dvec3 q[4];
+        for (int i = 0; i < 4; ++i) q[i] = t[size_t(i)] == moved ? x : P[t[size_t(i)]];
+        const dvec3 u = q[1] - q[0], v = q[2] - q[0], w = q[3] - q[0];
+        const double vol6 = u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x);
+        double l2 = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                const dvec3 e = q[i] - q[j];
+                l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+            }
+        const double lrms = std::sqrt(l2 / 6);
+        return lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0; // signed: the tets are stored positively oriented
+    };
+    uint32_t moved = 0;
+    for (int sweep = 0; sweep < 3; ++sweep)
+        for (uint32_t k = 0; k < star.size(); ++k) {
+            if (on_boundary[k] || star[k].empty()) continue;
+            const uint32_t m = n_input + k;
+            dvec3 centre{0, 0, 0};
+            double weight = 0;
+            double worst = 1e300;
+            for (const uint32_t t : star[k]) {
+                worst = std::min(worst, shape_at(T[t], m, P[m]));
+                for (const uint32_t x : T[t])
+                    if (x != m) centre = centre + P[x], weight += 1;
+            }
+            centre = centre * (1.0 / weight);
+            for (const double step : {1.0, 0.5, 0.25}) {
+                const dvec3 x = P[m] + (centre - P[m]) * step;
+                double fresh = 1e300;
+                bool valid = true;
+                for (const uint32_t t : star[k]) {
+                    fresh = std::min(fresh, shape_at(T[t], m, x));
+                    if (!(fresh > worst)) { valid = false; break; }
+                }
+                if (!valid) continue;
+                for (const uint32_t t : star[k]) { // exact orientation at the new position
+                    dvec3 q[4];
+                    for (int i = 0; i < 4; ++i) q[i] = T[t][size_t(i)] == m ? x : P[T[t][size_t(i)]];
+                    if (exact::Orient3D(q[0], q[1], q[2], q[3]) <= 0) { valid = false; break; }
+                }
+                if (!valid) continue;
+                P[m] = x;
+                ++moved;
+                break;
+            }
+        }
+    return moved;
+}
+
 Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options) {
     Result out;
     const uint32_t n_input = uint32_t(points.size());
@@ -899,6 +1169,14 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
     if (options.InteriorSteiner && out.BoundarySteinerCount) {
         for (auto &e : split_edge) e = {final_id(e[0]), final_id(e[1])};
         out.BoundarySteinerCount = LiftBoundaryPoints(out.Mesh, n_input, split_edge);
+    }
+    if (options.RepairSlivers) {
+        // connectivity and positions in turn: a moved point opens exchanges, an exchange changes what a point is connected to
+        out.SliverExchanges = RepairSlivers(out.Mesh, options.SliverTarget);
+        for (int round = 0; round < 2 && out.Mesh.Points.size() > n_input; ++round) {
+            if (!SmoothAddedPoints(out.Mesh, n_input)) break;
+            out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget);
+        }
     }
     return out;
 }

@@ -76,6 +76,7 @@ const Switches &switches() {
 constexpr int kPowerIterations = 20; // spectral-bound estimate of the smoothers (12 steps left the bound 15 % low on the scan meshes -- more than the 1.1 safety factor -- and one patch-threshold setting then failed to converge; the steps run beside the coarse elimination)
 constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
 constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
+constexpr size_t kDenseLastResort = 12288; // unknowns up to which a solve that did not converge is redone as one dense eigensolve (2 x 1.2 GB, seconds)
 
 // readers-writer lock with writer priority (glibc's shared_mutex prefers readers: iterating solves would starve a factorisation)
 struct PhaseLock {
@@ -1028,8 +1029,21 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
 }
 
 namespace {
-// Tiny problems: one dense generalised eigensolve on the device.
-void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues) {
+// x[i][j] = scale_j * z[(first + reversed j)] : the `ncols` LAST columns of a column-major n x n matrix, last first, as a row-major
+// panel, column j scaled by scale[j]
+__global__ void k_last_columns_to_panel(const double *__restrict__ z, size_t n, uint32_t ncols, const double *__restrict__ scale, double *__restrict__ x) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n * ncols) return;
+    const uint32_t j = uint32_t(i % ncols);
+    x[i] = scale[j] * z[(n - 1 - j) * n + i / ncols];
+}
+
+// One dense generalised eigensolve on the device: tiny problems, and the last resort of a small one whose iteration did not
+// converge.  `inverse` solves M x = nu A x instead of A x = theta M x and takes the LARGEST nu = 1 / theta: on a pencil whose
+// stiffness is inflated by near-degenerate elements (||A|| / theta ~ 1e13 on a UV sphere's tetrahedra of four ring points) the
+// direct form returns the low pairs with an absolute error of eps ||L^-1 A L^-T||, the inverse form -- like the reference's
+// shift-invert -- with a relative one.
+void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues, bool inverse = false) {
     mh_context *ctx = sys->ctx;
     const size_t n = size_t(3) * sys->n_nodes;
     auto &lvl = sys->L2;
@@ -1044,16 +1058,31 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues)
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ExclusivePhase alone_on_the_device;
-    ROCBLAS_CHECK(rocsolver_dsygvd(ctx->blas, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_lower, rocblas_int(n), a, rocblas_int(n), m, rocblas_int(n), d, e, info));
+    double *lhs = inverse ? m.get() : a.get(), *rhs = inverse ? a.get() : m.get(); // (vectors come back in lhs)
+    ROCBLAS_CHECK(rocsolver_dsygvd(ctx->blas, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_lower, rocblas_int(n), lhs, rocblas_int(n), rhs, rocblas_int(n), d, e, info));
     int hinfo = 0;
     info.download(&hinfo, 1);
     if (hinfo != 0) mh_throw(hinfo > int(n) ? MH_EFACTOR : MH_ENOTCONVERGED, "dense sygvd failed (info %d)", hinfo);
     std::vector<double> th(n);
     d.download(th.data(), n);
-    for (uint32_t i = 0; i < nev; ++i) eigenvalues[i] = th[i] + sigma;
     sys->evecs.reset(ctx, n * nev);
     sys->evec_cols = nev;
-    k_colmajor_to_panel<<<grid1(n * nev), TB, 0, ctx->stream>>>(a, n, nev, sys->evecs);
+    if (!inverse) {
+        for (uint32_t i = 0; i < nev; ++i) eigenvalues[i] = th[i] + sigma;
+        k_colmajor_to_panel<<<grid1(n * nev), TB, 0, ctx->stream>>>(lhs, n, nev, sys->evecs);
+    } else {
+        // nu ascending: the wanted pairs are the last ones, largest first; x^T A x = 1 as returned, so x^T M x = nu: scale by nu^-1/2
+        std::vector<double> scale(nev);
+        for (uint32_t i = 0; i < nev; ++i) {
+            const double nu = th[n - 1 - i];
+            if (!(nu > 0)) mh_throw(MH_ENOTCONVERGED, "dense inverse eigensolve: non-positive eigenvalue %g at position %u", nu, i);
+            eigenvalues[i] = 1.0 / nu + sigma;
+            scale[i] = 1.0 / std::sqrt(nu);
+        }
+        DevArray<double> dscale(ctx, nev);
+        dscale.upload(scale.data(), nev);
+        k_last_columns_to_panel<<<grid1(n * nev), TB, 0, ctx->stream>>>(lhs, n, nev, dscale, sys->evecs);
+    }
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
@@ -1696,8 +1725,24 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 prof.factorize = t.stop();
             }
             if (progress) *progress = 0.3f;
-            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
-            solver.run(eigenvalues);
+            try {
+                BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
+                solver.run(eigenvalues);
+            } catch (const MhError &e) {
+                // Last resort of a SMALL system whose iteration stalled (measured: a UV sphere's surface filled without interior
+                // points -- a quarter of the tetrahedra flat to 1e-8, ||A|| / theta ~ 1e13): one dense eigensolve in the inverse
+                // form.  O(n^3), seconds at the size limit: better than no modes for an editor primitive.
+                if (e.code != MH_ENOTCONVERGED || n > kDenseLastResort) throw;
+                if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- dense eigensolve of order %zu instead\n", e.what(), n);
+                Timer t(ctx);
+                dense_eigs(sys, nev, sigma, eigenvalues, true);
+                prof = sys->profile;
+                prof.dofs = uint32_t(n);
+                prof.iterate += t.stop();
+                prof.restarts = max_iters + 1;
+                sys->profile = prof;
+                if (profile) *profile = prof;
+            }
         }
     }
 }
