@@ -237,10 +237,11 @@ def edit_loop(api, ctx, pts, tets, m, ex, cfg, mesh):
         return {"error": repr(e)[:200]}
 
 
-def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior"), reps=2):
+def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior", "scan_s30k_repaired", "scan_s100k_repaired"), reps=2):
     """Secondary rows: the scan-like unstructured meshes (marching-tetrahedra skillet surface through the path's own
     tetrahedraliser: slivers, 2-60 tets per node, no interior points) beside the Kuhn grid of the same size -- iterations,
-    milliseconds and eigenpairs per second of the whole mesh2modes path, 65 pairs each."""
+    milliseconds and eigenpairs per second of the whole mesh2modes path, 65 pairs each.  "_interior": recovery points moved off
+    the surface; "_repaired": the front end's default since round 4 (that plus sliver repair and smoothing of the added points)."""
     from mesheditor_amd import meshes
     out = []
     for name in names:
@@ -267,7 +268,7 @@ def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k", "sca
 def config3_rows(api, ctx):
     """BASELINE config 3 as written -- a scanned ~100k-tet mesh, 200 modes (215 pairs) -- at the metric's size and at the
     RealImpact-true size, beside the Kuhn plate that stood in for it in rounds 1-3: iterations, ms, eigenpairs per second."""
-    return scan_like_rows(api, ctx, names=("config3_s30k", "config3_s100k", "skillet_s100k"), reps=1)
+    return scan_like_rows(api, ctx, names=("config3_s30k", "config3_s100k", "config3_s30k_repaired", "config3_s100k_repaired", "skillet_s100k"), reps=1)
 
 
 def batch64_pass(api, device, threads=3):

@@ -127,6 +127,16 @@ int mh_system_gather_shapes(const mh_system *, uint32_t n_nodes, const uint32_t 
 int mh_system_basis(const mh_system *, uint32_t n_cols, float *basis);
 /* The same in double, for parity tests. */
 int mh_system_eigenvectors(const mh_system *, uint32_t n_cols, double *vectors);
+/* What `residual_tol` of mh_eigs meant in the last solve (no reference counterpart: Spectra's tolerance is on Ritz values).
+ * On a mesh WITHOUT near-degenerate elements a pair is accepted at ||K x - lambda M x||_2 < residual_tol |lambda - sigma| ||M x||_2.
+ * On a mesh WITH them (elements of shape measure < 0.02: the sliver patches of the preconditioner exist) the same test is made
+ * in the Jacobi-scaled norm ||.||_{D^-1}, D = diag(K - sigma M): the rounding noise eps ||A|| |x| of the slivers' rows alone
+ * exceeds the tolerance in the 2-norm, while in the scaled norm those rows count as little as their noise means (identical on
+ * a uniform mesh).  *worst_plain_residual then holds the worst 2-norm relative residual among the returned elastic pairs,
+ * measured once after convergence (-1 when the 2-norm was the criterion); eigenvalue accuracy is checked against the oracle
+ * on every committed scan fixture (2e-11 ... 3e-9).  dropped_patches[2]: sliver patches of the P2 / P1 level whose block was
+ * not safely positive definite and contribute nothing to the smoother. */
+int mh_system_residual_report(const mh_system *, double *worst_plain_residual, uint32_t dropped_patches[2]);
 
 /* Host-side scalar stages of the path (the reference runs them on the calling thread as well). */
 /* ComputeMassProperties (mesh2modes.cpp:73-126) */

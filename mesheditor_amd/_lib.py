@@ -70,6 +70,7 @@ def lib():
         "mh_eigs": (i32, [vp, u32, f64, f64, u32, vp, u32, u32, vp, vp, vp, C.POINTER(Profile)]),
         "mh_system_gather_shapes": (i32, [vp, u32, vp, u32, vp]), "mh_system_basis": (i32, [vp, u32, vp]),
         "mh_system_eigenvectors": (i32, [vp, u32, vp]),
+        "mh_system_residual_report": (i32, [vp, vp, vp]),
         "mh_compute_mass_properties": (i32, [u32, vp, u32, vp, f64, vp, f64, C.POINTER(MassProps)]),
         "mh_postprocess_modes": (i32, [u32, vp, u32, vp, C.c_float, C.POINTER(Material), C.POINTER(SolverConfig), C.POINTER(u32), vp, vp, vp, C.POINTER(C.c_float)]),
         "mh_rescale_modes": (i32, [u32, vp, u32, vp, C.POINTER(Material), C.POINTER(Material), C.POINTER(SolverConfig), C.POINTER(i32), C.POINTER(u32), vp, vp, vp, C.POINTER(C.c_float)]),

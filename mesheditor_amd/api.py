@@ -168,6 +168,14 @@ class System:
         self.ctx.check(self.ctx.L.mh_system_basis(self.h, ncols, _p(out)))
         return out
 
+    def residual_report(self):
+        """(worst 2-norm relative residual of the last solve's elastic pairs when they were accepted in the Jacobi-scaled norm, else
+        -1; sliver patches dropped on the P2 / P1 level) -- include/modalhip.h: mh_system_residual_report."""
+        worst = C.c_double(0)
+        dropped = (C.c_uint32 * 2)()
+        self.ctx.check(self.ctx.L.mh_system_residual_report(self.h, C.byref(worst), dropped))
+        return worst.value, (int(dropped[0]), int(dropped[1]))
+
     def eigenvectors(self, ncols):
         out = np.zeros((self.n, ncols), np.float64, order="F")
         self.ctx.check(self.ctx.L.mh_system_eigenvectors(self.h, ncols, _p(out)))

@@ -132,7 +132,6 @@ int mh_context_create(int device, mh_context **out) {
         const int code = mh_guard(ctx, e);
         fprintf(stderr, "modalhip: %s\n", e.what());
         if (ctx->blas) rocblas_destroy_handle(ctx->blas);
-    if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
         if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
         if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -343,4 +342,10 @@ int mh_system_gather_shapes(const mh_system *s, uint32_t n_nodes, const uint32_t
 
 int mh_system_basis(const mh_system *s, uint32_t n_cols, float *basis) { return export_vectors<float>(s, n_cols, basis); }
 int mh_system_eigenvectors(const mh_system *s, uint32_t n_cols, double *vectors) { return export_vectors<double>(s, n_cols, vectors); }
+int mh_system_residual_report(const mh_system *s, double *worst_plain_residual, uint32_t *dropped_patches) {
+    if (!s) return MH_EINVAL;
+    if (worst_plain_residual) *worst_plain_residual = s->plain_residual;
+    if (dropped_patches) dropped_patches[0] = s->dropped_patches[0], dropped_patches[1] = s->dropped_patches[1];
+    return MH_OK;
+}
 }

@@ -253,13 +253,16 @@ struct PatchSet {
     uint32_t npe{0}, n_patches{0}, n_touched{0}; // nodes per element (10: P2 level, 4: P1 level)
     DevArray<uint32_t> nodes;                      // n_patches x npe, the level's node ids
     DevArray<double> inv64;                        // n_patches x (3 npe)^2, row-major (weighted)
-    DevArray<double> weight;                       // per patch: 1 / the largest number of patches sharing one of its nodes
+    DevArray<double> weight;                       // per patch: (the largest number of patches sharing one of its nodes)^-0.35 (exponent -1 lost)
+    DevArray<int> dropped;                         // [0]: patches whose block was not safely positive definite (they contribute nothing), [1]: one of them + 1
     DevArray<float> inv32;
     DevArray<uint32_t> touched, t_ptr, t_patch, t_local; // nodes in some patch; per touched node its (patch, local node) entries, CSR
 };
 
 struct mh_system {
     mh_context *ctx;
+    uint32_t dropped_patches[2]{0, 0}; // sliver patches dropped at the last hierarchy build (P2 level, P1 level)
+    double plain_residual{-1.0}; // last solve: worst 2-norm relative residual of the returned elastic pairs when they were accepted in the Jacobi-scaled norm, else -1
     mh_material material{};
     uint32_t n_points{0}, kept_tets{0}, n_nodes{0}, n_edges{0};
     DevArray<double> points; // copy of mesh points (P1 node coordinates), reference numbering

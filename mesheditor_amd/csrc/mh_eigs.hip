@@ -915,6 +915,15 @@ void mh_finish_hierarchy(mh_system *sys) {
     int hinfo = 0;
     sys->coarse_info.download(&hinfo, 1); // (on the main stream, i.e. after the elimination)
     for (auto &ws : sys->coarse_ws) ws.reset(ctx, 0);
+    for (PatchSet *ps : {&sys->patches2, &sys->patches1}) { // sliver patches that were dropped (block not safely positive definite)
+        if (!ps->n_patches || !ps->dropped.count) continue;
+        int dropped[2] = {0, 0};
+        ps->dropped.download(dropped, 2);
+        sys->dropped_patches[ps->npe == 10 ? 0 : 1] = uint32_t(dropped[0]);
+        if (dropped[0] && switches().verbose)
+            fprintf(stderr, "[lobpcg] %d of %u sliver patches of the %s level dropped (e.g. patch %d): their nodes keep the diagonal scaling only\n", dropped[0], ps->n_patches,
+                    ps->npe == 10 ? "P2" : "P1", dropped[1] - 1);
+    }
     if (hinfo != 0) {
         sys->hierarchy_ready = false;
         mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
@@ -1666,6 +1675,27 @@ struct BlockLobpcg {
         prof.op_solve = precond_seconds;
         if (!converged) mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged in %u iterations", nconv, nev, iters);
         for (uint32_t k = 0; k < nev; ++k) eigenvalues[k] = theta[order[k]] + sigma;
+        sys->plain_residual = -1.0;
+        if (scaled_norms) {
+            // The pairs were accepted in the Jacobi-scaled norm (above): say what that means in the 2-norm relative residual
+            // ||K x - lambda M x||_2 / (|lambda - sigma| ||M x||_2) the caller's tolerance is phrased in -- one pass, once per solve.
+            theta_d.upload(theta.data(), b);
+            const uint32_t rpb = 256, nblk = div_up(n, rpb);
+            if (scratch.count < size_t(nblk) * 3 * b) scratch.reset(ctx, size_t(nblk) * 3 * b);
+            k_residual_norms<<<dim3(nblk, div_up(b, 64)), 64, 0, st>>>(AX, MX, X, theta_d, 10.0 * std::abs(sigma), R, n, b, rpb, scratch, nullptr);
+            KERNEL_CHECK();
+            k_colsumsq_final<<<3 * b, 256, 0, st>>>(scratch, nblk, 3 * b, norms_d);
+            KERNEL_CHECK();
+            norms_d.download(norms.data(), 3 * size_t(b));
+            double worst = 0;
+            for (uint32_t k = 0; k < nev; ++k) {
+                const uint32_t i = order[k];
+                if (std::abs(theta[i]) < 10.0 * std::abs(sigma)) continue; // (the rigid-body pairs sit at the rounding floor by construction)
+                worst = std::max(worst, std::sqrt(norms[i]) / (std::abs(theta[i]) * std::sqrt(norms[b + i])));
+            }
+            sys->plain_residual = worst;
+            if (verbose) fprintf(stderr, "[lobpcg] accepted in the Jacobi-scaled norm at %.1e; worst elastic pair in the plain 2-norm: %.2e\n", residual_tol, worst);
+        }
         sys->evecs.reset(ctx, n * nev);
         sys->evec_cols = nev;
         idx_d.upload(order.data(), nev);

@@ -75,10 +75,20 @@ __global__ void __launch_bounds__(64) k_patch_inverse(const uint32_t *__restrict
             for (int j = 0; j < 3; ++j) a[(3 * ia + i) * LD + 3 * ib + j] = found ? aval[9 * size_t(lo) + 3 * i + j] : 0.0;
     }
     __syncthreads();
+    // a pivot that is not safely positive (below 1e-13 of the block's largest diagonal entry: a near-singular A_ee would put
+    // entries of 1e+15 into the inverse and infinities into its single-precision copy) fails the patch
+    __shared__ double floor_;
+    if (tid == 0) {
+        double dmax = 0;
+        for (int k = 0; k < N; ++k) dmax = fmax(dmax, a[k * LD + k]);
+        floor_ = 1e-13 * dmax;
+    }
+    __syncthreads();
+    const double floor = floor_;
     bool bad = false;
     for (int k = 0; k < N; ++k) {
         const double piv = a[k * LD + k];
-        if (!(piv > 0)) bad = true;
+        if (!(piv > floor)) bad = true;
         const double d = 1.0 / piv;
         __syncthreads();
         if (int(tid) < N && int(tid) != k) a[k * LD + tid] *= d; // row k scaled (entry (k, k) waits)
@@ -92,7 +102,10 @@ __global__ void __launch_bounds__(64) k_patch_inverse(const uint32_t *__restrict
         if (int(tid) == k) a[k * LD + k] = d;
         __syncthreads();
     }
-    if (bad && tid == 0) atomicMax(info, int(p) + 1);
+    if (bad && tid == 0) {
+        atomicAdd(info, 1);
+        atomicMax(info + 1, int(p) + 1);
+    }
     for (int e = tid; e < N * N; e += 64) {
         const double v = bad ? 0.0 : weight[p] * a[(e / N) * LD + e % N]; // a patch that failed contributes nothing (the diagonal scaling still covers its nodes)
         inv64[size_t(p) * N * N + e] = v;
@@ -237,10 +250,10 @@ void mh_build_patch_inverses(mh_context *ctx, const BsrLevel &lvl, PatchSet &ps)
     const size_t n = size_t(3) * ps.npe;
     ps.inv64.reset(ctx, size_t(ps.n_patches) * n * n);
     ps.inv32.reset(ctx, size_t(ps.n_patches) * n * n);
-    DevArray<int> info(ctx, 1);
-    info.zero();
-    if (ps.npe == 10) k_patch_inverse<10><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, info);
-    else k_patch_inverse<4><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, info);
+    ps.dropped.reset(ctx, 2); // read back by mh_finish_hierarchy, with the set-up's next synchronising download
+    ps.dropped.zero();
+    if (ps.npe == 10) k_patch_inverse<10><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, ps.dropped);
+    else k_patch_inverse<4><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, ps.dropped);
     KERNEL_CHECK();
 }
 

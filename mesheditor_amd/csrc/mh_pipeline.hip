@@ -562,23 +562,34 @@ uint32_t graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vecto
     const bool merging = uint64_t(n) * 3 < uint64_t(na) * target * 2 || uint64_t(6) * na > max_order;
     if (!any_tiny && !merging) return na;
     rebuild();
-    if (any_tiny) { // small aggregates join their most connected neighbour (one pass; a chain of tiny ones ends in a proper one or stays)
-        std::vector<uint32_t> into(na);
-        for (uint32_t a = 0; a < na; ++a) into[a] = a;
+    // Small aggregates join their most connected neighbour, repeated until none with a neighbour is left: a one- or two-node
+    // aggregate (or three collinear nodes) has linearly dependent rigid-body columns, T^T A T is then singular and the unpivoted
+    // coarse elimination sees rounding-level pivots.  Merges are resolved through a union-find, so a chain of
+    // tiny aggregates ends up under ONE label whatever order its links are visited in.
+    for (int round = 0; round < 8 && std::any_of(size.begin(), size.end(), [](uint32_t s_) { return s_ < 4; }); ++round) {
+        std::vector<uint32_t> parent(na);
+        for (uint32_t a = 0; a < na; ++a) parent[a] = a;
+        const auto find = [&](uint32_t a) {
+            while (parent[a] != a) a = parent[a] = parent[parent[a]];
+            return a;
+        };
         bool any = false;
         for (uint32_t a = 0; a < na; ++a) {
             if (size[a] >= 4 || links[a].empty()) continue;
             uint32_t best = links[a][0].first, count = 0;
             for (const auto &[nb, c] : links[a])
                 if (size[nb] >= 4 && c > count) count = c, best = nb;
-            if (count == 0) best = links[a][0].first;
-            into[a] = into[best];
-            any = true;
+            if (count == 0) // only tiny neighbours: the most connected of them
+                for (const auto &[nb, c] : links[a])
+                    if (c > count) count = c, best = nb;
+            const uint32_t ra = find(a), rb = find(best);
+            if (ra != rb) parent[ra] = rb, any = true;
         }
-        if (any) {
-            renumber(into);
-            rebuild();
-        }
+        if (!any) break;
+        std::vector<uint32_t> into(na);
+        for (uint32_t a = 0; a < na; ++a) into[a] = find(a);
+        renumber(into);
+        rebuild();
     }
     for (int round = 0; round < 12; ++round) { // 4
         const bool too_small = uint64_t(n) * 3 < uint64_t(na) * target * 2; // mean size < 2/3 target

@@ -4,6 +4,7 @@
 // sample scene glTF_PhysicalAudio/samples/test/StrikeOne/a_ThreeInstances.gltf (a data file, kept under tests/golden/).
 #include "harness.hpp"
 
+#include <cstring>
 #include <audio/ModalModelFile.h>
 
 #include <filesystem>
@@ -142,6 +143,70 @@ CASE(the_modal_store_is_write_once_and_content_addressed) {
     EXPECT(!DeserializeModalModel(bytes).has_value());
     EXPECT(!LoadModalModelFile(dir / "absent.modal").has_value());
     fs::remove_all(dir);
+}
+
+// The byte image of a `.modal` file, member by member.  The reference writes it with zpp::bits (src/audio/ModalModelFile.cpp:15-22,
+// `archive(data)` on the aggregate ModalModelData); the library is an un-vendored submodule (lib/zpp_bits, absent here), so the
+// layout is restated from its published format rules: aggregates are serialised member by member in declaration order with no
+// padding, arithmetic types as their little-endian object bytes, std::vector as a 4-byte element count (the default size type is
+// uint32_t) followed by the elements, glm vectors / quaternions component by component through the reference's own hooks
+// (src/action/SerializeGlm.h:23-35: vec as x y z, quat as x y z w).  This test pins that layout byte for byte on a small model,
+// so that a change of ours cannot drift from it unnoticed; equality with a file WRITTEN by the reference stays unverified (no
+// sample file, no library: INTEGRATION.md section 6).
+CASE(the_modal_image_follows_the_published_zpp_bits_layout) {
+    ModalModelData d;
+    d.Modes.Freqs = {440.f};
+    d.Modes.T60s = {0.5f};
+    d.Modes.Shapes = {{{1.f, 2.f, 3.f}}}; // [position][mode]
+    d.Modes.Vertices = {7};
+    d.Modes.Positions = {{0.25f, 0.5f, 0.75f}};
+    d.Modes.Indices = {};
+    d.Modes.OriginalFundamentalFreq = 440.f;
+    d.Modes.BakedScale = {1.f, 1.f, 1.f};
+    d.Mass.Mass = 2.0;
+    d.Mass.CenterOfMass = {0.f, 0.f, 0.f};
+    d.Mass.InertiaDiagonal = {1.f, 2.f, 4.f};
+    d.Mass.InertiaOrientation = {1.f, 0.f, 0.f, 0.f}; // glm::quat{w, x, y, z}
+    d.Tets.Positions = {};
+    d.Tets.EdgeIndices = {5, 6};
+    d.Summary.Eigenvalues = {1.0};
+    d.Summary.Shapes = {};
+    d.Summary.SolvedMaterial = {1000.0, 2.0, 0.25, 0.5, 0.125};
+    d.Summary.SolvedMinModeFreq = 20.f, d.Summary.SolvedMaxModeFreq = 16000.f, d.Summary.SolvedNumModes = 30;
+    d.Summary.TetInputsHash = 0x0102030405060708ull;
+    d.Summary.SolvedVertices = {9};
+    std::vector<uint8_t> want;
+    const auto u32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) want.push_back(uint8_t(v >> (8 * i))); };
+    const auto u64 = [&](uint64_t v) { for (int i = 0; i < 8; ++i) want.push_back(uint8_t(v >> (8 * i))); };
+    const auto f32 = [&](float v) { uint32_t b; std::memcpy(&b, &v, 4); u32(b); };
+    const auto f64 = [&](double v) { uint64_t b; std::memcpy(&b, &v, 8); u64(b); };
+    // ModalModes
+    u32(1), f32(440.f);                           // Freqs
+    u32(1), f32(0.5f);                            // T60s
+    u32(1), u32(1), f32(1.f), f32(2.f), f32(3.f); // Shapes: outer count, inner count, the vec3
+    u32(1), u32(7);                               // Vertices
+    u32(1), f32(0.25f), f32(0.5f), f32(0.75f);    // Positions
+    u32(0);                                       // Indices
+    f32(440.f);                                   // OriginalFundamentalFreq
+    f32(1.f), f32(1.f), f32(1.f);                 // BakedScale
+    // MassProperties
+    f64(2.0), f32(0.f), f32(0.f), f32(0.f), f32(1.f), f32(2.f), f32(4.f);
+    f32(0.f), f32(0.f), f32(0.f), f32(1.f);       // quaternion x y z w
+    // TetMeshData
+    u32(0);
+    u32(2), u32(5), u32(6);
+    // ModalEigenSummary
+    u32(1), f64(1.0);
+    u32(0);
+    f64(1000.0), f64(2.0), f64(0.25), f64(0.5), f64(0.125);
+    f32(20.f), f32(16000.f), u32(30);
+    u64(0x0102030405060708ull);                   // size_t on the reference's 64-bit targets
+    u32(1), u32(9);
+    const auto got = SerializeModalModel(d);
+    EXPECT(got.size() == want.size());
+    EXPECT(got.size() == want.size() && std::memcmp(got.data(), want.data(), want.size()) == 0);
+    const auto back = DeserializeModalModel(got);
+    EXPECT(back.has_value() && *back == d);
 }
 
 int main() { return check::run_all(); }

@@ -169,6 +169,31 @@ def test_graph_aggregates_are_connected_sets(core, name):
     assert ncomp3 == na3
 
 
+def test_graph_aggregates_leave_no_tiny_aggregate_on_chains(core):
+    """a one- or two-node aggregate has linearly dependent rigid-body columns (a singular coarse operator).  On graphs
+    whose first pass founds only tiny aggregates -- a path (three nodes each), a comb, the sample UV sphere's P1 graph -- the merge
+    pass must run until every aggregate that has a neighbour holds at least four nodes, whatever the chain of merges looks like."""
+    import scipy.sparse as sp
+    from tools import lab
+
+    def graph(edges, n):
+        r, c = np.array(edges).T
+        g = sp.coo_matrix((np.ones(2 * len(r) + n), (np.r_[r, c, np.arange(n)], np.r_[c, r, np.arange(n)])), shape=(n, n)).tocsr()
+        g.sum_duplicates()
+        g.sort_indices()
+        return g
+    path = graph([(i, i + 1) for i in range(200)], 201)
+    comb = graph([(i, i + 1) for i in range(0, 120, 2)] + [(i, i + 2) for i in range(0, 119, 2)], 121)  # a spine of even nodes, a tooth on each
+    full = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gltf_modal_models_full.npz"))
+    tri = full["Pile.gltf|Marble|indices"].astype(np.int64)
+    sphere = graph([(t[i], t[(i + 1) % 3]) for t in tri for i in range(3)], int(tri.max()) + 1)
+    for name, g in (("path", path), ("comb", comb), ("sphere surface", sphere)):
+        agg, na = lab.graph_aggregates(g.indptr.astype(np.uint32), g.indices.astype(np.uint32))
+        sizes = np.bincount(agg, minlength=na)
+        assert sizes.min() >= 4, (name, sizes.min(), na)
+        assert len(np.unique(agg)) == na
+
+
 def test_tet_front_end_keeps_the_input_triangulation_as_the_boundary():
     """SURVEY 8f row N3 through the Python binding (host C++, no GPU): the scan-like skillet surface filled with the tetrahedraliser's
     default options -- the boundary recovery's points moved inside afterwards -- has exactly the input triangles as boundary faces and

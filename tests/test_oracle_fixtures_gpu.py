@@ -5,8 +5,10 @@ eigenvalue to 1e-6 (rigid-body pairs absolutely), the kept frequencies and decay
 excitation map.  cube_s100k is bench.py's workload, skillet_s100k / ball_s10k BASELINE configs 3 / 2, cube_s30k the
 RealImpact-sized Kuhn grid, scan_s30k / scan_s100k the scan-like unstructured meshes (marching-tetrahedra skillet surface
 through the path's own tetrahedraliser: slivers, 2 to 60 tets around a node, no interior points), the "_interior" ones the
-same surfaces under the tetrahedraliser's default, which moves the boundary recovery's points inside afterwards (the mesh's
-boundary is then the scan's own triangulation, as the reference's contract wants; ~15 % more tets)."""
+same surfaces with the boundary recovery's points moved inside afterwards (the mesh's boundary is then the scan's own
+triangulation, as the reference's contract wants; ~15 % more tets), the "_repaired" ones the front end's round-4 default on top of
+that (connectivity-only sliver repair + smoothing of the added points, as the reference's tetrahedraliser always runs);
+config3_* = the scan meshes with NumModes = 200 (BASELINE configs[2] as written)."""
 import json
 import os
 
@@ -16,7 +18,10 @@ import pytest
 from mesheditor_amd import meshes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-WORKLOADS = ["ball_s10k", "cube_s30k", "cube_s100k", "skillet_s100k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior"]
+WORKLOADS = ["ball_s10k", "cube_s30k", "cube_s100k", "skillet_s100k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior",
+             # round 4: BASELINE config 3 as written (scan mesh x 200 modes = 215 pairs) at both sizes; the scan surfaces through the
+             # front end's default options (points moved inside, sliver repair, smoothing), 65 and 215 pairs
+             "config3_s30k", "config3_s100k", "scan_s30k_repaired", "scan_s100k_repaired", "config3_s30k_repaired", "config3_s100k_repaired"]
 
 
 def load_fixture(name):
