@@ -7,8 +7,10 @@
 // filling the two thin wedges that open under its restored triangles with a tetrahedron each (src/tetrahedralize.cpp,
 // LiftBoundaryPoints).  A point for which no valid inner position exists stays on the surface and is counted.
 // Where the general fill still DEPARTS from the reference's contract:
-//   * internal walls (an edge shared by an odd number of triangles) are rejected as "open", duplicate positions as
-//     "point coincides" -- the reference accepts non-manifold input;
+//   * non-manifold input is accepted since round 4 (internal walls attached along seams of three triangles, fins with a free
+//     border: every triangle a constraint, "inside" = what the outside cannot reach), but a recovery point on a WALL stays on it
+//     (counted in BoundarySteinerCount) and nested cavities are only understood on manifold input (parity rule); duplicate
+//     positions are rejected as "point coincides";
 //   * sliver repair changes connectivity only (edge removal, 2-3 flips: Options::RepairSlivers); no vertex smoothing, no quality
 //     refinement (the reference's Options::Quality / MaxVolume have no counterpart);
 //   * fans of needle triangles can exhaust the refinement budget: "did not converge" instead of a mesh.

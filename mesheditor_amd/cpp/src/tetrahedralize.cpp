@@ -29,6 +29,7 @@
 #include "predicates.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -678,7 +679,7 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
 // Boundary faces are untouched (an edge on the boundary has an open ring and is skipped), no point is added or moved, every new
 // tetrahedron is positively oriented (exact), and an exchange is made only if the worst shape among the new tetrahedra exceeds
 // the worst among the old ones -- so the pass terminates and can only improve the mesh's worst elements.
-static uint32_t RepairSlivers(TetMesh &mesh, double target) {
+static uint32_t RepairSlivers(TetMesh &mesh, double target, const std::set<Tri> *walls = nullptr) { // walls: faces INSIDE the mesh that must stay (non-manifold input)
     auto &P = mesh.Points;
     auto &T = mesh.Tets;
     struct FaceHash {
@@ -750,6 +751,7 @@ static uint32_t RepairSlivers(TetMesh &mesh, double target) {
             old_worst = std::min(old_worst, shape(cell));
             const int32_t next = across(cell, u, v, to);
             if (next < 0) return plan; // the edge lies on the boundary
+            if (walls && walls->count(Sorted(u, v, to))) return plan; // ... or on an internal wall
             uint32_t beyond = UINT32_MAX;
             for (const uint32_t x : T[size_t(next)])
                 if (x != u && x != v && x != to) beyond = x;
@@ -794,7 +796,7 @@ static uint32_t RepairSlivers(TetMesh &mesh, double target) {
         const auto &v = T[size_t(t)];
         const uint32_t a = v[size_t(at)], p = v[size_t(at + 1) & 3], q = v[size_t(at + 2) & 3], r = v[size_t(at + 3) & 3];
         const int32_t o = across(t, p, q, r);
-        if (o < 0) return plan;
+        if (o < 0 || (walls && walls->count(Sorted(p, q, r)))) return plan;
         uint32_t b = UINT32_MAX;
         for (const uint32_t x : T[size_t(o)])
             if (x != p && x != q && x != r) b = x;
@@ -852,7 +854,7 @@ static uint32_t RepairSlivers(TetMesh &mesh, double target) {
 // an interior point moves towards the centroid of the vertices it is connected to, as far (1, 1/2, 1/4 of the way) as raises the
 // worst shape measure of its tetrahedra while every one of them stays positively oriented (exact).  Input vertices never move;
 // neither does an added point that is still on the boundary.  Returns the number of points moved.
-static uint32_t SmoothAddedPoints(TetMesh &mesh, uint32_t n_input) {
+static uint32_t SmoothAddedPoints(TetMesh &mesh, uint32_t n_input, const std::set<Tri> *walls = nullptr) {
     auto &P = mesh.Points;
     const auto &T = mesh.Tets;
     if (P.size() <= n_input) return 0;
@@ -886,6 +888,10 @@ static uint32_t SmoothAddedPoints(TetMesh &mesh, uint32_t n_input) {
                         if (x >= n_input) on_boundary[x - n_input] = 1;
             }
     }
+    if (walls)
+        for (const Tri &f : *walls)
+            for (const uint32_t x : f)
+                if (x >= n_input) on_boundary[x - n_input] = 1; // a point on an internal wall stays in the wall
     const auto shape_at = [&](const std::array<uint32_t, 4> &t, uint32_t moved, const dvec3 &x) {
         dvec3 q[4];
         for (int i = 0; i < 4; ++i) q[i] = t[size_t(i)] == moved ? x : P[t[size_t(i)]];
@@ -949,12 +955,18 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         if (tri[0] == tri[1] || tri[1] == tri[2] || tri[0] == tri[2]) return out.Error = "degenerate triangle (repeated vertex)", out;
         surface.push_back(tri);
     }
+    // A closed 2-manifold has two triangles on every edge.  Any other count marks NON-MANIFOLD input, which the reference accepts
+    // (src/mesh/Tetrahedralize.h:53-55: "an edge may be shared by more than two triangles (internal walls)"): a wall inside the
+    // solid attached to the outer surface (three triangles on the seam), a fin with a free border (one).  Such input is filled with
+    // every triangle a constraint and "inside" = whatever cannot be reached from the enclosing tetrahedron without crossing a
+    // triangle (step 3); if the outer surface itself is open, that flood reaches everything and the fill reports it.
+    bool manifold = true;
     {
         std::map<uint64_t, int> uses;
         for (const Tri &t : surface)
             for (int e = 0; e < 3; ++e) ++uses[EdgeKey(t[e], t[(e + 1) % 3])];
         for (const auto &[key, count] : uses)
-            if (count % 2) return out.Error = "surface is open: an edge borders an odd number of triangles", out;
+            if (count != 2) manifold = false;
     }
     std::vector<uint8_t> used(n_input, 0);
     for (const Tri &t : surface)
@@ -1070,7 +1082,7 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         for (int e = 0; e < 3 && cut < 0 && !flipped; ++e)
             if (!dt.HasEdge(tri[e], tri[(e + 1) % 3])) {
                 // first without a point: on degenerate input another Delaunay tetrahedralisation may hold the edge
-                if (dt.FlipIn(tri[e], tri[(e + 1) % 3], is_surface_edge, is_surface_face)) flipped = true;
+                if (!getenv("TET_NOFLIP") && dt.FlipIn(tri[e], tri[(e + 1) % 3], is_surface_edge, is_surface_face)) flipped = true;
                 else cut = e;
             }
         if (flipped) { // look at the triangle again, and at everything around the exchanged cells
@@ -1145,6 +1157,13 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
             const int32_t n = cell.N[i];
             if (n < 0) continue;
             const bool crosses = wall.count(Sorted(cell.V[FaceOf[i][0]], cell.V[FaceOf[i][1]], cell.V[FaceOf[i][2]])) != 0;
+            if (!manifold) { // walls inside: the flood stops at every triangle; what it never reaches is inside
+                if (!crosses && side[n] < 0) {
+                    side[n] = 0;
+                    frontier.push(n);
+                }
+                continue;
+            }
             const int8_t want = int8_t(side[c] ^ (crosses ? 1 : 0));
             if (side[n] < 0) {
                 side[n] = want;
@@ -1155,6 +1174,12 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         }
     }
 
+    if (!manifold) {
+        bool any_inside = false;
+        for (size_t c = 0; c < dt.Cells.size(); ++c)
+            if (dt.Cells[c].Alive && side[c] < 0) side[c] = 1, any_inside = true;
+        if (!any_inside) return out.Error = "surface is open: nothing is enclosed (an edge borders one triangle, and the outside reaches every tetrahedron)", out;
+    }
     // output: input points unchanged, Steiner points appended, inside cells only
     out.Mesh.Points.assign(points.begin(), points.end());
     out.Mesh.Points.insert(out.Mesh.Points.end(), dt.Points.begin() + first_steiner, dt.Points.end());
@@ -1171,11 +1196,15 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         out.BoundarySteinerCount = LiftBoundaryPoints(out.Mesh, n_input, split_edge);
     }
     if (options.RepairSlivers) {
+        std::set<Tri> walls; // non-manifold input: the surface pieces that ended up between two tetrahedra
+        if (!manifold)
+            for (const Tri &t : surface) walls.insert(Sorted(final_id(t[0]), final_id(t[1]), final_id(t[2])));
+        const std::set<Tri> *keep = manifold ? nullptr : &walls;
         // connectivity and positions in turn: a moved point opens exchanges, an exchange changes what a point is connected to
-        out.SliverExchanges = RepairSlivers(out.Mesh, options.SliverTarget);
+        out.SliverExchanges = RepairSlivers(out.Mesh, options.SliverTarget, keep);
         for (int round = 0; round < 2 && out.Mesh.Points.size() > n_input; ++round) {
-            if (!SmoothAddedPoints(out.Mesh, n_input)) break;
-            out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget);
+            if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
+            out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
         }
     }
     return out;

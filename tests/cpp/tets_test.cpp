@@ -584,6 +584,60 @@ CASE(simplify_surface_keeps_a_closed_manifold_and_its_shape) {
     }
 }
 
+// Non-manifold input (src/mesh/Tetrahedralize.h:53-55: "an edge may be shared by more than two triangles (internal walls)"): a box
+// with a bulkhead across its middle, attached to the outer surface along seams of three triangles per edge, and a fin with a free
+// border standing on the floor.  Every triangle -- outer and wall -- must be a face of the mesh, the walls between two tetrahedra,
+// both compartments filled.
+CASE(internal_walls_are_kept_as_faces_between_tetrahedra) {
+    Surface s = BoxSurface(2, 1, 1, 2); // grid 3 x 3 x 3 of surface points: the plane i = 1 cuts the box in half
+    std::map<std::array<int, 3>, uint32_t> ids;
+    for (uint32_t v = 0; v < s.P.size(); ++v) ids[{int(std::lround(s.P[v].x)), int(std::lround(s.P[v].y * 2)), int(std::lround(s.P[v].z * 2))}] = v;
+    const uint32_t centre = uint32_t(s.P.size());
+    s.P.push_back({1.0, 0.5, 0.5});
+    ids[{1, 1, 1}] = centre;
+    const size_t outer_triangles = s.T.size() / 3;
+    for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t a = ids.at({1, j, k}), b = ids.at({1, j + 1, k}), c = ids.at({1, j + 1, k + 1}), d = ids.at({1, j, k + 1});
+            s.T.insert(s.T.end(), {a, b, c, a, c, d});
+        }
+    // a fin: one triangle standing on the floor edge (0,0,0)-(1,0,0)... with its apex inside the left compartment
+    const uint32_t apex = uint32_t(s.P.size());
+    s.P.push_back({0.5, 0.5, 0.4});
+    s.T.insert(s.T.end(), {ids.at({0, 1, 0}), ids.at({1, 1, 0}), apex});
+    const auto r = tetra::Tetrahedralize(s.P, s.T);
+    EXPECT_NOTE(bool(r), r.Error);
+    if (!r) return;
+    std::map<std::array<uint32_t, 3>, int> count;
+    double v6 = 0;
+    for (const auto &t : r.Mesh.Tets) {
+        const double v = Vol6(r.Mesh.Points[t[0]], r.Mesh.Points[t[1]], r.Mesh.Points[t[2]], r.Mesh.Points[t[3]]);
+        EXPECT(v > 0);
+        v6 += v;
+        for (int i = 0; i < 4; ++i) {
+            std::array<uint32_t, 3> f{t[size_t(i + 1) & 3], t[size_t(i + 2) & 3], t[size_t(i + 3) & 3]};
+            std::sort(f.begin(), f.end());
+            ++count[f];
+        }
+    }
+    EXPECT(check::near(v6 / 6, 2.0, 1e-12)); // both compartments
+    size_t kept = 0;
+    for (size_t t = 0; t < s.T.size() / 3; ++t) {
+        std::array<uint32_t, 3> f{s.T[3 * t], s.T[3 * t + 1], s.T[3 * t + 2]};
+        std::sort(f.begin(), f.end());
+        const auto it = count.find(f);
+        if (it != count.end() && it->second == (t < outer_triangles ? 1 : 2)) ++kept; // (a wall piece refined by recovery points would not be found whole)
+    }
+    std::printf("box with a bulkhead and a fin: %zu triangles (%zu outer), %zu tets, %zu added points, %zu input triangles are faces as given\n", s.T.size() / 3,
+                outer_triangles, r.Mesh.Tets.size(), r.Mesh.Points.size() - s.P.size(), kept);
+    EXPECT(kept == s.T.size() / 3);
+    // an outer surface with a hole leaks: the flood from outside reaches everything
+    Surface open = BoxSurface(1, 1, 1, 2);
+    open.T.resize(open.T.size() - 3);
+    const auto leak = tetra::Tetrahedralize(open.P, open.T);
+    EXPECT(!leak && leak.Error.find("open") != std::string::npos);
+}
+
 CASE(the_general_fill_reports_unsuitable_surfaces) {
     auto open = BoxSurface(1, 1, 1, 2);
     open.T.resize(open.T.size() - 3);
