@@ -29,7 +29,6 @@
 #include "predicates.hpp"
 
 #include <algorithm>
-#include <cstdlib>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -174,6 +173,154 @@ public:
         return true;
     }
 
+    // Replaces the cells of `region` (boundary faces kept: a cell counts as inside the region while its Stamp equals Epoch) by
+    // another tiling on the region's own vertices that holds the edges `must_edges`, the faces `must_faces` and every face / edge of
+    // the old tiling for which keep_face / keep_edge answer true: a backtracking advancing front over positively oriented
+    // tetrahedra (with `delaunay`: only those whose circumsphere holds no region vertex, and the exchange must be locally Delaunay
+    // against the outside as well).  A set of positively oriented tetrahedra whose faces pair up and whose outer faces are the
+    // region's boundary tiles the region (the map has degree one).  False, mesh untouched, when the search finds none in `budget` steps.
+    template <class KeepEdge, class KeepFace>
+    bool Retile(const std::vector<int32_t> &region, const std::vector<std::array<uint32_t, 2>> &must_edges, const std::vector<Tri> &must_faces, const KeepEdge &keep_edge,
+                const KeepFace &keep_face, bool delaunay, size_t max_vertices, size_t budget) {
+        std::vector<uint32_t> verts;
+        for (const int32_t id : region)
+            for (const uint32_t v : Cells[size_t(id)].V)
+                if (std::find(verts.begin(), verts.end(), v) == verts.end()) verts.push_back(v);
+        if (verts.size() > max_vertices) return false;
+        std::sort(verts.begin(), verts.end());
+        // faces: which of the two sides already has its tetrahedron (bit 0: the negative side of the sorted triple, bit 1: the positive one)
+        const auto side_bit = [&](const Tri &f, uint32_t v) { return exact::Orient3D(At(f[0]), At(f[1]), At(f[2]), At(v)) > 0 ? 2 : 1; };
+        std::map<Tri, int> used;
+        std::vector<Tri> kept_faces; // faces and edges inside the region that the new tiling must hold
+        std::vector<std::array<uint32_t, 2>> kept_edges = must_edges;
+        kept_faces = must_faces;
+        for (const int32_t id : region) {
+            const Cell &t = Cells[size_t(id)];
+            for (int i = 0; i < 4; ++i) {
+                const Tri f = Sorted(t.V[FaceOf[i][0]], t.V[FaceOf[i][1]], t.V[FaceOf[i][2]]);
+                if (t.N[i] < 0 || Cells[size_t(t.N[i])].Stamp != Epoch) used[f] |= 3 ^ side_bit(f, t.V[i]); // boundary: the outside is taken
+                else if (keep_face(f[0], f[1], f[2])) kept_faces.push_back(f);
+            }
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j)
+                    if (keep_edge(t.V[i], t.V[j])) kept_edges.push_back({t.V[i], t.V[j]});
+        }
+        std::map<std::array<uint32_t, 4>, bool> empty_ball; // candidate tetrahedron (sorted) -> no region vertex strictly inside its circumsphere
+        const auto admissible = [&](const Tri &f, uint32_t v) {
+            std::array<uint32_t, 4> key{f[0], f[1], f[2], v};
+            std::sort(key.begin(), key.end());
+            const auto it = empty_ball.find(key);
+            if (it != empty_ball.end()) return it->second;
+            std::array<uint32_t, 4> t = key;
+            if (exact::Orient3D(At(t[0]), At(t[1]), At(t[2]), At(t[3])) < 0) std::swap(t[0], t[1]);
+            bool ok = true;
+            for (const uint32_t w : verts)
+                if (delaunay && ok && w != t[0] && w != t[1] && w != t[2] && w != t[3] && exact::InSphere(At(t[0]), At(t[1]), At(t[2]), At(t[3]), At(w)) > 0) ok = false;
+            // a tetrahedron that a wanted edge passes through, or that reaches through a wanted face, is in no tiling that holds them
+            const auto has = [&](uint32_t v) { return t[0] == v || t[1] == v || t[2] == v || t[3] == v; };
+            for (size_t e = 0; e < kept_edges.size() && ok; ++e) {
+                const uint32_t c = kept_edges[e][0], d = kept_edges[e][1];
+                if (has(c) && has(d)) continue;
+                for (int i = 0; i < 4 && ok; ++i) {
+                    const uint32_t p = t[size_t(i + 1) & 3], q = t[size_t(i + 2) & 3], r = t[size_t(i + 3) & 3];
+                    if (p == c || q == c || r == c || p == d || q == d || r == d) continue; // (a face at an end of the edge is met there only, or along it: the other faces tell)
+                    const int sc = exact::Orient3D(At(p), At(q), At(r), At(c)), sd = exact::Orient3D(At(p), At(q), At(r), At(d));
+                    if (sc == 0 || sd == 0 || sc == sd) continue;
+                    const int s1 = exact::Orient3D(At(c), At(d), At(p), At(q)), s2 = exact::Orient3D(At(c), At(d), At(q), At(r)), s3 = exact::Orient3D(At(c), At(d), At(r), At(p));
+                    if ((s1 >= 0 && s2 >= 0 && s3 >= 0) || (s1 <= 0 && s2 <= 0 && s3 <= 0)) ok = false;
+                }
+            }
+            for (size_t k = 0; k < kept_faces.size() && ok; ++k) {
+                const Tri &g = kept_faces[k];
+                if (has(g[0]) && has(g[1]) && has(g[2])) continue;
+                for (int i = 0; i < 4 && ok; ++i)
+                    for (int j = i + 1; j < 4 && ok; ++j) {
+                        const uint32_t u = t[size_t(i)], w = t[size_t(j)];
+                        if (u == g[0] || u == g[1] || u == g[2] || w == g[0] || w == g[1] || w == g[2]) continue;
+                        const int su = exact::Orient3D(At(g[0]), At(g[1]), At(g[2]), At(u)), sw = exact::Orient3D(At(g[0]), At(g[1]), At(g[2]), At(w));
+                        if (su == 0 || sw == 0 || su == sw) continue;
+                        const int t1 = exact::Orient3D(At(u), At(w), At(g[0]), At(g[1])), t2 = exact::Orient3D(At(u), At(w), At(g[1]), At(g[2])), t3 = exact::Orient3D(At(u), At(w), At(g[2]), At(g[0]));
+                        if (t1 != 0 && t1 == t2 && t2 == t3) ok = false;
+                    }
+            }
+            return empty_ball[key] = ok;
+        };
+        std::vector<std::array<uint32_t, 4>> tiling;
+        const auto complete = [&] {
+            for (const uint32_t w : verts) { // a vertex whose whole star lies inside the region must not drop out of the mesh
+                bool held = false;
+                for (const auto &t : tiling) held = held || t[0] == w || t[1] == w || t[2] == w || t[3] == w;
+                if (!held) return false;
+            }
+            for (const auto &e : kept_edges) {
+                bool held = false;
+                for (const auto &t : tiling)
+                    held = held || (std::find(t.begin(), t.end(), e[0]) != t.end() && std::find(t.begin(), t.end(), e[1]) != t.end());
+                if (!held) return false;
+            }
+            for (const Tri &f : kept_faces) {
+                bool held = false;
+                for (const auto &t : tiling)
+                    held = held || (std::find(t.begin(), t.end(), f[0]) != t.end() && std::find(t.begin(), t.end(), f[1]) != t.end() && std::find(t.begin(), t.end(), f[2]) != t.end());
+                if (!held) return false;
+            }
+            return true;
+        };
+        const auto advance = [&](auto &&self) -> bool {
+            // the open face with the fewest tetrahedra that could still close it goes first (none: this branch is dead)
+            Tri f{};
+            int want = 0;
+            size_t fewest = SIZE_MAX;
+            std::vector<uint32_t> apexes, best_apexes;
+            for (const auto &[g, bits] : used) {
+                if (bits != 1 && bits != 2) continue;
+                apexes.clear();
+                for (const uint32_t v : verts) {
+                    if (v == g[0] || v == g[1] || v == g[2]) continue;
+                    if (exact::Orient3D(At(g[0]), At(g[1]), At(g[2]), At(v)) == 0 || side_bit(g, v) != (3 ^ bits) || !admissible(g, v)) continue;
+                    apexes.push_back(v);
+                    if (apexes.size() >= fewest) break;
+                }
+                if (apexes.size() < fewest) fewest = apexes.size(), f = g, want = 3 ^ bits, best_apexes = apexes;
+                if (fewest == 0) return false;
+            }
+            if (fewest == SIZE_MAX) return complete();
+            if (budget == 0) return false;
+            --budget;
+            (void)want;
+            for (const uint32_t v : best_apexes) {
+                const std::array<uint32_t, 4> t{f[0], f[1], f[2], v};
+                std::array<std::pair<Tri, int>, 4> marks;
+                bool fits = true;
+                for (int i = 0; i < 4 && fits; ++i) {
+                    const Tri g = Sorted(t[(i + 1) & 3], t[(i + 2) & 3], t[(i + 3) & 3]);
+                    marks[size_t(i)] = {g, side_bit(g, t[size_t(i)])};
+                    const auto it = used.find(g);
+                    fits = it == used.end() || !(it->second & marks[size_t(i)].second);
+                }
+                if (!fits) continue;
+                for (const auto &[g, bit] : marks) used[g] |= bit;
+                tiling.push_back(t);
+                if (self(self)) return true;
+                tiling.pop_back();
+                for (const auto &[g, bit] : marks) {
+                    const auto it = used.find(g);
+                    it->second &= ~bit;
+                    if (it->second == 0) used.erase(it);
+                }
+            }
+            return false;
+        };
+        if (!advance(advance)) return false;
+        std::vector<Cell> fresh;
+        for (const auto &t : tiling) {
+            Cell cell{{t[0], t[1], t[2], t[3]}, {-1, -1, -1, -1}};
+            if (exact::Orient3D(At(cell.V[0]), At(cell.V[1]), At(cell.V[2]), At(cell.V[3])) < 0) std::swap(cell.V[0], cell.V[1]);
+            fresh.push_back(cell);
+        }
+        return Exchange(region, fresh, delaunay);
+    }
+
     // Brings the missing edge {c, d} into the mesh WITHOUT adding a point, when the mesh can stay Delaunay: on degenerate
     // input (grid boxes: the corners of every cell cospherical, the corners of every surface quad concyclic) the Delaunay
     // tetrahedralisation is not unique, and the insertion order picked the other diagonal {a, b} of the planar quad
@@ -254,101 +401,8 @@ public:
             return true;
         };
         if (!flood(region, 0)) return false;
-        size_t budget = 0; // search steps left in an attempt (the attempts that succeed on grid bodies take tens to a few thousand)
-        const auto attempt = [&](const std::vector<int32_t> &region) -> bool {
-            budget = 8000;
-        std::vector<uint32_t> verts;
-        for (const int32_t id : region)
-            for (const uint32_t v : Cells[size_t(id)].V)
-                if (std::find(verts.begin(), verts.end(), v) == verts.end()) verts.push_back(v);
-        if (verts.size() > MaxRegionVertices) return false;
-        std::sort(verts.begin(), verts.end());
-        // faces: which of the two sides already has its tetrahedron (bit 0: the negative side of the sorted triple, bit 1: the positive one)
-        const auto side_bit = [&](const Tri &f, uint32_t v) { return exact::Orient3D(At(f[0]), At(f[1]), At(f[2]), At(v)) > 0 ? 2 : 1; };
-        std::map<Tri, int> used;
-        std::vector<Tri> kept_faces; // faces and edges inside the region that the new tiling must hold
-        std::vector<std::array<uint32_t, 2>> kept_edges{{c, d}};
-        for (const int32_t id : region) {
-            const Cell &t = Cells[size_t(id)];
-            for (int i = 0; i < 4; ++i) {
-                const Tri f = Sorted(t.V[FaceOf[i][0]], t.V[FaceOf[i][1]], t.V[FaceOf[i][2]]);
-                if (t.N[i] < 0 || Cells[size_t(t.N[i])].Stamp != Epoch) used[f] |= 3 ^ side_bit(f, t.V[i]); // boundary: the outside is taken
-                else if (keep_face(f[0], f[1], f[2])) kept_faces.push_back(f);
-            }
-            for (int i = 0; i < 4; ++i)
-                for (int j = i + 1; j < 4; ++j)
-                    if (keep_edge(t.V[i], t.V[j])) kept_edges.push_back({t.V[i], t.V[j]});
-        }
-        std::map<std::array<uint32_t, 4>, bool> empty_ball; // candidate tetrahedron (sorted) -> no region vertex strictly inside its circumsphere
-        const auto delaunay = [&](const Tri &f, uint32_t v) {
-            std::array<uint32_t, 4> key{f[0], f[1], f[2], v};
-            std::sort(key.begin(), key.end());
-            const auto it = empty_ball.find(key);
-            if (it != empty_ball.end()) return it->second;
-            std::array<uint32_t, 4> t = key;
-            if (exact::Orient3D(At(t[0]), At(t[1]), At(t[2]), At(t[3])) < 0) std::swap(t[0], t[1]);
-            bool ok = true;
-            for (const uint32_t w : verts)
-                if (ok && w != t[0] && w != t[1] && w != t[2] && w != t[3] && exact::InSphere(At(t[0]), At(t[1]), At(t[2]), At(t[3]), At(w)) > 0) ok = false;
-            return empty_ball[key] = ok;
-        };
-        std::vector<std::array<uint32_t, 4>> tiling;
-        const auto complete = [&] {
-            for (const auto &e : kept_edges) {
-                bool held = false;
-                for (const auto &t : tiling)
-                    held = held || (std::find(t.begin(), t.end(), e[0]) != t.end() && std::find(t.begin(), t.end(), e[1]) != t.end());
-                if (!held) return false;
-            }
-            for (const Tri &f : kept_faces) {
-                bool held = false;
-                for (const auto &t : tiling)
-                    held = held || (std::find(t.begin(), t.end(), f[0]) != t.end() && std::find(t.begin(), t.end(), f[1]) != t.end() && std::find(t.begin(), t.end(), f[2]) != t.end());
-                if (!held) return false;
-            }
-            return true;
-        };
-        const auto advance = [&](auto &&self) -> bool {
-            const auto open = std::find_if(used.begin(), used.end(), [](const auto &e) { return e.second == 1 || e.second == 2; });
-            if (open == used.end()) return complete();
-            if (budget == 0) return false;
-            --budget;
-            const Tri f = open->first;
-            const int want = 3 ^ open->second;
-            for (const uint32_t v : verts) {
-                if (v == f[0] || v == f[1] || v == f[2]) continue;
-                if (exact::Orient3D(At(f[0]), At(f[1]), At(f[2]), At(v)) == 0 || side_bit(f, v) != want || !delaunay(f, v)) continue;
-                const std::array<uint32_t, 4> t{f[0], f[1], f[2], v};
-                std::array<std::pair<Tri, int>, 4> marks;
-                bool fits = true;
-                for (int i = 0; i < 4 && fits; ++i) {
-                    const Tri g = Sorted(t[(i + 1) & 3], t[(i + 2) & 3], t[(i + 3) & 3]);
-                    marks[size_t(i)] = {g, side_bit(g, t[size_t(i)])};
-                    const auto it = used.find(g);
-                    fits = it == used.end() || !(it->second & marks[size_t(i)].second);
-                }
-                if (!fits) continue;
-                for (const auto &[g, bit] : marks) used[g] |= bit;
-                tiling.push_back(t);
-                if (self(self)) return true;
-                tiling.pop_back();
-                for (const auto &[g, bit] : marks) {
-                    const auto it = used.find(g);
-                    it->second &= ~bit;
-                    if (it->second == 0) used.erase(it);
-                }
-            }
-            return false;
-        };
-        if (!advance(advance)) return false;
-        std::vector<Cell> fresh;
-        for (const auto &t : tiling) {
-            Cell cell{{t[0], t[1], t[2], t[3]}, {-1, -1, -1, -1}};
-            if (exact::Orient3D(At(cell.V[0]), At(cell.V[1]), At(cell.V[2]), At(cell.V[3])) < 0) std::swap(cell.V[0], cell.V[1]);
-            fresh.push_back(cell);
-        }
-        return Exchange(region, fresh);
-        };
+        const std::vector<std::array<uint32_t, 2>> wanted{{c, d}};
+        const auto attempt = [&](const std::vector<int32_t> &cells) { return Retile(cells, wanted, {}, keep_edge, keep_face, true, MaxRegionVertices, 8000); };
         if (attempt(region)) return true;
         // no tiling with the region's own boundary: the faces it shares with neighbouring degenerate cells may be what stands in
         // the way (a grid cell's side faces were triangulated for the neighbours' convenience).  The neighbours join, one at a
@@ -388,6 +442,188 @@ public:
         return false;
     }
 
+    // ---- constrained recovery (no points added, the mesh stops being Delaunay) ------------------------------------------
+    // The cells that the open segment c d meets, found by a flood from the cells around c through every face the segment
+    // touches (exact tests; a segment that runs through an edge or a vertex takes all the cells around it along).  False when the
+    // segment lies in the plane of a face it touches (a degenerate position this recovery does not handle) or the set outgrows `cap`.
+    bool CellsAlongSegment(uint32_t c, uint32_t d, std::vector<int32_t> &cells, size_t cap) {
+        ++Epoch;
+        cells.clear();
+        bool flat = false;
+        ForStar(c, [&](int32_t id) {
+            const Cell &t = Cells[size_t(id)];
+            int at = 0;
+            for (int i = 0; i < 4; ++i)
+                if (t.V[i] == c) at = i;
+            const uint32_t f0 = t.V[FaceOf[at][0]], f1 = t.V[FaceOf[at][1]], f2 = t.V[FaceOf[at][2]];
+            if (f0 == d || f1 == d || f2 == d) return true; // (the edge exists: not asked for)
+            const int ref = exact::Orient3D(At(c), At(f0), At(f1), At(f2));
+            const int s1 = exact::Orient3D(At(c), At(f0), At(f1), At(d)), s2 = exact::Orient3D(At(c), At(f1), At(f2), At(d)), s3 = exact::Orient3D(At(c), At(f2), At(f0), At(d));
+            if ((s1 == ref || s1 == 0) && (s2 == ref || s2 == 0) && (s3 == ref || s3 == 0)) {
+                if (s1 == 0 && s2 == 0 && s3 == 0) flat = true; // (cannot happen for distinct points)
+                Cells[size_t(id)].Stamp = Epoch;
+                cells.push_back(id);
+            }
+            return true;
+        });
+        if (flat || cells.empty()) return false;
+        for (size_t k = 0; k < cells.size(); ++k) {
+            const Cell t = Cells[size_t(cells[k])];
+            bool holds_d = false;
+            for (const uint32_t v : t.V) holds_d = holds_d || v == d;
+            if (holds_d) continue; // the far end: the segment stops here
+            for (int i = 0; i < 4; ++i) {
+                const int32_t n = t.N[i];
+                if (n < 0 || Cells[size_t(n)].Stamp == Epoch) continue;
+                const uint32_t p = t.V[FaceOf[i][0]], q = t.V[FaceOf[i][1]], r = t.V[FaceOf[i][2]];
+                if (p == c || q == c || r == c) continue; // faces at c are met at c only (or lie along the segment: the cone test took their cells)
+                const int sc = exact::Orient3D(At(p), At(q), At(r), At(c)), sd = exact::Orient3D(At(p), At(q), At(r), At(d));
+                if (sc == 0 || sd == 0) {
+                    if (sc == 0 && sd == 0) return false; // the segment lies in this face's plane
+                    if (sd == 0 && (p == d || q == d || r == d)) { // the face holds the far end: its neighbour does too
+                        Cells[size_t(n)].Stamp = Epoch;
+                        cells.push_back(n);
+                    }
+                    continue;
+                }
+                if (sc == sd) continue;
+                const int s1 = exact::Orient3D(At(c), At(d), At(p), At(q)), s2 = exact::Orient3D(At(c), At(d), At(q), At(r)), s3 = exact::Orient3D(At(c), At(d), At(r), At(p));
+                const bool touches = (s1 >= 0 && s2 >= 0 && s3 >= 0) || (s1 <= 0 && s2 <= 0 && s3 <= 0);
+                if (!touches) continue;
+                if (cells.size() >= cap) return false;
+                Cells[size_t(n)].Stamp = Epoch;
+                cells.push_back(n);
+            }
+        }
+        return true;
+    }
+
+    // The cells that the open triangle (a, b, c) cuts through -- every cell with an edge that pierces it -- when its three edges
+    // are edges of the mesh already.  False when a vertex lies in the triangle's interior or the set outgrows `cap`.
+    bool CellsAcrossTriangle(uint32_t a, uint32_t b, uint32_t c, std::vector<int32_t> &cells, size_t cap) {
+        ++Epoch;
+        cells.clear();
+        bool bad = false;
+        const auto pierced = [&](const Cell &t) { // does an edge of the cell pass through the triangle's interior?
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j) {
+                    const uint32_t u = t.V[i], v = t.V[j];
+                    if (u == a || u == b || u == c || v == a || v == b || v == c) continue;
+                    const int su = exact::Orient3D(At(a), At(b), At(c), At(u)), sv = exact::Orient3D(At(a), At(b), At(c), At(v));
+                    if (su == 0 || sv == 0 || su == sv) continue;
+                    const int t1 = exact::Orient3D(At(u), At(v), At(a), At(b)), t2 = exact::Orient3D(At(u), At(v), At(b), At(c)), t3 = exact::Orient3D(At(u), At(v), At(c), At(a));
+                    if (t1 != 0 && t1 == t2 && t2 == t3) return true;
+                }
+            return false;
+        };
+        std::vector<int32_t> frontier;
+        for (const uint32_t corner : {a, b, c})
+            ForStar(corner, [&](int32_t id) {
+                if (Cells[size_t(id)].Stamp != Epoch && pierced(Cells[size_t(id)])) {
+                    Cells[size_t(id)].Stamp = Epoch;
+                    cells.push_back(id);
+                }
+                return true;
+            });
+        for (size_t k = 0; k < cells.size(); ++k) {
+            const Cell t = Cells[size_t(cells[k])];
+            for (int i = 0; i < 4; ++i) {
+                const int32_t n = t.N[i];
+                if (n < 0 || Cells[size_t(n)].Stamp == Epoch || !pierced(Cells[size_t(n)])) continue;
+                if (cells.size() >= cap) return false;
+                Cells[size_t(n)].Stamp = Epoch;
+                cells.push_back(n);
+            }
+        }
+        (void)bad;
+        return !cells.empty();
+    }
+
+    // Adds to `cells` (all stamped with the current Epoch) every live cell that shares a face with one of them, except across faces
+    // for which keep_face answers true.
+    template <class KeepFace> bool Widen(std::vector<int32_t> &cells, const KeepFace &keep_face, size_t cap) {
+        const size_t own = cells.size();
+        for (size_t k = 0; k < own; ++k) {
+            const Cell t = Cells[size_t(cells[k])];
+            for (int i = 0; i < 4; ++i) {
+                const int32_t n = t.N[i];
+                if (n < 0 || Cells[size_t(n)].Stamp == Epoch) continue;
+                if (keep_face(t.V[FaceOf[i][0]], t.V[FaceOf[i][1]], t.V[FaceOf[i][2]])) continue;
+                if (cells.size() >= cap) return false;
+                Cells[size_t(n)].Stamp = Epoch;
+                cells.push_back(n);
+            }
+        }
+        return cells.size() > own;
+    }
+
+    // Inserts the point m, which lies on the open segment u v (its exact midpoint), WITHOUT keeping the mesh Delaunay: the cells whose
+    // closure holds m -- one, the two on a face, or the ring around an edge -- are replaced by the cone from m over their outer
+    // faces.  The constrained recovery's way of adding a point: nothing outside those cells changes, so what has been recovered stays.
+    bool InsertBySplitting(uint32_t m, uint32_t u, uint32_t v) {
+        const auto holds = [&](const Cell &t) {
+            for (int i = 0; i < 4; ++i)
+                if (exact::Orient3D(At(t.V[FaceOf[i][0]]), At(t.V[FaceOf[i][1]]), At(t.V[FaceOf[i][2]]), At(m)) < 0) return false;
+            return true;
+        };
+        std::vector<int32_t> seeds;
+        if (!CellsAlongSegment(u, v, seeds, 4096) || seeds.empty()) { // (the edge may exist already: the cells around it)
+            seeds.clear();
+            ForStar(u, [&](int32_t id) {
+                for (const uint32_t x : Cells[size_t(id)].V)
+                    if (x == v) seeds.push_back(id);
+                return true;
+            });
+        }
+        ++Epoch;
+        std::vector<int32_t> region;
+        for (const int32_t id : seeds)
+            if (Cells[size_t(id)].Stamp != Epoch && holds(Cells[size_t(id)])) Cells[size_t(id)].Stamp = Epoch, region.push_back(id);
+        for (size_t k = 0; k < region.size(); ++k) {
+            const Cell t = Cells[size_t(region[k])];
+            for (const int32_t n : t.N)
+                if (n >= 0 && Cells[size_t(n)].Stamp != Epoch && holds(Cells[size_t(n)])) Cells[size_t(n)].Stamp = Epoch, region.push_back(n);
+        }
+        if (region.empty()) return Error = "a boundary point lies in no cell of the constrained mesh", false;
+        std::vector<Cell> fresh;
+        for (const int32_t id : region) {
+            const Cell &t = Cells[size_t(id)];
+            for (int i = 0; i < 4; ++i) {
+                if (t.N[i] >= 0 && Cells[size_t(t.N[i])].Stamp == Epoch) continue;
+                const uint32_t f0 = t.V[FaceOf[i][0]], f1 = t.V[FaceOf[i][1]], f2 = t.V[FaceOf[i][2]];
+                const int s = exact::Orient3D(At(f0), At(f1), At(f2), At(m));
+                if (s < 0) return Error = "a boundary point is not seen by the cells around it", false;
+                if (s == 0) continue; // m lies in this outer face's plane: only possible on the enclosing tetrahedron's hull
+                fresh.push_back(Cell{{f0, f1, f2, m}, {-1, -1, -1, -1}});
+            }
+        }
+        if (CellOf.size() < Points.size()) CellOf.resize(Points.size(), -1);
+        return Exchange(region, fresh, false);
+    }
+
+    // Forces the edge {c, d} / the face {a, b, c} into the mesh by re-tiling the cells it cuts through (then those and their
+    // neighbours), giving up the Delaunay property.  False, mesh untouched, when no tiling is found.
+    template <class KeepEdge, class KeepFace> bool ConstrainEdge(uint32_t c, uint32_t d, const KeepEdge &keep_edge, const KeepFace &keep_face) {
+        std::vector<int32_t> cells;
+        if (!CellsAlongSegment(c, d, cells, 48)) return false;
+        const std::vector<std::array<uint32_t, 2>> wanted{{c, d}};
+        for (int widen = 0; widen < 4; ++widen) {
+            if (Retile(cells, wanted, {}, keep_edge, keep_face, false, 48, 40000)) return true;
+            if (!Widen(cells, keep_face, 160)) return false;
+        }
+        return false;
+    }
+    template <class KeepEdge, class KeepFace> bool ConstrainFace(uint32_t a, uint32_t b, uint32_t c, const KeepEdge &keep_edge, const KeepFace &keep_face) {
+        std::vector<int32_t> cells;
+        if (!CellsAcrossTriangle(a, b, c, cells, 48)) return false;
+        const std::vector<Tri> wanted{Sorted(a, b, c)};
+        for (int widen = 0; widen < 4; ++widen) {
+            if (Retile(cells, {}, wanted, keep_edge, keep_face, false, 48, 40000)) return true;
+            if (!Widen(cells, keep_face, 160)) return false;
+        }
+        return false;
+    }
+
 private:
     int32_t Last{0};
     uint32_t Epoch{0};
@@ -415,7 +651,7 @@ private:
 
     // Replaces the cells `old` by `fresh` (same region, positively oriented, adjacency not yet set) if every fresh cell is
     // locally Delaunay; false and nothing changed otherwise.
-    bool Exchange(const std::vector<int32_t> &old, std::vector<Cell> &fresh) {
+    bool Exchange(const std::vector<int32_t> &old, std::vector<Cell> &fresh, bool delaunay = true) {
         enum class Kind { Unmatched, Hull, Outside, Fresh };
         struct Side {
             Kind What{Kind::Unmatched};
@@ -455,7 +691,7 @@ private:
                 if (s.What == Kind::Unmatched) return false;
                 if (s.What == Kind::Hull) continue;
                 const uint32_t facing = s.What == Kind::Outside ? Cells[size_t(s.Cell)].V[s.Face] : fresh[size_t(s.Cell)].V[s.Face];
-                if (exact::InSphere(At(fresh[f].V[0]), At(fresh[f].V[1]), At(fresh[f].V[2]), At(fresh[f].V[3]), At(facing)) > 0) return false;
+                if (delaunay && exact::InSphere(At(fresh[f].V[0]), At(fresh[f].V[1]), At(fresh[f].V[2]), At(fresh[f].V[3]), At(facing)) > 0) return false;
             }
         const int32_t base = int32_t(Cells.size());
         Touched.clear();
@@ -943,7 +1179,9 @@ static uint32_t SmoothAddedPoints(TetMesh &mesh, uint32_t n_input, const std::se
     return moved;
 }
 
-Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options) {
+// One attempt.  `constrained`: no point is added; what the Delaunay tetrahedralisation of the vertices lacks is forced in by
+// re-tiling the cells it cuts through (DelaunayMesh::ConstrainEdge / ConstrainFace).
+static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options, bool constrained) {
     Result out;
     const uint32_t n_input = uint32_t(points.size());
     if (triangle_indices.size() < 12 || triangle_indices.size() % 3) return out.Error = "a closed surface needs at least four triangles (three indices each)", out;
@@ -1003,7 +1241,7 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
 
     // 2. boundary recovery by refinement, one split at a time: a split can knock neighbouring constraints out of the mesh (and
     //    make queued ones present again), so everything near the new point is re-examined before anything else is cut
-    const size_t steiner_cap = options.MaxSteinerPoints ? options.MaxSteinerPoints : 2 * size_t(n_input) + 4096; // (surfaces that fill at all needed at most 0.4 x their vertices; a run-away refinement is cut short: seconds instead of a minute)
+    const size_t steiner_cap = options.MaxSteinerPoints ? options.MaxSteinerPoints : size_t(n_input) + 2048; // (surfaces that fill at all needed at most 0.4 x their vertices; a run-away refinement is cut short and the constrained recovery takes over)
     const auto length2 = [&](uint32_t a, uint32_t b) {
         const dvec3 d = dt.Points[a] - dt.Points[b];
         return d.x * d.x + d.y * d.y + d.z * d.z;
@@ -1056,7 +1294,7 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
                 enlist(uint32_t(surface.size() - 1));
             }
         }
-        if (!dt.Insert(m)) return false;
+        if (!(constrained ? dt.InsertBySplitting(m, u, v) : dt.Insert(m))) return false;
         requeue_near(dt.Touched);
         return true;
     };
@@ -1082,13 +1320,24 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         for (int e = 0; e < 3 && cut < 0 && !flipped; ++e)
             if (!dt.HasEdge(tri[e], tri[(e + 1) % 3])) {
                 // first without a point: on degenerate input another Delaunay tetrahedralisation may hold the edge
-                if (!getenv("TET_NOFLIP") && dt.FlipIn(tri[e], tri[(e + 1) % 3], is_surface_edge, is_surface_face)) flipped = true;
-                else cut = e;
+                // (between input vertices only: the recovery's own points sit exactly in the planes of the triangles they split, where
+                // a coplanar crossing is the rule and the search behind it costs more than the bisection it would save)
+                const uint32_t eu = tri[e], ev = tri[(e + 1) % 3];
+                if (eu < n_input && ev < n_input && dt.FlipIn(eu, ev, is_surface_edge, is_surface_face)) flipped = true;
+                else if (constrained && dt.ConstrainEdge(eu, ev, is_surface_edge, is_surface_face)) flipped = true;
+                else cut = e; // (constrained: a point on the edge, inserted by splitting the cells that hold it)
             }
         if (flipped) { // look at the triangle again, and at everything around the exchanged cells
             requeue_near(dt.Touched);
             if (!queued[t]) queued[t] = 1, pending.push_back(t);
             continue;
+        }
+        if (cut < 0 && constrained && !dt.HasFace(tri[0], tri[1], tri[2])) {
+            if (dt.ConstrainFace(tri[0], tri[1], tri[2], is_surface_edge, is_surface_face)) {
+                requeue_near(dt.Touched);
+                if (!queued[t]) queued[t] = 1, pending.push_back(t);
+                continue;
+            }
         }
         if (cut < 0 && !dt.HasFace(tri[0], tri[1], tri[2])) { // edges present, face absent: cut the longest edge
             cut = 0;
@@ -1103,7 +1352,7 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         // at the wanted edge and keeps moving to the longest edge of a neighbouring surface triangle while that one is longer;
         // the pieces then never get angles below half the smallest input angle.  The triangle comes back for another look.
         uint32_t cu = tri[cut], cv = tri[(cut + 1) % 3];
-        for (int hop = 0; hop < 64; ++hop) {
+        for (int hop = 0; hop < 64 && !constrained; ++hop) { // (constrained: this edge itself -- nothing cascades there)
             bool moved = false;
             const auto it = on_edge.find(EdgeKey(cu, cv));
             if (it == on_edge.end()) break;
@@ -1208,5 +1457,21 @@ Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> t
         }
     }
     return out;
+}
+
+// Conforming Delaunay first (well-shaped cells, what every surface of round 3 goes through); a surface whose refinement runs away
+// -- coarse triangles on a thin wall, needle fans: quadric-decimated scans -- is filled by the constrained recovery instead.
+Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options) {
+    Result conforming = TetrahedralizeOnce(points, triangle_indices, options, false);
+    if (options.MaxSteinerPoints) return conforming; // (an explicit budget asks for the refinement alone)
+    if (conforming && (conforming.BoundarySteinerCount == 0 || !options.InteriorSteiner)) return conforming;
+    if (!conforming && conforming.Error.find("did not converge") == std::string::npos) return conforming;
+    // the refinement ran away, or left points on the surface that could not be moved inside: the constrained recovery adds a point
+    // only where no tiling exists without one
+    Result constrained = TetrahedralizeOnce(points, triangle_indices, options, true);
+    if (constrained && (!conforming || constrained.BoundarySteinerCount < conforming.BoundarySteinerCount)) return constrained;
+    if (conforming) return conforming;
+    conforming.Error += "; " + constrained.Error;
+    return conforming;
 }
 } // namespace tetra

@@ -1762,7 +1762,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // Last resort of a SMALL system whose iteration stalled (measured: a UV sphere's surface filled without interior
                 // points -- a quarter of the tetrahedra flat to 1e-8, ||A|| / theta ~ 1e13): one dense eigensolve in the inverse
                 // form.  O(n^3), seconds at the size limit: better than no modes for an editor primitive.
-                if (e.code != MH_ENOTCONVERGED || n > kDenseLastResort) throw;
+                // (not when the caller's own iteration limit is what stopped it: MaxRestarts exceeded stays the reference's empty result)
+                if (e.code != MH_ENOTCONVERGED || n > kDenseLastResort || max_iters < 50) throw;
                 if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- dense eigensolve of order %zu instead\n", e.what(), n);
                 Timer t(ctx);
                 dense_eigs(sys, nev, sigma, eigenvalues, true);
