@@ -607,9 +607,9 @@ public:
         std::vector<int32_t> cells;
         if (!CellsAlongSegment(c, d, cells, 48)) return false;
         const std::vector<std::array<uint32_t, 2>> wanted{{c, d}};
-        for (int widen = 0; widen < 4; ++widen) {
-            if (Retile(cells, wanted, {}, keep_edge, keep_face, false, 48, 40000)) return true;
-            if (!Widen(cells, keep_face, 160)) return false;
+        for (int widen = 0; widen < 3; ++widen) { // (a search that runs out of steps costs seconds on 40 vertices; a point on the edge costs nothing)
+            if (Retile(cells, wanted, {}, keep_edge, keep_face, false, 32, 3000)) return true;
+            if (!Widen(cells, keep_face, 96)) return false;
         }
         return false;
     }
@@ -617,9 +617,9 @@ public:
         std::vector<int32_t> cells;
         if (!CellsAcrossTriangle(a, b, c, cells, 48)) return false;
         const std::vector<Tri> wanted{Sorted(a, b, c)};
-        for (int widen = 0; widen < 4; ++widen) {
-            if (Retile(cells, {}, wanted, keep_edge, keep_face, false, 48, 40000)) return true;
-            if (!Widen(cells, keep_face, 160)) return false;
+        for (int widen = 0; widen < 3; ++widen) {
+            if (Retile(cells, {}, wanted, keep_edge, keep_face, false, 32, 3000)) return true;
+            if (!Widen(cells, keep_face, 96)) return false;
         }
         return false;
     }
