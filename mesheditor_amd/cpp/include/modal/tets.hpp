@@ -13,11 +13,14 @@
 //     positions are rejected as "point coincides";
 //   * sliver repair changes connectivity only (edge removal, 2-3 flips: Options::RepairSlivers); no vertex smoothing, no quality
 //     refinement (the reference's Options::Quality / MaxVolume have no counterpart);
-//   * fans of needle triangles can exhaust the refinement budget: "did not converge" instead of a mesh.
+//   * tetrahedra are not the reference's: same contract, other interior (it flips and carves, this refines, re-tiles and repairs).
 // Two fills:
 //   tetra::Tetrahedralize   any closed, non-self-intersecting surface -- non-convex, non-star-shaped, any genus, nested
 //                           cavities: a conforming Delaunay tetrahedralisation on exact predicates.  Surface triangles the
 //                           Delaunay mesh lacks are recovered by bisecting their edges; the added points then move inside.
+//                           Where that refinement runs away (coarse triangles on thin walls, needle fans: quadric-decimated
+//                           scans, UV-sphere poles) a constrained recovery re-tiles the cells a missing edge or triangle cuts
+//                           through instead, adding a point only where no tiling exists (src/tetrahedralize.cpp, step 2b).
 //   tetra::FillStarShaped   surfaces star-shaped about their centroid: layered shells, no point on the surface is added,
 //                           well-shaped elements (the Delaunay fill of a bare surface has long interior tets).
 #pragma once

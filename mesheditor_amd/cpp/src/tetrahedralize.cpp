@@ -4,8 +4,8 @@
 // accepts refinements and counts them as boundary Steiner points), every tet is positively oriented, the tets fill exactly
 // the enclosed volume, winding is ignored, and an open / self-intersecting / unrecoverable surface yields an error string.
 //
-// Method -- a conforming Delaunay tetrahedralisation, written from the textbook algorithms, not from the reference's
-// 10 k-line TetGen rewrite:
+// Method -- a conforming Delaunay tetrahedralisation with a constrained recovery behind it, written from the textbook
+// algorithms, not from the reference's 10 k-line TetGen rewrite:
 //   1. Delaunay tetrahedralisation of the surface vertices by incremental Bowyer-Watson insertion inside a far enclosing
 //      tetrahedron, on exact predicates (predicates.hpp): visibility walk to the containing tet, cavity = tets whose open
 //      circumball holds the point, re-triangulated as a fan.  Exact arithmetic keeps every cavity star-shaped, so fully
@@ -17,12 +17,22 @@
 //      neighbouring surface triangle while that is longer -- arbitrary-edge bisection breeds ever thinner pieces whose new
 //      edges are again not Delaunay.  Cut points are the EXACT midpoints (coordinates kept as floating-point expansions), so
 //      the pieces of an edge stay exactly collinear and the pieces of a triangle exactly coplanar.
-//      Limits: fans of needle triangles (apex angles of a few degrees) on a rough surface can refine without end; a cap on
-//      the added points (2 x the input vertices + 4096) turns that into an error string.  Scan-like surfaces with reasonably
-//      shaped triangles (20 k triangles: ~10 % added points, well under a second), boxes with rectangular cells, brackets,
-//      tori, bowls and nested cavities go through.
+//      On degenerate input (grid boxes: the cells' corners cospherical) the Delaunay tetrahedralisation is not unique; before a
+//      point is added the degenerate cells around a missing edge are re-tiled among their own vertices (FlipIn): one-cell-thick
+//      grid bodies -- the reference's sample boxes -- need no point at all.
+//      Limits: coarse triangles on a thin wall and fans of needle triangles (quadric-decimated scans) make the refinement run
+//      away; a cap on the added points (the input vertices + 2048) stops it and step 2b takes over.
+//  2b. Constrained recovery (round 4), from the plain Delaunay tetrahedralisation of the vertices again: the cells a missing edge
+//      passes through / a missing triangle cuts through are re-tiled among their own vertices so that they hold it (a backtracking
+//      advancing front over positively oriented tetrahedra, pruned by what must stay: every surface edge and face already
+//      there; the cells' neighbours join when no tiling exists).  The mesh stops being Delaunay, so the rare point that is still
+//      needed -- a Schoenhardt-like pocket admits no tiling -- is inserted by splitting the cells that hold it, not by a cavity.
+//      Decimated scan surfaces (25 %, 10 % of the triangles) fill in 1-3 s with 1-10 added points.
 //   3. Inside / outside by parity: a flood from the enclosing tetrahedron that flips each time it crosses a surface face;
-//      an inconsistent parity means the surface does not close.
+//      an inconsistent parity means the surface does not close.  Non-manifold input (internal walls): the flood stops at every
+//      triangle and what it never reaches is inside.
+//   4. The recovery's points are moved off the surface (LiftBoundaryPoints), then slivers are repaired by edge removal and 2-3
+//      flips and the added points smoothed (RepairSlivers, SmoothAddedPoints) -- as the reference does whatever its options.
 // Non-star-shaped, non-convex and higher-genus bodies (brackets, tori, bowls) go through unchanged code paths.
 #include "modal/tets.hpp"
 
