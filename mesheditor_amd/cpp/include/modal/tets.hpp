@@ -38,6 +38,7 @@ struct Result {
     std::string Error; // empty on success
     uint32_t BoundarySteinerCount{0}; // added points left ON the surface (input triangles they refine are not boundary faces); 0 = the input triangulation is the boundary
     uint32_t SliverExchanges{0}; // edge removals and 2-3 flips the sliver repair made
+    uint32_t ShellPoints{0}; // interior points added under the surface (Options::InteriorShell)
     explicit operator bool() const { return Error.empty(); }
 };
 struct Options {
@@ -45,6 +46,11 @@ struct Options {
     bool InteriorSteiner{true}; // after the fill, move the recovery's points off the surface (every input triangle a boundary face again)
     bool RepairSlivers{true}; // connectivity-only sliver repair afterwards (the reference repairs slivers whatever its options: Tetrahedralize.h:20)
     double SliverTarget{0.25}; // tetrahedra with a shape measure below this are worked on (1 = regular, 0 = flat)
+    // One interior point under every surface vertex (with RepairSlivers).  WhenFlat: only if the fill is left with flat cells at the
+    // surface -- a smooth surface that is finely tessellated and has no interior points of its own, e.g. a 96 x 48 UV sphere, whose
+    // cells of shape 1e-9 no iterative eigensolver converges on; coarse primitives and thin-walled scans are left as they are.
+    enum class Shell { Never, WhenFlat, Always };
+    Shell InteriorShell{Shell::WhenFlat};
 };
 Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options = {});
 // `layers` shells between the surface and the centroid (0: a plain fan of one tet per triangle).  Each layer is a copy of

@@ -919,7 +919,7 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
 // recovered edge -- whose stiffness entries dwarf their neighbours' and stall iterative eigensolvers (shape 2e-8 on the reference's
 // sample sphere: ||A|| / theta ~ 1e13).  This pass changes the CONNECTIVITY only, by hill climbing on the worst shape measure of
 // the tetrahedra involved (shape = 6 sqrt 2 V / l_rms^3: 1 for the regular tetrahedron, 0 for a flat one):
-//   * edge removal: the n <= 7 tetrahedra around an interior edge {u, v} are replaced by the best triangulation of their link
+//   * edge removal: the n <= 12 tetrahedra around an interior edge {u, v} are replaced by the best triangulation of their link
 //     polygon coned to u and to v (Klincsek's dynamic programme over the polygon: n = 3 is the 3-2 flip, n = 4 the 4-4 flip);
 //   * the 2-3 flip of an interior face.
 // Boundary faces are untouched (an edge on the boundary has an open ring and is skipped), no point is added or moved, every new
@@ -979,7 +979,7 @@ static uint32_t RepairSlivers(TetMesh &mesh, double target, const std::set<Tri> 
         std::vector<int32_t> Old;
         std::vector<std::array<uint32_t, 4>> Fresh;
     };
-    constexpr int MaxRing = 7;
+    constexpr int MaxRing = 12;
     // best re-tiling of the tets around the edge {u, v} of tet t; Worst = 0 when there is none
     const auto remove_edge = [&](int32_t t, uint32_t u, uint32_t v) {
         Plan plan;
@@ -1094,6 +1094,261 @@ static uint32_t RepairSlivers(TetMesh &mesh, double target, const std::set<Tri> 
         if (alive[t]) kept.push_back(T[t]);
     T.swap(kept);
     return exchanges;
+}
+
+// Caps and other flat cells of a bare surface's fill.  A cap is a flat tetrahedron on TWO boundary faces -- the two triangles of a (nearly) planar surface quad joined into one cell, the
+// rule on a UV sphere, whose latitude-longitude quads are planar trapezoids -- cannot be exchanged away: its only removable edge is
+// the quad's other diagonal {b, d}, and the cells around that edge seldom re-tile without it.  With shape measures of 1e-7 ... 1e-9
+// such cells inflate ||K|| by as much and stall the eigensolver (measured: a 96 x 48 UV sphere did not converge at all).  Here the
+// cells around {b, d} are replaced by the cone over their outer faces from a new point m just inside the body under the middle of
+// {b, d}: every cell around an edge is star-shaped about the edge's interior, so for m close enough the cone is a valid tiling --
+// checked exactly -- and the cap becomes (a, b, c, m), (a, c, d, m) of height |m - quad|.  Both surface triangles stay.  The sliver
+// repair and the smoothing that follow do the rest.  The same is done at an edge of a flat cell with one boundary face (a triangle
+// of a pole fan and a fourth point of the first ring: the fan is all but planar) or with none.  Returns the number of points added.
+static uint32_t BreakCaps(TetMesh &mesh, double flat) {
+    auto &P = mesh.Points;
+    auto &T = mesh.Tets;
+    struct FaceHash {
+        size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
+    };
+    const auto shape = [&](const std::array<uint32_t, 4> &t) {
+        const dvec3 u = P[t[1]] - P[t[0]], v = P[t[2]] - P[t[0]], w = P[t[3]] - P[t[0]];
+        const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+        double l2 = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                const dvec3 e = P[t[size_t(i)]] - P[t[size_t(j)]];
+                l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+            }
+        const double lrms = std::sqrt(l2 / 6);
+        return lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0;
+    };
+    uint32_t added = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> faces;
+        faces.reserve(T.size() * 2);
+        for (size_t t = 0; t < T.size(); ++t)
+            for (int i = 0; i < 4; ++i) {
+                auto [it, fresh] = faces.try_emplace(Sorted(T[t][size_t(i + 1) & 3], T[t][size_t(i + 2) & 3], T[t][size_t(i + 3) & 3]), std::array<int32_t, 2>{int32_t(t), -1});
+                if (!fresh) it->second[1] = int32_t(t);
+            }
+        const auto across = [&](int32_t t, uint32_t x, uint32_t y, uint32_t z) -> int32_t {
+            const auto it = faces.find(Sorted(x, y, z));
+            if (it == faces.end()) return -1;
+            return it->second[0] == t ? it->second[1] : it->second[0];
+        };
+        const size_t n_before = T.size();
+        std::vector<uint8_t> dead(n_before, 0);
+        uint32_t broken = 0;
+        for (size_t t = 0; t < n_before; ++t) {
+            if (dead[t] || shape(T[t]) >= flat) continue;
+            const auto tet = T[t];
+            bool open[4];
+            int n_open = 0;
+            for (int i = 0; i < 4; ++i) n_open += (open[i] = across(int32_t(t), tet[size_t(i + 1) & 3], tet[size_t(i + 2) & 3], tet[size_t(i + 3) & 3]) < 0);
+            if (n_open == 0) continue; // (an interior sliver split at an edge only breeds more of them: those are the exchanges' business)
+            // the edges of the cell that lie on none of its boundary faces: for a cap the quad's other diagonal; for a flat cell on one
+            // boundary face (a pole fan's triangle and a fourth ring point) the three edges at its fourth vertex
+            bool done = false;
+            for (int i = 0; i < 4 && !done; ++i)
+                for (int j = i + 1; j < 4 && !done; ++j) {
+                    bool on_boundary = false;
+                    for (int f = 0; f < 4; ++f) on_boundary = on_boundary || (open[f] && f != i && f != j); // face f (opposite vertex f) holds both i and j
+                    if (on_boundary) continue;
+                    const uint32_t b = tet[size_t(i)], d = tet[size_t(j)];
+                    // the cells around {b, d}
+                    std::vector<int32_t> ring;
+                    std::vector<std::array<uint32_t, 2>> far; // per ring cell its two vertices other than b, d
+                    uint32_t from = UINT32_MAX, to = UINT32_MAX;
+                    for (const uint32_t x : tet)
+                        if (x != b && x != d) (from == UINT32_MAX ? from : to) = x;
+                    int32_t cell = int32_t(t);
+                    bool closed = false, clean = true;
+                    for (int guard = 0; guard < 32; ++guard) {
+                        ring.push_back(cell);
+                        far.push_back({from, to});
+                        clean = clean && !dead[size_t(cell)];
+                        const int32_t next = across(cell, b, d, to);
+                        if (next < 0) break;
+                        uint32_t beyond = UINT32_MAX;
+                        for (const uint32_t x : T[size_t(next)])
+                            if (x != b && x != d && x != to) beyond = x;
+                        from = to, to = beyond, cell = next;
+                        if (cell == int32_t(t)) { closed = true; break; }
+                    }
+                    if (!closed || !clean) continue;
+                    // away from the flat cell: from the middle of {b, d} towards the ring's vertices that are not the cell's
+                    const dvec3 mid = (P[b] + P[d]) * 0.5;
+                    dvec3 inner{0, 0, 0};
+                    double count = 0;
+                    for (const auto &f : far)
+                        for (const uint32_t x : f)
+                            if (x != tet[0] && x != tet[1] && x != tet[2] && x != tet[3]) inner = inner + P[x], count += 1;
+                    if (count == 0) continue;
+                    const dvec3 towards = inner * (1.0 / count) - mid;
+                    const dvec3 bd = P[d] - P[b];
+                    const double reach2 = towards.x * towards.x + towards.y * towards.y + towards.z * towards.z, edge2 = bd.x * bd.x + bd.y * bd.y + bd.z * bd.z;
+                    for (const double step : {0.3, 0.15, 0.07}) {
+                        if (step * step * reach2 < 0.01 * edge2) continue; // (closer to the edge than a tenth of its length the new cells are flat themselves)
+                        const dvec3 m = mid + towards * step;
+                        bool valid = true;
+                        std::vector<std::array<uint32_t, 4>> cone;
+                        const uint32_t id = uint32_t(P.size());
+                        for (size_t k = 0; k < ring.size() && valid; ++k)
+                            for (const uint32_t pole : {b, d}) { // the face of the cell that holds `pole` but not the other end of the edge
+                                std::array<uint32_t, 4> piece = T[size_t(ring[k])];
+                                const uint32_t gone = pole == b ? d : b;
+                                dvec3 q[4];
+                                for (int c = 0; c < 4; ++c) {
+                                    if (piece[size_t(c)] == gone) piece[size_t(c)] = id;
+                                    q[c] = piece[size_t(c)] == id ? m : P[piece[size_t(c)]];
+                                }
+                                if (exact::Orient3D(q[0], q[1], q[2], q[3]) <= 0) { valid = false; break; }
+                                cone.push_back(piece);
+                            }
+                        if (!valid) continue;
+                        P.push_back(m);
+                        for (const auto &piece : cone) T.push_back(piece);
+                        for (const int32_t r : ring) dead[size_t(r)] = 1;
+                        ++broken;
+                        done = true;
+                        break;
+                    }
+                }
+        }
+        if (!broken) break;
+        added += broken;
+        std::vector<std::array<uint32_t, 4>> kept;
+        kept.reserve(T.size());
+        for (size_t t = 0; t < T.size(); ++t)
+            if (t >= n_before || !dead[t]) kept.push_back(T[t]);
+        T.swap(kept);
+    }
+    return added;
+}
+
+// A shell of interior points under the surface.  A finely tessellated SMOOTH surface filled without interior points has flat cells
+// everywhere -- wherever four of its vertices lie within a patch that is nearly planar at the mesh's own scale (two adjacent surface
+// triangles at a dihedral angle of 176 degrees and a neighbour's vertex; a pole fan) -- and no exchange helps, because every vertex
+// available sits on the same nearly flat patch.  The cure is a vertex UNDER the patch: one point per surface vertex, offset inwards along
+// the vertex normal by 0.45 ... 0.75 of the mean length of the surface edges at it (the reference's own quality arm refines with hundreds of
+// such points: tests/fixtures/TetCorpusSnapshot.txt, the q rows).  A point is inserted by splitting the cell that holds it (found
+// among the cells around its surface vertex), so no face of the mesh is touched; the sliver repair and the smoothing that follow
+// turn the long cells towards the interior into well-shaped ones.  Returns the number of points added.
+static uint32_t AddInteriorShell(TetMesh &mesh, uint32_t n_surface_vertices) {
+    auto &P = mesh.Points;
+    auto &T = mesh.Tets;
+    struct FaceHash {
+        size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
+    };
+    std::unordered_map<Tri, int, FaceHash> face_count;
+    face_count.reserve(T.size() * 2);
+    for (const auto &t : T)
+        for (int i = 0; i < 4; ++i) ++face_count[Sorted(t[size_t(i + 1) & 3], t[size_t(i + 2) & 3], t[size_t(i + 3) & 3])];
+    // outward normals and edge lengths at the surface vertices, from the boundary faces (each seen from its one cell)
+    std::vector<dvec3> normal(n_surface_vertices, dvec3{0, 0, 0});
+    std::vector<double> length(n_surface_vertices, 0.0), edges(n_surface_vertices, 0.0);
+    for (const auto &t : T)
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = t[size_t(i + 1) & 3], b = t[size_t(i + 2) & 3], c = t[size_t(i + 3) & 3];
+            if (face_count[Sorted(a, b, c)] != 1) continue;
+            const dvec3 u = P[b] - P[a], v = P[c] - P[a];
+            dvec3 n{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; // twice the area, either way round
+            const dvec3 in = P[t[size_t(i)]] - P[a];
+            if (n.x * in.x + n.y * in.y + n.z * in.z > 0) n = n * -1.0; // away from the cell's fourth vertex
+            for (const uint32_t x : {a, b, c})
+                if (x < n_surface_vertices) normal[x] = normal[x] + n;
+            const uint32_t tri[3] = {a, b, c};
+            for (int e = 0; e < 3; ++e) {
+                const dvec3 d = P[tri[e]] - P[tri[(e + 1) % 3]];
+                const double l = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+                for (const uint32_t x : {tri[e], tri[(e + 1) % 3]})
+                    if (x < n_surface_vertices) length[x] += l, edges[x] += 1;
+            }
+        }
+    // cells by face, kept up to date as cells are split: the point is located by a walk that starts at a cell around its vertex
+    std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> cells_on;
+    cells_on.reserve(T.size() * 2);
+    const auto link = [&](int32_t t, bool add) {
+        const auto &v = T[size_t(t)];
+        for (int i = 0; i < 4; ++i) {
+            const Tri key = Sorted(v[size_t(i + 1) & 3], v[size_t(i + 2) & 3], v[size_t(i + 3) & 3]);
+            if (add) {
+                auto [it, fresh] = cells_on.try_emplace(key, std::array<int32_t, 2>{t, -1});
+                if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
+            } else {
+                auto it = cells_on.find(key);
+                if (it->second[0] == t) it->second[0] = it->second[1];
+                it->second[1] = -1;
+                if (it->second[0] < 0) cells_on.erase(it);
+            }
+        }
+    };
+    for (size_t t = 0; t < T.size(); ++t) link(int32_t(t), true);
+    std::vector<int32_t> cell_at(n_surface_vertices, -1); // one live cell per surface vertex
+    for (size_t t = 0; t < T.size(); ++t)
+        for (const uint32_t x : T[t])
+            if (x < n_surface_vertices) cell_at[x] = int32_t(t);
+    std::vector<uint8_t> dead(T.size(), 0);
+    uint32_t added = 0;
+    for (uint32_t v = 0; v < n_surface_vertices; ++v) {
+        const double nl = std::sqrt(normal[v].x * normal[v].x + normal[v].y * normal[v].y + normal[v].z * normal[v].z);
+        if (!(nl > 0) || !(edges[v] > 0) || cell_at[v] < 0) continue;
+        const dvec3 inward = normal[v] * (-1.0 / nl);
+        const double h = length[v] / edges[v];
+        // (depths staggered from vertex to vertex -- a deterministic hash, 0.45 ... 0.75: points at ONE depth form a surface parallel
+        // to the input, and the quads between an edge and its offset copy are planar: the flat cells would be back one layer down)
+        const double stagger = 0.45 + 0.3 * double((v * 2654435761u) >> 8 & 0xffffu) / 65536.0;
+        for (const double depth : {stagger, 0.6 * stagger, 1.4 * stagger}) {
+            const dvec3 p = P[v] + inward * (depth * h);
+            // visibility walk from a cell at v: through any face that has p strictly on its far side
+            int32_t at = cell_at[v];
+            bool found = false;
+            for (int step = 0; step < 200 && at >= 0; ++step) {
+                const auto cell = T[size_t(at)];
+                int32_t next = -2;
+                bool strictly = true;
+                for (int k = 0; k < 4; ++k) {
+                    const int i = (k + step) & 3; // (vary the order: a walk must not circle)
+                    dvec3 q[4];
+                    for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cell[size_t(j)]];
+                    const int side = exact::Orient3D(q[0], q[1], q[2], q[3]);
+                    if (side < 0 && next == -2) {
+                        const auto it = cells_on.find(Sorted(cell[size_t(i + 1) & 3], cell[size_t(i + 2) & 3], cell[size_t(i + 3) & 3]));
+                        next = it == cells_on.end() ? -1 : (it->second[0] == at ? it->second[1] : it->second[0]);
+                    }
+                    strictly = strictly && side > 0;
+                }
+                if (next == -2) { found = strictly; break; } // inside (or on a face: another depth)
+                at = next; // -1: p is outside the body
+            }
+            if (!found || at < 0) continue;
+            const auto cell = T[size_t(at)];
+            const uint32_t id = uint32_t(P.size());
+            P.push_back(p);
+            link(at, false);
+            dead[size_t(at)] = 1;
+            for (int i = 0; i < 4; ++i) {
+                std::array<uint32_t, 4> piece = cell;
+                piece[size_t(i)] = id;
+                T.push_back(piece);
+                dead.push_back(0);
+                link(int32_t(T.size() - 1), true);
+                for (const uint32_t x : piece)
+                    if (x < n_surface_vertices) cell_at[x] = int32_t(T.size() - 1);
+            }
+            ++added;
+            break;
+        }
+    }
+    if (added) {
+        std::vector<std::array<uint32_t, 4>> kept;
+        kept.reserve(T.size());
+        for (size_t t = 0; t < T.size(); ++t)
+            if (!dead[t]) kept.push_back(T[t]);
+        T.swap(kept);
+    }
+    return added;
 }
 
 // Vertex smoothing of the ADDED points (the reference's "vertex optimisation" runs with its sliver repair: Tetrahedralize.h:20):
@@ -1463,6 +1718,60 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
         out.SliverExchanges = RepairSlivers(out.Mesh, options.SliverTarget, keep);
         for (int round = 0; round < 2 && out.Mesh.Points.size() > n_input; ++round) {
             if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
+            out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+        }
+        // Flat cells at the surface.  A few of them (planar surface quads joined into one cell: a coarse UV sphere) each get an apex
+        // underneath (BreakCaps); if the fill is still left with flat cells after that, the surface is smooth at its own resolution
+        // and every surface vertex needs a vertex underneath (AddInteriorShell, from the mesh as it was before the caps).
+        const auto flat_at_surface = [&](const TetMesh &m) {
+            const auto &P = m.Points;
+            size_t flat = 0;
+            for (const auto &t : m.Tets) {
+                if ((t[0] >= n_input) + (t[1] >= n_input) + (t[2] >= n_input) + (t[3] >= n_input) > 1) continue; // (three or four surface vertices)
+                const dvec3 u = P[t[1]] - P[t[0]], v = P[t[2]] - P[t[0]], w = P[t[3]] - P[t[0]];
+                const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+                double l2 = 0;
+                for (int i = 0; i < 4; ++i)
+                    for (int j = i + 1; j < 4; ++j) {
+                        const dvec3 e = P[t[size_t(i)]] - P[t[size_t(j)]];
+                        l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+                    }
+                const double lrms = std::sqrt(l2 / 6);
+                flat += lrms > 0 && 1.4142135623730951 * vol6 / (lrms * lrms * lrms) < 1e-3;
+            }
+            return flat;
+        };
+        if (manifold && flat_at_surface(out.Mesh) > 0) {
+            const TetMesh before = out.Mesh;
+            const uint32_t exchanges_before = out.SliverExchanges;
+            if (BreakCaps(out.Mesh, 1e-3)) {
+                out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                SmoothAddedPoints(out.Mesh, n_input, keep);
+                out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+            }
+            const bool shell = options.InteriorShell == Options::Shell::Always ||
+                               (options.InteriorShell == Options::Shell::WhenFlat && flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size()); // > 0.5 % of the cells
+            if (shell) {
+                out.Mesh = before;
+                out.SliverExchanges = exchanges_before;
+                if ((out.ShellPoints = AddInteriorShell(out.Mesh, n_input)) > 0) {
+                    for (int round = 0; round < 3; ++round) {
+                        out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                        if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
+                    }
+                    out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                    if (BreakCaps(out.Mesh, 1e-3)) { // (the caps that no exchange could open: now with points underneath to aim at)
+                        out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                        SmoothAddedPoints(out.Mesh, n_input, keep);
+                        out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                    }
+                }
+            }
+        } else if (manifold && options.InteriorShell == Options::Shell::Always && (out.ShellPoints = AddInteriorShell(out.Mesh, n_input)) > 0) {
+            for (int round = 0; round < 3; ++round) {
+                out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
+            }
             out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
         }
     }

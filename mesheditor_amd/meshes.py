@@ -115,6 +115,28 @@ def workload(name):
     raise KeyError(name)
 
 
+def uv_sphere_surface(radius, segments, rings):
+    """A UV sphere as a mesh editor makes it (the reference's sample generator: glTF_PhysicalAudio/samples/generate.py `sphere`): a pole
+    vertex, rings - 1 latitude rings of `segments` points, a pole vertex; triangle fans at the poles, two triangles per quad between
+    rings.  Positions through float32 (an .obj round trip).  Returns (points float64 [V, 3], triangles uint32 [F, 3])."""
+    pts = [(0.0, radius, 0.0)]
+    for i in range(1, rings):
+        th = np.pi * i / rings
+        for j in range(segments):
+            ph = 2 * np.pi * j / segments
+            pts.append((radius * np.sin(th) * np.cos(ph), radius * np.cos(th), radius * np.sin(th) * np.sin(ph)))
+    pts.append((0.0, -radius, 0.0))
+    tri = [(0, 1 + j, 1 + (j + 1) % segments) for j in range(segments)]
+    for i in range(rings - 2):
+        a, b = 1 + i * segments, 1 + (i + 1) * segments
+        for j in range(segments):
+            k = (j + 1) % segments
+            tri += [(a + j, b + j, b + k), (a + j, b + k, a + k)]
+    last, a = len(pts) - 1, 1 + (rings - 2) * segments
+    tri += [(last, a + (j + 1) % segments, a + j) for j in range(segments)]
+    return np.array(pts, np.float32).astype(np.float64), np.array(tri, np.uint32)
+
+
 # ---- scan-like surfaces (SURVEY 8d: the RealImpact scans are absent) -------------------------------------------------
 def _skillet_sdf(p, thickness=0.008, noise_seed=7):
     """Signed distance (negative inside) of a skillet-like solid: bottom disc + rim wall + handle bar, metres; a smooth

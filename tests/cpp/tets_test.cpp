@@ -428,7 +428,7 @@ CASE(sliver_repair_keeps_the_mesh_valid_and_removes_most_slivers) {
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
         const auto contract = InputSurfaceIsTheBoundary(c.S, after.Mesh);
         EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
-        EXPECT(after.Mesh.Points.size() == before.Mesh.Points.size() && after.SliverExchanges > 0);
+        EXPECT(after.Mesh.Points.size() >= before.Mesh.Points.size() && after.SliverExchanges > 0); // (a flat cell on two surface triangles gets a point underneath)
         double v_before = 0, v_after = 0;
         size_t flat_before = 0, flat_after = 0;
         for (const auto &t : before.Mesh.Tets) v_before += Vol6(before.Mesh.Points[t[0]], before.Mesh.Points[t[1]], before.Mesh.Points[t[2]], before.Mesh.Points[t[3]]), flat_before += shape(before.Mesh, t) < 0.05;

@@ -40,10 +40,14 @@ REFERENCE_MESH = {"Solved box": "box_12x3x1", "Bar": "box_12x3x1", "Platform": "
 # front end: (relative frequency tolerance over all stored modes, measured worst) -- the interior differs from the reference's
 # (Cube: the 8 x 8 x 8 surface grid has an empty interior; our recovery adds 36 points there, which the repair pass then spreads --
 # the finer interior LOWERS the P2 frequencies by up to 4.8 % against the reference's fill, which lists surface vertices only;
-# without Options::RepairSlivers the same surface gives 0.9 %.  The two balls: flat cap tetrahedra under the UV sphere's quads.)
-FRONT_END_TOL = {"Solved box": 4e-3, "Bar": 4e-3, "Platform": 3e-3, "Slab": 2e-3, "Cube": 6e-2, "Bracket": 1e-2, "Marble": 0.12, "Solved sphere": 0.12}
+# without Options::RepairSlivers the same surface gives 0.9 %.  The two balls: the UV sphere's planar quads leave flat cap tetrahedra
+# (shape 1e-8) in a fill without interior points, on which no iterative eigensolver converges; the front end therefore puts a shell
+# of 266 points under the surface (Options::InteriorShell, WhenFlat) -- 536 points instead of the reference's 266, and frequencies
+# 1-14 % BELOW the golden's (a finer interior is softer).  The reference's interior-free mesh gives the golden; ours is another
+# discretisation of the same ball.)
+FRONT_END_TOL = {"Solved box": 4e-3, "Bar": 4e-3, "Platform": 3e-3, "Slab": 2e-3, "Cube": 6e-2, "Bracket": 1e-2, "Marble": 0.15, "Solved sphere": 0.15}
 # ... and the inertia, which the reference sums from vertex-lumped tet volumes (mesh2modes.cpp:61-110): it sees the interior too
-FRONT_END_INERTIA_TOL = {"Solved box": 1e-3, "Bar": 1e-3, "Platform": 1e-3, "Slab": 1e-3, "Bracket": 2e-2, "Cube": 0.15, "Marble": 0.25, "Solved sphere": 0.25}
+FRONT_END_INERTIA_TOL = {"Solved box": 1e-3, "Bar": 1e-3, "Platform": 1e-3, "Slab": 1e-3, "Bracket": 2e-2, "Cube": 0.15, "Marble": 0.35, "Solved sphere": 0.35}
 
 
 @pytest.fixture(autouse=True)
