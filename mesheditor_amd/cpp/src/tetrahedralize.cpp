@@ -227,7 +227,7 @@ public:
             for (const uint32_t w : verts)
                 if (delaunay && ok && w != t[0] && w != t[1] && w != t[2] && w != t[3] && exact::InSphere(At(t[0]), At(t[1]), At(t[2]), At(t[3]), At(w)) > 0) ok = false;
             // a tetrahedron that a wanted edge passes through, or that reaches through a wanted face, is in no tiling that holds them
-            const auto has = [&](uint32_t v) { return t[0] == v || t[1] == v || t[2] == v || t[3] == v; };
+            const auto has = [&](uint32_t x) { return t[0] == x || t[1] == x || t[2] == x || t[3] == x; };
             for (size_t e = 0; e < kept_edges.size() && ok; ++e) {
                 const uint32_t c = kept_edges[e][0], d = kept_edges[e][1];
                 if (has(c) && has(d)) continue;
@@ -509,11 +509,11 @@ public:
     }
 
     // The cells that the open triangle (a, b, c) cuts through -- every cell with an edge that pierces it -- when its three edges
-    // are edges of the mesh already.  False when a vertex lies in the triangle's interior or the set outgrows `cap`.
+    // are edges of the mesh already.  False when no cell is cut (a vertex in the triangle's plane is the only other way to miss it) or the
+    // set outgrows `cap`.
     bool CellsAcrossTriangle(uint32_t a, uint32_t b, uint32_t c, std::vector<int32_t> &cells, size_t cap) {
         ++Epoch;
         cells.clear();
-        bool bad = false;
         const auto pierced = [&](const Cell &t) { // does an edge of the cell pass through the triangle's interior?
             for (int i = 0; i < 4; ++i)
                 for (int j = i + 1; j < 4; ++j) {
@@ -526,7 +526,6 @@ public:
                 }
             return false;
         };
-        std::vector<int32_t> frontier;
         for (const uint32_t corner : {a, b, c})
             ForStar(corner, [&](int32_t id) {
                 if (Cells[size_t(id)].Stamp != Epoch && pierced(Cells[size_t(id)])) {
@@ -545,7 +544,6 @@ public:
                 cells.push_back(n);
             }
         }
-        (void)bad;
         return !cells.empty();
     }
 
