@@ -237,8 +237,9 @@ def edit_loop(api, ctx, pts, tets, m, ex, cfg, mesh):
         return {"error": repr(e)[:200]}
 
 
-def scan_like_rows(api, ctx, names=("cube_s30k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior", "scan_s30k_repaired", "scan_s100k_repaired"), reps=2):
-    """Secondary rows: the scan-like unstructured meshes (marching-tetrahedra skillet surface through the path's own
+def scan_like_rows(api, ctx, names=("ball_s10k", "uvsphere_s10k", "cube_s30k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior", "scan_s30k_repaired", "scan_s100k_repaired"), reps=2):
+    """Secondary rows: BASELINE config 2 (the Kuhn-mapped ball of rounds 1-3 and the UV-sphere primitive itself through the front end), then
+    the scan-like unstructured meshes (marching-tetrahedra skillet surface through the path's own
     tetrahedraliser: slivers, 2-60 tets per node, no interior points) beside the Kuhn grid of the same size -- iterations,
     milliseconds and eigenpairs per second of the whole mesh2modes path, 65 pairs each.  "_interior": recovery points moved off
     the surface; "_repaired": the front end's default since round 4 (that plus sliver repair and smoothing of the added points)."""

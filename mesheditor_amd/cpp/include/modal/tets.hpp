@@ -47,8 +47,10 @@ struct Options {
     bool RepairSlivers{true}; // connectivity-only sliver repair afterwards (the reference repairs slivers whatever its options: Tetrahedralize.h:20)
     double SliverTarget{0.25}; // tetrahedra with a shape measure below this are worked on (1 = regular, 0 = flat)
     // One interior point under every surface vertex (with RepairSlivers).  WhenFlat: only if the fill is left with flat cells at the
-    // surface -- a smooth surface that is finely tessellated and has no interior points of its own, e.g. a 96 x 48 UV sphere, whose
-    // cells of shape 1e-9 no iterative eigensolver converges on; coarse primitives and thin-walled scans are left as they are.
+    // surface (a 96 x 48 UV sphere: cells of shape 1e-9, on which no iterative eigensolver converges) or is poorly shaped throughout
+    // (10th-percentile shape measure below 0.08: a thick body without interior points of its own -- the shell then HALVES the solve time
+    // at 2.4 x the unknowns and lowers the P2 frequencies towards their limit); thin-walled scans and grid bodies are left as they are.
+    // The reference's default fill adds no such points (its quality arm does): a fill with a shell has more points than the reference's.
     enum class Shell { Never, WhenFlat, Always };
     Shell InteriorShell{Shell::WhenFlat};
 };

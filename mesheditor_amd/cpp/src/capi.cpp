@@ -204,6 +204,7 @@ mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint
         options.MaxSteinerPoints = size_t(max_steiner);
         options.InteriorSteiner = (interior_steiner & 1) != 0; // bit 0: points moved off the surface, bit 1: sliver repair
         options.RepairSlivers = (interior_steiner & 2) != 0;
+        options.InteriorShell = (interior_steiner & 4) ? tetra::Options::Shell::Never : (interior_steiner & 8) ? tetra::Options::Shell::Always : tetra::Options::Shell::WhenFlat; // bits 2, 3
         h->Result = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
     } catch (const std::exception &e) { h->Result.Error = e.what(); }
     return h;

@@ -1739,7 +1739,33 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
             }
             return flat;
         };
-        if (manifold && flat_at_surface(out.Mesh) > 0) {
+        // ... or with long thin cells from the surface to the far interior throughout: a thick body without interior points (a fine UV
+        // sphere, a scanned rock).  Measured on the device (tools/probe/shell_probe.py): UV sphere 80 x 40 40 iterations / 303 ms without
+        // the shell, 23 / 132 ms with it at 2.4 x the unknowns (and a fundamental 0.6 % lower: P2 converges from above); a solid scan 30 /
+        // 168 ms -> 18 / 153 ms; the thin-walled skillet, whose fill is well shaped as it is (10th percentile 0.28), 19 / 120 -> 17 / 175 ms:
+        // the shell is for fills whose 10th-percentile shape measure is below 0.08.
+        const auto poorly_shaped = [&](const TetMesh &m) {
+            const auto &P = m.Points;
+            std::vector<double> shapes;
+            shapes.reserve(m.Tets.size());
+            for (const auto &t : m.Tets) {
+                const dvec3 u = P[t[1]] - P[t[0]], v = P[t[2]] - P[t[0]], w = P[t[3]] - P[t[0]];
+                const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+                double l2 = 0;
+                for (int i = 0; i < 4; ++i)
+                    for (int j = i + 1; j < 4; ++j) {
+                        const dvec3 e = P[t[size_t(i)]] - P[t[size_t(j)]];
+                        l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+                    }
+                const double lrms = std::sqrt(l2 / 6);
+                shapes.push_back(lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0);
+            }
+            if (shapes.size() < 64) return false; // (a coarse primitive: a handful of cells say nothing about a percentile)
+            const size_t tenth = shapes.size() / 10;
+            std::nth_element(shapes.begin(), shapes.begin() + long(tenth), shapes.end());
+            return shapes[tenth] < 0.08;
+        };
+        if (manifold && (flat_at_surface(out.Mesh) > 0 || (options.InteriorShell == Options::Shell::WhenFlat && poorly_shaped(out.Mesh)))) {
             const TetMesh before = out.Mesh;
             const uint32_t exchanges_before = out.SliverExchanges;
             if (BreakCaps(out.Mesh, 1e-3)) {
@@ -1748,7 +1774,7 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
                 out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
             }
             const bool shell = options.InteriorShell == Options::Shell::Always ||
-                               (options.InteriorShell == Options::Shell::WhenFlat && flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size()); // > 0.5 % of the cells
+                               (options.InteriorShell == Options::Shell::WhenFlat && (flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size() || poorly_shaped(out.Mesh))); // > 0.5 % of the cells
             if (shell) {
                 out.Mesh = before;
                 out.SliverExchanges = exchanges_before;

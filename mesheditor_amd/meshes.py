@@ -74,6 +74,15 @@ def workload(name):
     if name == "ball_s10k":  # BASELINE.json configs[1]
         p, t = ball(12, 0.15)
         return p, t, MATERIALS["Ceramic"], {"num_modes": 50, "num_fem_modes": 65}
+    if name == "uvsphere_s10k":  # BASELINE.json configs[1] as written: the UV-sphere PRIMITIVE (48 x 24: pole fans, planar quads) through the front
+        key = ("uvsphere", 48, 24)  # end's default -- 1 106 surface vertices, a shell of interior points under them: 2 228 points, 9 457 tets
+        if key not in _SCAN_CACHE:
+            from . import tets as tet_front_end
+            v, f = uv_sphere_surface(0.15, 48, 24)
+            p, t, _ = tet_front_end.tetrahedralize(v, f)
+            _SCAN_CACHE[key] = (p, t)
+        p, t = _SCAN_CACHE[key]
+        return p.copy(), t.copy(), MATERIALS["Ceramic"], {"num_modes": 50, "num_fem_modes": 65}
     if name == "cube_s10k":
         p, t = kuhn_box(12, 12, 12, 0.3, 0.3, 0.3)
         return p, t, MATERIALS["Ceramic"], {"num_modes": 50, "num_fem_modes": 65}

@@ -20,17 +20,20 @@ def _lib():
     return L
 
 
-def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repair_slivers=True):
+def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repair_slivers=True, interior_shell="when_flat"):
     """(points float64 [V', 3], tets uint32 [T, 4], boundary_steiner_count): input vertex i keeps index i, added points follow.
     interior_steiner (tetra::Options::InteriorSteiner): the recovery's points are moved off the surface afterwards, so that every
     input triangle is a boundary face (the count returned is what had to stay on it; 0 = the reference's contract holds).
     repair_slivers (tetra::Options::RepairSlivers): connectivity-only sliver repair afterwards (edge removal, 2-3 flips), as the
     reference's tetrahedraliser always does.
+    interior_shell (tetra::Options::InteriorShell): "when_flat" (default: a point under every surface vertex only if the fill is left
+    with flat cells at the surface), "never", "always".
     Raises RuntimeError with the tetrahedraliser's message for open / self-intersecting / unrecoverable surfaces."""
     L = _lib()
     pts = np.ascontiguousarray(points, dtype=np.float64)
     tri = np.ascontiguousarray(triangles, dtype=np.uint32)
-    h = L.mhx_tetrahedralize(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner), int(bool(interior_steiner)) | (2 if repair_slivers else 0))
+    h = L.mhx_tetrahedralize(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner),
+                             int(bool(interior_steiner)) | (2 if repair_slivers else 0) | {"when_flat": 0, "never": 4, "always": 8}[interior_shell])
     try:
         err = L.mhx_tets_error(h).decode()
         if err:

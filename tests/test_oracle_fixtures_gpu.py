@@ -21,7 +21,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKLOADS = ["ball_s10k", "cube_s30k", "cube_s100k", "skillet_s100k", "scan_s30k", "scan_s100k", "scan_s30k_interior", "scan_s100k_interior",
              # round 4: BASELINE config 3 as written (scan mesh x 200 modes = 215 pairs) at both sizes; the scan surfaces through the
              # front end's default options (points moved inside, sliver repair, smoothing), 65 and 215 pairs
-             "config3_s30k", "config3_s100k", "scan_s30k_repaired", "scan_s100k_repaired", "config3_s30k_repaired", "config3_s100k_repaired"]
+             "config3_s30k", "config3_s100k", "scan_s30k_repaired", "scan_s100k_repaired", "config3_s30k_repaired", "config3_s100k_repaired",
+             # BASELINE config 2 as written: the UV-sphere primitive (48 x 24 surface, 9 457 tets after the front end) -- ball_s10k is its Kuhn-mapped stand-in
+             "uvsphere_s10k"]
 
 
 def load_fixture(name):
