@@ -787,3 +787,31 @@ def test_residual_report_says_what_the_tolerance_meant():
                 assert worst == -1.0 and dropped == (0, 0)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_a_small_system_that_stalls_is_redone_as_one_dense_eigensolve(oracle):
+    """The sample UV sphere (24 x 12) filled WITHOUT the front end's repair passes: a quarter of its 842 tetrahedra are flat to 1e-8 (planar
+    surface quads joined into one cell), ||A|| / theta ~ 1e13, and the iteration does not converge.  With at most 12 288 unknowns the
+    solve is redone as one dense eigensolve in the inverse form (M x = nu A x: relative accuracy on the low pairs, like the reference's
+    shift-invert) instead of coming back empty; the caller's own iteration limit is still honoured (ENOTCONVERGED)."""
+    from mesheditor_amd import api, tets as front_end
+    P, F = meshes.uv_sphere_surface(0.045, 24, 12)
+    pts, tets, _ = front_end.tetrahedralize(P, F, repair_slivers=False)
+    m = meshes.MATERIALS["Glass"]
+    ctx = api.Context(0)
+    try:
+        system = api.System(ctx, api.Mesh(ctx, pts, tets), api.material(*m))
+        with pytest.raises(api.ModalHipError) as e:
+            system.eigs(45, SIGMA, 1e-5, max_iters=20)
+        assert e.value.code == 4
+        ev, prof = system.eigs(45, SIGMA, 1e-5, max_iters=300)
+        assert prof["restarts"] == 301  # every iteration was spent; the dense solve follows
+        ref, _, _ = oracle.System(pts, tets, oracle.material(*m)).eigs(45)
+        elastic = ref > 1e-6 * ref[-1]
+        assert elastic.sum() == 39
+        # both sides work on a pencil conditioned 1e13: they agree to 2e-6 (measured), not to the 1e-6 of a healthy mesh
+        assert np.abs(ev[elastic] / ref[elastic] - 1).max() < 1e-5
+        system.close()
+    finally:
+        ctx.close()
