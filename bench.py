@@ -286,7 +286,7 @@ def batch64_pass(api, device, threads=3):
         solve(0, items[0])
         [c.synchronize() for c in ctxs]
         t0 = time.perf_counter()
-        recs = sharding.solve_batch(items, solve, NEV_MAX, None, "cpu", threads=threads, pos_max=POS_MAX)
+        recs = sharding.solve_batch(items, solve, 64, None, "cpu", threads=threads, pos_max=POS_MAX)  # (45 pairs per mesh: records of 64, not of NEV_MAX)
         [c.synchronize() for c in ctxs]
         dt = time.perf_counter() - t0
         [c.close() for c in ctxs]
