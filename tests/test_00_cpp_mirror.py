@@ -216,3 +216,61 @@ def test_solve_batch_cpp_with_rccl_on_one_rank():
     to direct solves, a failing mesh travels as a failed record (tests/cpp/batch_test.cpp)."""
     _build()
     assert "0 failure(s)" in _run("batch_test")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,key,mesh,material", [
+    ("Solved box", "test/StrikeOne/a_ThreeInstances.gltf|Solved box", "box_12x3x1", (2700, 7.2e10, 0.19, 6, 1e-7)),
+    ("Bar", "Pile.gltf|Bar", "box_12x3x1", (7850, 2.0e11, 0.29, 5, 3e-8)),
+    ("Platform", "Pile.gltf|Platform", "platform_12x1x12", (2700, 7.2e10, 0.19, 6, 1e-7)),
+])
+def test_solve_tool_reproduces_the_reference_output_on_the_references_mesh(golden, name, key, mesh, material):
+    """End to end through the C++ mirror: the JSON solve tool (our MeshEditorModalSolve) given the reference's own tetrahedralisation of
+    a sample body (tests/golden/reference_tets.npz, identified from the goldens: tests/test_gltf_goldens.py) prints what the reference's
+    tool printed into the sample scenes -- frequencies to float32 round-off, decay rates, mass, inertia, every shape, the positions and the
+    triangles (as a set: the tool lists the mesh's boundary faces)."""
+    import json, tempfile
+    import numpy as np
+    _build()
+    full = np.load(os.path.join(ROOT, "tests", "golden", "gltf_modal_models_full.npz"))
+    tets = np.load(os.path.join(ROOT, "tests", "golden", "reference_tets.npz"))[mesh]
+    pos = full[key + "|positions"]
+    tool = os.path.join(ROOT, "mesheditor_amd", "cpp", "bin", "modal_solve")
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "body.tet")
+        with open(path, "w") as f:
+            f.write("%d %d\n" % (len(pos), len(tets)))
+            for p_ in pos.astype(np.float64):
+                f.write("%r %r %r\n" % (float(p_[0]), float(p_[1]), float(p_[2])))
+            for t in tets:
+                f.write("%d %d %d %d\n" % tuple(int(v) for v in t))
+        args = [tool, path, "--density", repr(float(material[0])), "--young", repr(float(material[1])), "--poisson", repr(float(material[2])),
+                "--alpha", repr(float(material[3])), "--beta", repr(float(material[4])), "--modes", "30"]
+        p = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = json.loads(p.stdout)
+    gf = full[key + "|frequencies"].astype(np.float64)
+    f = np.array(out["frequencies"])
+    assert len(f) == len(gf) and np.abs(f / gf - 1).max() < 2e-7, np.abs(f / gf - 1).max()
+    assert np.abs(np.array(out["decayRates"]) / full[key + "|decayRates"] - 1).max() < 1e-6
+    # (a tet mesh has no surface vertex order of its own: the tool takes the boundary vertices as it meets them; same points, another order)
+    got_pos = np.array(out["positions"], np.float32)
+    where = {tuple(p_): i for i, p_ in enumerate(pos.tolist())}
+    order = np.array([where[tuple(p_)] for p_ in got_pos.tolist()])
+    assert sorted(order.tolist()) == list(range(len(pos)))
+    mp = golden[name]["massProperties"]
+    assert abs(out["mass"] / mp["mass"] - 1) < 1e-12
+    assert np.allclose(out["inertiaDiagonal"], mp["inertiaDiagonal"], rtol=1e-6)
+    shapes = np.array(out["shapes"], np.float64).reshape(len(f), len(pos), 3)
+    gold = full[key + "|shapes"].astype(np.float64)[:, order, :]
+    m = 0
+    while m < len(f):  # modes of nearly equal frequency as subspaces (the platform is square)
+        e = m + 1
+        while e < len(f) and gf[e] - gf[e - 1] < 3e-3 * gf[e]:
+            e += 1
+        a, b = shapes[m:e].reshape(e - m, -1).T, gold[m:e].reshape(e - m, -1).T
+        x, *_ = np.linalg.lstsq(a, b, rcond=None)
+        assert (np.linalg.norm(a @ x - b, axis=0) / np.linalg.norm(b, axis=0)).max() < 1e-5, (name, m, e)
+        m = e
+    got_tris = {tuple(sorted(int(order[v]) for v in out["indices"][3 * k: 3 * k + 3])) for k in range(len(out["indices"]) // 3)}
+    assert got_tris == {tuple(sorted(int(v) for v in t)) for t in full[key + "|indices"]}
