@@ -147,8 +147,14 @@ int mhl_context_bench_dense(mh_context *ctx, int kind, uint64_t n, uint32_t wa, 
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, double *reflectors, double *tau, uint32_t reps, double *avg_ms);
 int mhl_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms) {
-    if (!ctx || !a || !d || !e || m < 2 || m > 256 || variant < 0 || variant > 1) return MH_EINVAL;
+    return mhl_context_tridiagonalize_full(ctx, variant, m, a, d, e, nullptr, nullptr, reps, avg_ms);
+}
+
+// variant 2: the wide kernel (orders up to 768).  reflectors (m x m, LAPACK's lower storage) and tau (m) are returned when asked for.
+int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, double *reflectors, double *tau, uint32_t reps, double *avg_ms) {
+    if (!ctx || !a || !d || !e || m < 2 || variant < 0 || variant > 2 || m > (variant == 2 ? 768u : 256u)) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
         MhSharedPhase not_during_a_factorisation; // (no process-wide lock: calls on different contexts are meant to overlap)
@@ -161,7 +167,8 @@ int mhl_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const d
         for (uint32_t r = 0; r < std::max(1u, reps); ++r) {
             HIP_CHECK(hipMemcpyAsync(work, da, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             HIP_CHECK(hipEventRecord(e0, ctx->stream));
-            mh_sytrd_small(ctx, work, m, dd, de, dtau, variant);
+            if (variant == 2) mh_sytrd_wide(ctx, work, m, dd, de, dtau);
+            else mh_sytrd_small(ctx, work, m, dd, de, dtau, variant);
             HIP_CHECK(hipEventRecord(e1, ctx->stream));
             HIP_CHECK(hipEventSynchronize(e1));
             float ms = 0;
@@ -172,6 +179,8 @@ int mhl_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const d
         (void)hipEventDestroy(e1);
         dd.download(d, m);
         de.download(e, m - 1);
+        if (reflectors) work.download(reflectors, size_t(m) * m);
+        if (tau) dtau.download(tau, m);
         if (mh_sytrd_gave_up(ctx)) mh_throw(MH_EHIP, "tridiagonalisation: a workgroup timed out waiting for the others' values");
         if (avg_ms) *avg_ms = total / std::max(1u, reps);
         return MH_OK;

@@ -16,6 +16,8 @@ int mhl_context_bench_dense(mh_context *, int kind, uint64_t n, uint32_t wa, uin
 /* The Rayleigh-Ritz step's Householder tridiagonalisation called directly: a (m x m, symmetric, both triangles, m <= 256) ->
  * d[m], e[m - 1]; variant 0 = one workgroup, 1 = several workgroups exchanging tagged values. */
 int mhl_context_tridiagonalize(mh_context *, int variant, uint32_t m, const double *a, double *d, double *e, uint32_t reps, double *avg_ms);
+/* the same with the reflectors (m x m, LAPACK's lower storage) and tau returned; variant 2 = the wide kernel, orders up to 768 */
+int mhl_context_tridiagonalize_full(mh_context *, int variant, uint32_t m, const double *a, double *d, double *e, double *reflectors, double *tau, uint32_t reps, double *avg_ms);
 /* The rigid-body level's graph aggregation (host code): CSR node graph in (diagonal entries included), aggregate per node out. */
 uint32_t mhl_graph_aggregates(const uint32_t *row_ptr, const uint32_t *col, uint32_t n, uint32_t target, uint32_t max_order, uint32_t *agg_of);
 #ifdef __cplusplus

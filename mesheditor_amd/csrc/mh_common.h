@@ -135,6 +135,8 @@ struct mh_context {
     unsigned long long *sytrd_xch{nullptr}; // exchange slots of the multi-workgroup tridiagonalisation (+ its give-up flag), created on first use
     uint32_t sytrd_epoch{0};                // launch counter folded into the slots' tags
     int *sytrd_flag{nullptr};               // set by a workgroup that gave up waiting (mh_sytrd_gave_up)
+    unsigned long long *sytrd_xch_wide{nullptr}; // the same for orders 257 .. 768 (mh_sytrd_wide)
+    uint32_t sytrd_epoch_wide{0};
     // Optional per-launch timing of the path's named kernels (measurement aid for bench.py's roofline objects): HIP
     // events on this stream around every launch of a kernel class, resolved lazily.  `work` is the class's algorithmic
     // unit: bytes for the HBM-bound classes, flops for the resonator bank.
@@ -365,6 +367,7 @@ bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info); // mh_dense.hip
 void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info); // mh_dense.hip: lower Cholesky, order <= 128, one workgroup
 bool mh_sytrd_gave_up(mh_context *ctx);
+void mh_sytrd_wide(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau); // orders up to 768, 48 workgroups over all XCDs (mh_dense.hip)
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant = -1); // variant: -1 = the process default, 0 = one workgroup, 1 = several; mh_dense.hip: A (column-major, ld m, symmetric, full) -> D, E, tau, reflectors
 void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices);
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);

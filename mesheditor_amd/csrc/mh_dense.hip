@@ -968,6 +968,152 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
 }
 } // namespace
 
+// ---- the same for orders up to 768 (the Rayleigh-Ritz problem of a 215-pair solve: 3 x 240 columns) ---------------------------
+// k_sytrd_multi keeps one matrix row per thread (256 threads) and sixteen columns per workgroup in LDS: order <= 256.  Here a workgroup
+// has 1 024 threads -- still one row per thread, and one WAVE per local column in the sweep -- and still holds sixteen columns (column c with workgroup c mod G, G = 48: 100 KB of
+// LDS for the columns, 43 KB for the step's vectors), and the workgroups sit on all eight XCDs -- 48 of them with 143 KB of LDS each
+// do not fit the 32 CUs of one.  The exchange is the same: self-tagged granules, one round per column, bounded polls, the leaver's
+// acknowledgement; the tag takes ten bits for the step.  rocSOLVER's sytrd, which this replaces above order 256, issues ~110 launches
+// per column block (latrd: four kernels per column): 8.3 ms at order 720.
+namespace {
+constexpr int WIDE_MAXM = 768, WIDE_LD = 784, WIDE_COLS = 16, WIDE_G = 48;
+constexpr size_t WIDE_XCH_WORDS = 2 * 2 * size_t(WIDE_MAXM) * 2;
+__global__ void __launch_bounds__(1024) k_sytrd_wide(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU,
+                                                    unsigned long long *__restrict__ xch, unsigned epoch, int *__restrict__ gave_up) {
+    constexpr int G = WIDE_G;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *a = lds;                           // WIDE_COLS x WIDE_LD
+    double *v = a + WIDE_COLS * WIDE_LD;       // reflector of the step, by global row
+    double *vp = v + WIDE_MAXM, *wp = vp + WIDE_MAXM; // the pending pair, by global row
+    double *xs = wp + WIDE_MAXM;               // the up-to-date column of the step from its diagonal entry down (l + 1 entries)
+    double *sq = xs + WIDE_MAXM + 8, *pq = sq + WIDE_MAXM + 8, *prs = pq + WIDE_MAXM;
+    __shared__ int s_fail;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; // one thread per matrix row, one wave per local column
+    auto slot = [&](int parity, int kind, int index) { return xch + ((size_t(parity) * 2 + kind) * WIDE_MAXM + index) * 2; };
+    auto ack_slot = [&](int parity) { return xch + WIDE_XCH_WORDS + size_t(parity) * 2; };
+    auto wave_sum = [&](const double *buf, int count) { // every wave for itself, fixed order
+        double s_ = 0.0;
+        for (int i = lane; i < count; i += 64) s_ += buf[i];
+        for (int off = 32; off > 0; off >>= 1) s_ += __shfl_xor(s_, off, 64);
+        return s_;
+    };
+    const int cl = g + wave * G; // this wave's column in the sweep
+    if (g >= m) return;          // (fewer columns than workgroups: this one owns none)
+    const int last_col = g + G * ((m - 1 - g) / G);
+    for (int j = 0; j < WIDE_COLS; ++j) {
+        const int c = g + j * G;
+        if (c < m && tid < m) a[j * WIDE_LD + tid] = A[size_t(c) * m + tid];
+    }
+    if (tid < m) {
+        const double x = A[tid]; // column 0
+        xs[tid] = x;
+        sq[tid] = tid >= 2 ? x * x : 0.0;
+    }
+    if (tid < WIDE_MAXM) v[tid] = 0.0, vp[tid] = 0.0, wp[tid] = 0.0;
+    if (tid == 0) s_fail = 0;
+    const int workgroups = m < G ? m : G; // the ones that own a column
+    for (int k = 0; k + 1 < m; ++k) {
+        const int l = m - k - 1;
+        const unsigned tag = (epoch << 10) | unsigned(k + 1);
+        const int parity = k & 1;
+        const bool mine = g == k % G;
+        __syncthreads(); // (1) xs, sq and the pending pair are in place
+        const double xnorm2 = wave_sum(sq, l + 1);
+        const double alpha = xs[1];
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (xnorm2 > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (mine && tid == 0) {
+            D[k] = xs[0];
+            E[k] = beta;
+            TAU[k] = tau;
+        }
+        double vi = 0.0;
+        if (tid < l) {
+            vi = tau == 0.0 ? 0.0 : (tid == 0 ? 1.0 : xs[tid + 1] * scale);
+            v[k + 1 + tid] = vi;
+            if (mine && k > 0) A[size_t(k) * m + k + 1 + tid] = tid == 0 ? beta : vi; // (step 0's store waits for the collection: see k_sytrd_multi)
+        }
+        const bool someone_leaves = k >= m - workgroups;
+        if (last_col <= k) {
+            if (last_col == k && tid == 0) publish_tagged(ack_slot(parity), 1.0, tag);
+            return;
+        }
+        __syncthreads(); // (2) reflector published inside the workgroup
+        if (cl > k && cl < m) {
+            const double vpc = vp[cl], wpc = wp[cl];
+            double *col = a + wave * WIDE_LD;
+            double acc = 0.0;
+            for (int r = k + 1 + lane; r < m; r += 64) {
+                const double aa = col[r] - (vp[r] * wpc + wp[r] * vpc);
+                col[r] = aa;
+                acc += aa * v[r];
+                if (cl == k + 1) publish_tagged(slot(parity, 1, r), aa, tag);
+            }
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) publish_tagged(slot(parity, 0, cl), acc, tag);
+        }
+        double pr = 0.0, xn = 0.0;
+        bool ok = true;
+        if (tid < l) {
+            ok = collect_tagged2(slot(parity, 0, k + 1 + tid), slot(parity, 1, k + 1 + tid), tag, pr, xn);
+            pr *= tau;
+            prs[tid] = pr;
+            pq[tid] = pr * vi;
+        } else if (someone_leaves && tid == 1023) { // (l <= 767: this thread never collects a value) the leaver's acknowledgement
+            double a0, a1;
+            ok = collect_tagged2(ack_slot(parity), ack_slot(parity), tag, a0, a1);
+        }
+        if (!ok) s_fail = 1;
+        __syncthreads(); // (3) p and its products with v published inside the workgroup
+        if (s_fail) {
+            if (tid == 0) *gave_up = 1;
+            return;
+        }
+        const double pv = wave_sum(pq, l);
+        if (tid < l) {
+            const double wi = pr - 0.5 * tau * pv * vi;
+            const double v0 = v[k + 1], w0 = prs[0] - 0.5 * tau * pv * v0;
+            const double xc = xn - (vi * w0 + wi * v0); // column k + 1 brought up to date with this step's pair
+            if (mine && k == 0) A[size_t(k) * m + k + 1 + tid] = tid == 0 ? beta : vi;
+            vp[k + 1 + tid] = vi;
+            wp[k + 1 + tid] = wi;
+            xs[tid] = xc;
+            sq[tid] = tid >= 2 ? xc * xc : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // (the owner of column m - 1 is the one workgroup that gets here)
+        D[m - 1] = xs[0];
+        TAU[m - 1] = 0.0;
+    }
+}
+} // namespace
+
+// Orders 257 .. 768.  The exchange area is the context's (grown on first use); a give-up is reported through mh_sytrd_gave_up.
+void mh_sytrd_wide(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau) {
+    if (m < 2 || m > uint32_t(WIDE_MAXM)) mh_throw(MH_EINVAL, "sytrd_wide: order %u outside 2..%d", m, WIDE_MAXM);
+    constexpr size_t words = WIDE_XCH_WORDS + SYTRD_ACK_WORDS;
+    if (!ctx->sytrd_xch_wide) {
+        ctx->sytrd_xch_wide = static_cast<unsigned long long *>(ctx->pool.alloc(words * sizeof(unsigned long long) + 64));
+        HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch_wide, 0, words * sizeof(unsigned long long) + 64, ctx->stream));
+    }
+    if ((++ctx->sytrd_epoch_wide & 0x3fffffu) == 0) { // the tag's epoch field wraps: clear the slots so that no old tag can match
+        ctx->sytrd_epoch_wide = 1;
+        HIP_CHECK(hipMemsetAsync(ctx->sytrd_xch_wide, 0, words * sizeof(unsigned long long) + 64, ctx->stream));
+    }
+    ctx->sytrd_flag = reinterpret_cast<int *>(ctx->sytrd_xch_wide + words);
+    HIP_CHECK(hipMemsetAsync(ctx->sytrd_flag, 0, sizeof(int), ctx->stream));
+    constexpr size_t lds = (size_t(WIDE_COLS) * WIDE_LD + 3 * size_t(WIDE_MAXM) + 2 * (size_t(WIDE_MAXM) + 8) + 2 * size_t(WIDE_MAXM)) * sizeof(double);
+    static PerDeviceOnce attr;
+    attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sytrd_wide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); }); // (the kernel has four static bytes too: not the full 160 KB)
+    k_sytrd_wide<<<WIDE_G, 1024, lds, ctx->stream>>>(a, int(m), d, e, tau, ctx->sytrd_xch_wide, ctx->sytrd_epoch_wide, ctx->sytrd_flag);
+    KERNEL_CHECK();
+}
+
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant) {
     if (m < 1 || m > 256) mh_throw(MH_EINVAL, "sytrd_small: order %u outside 1..256", m);
     constexpr bool fused = true;

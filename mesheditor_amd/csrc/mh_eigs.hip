@@ -50,7 +50,8 @@ std::mutex g_solve_mutex;
 //   MH_PRECOND_FP64=1       double-precision smoothers (default: single precision with double residuals between levels)
 //   MH_CYCLE=d2,d1,g,ratio  shape of the preconditioner cycle: Chebyshev degrees of the P2 and P1 smoothers, P1 cycles per
 //                           application, spectrum ratio lmax / lmin the smoothers target; 0 or missing keeps a built-in value
-//   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out)
+//   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out),
+//                           no_sytrd_wide (orders above 256 go to the library's syevd whole: the A/B of k_sytrd_wide)
 // and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
 // threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
 struct Switches {
@@ -59,6 +60,7 @@ struct Switches {
     int deg2 = 0, deg1 = 0, gamma = 0; // 0: the built-in cycle shape
     double cheb_ratio = 0.0;
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
+    bool no_sytrd_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_sytrd_wide");
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
             double v[4] = {0, 0, 0, 0};
@@ -700,9 +702,35 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         HIP_CHECK(hipMemcpyAsync(gA, zres, size_t(m) * ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         // no synchronisation: the workspaces return to the context's pool, whose blocks are only ever used on this same stream
     } else {
-        ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
-        info.download(&hinfo, 1);
-        if (hinfo != 0) return hinfo;
+        // Orders 257 .. 768 (the 200-mode configuration iterates at 3 x 240): the tridiagonalisation is 55 % of rocSOLVER's syevd
+        // there (8.3 of 15 ms at order 720); k_sytrd_wide does it in 4.4 ms across 48 workgroups, then the library's divide and
+        // conquer on T and its back-transformation.  A give-up (see above) falls back to the library's syevd on the saved matrix.
+        bool done = false;
+        if (m > 256 && m <= 768 && !switches().no_sytrd_wide) {
+            DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
+            HIP_CHECK(hipMemcpyAsync(z.get(), gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            mh_sytrd_wide(ctx, gA, m, evals, ework, tau);
+            int gave_up = 0;
+            HIP_CHECK(hipMemcpyAsync(&gave_up, ctx->sytrd_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (switches().test_sytrd_giveup) gave_up = 1;
+            if (gave_up) {
+                HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            } else {
+                ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
+                info.download(&hinfo, 1);
+                if (hinfo != 0) return hinfo;
+                ROCBLAS_CHECK(rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, m, m, gA, m, tau, z, m));
+                HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the library's internal workspace use is not ours to reason about: z goes back to the pool after it is done
+                done = true;
+            }
+        }
+        if (!done) {
+            ROCBLAS_CHECK(rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, m, gA, m, evals, ework, info));
+            info.download(&hinfo, 1);
+            if (hinfo != 0) return hinfo;
+        }
     }
     if (series) { // c = S z
         ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, stmp, m));

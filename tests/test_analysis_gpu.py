@@ -632,6 +632,116 @@ def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
     assert not bad, bad
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [257, 300, 511, 720, 767, 768])
+def test_wide_tridiagonalisation_returns_t_and_its_reflectors(ctx, m):
+    """k_sytrd_wide (Rayleigh-Ritz orders 257 .. 768: the 200-mode configuration): T has A's spectrum, the reflectors left in
+    the lower triangle with tau rebuild a Q with Q^T A Q = T (what the library's back-transformation consumes), and the output
+    is reproducible run to run."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    rng = np.random.default_rng(2000 + m)
+    q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    lam = np.sort(rng.uniform(1.0, 1e4, m))
+    lam[:3] = lam[3]
+    a = (q * lam) @ q.T
+    a = 0.5 * (a + a.T)
+    d, e, refl, tau, _ = lab.tridiagonalize_full(ctx, a, variant=2)
+    assert np.max(np.abs(eigvalsh_tridiagonal(d, e) - np.linalg.eigvalsh(a))) <= 1e-12 * lam[-1] * m
+    qq = np.eye(m)
+    for k in range(m - 2, -1, -1):
+        v = np.zeros(m)
+        v[k + 1] = 1.0
+        v[k + 2:] = refl[k + 2:, k]
+        qq -= tau[k] * np.outer(v, v @ qq)
+    t = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    assert np.abs(qq.T @ a @ qq - t).max() <= 1e-13 * lam[-1] * m
+    d2, e2, refl2, tau2, _ = lab.tridiagonalize_full(ctx, a, variant=2)
+    assert np.array_equal(d, d2) and np.array_equal(e, e2) and np.array_equal(tau, tau2) and np.array_equal(refl, refl2)
+
+
+@pytest.mark.gpu
+def test_wide_tridiagonalisation_under_uneven_load(api):
+    """As the test above for k_sytrd_multi: three contexts reduce matrices of orders 300 .. 720 with k_sytrd_wide at the same
+    time (48 workgroups each, a whole CU's LDS per workgroup) while a fourth thread keeps the device busy; every result equals
+    the one the same context produced alone, bit for bit."""
+    import threading
+    rng = np.random.default_rng(78)
+    orders = [300, 480, 720]
+    mats = []
+    for m in orders:
+        a = rng.standard_normal((m, m))
+        mats.append(a + a.T + 2 * m * np.eye(m))
+    ctxs = [api.Context(0) for _ in orders]
+    alone = [lab.tridiagonalize_full(c, a, variant=2)[:2] for c, a in zip(ctxs, mats)]
+    busy_ctx = api.Context(0)
+    p, t, mat, _ = meshes.workload("cube_s10k")
+    system = api.System(busy_ctx, api.Mesh(busy_ctx, p, t), api.material(*mat))
+    stop = threading.Event()
+    bad, errs = [], []
+
+    def load():
+        try:
+            while not stop.is_set():
+                lab.bench_spmm(system, 32, 5)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    def work(i):
+        try:
+            for rep in range(40):
+                d, e = lab.tridiagonalize_full(ctxs[i], mats[i], variant=2)[:2]
+                if not (np.array_equal(d, alone[i][0]) and np.array_equal(e, alone[i][1])):
+                    bad.append((orders[i], rep))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(orders))] + [threading.Thread(target=load)]
+    [x.start() for x in th]
+    [x.join() for x in th[:-1]]
+    stop.set()
+    th[-1].join()
+    system.close()
+    [c.close() for c in ctxs + [busy_ctx]]
+    assert not errs, errs
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_a_timed_out_tridiagonalisation_falls_back_without_changing_the_answer():
+    """MH_TEST=sytrd_giveup treats every multi-workgroup reduction (k_sytrd_multi, k_sytrd_wide) as timed out: the Rayleigh-Ritz
+    step then redoes it with the one-workgroup kernel / the library's syevd on the saved matrix.  A 215-pair solve (order 720) and a
+    65-pair solve (order 240) in that mode agree with the normal run to the solver's tolerance."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import json, numpy as np\n"
+        "from mesheditor_amd import api, meshes\n"
+        "ctx = api.Context(0)\n"
+        "out = {}\n"
+        "for name, k in (('cube_s10k', 65), ('cube_s10k', 215)):\n"
+        "    pts, tets, m, kw = meshes.workload(name)\n"
+        "    mesh = api.Mesh(ctx, pts, tets)\n"
+        "    s = api.System(ctx, mesh, api.material(*m))\n"
+        "    ev, prof = s.eigs(k, -(2 * np.pi * 20.0) ** 2, 1e-6)\n"
+        "    out[str(k)] = [float(v) for v in ev]\n"
+        "    s.close(); mesh.close()\n"
+        "print(json.dumps(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for hook in ("", "sytrd_giveup"):
+        env = dict(os.environ, MH_TEST=hook, PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for k in ("65", "215"):
+        a, b = np.array(runs[0][k]), np.array(runs[1][k])
+        assert len(a) == len(b) == int(k)
+        el = a > 1e-6 * a[-1]
+        assert np.max(np.abs(a[el] - b[el]) / a[el]) < 1e-6
+
+
 def _rough_torus_tets(tmp_path, nu=40, nv=16, noise=0.16):
     """An UNSTRUCTURED tet mesh: a rough torus surface (irregular triangles, genus 1) filled by the general tetrahedraliser through
     the solve tool's --write-tets --tets-only (host code, no device)."""

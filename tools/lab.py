@@ -25,6 +25,7 @@ def lib():
         L.mhl_system_elementwise_matvec.restype, L.mhl_system_elementwise_matvec.argtypes = i32, [vp, vp, vp, u32]
         L.mhl_context_bench_dense.restype, L.mhl_context_bench_dense.argtypes = i32, [vp, i32, C.c_uint64, u32, u32, u32, f64p]
         L.mhl_context_tridiagonalize.restype, L.mhl_context_tridiagonalize.argtypes = i32, [vp, i32, u32, vp, vp, vp, u32, f64p]
+        L.mhl_context_tridiagonalize_full.restype, L.mhl_context_tridiagonalize_full.argtypes = i32, [vp, i32, u32, vp, vp, vp, vp, vp, u32, f64p]
         L.mhl_graph_aggregates.restype, L.mhl_graph_aggregates.argtypes = u32, [vp, vp, u32, u32, u32, vp]
         _LIB = L
     return _LIB
@@ -70,6 +71,15 @@ def tridiagonalize(ctx, a, variant=0, reps=1):
     d, e, ms = np.zeros(m), np.zeros(m - 1), C.c_double(0)
     ctx.check(lib().mhl_context_tridiagonalize(ctx.h, variant, m, _p(a), _p(d), _p(e), reps, C.byref(ms)))
     return d, e, ms.value
+
+
+def tridiagonalize_full(ctx, a, variant=2, reps=1):
+    """(d, e, reflectors [column-major m x m, LAPACK's lower storage], tau, average ms); variant 2 = the wide kernel (order <= 768)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    m = a.shape[0]
+    d, e, refl, tau, ms = np.zeros(m), np.zeros(m - 1), np.zeros((m, m)), np.zeros(m), C.c_double(0)
+    ctx.check(lib().mhl_context_tridiagonalize_full(ctx.h, variant, m, _p(a), _p(d), _p(e), _p(refl), _p(tau), reps, C.byref(ms)))
+    return d, e, refl.T.copy(), tau, ms.value  # (the device's column-major image read as rows: transposed back)
 
 
 def graph_aggregates(row_ptr, col, target=16, max_order=6144):
