@@ -187,4 +187,38 @@ int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, co
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+// C = alpha op(A) op(B) + beta C with the Rayleigh-Ritz step's small-product kernel (column-major host arrays; c in and out).
+int mhl_context_small_gemm(mh_context *ctx, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, double alpha, const double *a, uint32_t lda, const double *b, uint32_t ldb, double beta,
+                           double *c, uint32_t ldc, uint32_t reps, double *avg_ms) {
+    if (!ctx || !a || !b || !c || !M || !N || !K || lda < (ta ? K : M) || ldb < (tb ? N : K) || ldc < M) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        MhSharedPhase not_during_a_factorisation;
+        const size_t na = size_t(lda) * (ta ? M : K), nb = size_t(ldb) * (tb ? K : N), nc = size_t(ldc) * N;
+        DevArray<double> da(ctx, na), db(ctx, nb), dc(ctx, nc), work(ctx, nc);
+        da.upload(a, na);
+        db.upload(b, nb);
+        dc.upload(c, nc);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float total = 0;
+        for (uint32_t r = 0; r < std::max(1u, reps); ++r) {
+            HIP_CHECK(hipMemcpyAsync(work, dc, nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_CHECK(hipEventRecord(e0, ctx->stream));
+            mh_small_gemm(ctx, ta != 0, tb != 0, M, N, K, alpha, da, lda, db, ldb, beta, work, ldc);
+            HIP_CHECK(hipEventRecord(e1, ctx->stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        work.download(c, nc);
+        if (avg_ms) *avg_ms = total / std::max(1u, reps);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 }

@@ -369,6 +369,9 @@ void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info); // mh_de
 bool mh_sytrd_gave_up(mh_context *ctx);
 void mh_sytrd_wide(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau); // orders up to 768, 48 workgroups over all XCDs (mh_dense.hip)
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant = -1); // variant: -1 = the process default, 0 = one workgroup, 1 = several; mh_dense.hip: A (column-major, ld m, symmetric, full) -> D, E, tau, reflectors
+// C = alpha op(A) op(B) + beta C, column-major, orders up to ~1000 (the Rayleigh-Ritz step's small matrices)
+void mh_small_gemm(mh_context *ctx, bool ta, bool tb, uint32_t M, uint32_t N, uint32_t K, double alpha, const double *a, uint32_t lda, const double *b, uint32_t ldb, double beta, double *c,
+                   uint32_t ldc);
 void mh_short_product(mh_context *ctx, size_t n, const double *a, uint32_t m, const double *ct, uint32_t nc, double *out, double *partial, uint32_t slices);
 void mh_pack_stacked(mh_context *ctx, const double *c1, uint32_t r1, const double *c2, uint32_t r2, uint32_t cols, double scale, double *ct);
 void mh_pack_coefficients(mh_context *ctx, const double *c1, uint32_t n1, const double *c2, uint32_t n2, uint32_t m, uint32_t ld, double *ct);

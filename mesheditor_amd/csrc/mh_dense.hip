@@ -1784,3 +1784,51 @@ void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
     KERNEL_CHECK();
 }
 
+// ---- small dense products --------------------------------------------------------------------------------------
+// C (M x N) = alpha op(A) op(B) + beta C, column-major, for the ORDER-m matrices of the Rayleigh-Ritz step (m = 3 x block
+// width: 240 .. 720).  The library's dgemm picks a 128 x 128 macro tile at these sizes: 4 workgroups at order 240 (131 us a
+// call), 36 at order 720 (487 us) on a 256-CU device.  Here a workgroup of four waves owns a 32 x 32 tile of C (64 / 529
+// workgroups), a wave one 16 x 16 tile accumulated with v_mfma_f64_16x16x4_f64 straight from global memory (the operands are
+// L2 resident: at most 3 x 4.4 MB), eight k-steps of loads in flight per wave.  Strides carry the transpositions.
+namespace {
+__global__ void __launch_bounds__(256) k_small_gemm(int M, int N, int K, double alpha, const double *__restrict__ A, long sai, long sak, const double *__restrict__ B, long sbk, long sbj,
+                                                   double beta, double *__restrict__ C, int ldc) {
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c_lane = lane & 15, k_lane = lane >> 4;
+    const int i0 = blockIdx.x * 32 + (wave & 1) * 16, j0 = blockIdx.y * 32 + (wave >> 1) * 16;
+    if (i0 >= M || j0 >= N) return;
+    const int ia = i0 + c_lane, jb = j0 + c_lane;
+    const bool a_ok = ia < M, b_ok = jb < N;
+    const double *ap = A + (a_ok ? ia : 0) * sai + k_lane * sak, *bp = B + (b_ok ? jb : 0) * sbj + k_lane * sbk;
+    double4_t acc = {0, 0, 0, 0};
+    int k = 0;
+    for (; k + 32 <= K; k += 32) {
+        double af[8], bf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) af[u] = ap[(k + 4 * u) * sak], bf[u] = bp[(k + 4 * u) * sbk];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ok ? af[u] : 0.0, b_ok ? bf[u] : 0.0, acc, 0, 0, 0);
+    }
+    for (; k < K; k += 4) {
+        const bool k_ok = k + k_lane < K;
+        const double av = a_ok && k_ok ? ap[k * sak] : 0.0, bv = b_ok && k_ok ? bp[k * sbk] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    if (!b_ok) return;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = i0 + k_lane + 4 * reg;
+        if (row >= M) continue;
+        double *c = C + size_t(jb) * ldc + row;
+        *c = beta == 0.0 ? alpha * acc[reg] : alpha * acc[reg] + beta * *c;
+    }
+}
+} // namespace
+
+void mh_small_gemm(mh_context *ctx, bool ta, bool tb, uint32_t M, uint32_t N, uint32_t K, double alpha, const double *a, uint32_t lda, const double *b, uint32_t ldb, double beta, double *c,
+                   uint32_t ldc) {
+    if (!M || !N) return;
+    const dim3 grid(div_up(M, 32), div_up(N, 32));
+    k_small_gemm<<<grid, 256, 0, ctx->stream>>>(int(M), int(N), int(K), alpha, a, ta ? long(lda) : 1L, ta ? 1L : long(lda), b, tb ? long(ldb) : 1L, tb ? 1L : long(ldb), beta, c, int(ldc));
+    KERNEL_CHECK();
+}

@@ -51,7 +51,8 @@ std::mutex g_solve_mutex;
 //   MH_CYCLE=d2,d1,g,ratio  shape of the preconditioner cycle: Chebyshev degrees of the P2 and P1 smoothers, P1 cycles per
 //                           application, spectrum ratio lmax / lmin the smoothers target; 0 or missing keeps a built-in value
 //   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out),
-//                           no_sytrd_wide (orders above 256 go to the library's syevd whole: the A/B of k_sytrd_wide)
+//                           no_sytrd_wide (orders above 256 go to the library's syevd whole: the A/B of k_sytrd_wide),
+//                           library_small_gemm (the step's order-m products through rocBLAS: the A/B of k_small_gemm)
 // and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
 // threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
 struct Switches {
@@ -61,6 +62,7 @@ struct Switches {
     double cheb_ratio = 0.0;
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_sytrd_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_sytrd_wide");
+    bool library_small_gemm = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "library_small_gemm");
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
             double v[4] = {0, 0, 0, 0};
@@ -564,6 +566,16 @@ void panel_trsm(mh_context *ctx, size_t n, double *wp, uint32_t w, const double 
 }
 
 
+// The step's order-m products: our 32 x 32-tile MFMA kernel (mh_small_gemm: the library's 128 x 128 macro tile leaves 4 .. 36 workgroups
+// on the device at these orders); anything larger goes to the library.
+void small_dgemm(mh_context *ctx, rocblas_operation ta, rocblas_operation tb, rocblas_int M, rocblas_int N, rocblas_int K, const double *alpha, const double *a, rocblas_int lda, const double *b,
+                 rocblas_int ldb, const double *beta, double *c, rocblas_int ldc) {
+    if (M <= 1024 && N <= 1024 && K <= 4096 && !switches().library_small_gemm)
+        mh_small_gemm(ctx, ta != rocblas_operation_none, tb != rocblas_operation_none, uint32_t(M), uint32_t(N), uint32_t(K), *alpha, a, uint32_t(lda), b, uint32_t(ldb), *beta, c, uint32_t(ldc));
+    else
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, ta, tb, M, N, K, alpha, a, lda, b, ldb, beta, c, ldc));
+}
+
 // Small generalised symmetric eigenproblem gA c = theta gM c (lower triangles given, order m, ld m):
 // Cholesky reduction + rocSOLVER syevd (rocSOLVER's sygvd reduces with an unblocked sygs2 that launches O(m) tiny
 // kernels; this form measured 2.3x faster at m = 225).  On return gA holds the gM-orthonormal eigenvectors.
@@ -629,11 +641,11 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         double *e = stmp.get(), *e2 = stmp.get() + size_t(m) * m;
         k_defect_matrix<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gM, m, e);
         KERNEL_CHECK();
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, e, m, e, m, &zero, e2, m));
+        small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, e, m, e, m, &zero, e2, m);
         k_inverse_sqrt_series<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(e, e2, m, sroot);
         KERNEL_CHECK();
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, e, m));
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, e, m, sroot, m, &zero, gA, m));
+        small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, e, m);
+        small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, e, m, sroot, m, &zero, gA, m);
         k_symmetrize_lower<<<grid1(size_t(m) * m), TB, 0, ctx->stream>>>(gA, m, m);
         KERNEL_CHECK();
         identity = true;
@@ -733,7 +745,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         }
     }
     if (series) { // c = S z
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, stmp, m));
+        small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, sroot, m, gA, m, &zero, stmp, m);
         HIP_CHECK(hipMemcpyAsync(gA, stmp.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the workspaces go back to the pool on return
     } else if (!identity)
@@ -1236,8 +1248,8 @@ struct BlockLobpcg {
         gram(ctx, n, V, w, MV, w, G, w);
         if (hp) {
             const double minus = -1, plus = 1;
-            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(hp_rows), &minus, hp,
-                                        rocblas_int(hp_rows), hp, rocblas_int(hp_rows), &plus, G, rocblas_int(w)));
+            small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(hp_rows), &minus, hp,
+                                        rocblas_int(hp_rows), hp, rocblas_int(hp_rows), &plus, G, rocblas_int(w));
         }
         k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
         KERNEL_CHECK();
@@ -1540,12 +1552,12 @@ struct BlockLobpcg {
                 const double plus = 1, nil = 0;
                 double *bw = gA.get() + size_t(wa) * m + wa, *bp = gA.get() + size_t(wa) * m + wa + w;
                 gram(ctx, n, P, wp, AW, w, bp, m);
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), bp,
-                                            rocblas_int(m), &nil, Up, rocblas_int(w)));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(wp), rocblas_int(w), rocblas_int(wp), &plus, App, rocblas_int(wp), Hp,
-                                            rocblas_int(wp), &nil, T1p, rocblas_int(wp)));
-                ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), T1p,
-                                            rocblas_int(wp), &nil, Vp, rocblas_int(w)));
+                small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), bp,
+                                            rocblas_int(m), &nil, Up, rocblas_int(w));
+                small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, rocblas_int(wp), rocblas_int(w), rocblas_int(wp), &plus, App, rocblas_int(wp), Hp,
+                                            rocblas_int(wp), &nil, T1p, rocblas_int(wp));
+                small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(w), rocblas_int(w), rocblas_int(wp), &plus, Hp, rocblas_int(wp), T1p,
+                                            rocblas_int(wp), &nil, Vp, rocblas_int(w));
                 k_sub_block<<<grid1(size_t(wp) * w), TB, 0, st>>>(bp, m, T1p, wp, wp, w); // Bp -= App Hp
                 k_wblock_fix<<<grid1(size_t(w) * w), TB, 0, st>>>(bw, m, Up, Vp, w);
                 KERNEL_CHECK();
@@ -1601,10 +1613,10 @@ struct BlockLobpcg {
         // (gM0 Cp is Cp itself when gM0 is the identity by construction: the two symmetric products are skipped)
         const double *mcp = gm_identity ? Cp.get() : T1.get();
         if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, mcp, m, &zero, H, wa));
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, w, wa, &mone, gA, m, H, wa, &one, Cp, m));
+        small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, wa, w, m, &one, gA, m, mcp, m, &zero, H, wa);
+        small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, w, wa, &mone, gA, m, H, wa, &one, Cp, m);
         if (!gm_identity) ROCBLAS_CHECK(rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, m, w, &one, gM0, m, Cp, m, &zero, T1, m));
-        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, mcp, m, &zero, G, w));
+        small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, w, w, m, &one, Cp, m, mcp, m, &zero, G, w);
         k_scale_gram<<<grid1(size_t(w) * w), TB, 0, st>>>(G, w, w, dscale);
         KERNEL_CHECK();
         {
@@ -1633,8 +1645,8 @@ struct BlockLobpcg {
         // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
         if (!warm && it < kSkipP && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
         if (wp_new) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
-            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m));
-            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new));
+            small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m);
+            small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new);
         }
     }
 

@@ -633,6 +633,24 @@ def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(240, 240, 240), (720, 720, 720), (215, 240, 720), (720, 77, 215), (33, 17, 5), (1, 1, 3), (130, 259, 1001)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_small_product_kernel_against_numpy(ctx, shape, ta, tb):
+    """k_small_gemm (the Rayleigh-Ritz step's order-m products): alpha op(A) op(B) + beta C for every transposition, ragged
+    sizes, and beta = 0 not reading C (NaN in)."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.standard_normal((K, M) if ta else (M, K))
+    b = rng.standard_normal((N, K) if tb else (K, N))
+    c = rng.standard_normal((M, N))
+    want = (a.T if ta else a) @ (b.T if tb else b)
+    got, _ = lab.small_gemm(ctx, a, b, c, ta, tb, alpha=-0.5, beta=2.0)
+    assert np.abs(got - (-0.5 * want + 2.0 * c)).max() <= 1e-13 * K * max(1.0, np.abs(want).max())
+    got0, _ = lab.small_gemm(ctx, a, b, np.full((M, N), np.nan), ta, tb)
+    assert np.abs(got0 - want).max() <= 1e-13 * K * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m", [257, 300, 511, 720, 767, 768])
 def test_wide_tridiagonalisation_returns_t_and_its_reflectors(ctx, m):
     """k_sytrd_wide (Rayleigh-Ritz orders 257 .. 768: the 200-mode configuration): T has A's spectrum, the reflectors left in

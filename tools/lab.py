@@ -25,6 +25,7 @@ def lib():
         L.mhl_system_elementwise_matvec.restype, L.mhl_system_elementwise_matvec.argtypes = i32, [vp, vp, vp, u32]
         L.mhl_context_bench_dense.restype, L.mhl_context_bench_dense.argtypes = i32, [vp, i32, C.c_uint64, u32, u32, u32, f64p]
         L.mhl_context_tridiagonalize.restype, L.mhl_context_tridiagonalize.argtypes = i32, [vp, i32, u32, vp, vp, vp, u32, f64p]
+        L.mhl_context_small_gemm.restype, L.mhl_context_small_gemm.argtypes = i32, [vp, i32, i32, u32, u32, u32, C.c_double, vp, u32, vp, u32, C.c_double, vp, u32, u32, f64p]
         L.mhl_context_tridiagonalize_full.restype, L.mhl_context_tridiagonalize_full.argtypes = i32, [vp, i32, u32, vp, vp, vp, vp, vp, u32, f64p]
         L.mhl_graph_aggregates.restype, L.mhl_graph_aggregates.argtypes = u32, [vp, vp, u32, u32, u32, vp]
         _LIB = L
@@ -80,6 +81,18 @@ def tridiagonalize_full(ctx, a, variant=2, reps=1):
     d, e, refl, tau, ms = np.zeros(m), np.zeros(m - 1), np.zeros((m, m)), np.zeros(m), C.c_double(0)
     ctx.check(lib().mhl_context_tridiagonalize_full(ctx.h, variant, m, _p(a), _p(d), _p(e), _p(refl), _p(tau), reps, C.byref(ms)))
     return d, e, refl.T.copy(), tau, ms.value  # (the device's column-major image read as rows: transposed back)
+
+
+def small_gemm(ctx, a, b, c=None, ta=False, tb=False, alpha=1.0, beta=0.0, reps=1):
+    """(alpha op(a) op(b) + beta c, average ms) through the Rayleigh-Ritz step's small-product kernel; a, b, c are numpy matrices
+    (handed over column-major)."""
+    af, bf = np.asfortranarray(a, dtype=np.float64), np.asfortranarray(b, dtype=np.float64)
+    M, K = (af.shape[1], af.shape[0]) if ta else af.shape
+    N = bf.shape[0] if tb else bf.shape[1]
+    cf = np.asfortranarray(np.zeros((M, N)) if c is None else c, dtype=np.float64).copy(order="F")
+    ms = C.c_double(0)
+    ctx.check(lib().mhl_context_small_gemm(ctx.h, int(ta), int(tb), M, N, K, alpha, _p(af), af.shape[0], _p(bf), bf.shape[0], beta, _p(cf), M, reps, C.byref(ms)))
+    return cf, ms.value
 
 
 def graph_aggregates(row_ptr, col, target=16, max_order=6144):
