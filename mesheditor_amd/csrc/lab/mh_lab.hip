@@ -221,4 +221,13 @@ int mhl_context_small_gemm(mh_context *ctx, int ta, int tb, uint32_t M, uint32_t
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+// The context's device pool: bytes held from the device, bytes of them idle in the cache, and the cap on the idle part.
+int mhl_context_pool_stats(mh_context *ctx, uint64_t *reserved, uint64_t *idle, uint64_t *cap) {
+    if (!ctx || !reserved || !idle || !cap) return MH_EINVAL;
+    *reserved = ctx->pool.bytes_reserved;
+    *idle = ctx->pool.bytes_idle;
+    *cap = ctx->pool.cap;
+    return MH_OK;
+}
+
 }

@@ -121,6 +121,11 @@ int mh_context_create(int device, mh_context **out) {
         ctx->device = device;
         if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->cu_count <= 0) ctx->cu_count = 256;
         HIP_CHECK(hipSetDevice(device));
+        {
+            size_t free_bytes = 0, total_bytes = 0;
+            if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) total_bytes = 0, (void)hipGetLastError();
+            ctx->pool.set_cap_for_device(total_bytes);
+        }
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ROCBLAS_CHECK(rocblas_create_handle(&ctx->blas));
         ROCBLAS_CHECK(rocblas_set_stream(ctx->blas, ctx->stream));

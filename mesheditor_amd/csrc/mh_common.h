@@ -46,16 +46,22 @@ struct MhError : std::runtime_error {
 #define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
 
 // Size-bucketed caching allocator: device buffers are recycled across solves so a steady-state solve performs no
-// hipMalloc/hipFree (which synchronise the device).  The cache of idle blocks is capped (MH_POOL_CAP_MB, default 16 GiB):
-// a release that takes it over the cap frees the largest idle blocks first, so a long-lived process that once solved
-// a huge mesh does not sit on that memory for ever.
+// hipMalloc/hipFree (which synchronise the device).  The cache of idle blocks is capped (MH_POOL_CAP_MB; default: the larger
+// of 16 GiB and a quarter of the device's memory): a release that takes it over the cap frees the blocks that have been idle
+// LONGEST first, so a long-lived process that once solved a huge mesh does not sit on that memory for ever -- and a solve
+// whose own working set is near the cap keeps it from one solve to the next (freeing the largest blocks first, as this did
+// before, threw away exactly the panels the next solve of the same mesh asks for: 1.2 s became 1.7 s for a 215-pair solve of
+// 540 k unknowns after any other workload had left its blocks in the cache).
 struct DevicePool {
-    std::multimap<size_t, void *> free_blocks;
+    struct Idle { void *p; unsigned long long stamp; };
+    std::multimap<size_t, Idle> free_blocks;
     std::map<void *, size_t> live;
     size_t bytes_reserved{0}, bytes_idle{0};
-    static size_t idle_cap() {
-        static const size_t cap = (getenv("MH_POOL_CAP_MB") ? size_t(std::max(0, atoi(getenv("MH_POOL_CAP_MB")))) : size_t(16) << 10) << 20;
-        return cap;
+    unsigned long long clock{0};
+    size_t cap{size_t(16) << 30};
+    void set_cap_for_device(size_t device_bytes) {
+        if (const char *c = getenv("MH_POOL_CAP_MB")) cap = size_t(std::max(0, atoi(c))) << 20;
+        else cap = std::max(size_t(16) << 30, device_bytes / 4);
     }
     static size_t round_up(size_t n) {
         if (n < 256) return 256;
@@ -66,7 +72,7 @@ struct DevicePool {
         const size_t r = round_up(n);
         auto it = free_blocks.lower_bound(r);
         if (it != free_blocks.end() && it->first <= r + r / 4 + (size_t(1) << 20)) {
-            void *p = it->second;
+            void *p = it->second.p;
             live[p] = it->first;
             bytes_idle -= it->first;
             free_blocks.erase(it);
@@ -86,19 +92,21 @@ struct DevicePool {
         if (!p) return;
         auto it = live.find(p);
         if (it == live.end()) return;
-        free_blocks.emplace(it->second, p);
+        free_blocks.emplace(it->second, Idle{p, ++clock});
         bytes_idle += it->second;
         live.erase(it);
-        while (bytes_idle > idle_cap() && !free_blocks.empty()) { // largest idle block first
-            auto big = std::prev(free_blocks.end());
-            (void)hipFree(big->second);
-            bytes_idle -= big->first;
-            bytes_reserved -= big->first;
-            free_blocks.erase(big);
+        while (bytes_idle > cap && !free_blocks.empty()) { // the block idle longest goes first
+            auto oldest = free_blocks.begin();
+            for (auto f = free_blocks.begin(); f != free_blocks.end(); ++f)
+                if (f->second.stamp < oldest->second.stamp) oldest = f;
+            (void)hipFree(oldest->second.p);
+            bytes_idle -= oldest->first;
+            bytes_reserved -= oldest->first;
+            free_blocks.erase(oldest);
         }
     }
     void trim() {
-        for (auto &kv : free_blocks) (void)hipFree(kv.second), bytes_reserved -= kv.first;
+        for (auto &kv : free_blocks) (void)hipFree(kv.second.p), bytes_reserved -= kv.first;
         free_blocks.clear();
         bytes_idle = 0;
     }
@@ -361,7 +369,9 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
                 double *out1, uint32_t n1, double *out2, bool accumulate = false, uint32_t ldx = 0, const uint32_t *xmap = nullptr, uint32_t ld1 = 0,
                 const uint32_t *omap = nullptr, uint32_t col_begin = 0, uint32_t col_count = 0); // optional column maps on X (read) and out1 (write), pitches
                                                                                                 // ldx / ld1; col_count > 0: only columns [col_begin, +col_count) of Ct
-void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols); // mh_dense.hip: Z <- Q Z after mh_sytrd_small
+bool mh_tridiag_lowest_wide(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *work, int *info2,
+                            double *quality_host); // orders 257 .. 768 (mh_dense.hip)
+void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols); // mh_dense.hip: Z <- Q Z after mh_sytrd_small / mh_sytrd_wide (order <= 768)
 bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *ufac,
                        double *quality, double *lam_scratch); // mh_dense.hip: k lowest eigenpairs of a tridiagonal matrix (quality: 8 doubles, lam_scratch: k)
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info); // mh_dense.hip

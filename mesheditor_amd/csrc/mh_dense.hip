@@ -1154,46 +1154,52 @@ bool mh_sytrd_gave_up(mh_context *ctx) {
 
 // Z <- Q Z for the orthogonal factor of mh_sytrd_small (LAPACK's lower storage: reflector k has v[k+1] = 1 and its tail in
 // A(k+2:, k)), one wave per column of Z: the column lives in registers (4 entries per lane, m <= 256), each reflector costs one
-// wave reduction, the next reflector's entries are requested before the current one is applied.  Replaces rocSOLVER's blocked
+// wave reduction, the next reflector's entries are requested before the current one is applied (orders up to 768 after
+// mh_sytrd_wide: 8 or 12 entries per lane).  Replaces rocSOLVER's blocked
 // ormtr (~35 launches of larft/larfb pieces per call at these orders) by one launch.
 namespace {
+template<int Q, int PF> // Q entries of the column per lane (order <= 64 Q), PF reflectors in flight
 __global__ void __launch_bounds__(64) k_apply_q(const double *__restrict__ A, const double *__restrict__ tau, int m, double *__restrict__ Z, int ldz) {
     const int lane = threadIdx.x;
     double *zc = Z + size_t(blockIdx.x) * ldz;
-    double z[4], v[4], vn[4];
+    double z[Q], v[PF][Q], tk[PF];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = lane + 64 * q < m ? zc[lane + 64 * q] : 0.0;
-    auto load = [&](int k, double (&dst)[4]) { // reflector k on rows k + 1 .. m - 1
+    for (int q = 0; q < Q; ++q) z[q] = lane + 64 * q < m ? zc[lane + 64 * q] : 0.0;
+    auto load = [&](int k, double (&dst)[Q], double &t) { // reflector k on rows k + 1 .. m - 1 (k < 0: nothing, tau 0)
+        t = k >= 0 ? tau[k] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int i = lane + 64 * q;
             dst[q] = (k >= 0 && i < m && i > k + 1) ? A[size_t(k) * m + i] : (i == k + 1 ? 1.0 : 0.0);
         }
     };
-    load(m - 2, v);
-    for (int k = m - 2; k >= 0; --k) {
-        load(k - 1, vn);
-        double dot = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dot += v[q] * z[q];
-        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-        const double t = tau[k] * dot;
+    for (int u = 0; u < PF; ++u) load(m - 2 - u, v[u], tk[u]);
+    for (int k0 = m - 2; k0 >= 0; k0 -= PF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            z[q] -= t * v[q];
-            v[q] = vn[q];
+        for (int u = 0; u < PF; ++u) { // reflector k0 - u sits in slot u; its slot is refilled with reflector k0 - u - PF once applied
+            double dot = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) dot += v[u][q] * z[q];
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            const double t = tk[u] * dot;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) z[q] -= t * v[u][q];
+            load(k0 - u - PF, v[u], tk[u]);
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < Q; ++q)
         if (lane + 64 * q < m) zc[lane + 64 * q] = z[q];
 }
 } // namespace
 
 void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols) {
-    if (m > 256) mh_throw(MH_EINVAL, "apply_q: order %u above 256", m);
+    if (m > 768) mh_throw(MH_EINVAL, "apply_q: order %u above 768", m);
     if (!ncols || m < 2) return;
-    k_apply_q<<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
+    if (m <= 256) k_apply_q<4, 2><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
+    else if (m <= 512) k_apply_q<8, 4><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
+    else k_apply_q<12, 4><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
     KERNEL_CHECK();
 }
 
@@ -1218,22 +1224,30 @@ namespace {
 // Eigenvalue j of the tridiagonal matrix by 255-way multisection, one workgroup per eigenvalue (the counts are independent, and
 // one CU alone is throughput-bound on the k * m * evaluations divisions): 8 steps instead of the 17 thirteen-way steps the
 // single-workgroup kernel needs.  lam[j] = j-th smallest eigenvalue.
+template<int R> // order <= 256 R
 __global__ void __launch_bounds__(256) k_tridiag_values(const double *__restrict__ D, const double *__restrict__ E, int m, double *__restrict__ lam) {
-    __shared__ double d[256], e2[256], bnd[2];
+    __shared__ double d[256 * R], e2[256 * R], sabs[256 * R], bnd[2];
     __shared__ int cnt[256];
     const int tid = threadIdx.x, j = blockIdx.x;
-    double ea = 0;
-    if (tid < m) d[tid] = D[tid];
-    if (tid + 1 < m) ea = E[tid];
-    e2[tid] = ea * ea;
-    __shared__ double sabs[256];
-    sabs[tid] = fabs(ea);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int i = tid + 256 * q;
+        const double ea = i + 1 < m ? E[i] : 0.0;
+        d[i] = i < m ? D[i] : 0.0;
+        e2[i] = ea * ea;
+        sabs[i] = fabs(ea);
+    }
     __syncthreads();
-    double gl = 1.7976931348623157e308, gh = -1.7976931348623157e308, emax = e2[tid];
-    if (tid < m) {
-        const double r = (tid ? sabs[tid - 1] : 0.0) + sabs[tid];
-        gl = d[tid] - r;
-        gh = d[tid] + r;
+    double gl = 1.7976931348623157e308, gh = -1.7976931348623157e308, emax = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int i = tid + 256 * q;
+        emax = fmax(emax, e2[i]);
+        if (i < m) {
+            const double r = (i ? sabs[i - 1] : 0.0) + sabs[i];
+            gl = fmin(gl, d[i] - r);
+            gh = fmax(gh, d[i] + r);
+        }
     }
     __shared__ double rl[256], rh[256], rm[256];
     rl[tid] = gl; rh[tid] = gh; rm[tid] = emax;
@@ -1272,6 +1286,152 @@ __global__ void __launch_bounds__(256) k_tridiag_values(const double *__restrict
         __syncthreads();
     }
     if (tid == 0) lam[j] = 0.5 * (bnd[0] + bnd[1]);
+}
+
+// ---- the same for orders 257 .. 768 (the 200-mode configuration), where the k vectors no longer fit one workgroup's LDS ----------
+//   1. k_tridiag_values<3>: one workgroup per eigenvalue, as above;
+//   2. k_tridiag_invit: one thread per eigenvalue (one wave per workgroup), the vector and the U factor in global memory
+//      ([row][vector]: a wave's accesses are one 512-byte run), the start vector generated on the fly;
+//   3. Cholesky-QR twice on the k vectors (Gram matrix and updates by mh_small_gemm, the order-k factorisation and triangular
+//      inverse by the library): exact multiplets and close pairs come out of step 2 as independent but not orthogonal vectors;
+//   4. k_tridiag_residual: max_j ||T z_j - lambda_j z_j||_inf / ||T|| for the caller to judge, as in the one-workgroup kernel.
+constexpr int WIDE_T = 768;
+__device__ inline void tridiag_scale(const double *d, const double *e, int m, int tid, int nthreads, double *red, double &tnorm, double &pivmin) {
+    // Gershgorin bound of |T| and the pivot floor, by one wave or workgroup (red: 2 * 16 doubles of LDS); all threads return the same bits
+    double gh = 0.0, em = 0.0;
+    for (int i = tid; i < m; i += nthreads) {
+        const double el = i ? fabs(e[i - 1]) : 0.0, er = i + 1 < m ? fabs(e[i]) : 0.0;
+        gh = fmax(gh, fabs(d[i]) + el + er);
+        em = fmax(em, er * er);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        gh = fmax(gh, __shfl_xor(gh, off, 64));
+        em = fmax(em, __shfl_xor(em, off, 64));
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = gh, red[16 + (tid >> 6)] = em;
+    __syncthreads();
+    tnorm = 0.0;
+    double e2max = 0.0;
+    for (int q = 0; q < (nthreads + 63) / 64; ++q) tnorm = fmax(tnorm, red[q]), e2max = fmax(e2max, red[16 + q]);
+    pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max);
+    __syncthreads();
+}
+__global__ void __launch_bounds__(64) k_tridiag_invit(const double *__restrict__ D, const double *__restrict__ E, int m, int k, const double *__restrict__ lam, double *__restrict__ X,
+                                                     double *__restrict__ ufac) {
+    __shared__ double d[WIDE_T], e[WIDE_T], red[32];
+    const int tid = threadIdx.x, j = blockIdx.x * 64 + tid;
+    for (int i = tid; i < m; i += 64) d[i] = D[i], e[i] = i + 1 < m ? E[i] : 0.0;
+    __syncthreads();
+    double tnorm, pivmin;
+    tridiag_scale(d, e, m, tid, 64, red, tnorm, pivmin);
+    if (j >= k) return;
+    const double tiny = fmax(2.220446049250313e-16 * tnorm, pivmin);
+    const double lj = lam[j];
+    unsigned long long st = 0x9e3779b97f4a7c15ull * (unsigned long long)(j + 1);
+    auto next_start = [&]() { // pseudo-random start, different per vector (splitmix-style), entries in (-1, 1)
+        st += 0x9e3779b97f4a7c15ull;
+        unsigned long long zz = st;
+        zz = (zz ^ (zz >> 30)) * 0xbf58476d1ce4e5b9ull;
+        zz = (zz ^ (zz >> 27)) * 0x94d049bb133111ebull;
+        zz ^= zz >> 31;
+        return double(zz >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    };
+    // forward elimination with row interchanges (dlagtf), applied to the right-hand side on the way
+    double cd = d[0] - lj, cs = m > 1 ? e[0] : 0.0;
+    double ri = next_start();
+    for (int i = 0; i + 1 < m; ++i) {
+        const double sb = e[i], nd = d[i + 1] - lj, ns = i + 2 < m ? e[i + 1] : 0.0;
+        double rn = next_start();
+        double u0, u1, u2, keep;
+        if (fabs(cd) >= fabs(sb)) {
+            if (fabs(cd) < tiny) cd = copysign(tiny, cd);
+            const double mult = sb / cd;
+            u0 = cd; u1 = cs; u2 = 0.0;
+            cd = nd - mult * cs;
+            cs = ns;
+            rn -= mult * ri;
+            keep = ri;
+        } else {
+            const double mult = cd / sb;
+            u0 = sb; u1 = nd; u2 = ns;
+            cd = cs - mult * nd;
+            cs = -mult * ns;
+            keep = rn;
+            rn = ri - mult * rn;
+        }
+        X[size_t(i) * k + j] = keep;
+        ufac[(size_t(3) * i) * k + j] = u0;
+        ufac[(size_t(3) * i + 1) * k + j] = u1;
+        ufac[(size_t(3) * i + 2) * k + j] = u2;
+        ri = rn;
+    }
+    if (fabs(cd) < tiny) cd = copysign(tiny, cd);
+    // back substitution (dlagts), overwriting the right-hand side; the rows come back eight at a time
+    double y1 = ri / cd, y2 = 0.0, big = fabs(y1);
+    X[size_t(m - 1) * k + j] = y1;
+    for (int i0 = m - 2; i0 >= 0; i0 -= 8) {
+        double u[8][3], x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = max(i0 - q, 0);
+            u[q][0] = ufac[(size_t(3) * i) * k + j];
+            u[q][1] = ufac[(size_t(3) * i + 1) * k + j];
+            u[q][2] = ufac[(size_t(3) * i + 2) * k + j];
+            x[q] = X[size_t(i) * k + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 - q;
+            if (i < 0) break;
+            const double y = (x[q] - u[q][1] * y1 - u[q][2] * y2) / u[q][0];
+            X[size_t(i) * k + j] = y;
+            big = fmax(big, fabs(y));
+            y2 = y1;
+            y1 = y;
+        }
+    }
+    // unit 2-norm, scaled by the largest entry first (the solution of a nearly singular system is huge)
+    const double ib = 1.0 / fmax(big, 2.2250738585072014e-308);
+    double nrm = 0.0;
+    for (int i = 0; i < m; ++i) {
+        const double v = X[size_t(i) * k + j] * ib;
+        nrm += v * v;
+    }
+    const double sc = ib / sqrt(nrm);
+    for (int i = 0; i < m; ++i) X[size_t(i) * k + j] *= sc;
+}
+// quality[0] = max over the k columns of ||T z - lambda z||_inf / ||T|| (bits of a non-negative double: atomicMax on the word; NaN
+// compares above everything), one workgroup per column of Z (m x k column-major).  quality[0] is zeroed by the caller.
+__global__ void __launch_bounds__(256) k_tridiag_residual(const double *__restrict__ D, const double *__restrict__ E, int m, const double *__restrict__ lam, const double *__restrict__ Z, int ldz,
+                                                         unsigned long long *__restrict__ quality) {
+    __shared__ double d[WIDE_T], e[WIDE_T], red[32], worst_of[4];
+    const int tid = threadIdx.x, j = blockIdx.x;
+    for (int i = tid; i < m; i += 256) d[i] = D[i], e[i] = i + 1 < m ? E[i] : 0.0;
+    __syncthreads();
+    double tnorm, pivmin;
+    tridiag_scale(d, e, m, tid, 256, red, tnorm, pivmin);
+    const double *z = Z + size_t(j) * ldz, lj = lam[j];
+    double worst = 0.0;
+    bool bad = false;
+    for (int i = tid; i < m; i += 256) {
+        const double r = (d[i] - lj) * z[i] + (i ? e[i - 1] * z[i - 1] : 0.0) + (i + 1 < m ? e[i] * z[i + 1] : 0.0);
+        bad |= !(fabs(r) <= 1.7976931348623157e308);
+        worst = fmax(worst, fabs(r));
+    }
+    if (bad) worst = __longlong_as_double(0x7ff8000000000000ll);
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(worst, off, 64);
+        worst = (o != o || worst != worst) ? __longlong_as_double(0x7ff8000000000000ll) : fmax(worst, o);
+    }
+    if ((tid & 63) == 0) worst_of[tid >> 6] = worst;
+    __syncthreads();
+    if (tid == 0) {
+        double q = 0.0;
+        bool nan = false;
+        for (int a = 0; a < 4; ++a) nan |= worst_of[a] != worst_of[a], q = fmax(q, worst_of[a]);
+        q = nan ? __longlong_as_double(0x7ff8000000000000ll) : q / fmax(tnorm, 2.2250738585072014e-308);
+        atomicMax(quality, static_cast<unsigned long long>(__double_as_longlong(q)));
+    }
 }
 __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restrict__ D, const double *__restrict__ E, int m, int k, double *__restrict__ w,
                                                         double *__restrict__ z, int ldz, double *__restrict__ ufac, double *__restrict__ quality, const double *__restrict__ lam_in) {
@@ -1533,11 +1693,43 @@ bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32
     attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tridiag_lowest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     constexpr bool spread = true;
     if (spread) {
-        k_tridiag_values<<<k, 256, 0, ctx->stream>>>(d, e, int(m), lam_scratch);
+        k_tridiag_values<1><<<k, 256, 0, ctx->stream>>>(d, e, int(m), lam_scratch);
         KERNEL_CHECK();
     }
     k_tridiag_lowest<<<1, 1024, lds, ctx->stream>>>(d, e, int(m), int(k), w, z, int(ldz), ufac, quality, spread ? lam_scratch : nullptr);
     KERNEL_CHECK();
+    return true;
+}
+
+// Orders 257 .. 768, k <= 256: see the comment above k_tridiag_invit.  work: 2 k m + 3 k m + 2 k k + k doubles; z (m x k, ldz) receives the
+// orthonormal vectors, w the eigenvalues; *quality_host the residual measure (NaN when a factorisation failed).  Synchronises the stream.
+bool mh_tridiag_lowest_wide(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *work, int *info2, double *quality_host) {
+    if (m <= 256 || m > WIDE_T || k < 1 || k > 256 || k > m) return false;
+    const size_t km = size_t(k) * m;
+    double *xt = work, *xt2 = xt + km, *ufac = xt2 + km, *g = ufac + 3 * km, *linv = g + size_t(k) * k, *qual = linv + size_t(k) * k;
+    k_tridiag_values<3><<<k, 256, 0, ctx->stream>>>(d, e, int(m), w);
+    KERNEL_CHECK();
+    k_tridiag_invit<<<div_up(k, 64), 64, 0, ctx->stream>>>(d, e, int(m), int(k), w, xt, ufac);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemsetAsync(info2, 0, 2 * sizeof(int), ctx->stream));
+    // xt is X^T (k x m column-major).  Pass 1: xt2 = L^-1 xt; pass 2: z = xt2^T L^-T
+    for (int pass = 0; pass < 2; ++pass) {
+        const double *src = pass == 0 ? xt : xt2;
+        mh_small_gemm(ctx, false, true, k, k, m, 1.0, src, k, src, k, 0.0, g, k);
+        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(k), g, rocblas_int(k), info2 + pass));
+        HIP_CHECK(hipMemsetAsync(linv, 0, size_t(k) * k * sizeof(double), ctx->stream));
+        ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, rocblas_int(k), g, rocblas_int(k), linv, rocblas_int(k)));
+        if (pass == 0) mh_small_gemm(ctx, false, false, k, m, k, 1.0, linv, k, src, k, 0.0, xt2, k);
+        else mh_small_gemm(ctx, true, true, m, k, k, 1.0, src, k, linv, k, 0.0, z, ldz);
+    }
+    HIP_CHECK(hipMemsetAsync(qual, 0, sizeof(double), ctx->stream));
+    k_tridiag_residual<<<k, 256, 0, ctx->stream>>>(d, e, int(m), w, z, int(ldz), reinterpret_cast<unsigned long long *>(qual));
+    KERNEL_CHECK();
+    int hinfo[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(quality_host, qual, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(hinfo, info2, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (hinfo[0] != 0 || hinfo[1] != 0) *quality_host = std::numeric_limits<double>::quiet_NaN();
     return true;
 }
 

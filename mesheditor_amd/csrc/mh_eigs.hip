@@ -52,6 +52,7 @@ std::mutex g_solve_mutex;
 //                           application, spectrum ratio lmax / lmin the smoothers target; 0 or missing keeps a built-in value
 //   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out),
 //                           no_sytrd_wide (orders above 256 go to the library's syevd whole: the A/B of k_sytrd_wide),
+//                           no_tridiag_wide (orders above 256: the library's divide and conquer for all pairs instead of our partial spectrum),
 //                           library_small_gemm (the step's order-m products through rocBLAS: the A/B of k_small_gemm)
 // and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
 // threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
@@ -62,6 +63,7 @@ struct Switches {
     double cheb_ratio = 0.0;
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_sytrd_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_sytrd_wide");
+    bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
     bool library_small_gemm = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "library_small_gemm");
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
@@ -728,6 +730,22 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
             if (switches().test_sytrd_giveup) gave_up = 1;
             if (gave_up) {
                 HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            } else if (nwant && nwant < m && nwant <= 256 && !switches().no_tridiag_wide && [&] {
+                           // only the nwant lowest pairs are needed: multisection, inverse iteration and Cholesky-QR (mh_tridiag_lowest_wide)
+                           // instead of the full divide and conquer (stedc + ormtr: ~5 ms of library launches at order 720), accepted when
+                           // its residual check passes; Z <- Q Z by our one-launch kernel
+                           DevArray<double> work(ctx, size_t(5) * nwant * m + size_t(2) * nwant * nwant + 8), lam(ctx, nwant);
+                           double quality = 1.0;
+                           if (!mh_tridiag_lowest_wide(ctx, evals, ework, m, nwant, lam, z, m, work, info, &quality)) return false;
+                           if (switches().verbose) fprintf(stderr, "[rr] tridiagonal m %u lowest %u (wide): residual / ||T|| %.2e\n", m, nwant, quality);
+                           if (!(quality < 1e-10)) return false;
+                           HIP_CHECK(hipMemcpyAsync(evals, lam.get(), size_t(nwant) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                           mh_apply_q(ctx, gA, tau, m, z, m, nwant);
+                           HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * nwant * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                           HIP_CHECK(hipStreamSynchronize(ctx->stream)); // (work and lam go back to the pool)
+                           return true;
+                       }()) {
+                done = true;
             } else {
                 ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
                 info.download(&hinfo, 1);

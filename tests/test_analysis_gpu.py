@@ -414,6 +414,45 @@ def test_results_do_not_depend_on_recycled_device_memory(api, ctx):
     assert runs[0]["sig"] == runs[1]["sig"] and any(float.fromhex(v) != 0 for v in runs[0]["sig"])
 
 
+def test_device_pool_keeps_its_idle_cache_under_the_cap():
+    """The cache of idle device blocks is capped, the longest-idle blocks leave first, and a cap far below a solve's working
+    set changes nothing but the allocation traffic: two workloads alternated under MH_POOL_CAP_MB=64 reproduce the uncapped
+    eigenvalues bit for bit, with the idle bytes at or under the cap after every solve.  The default cap is a quarter of the
+    device (at least 16 GiB)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import json, numpy as np\n"
+        "from mesheditor_amd import api, meshes\n"
+        "from tools import lab\n"
+        "ctx = api.Context(0)\n"
+        "out = {'ev': [], 'idle': [], 'cap': lab.pool_stats(ctx)[2]}\n"
+        "for name in ('cube_s10k', 'ball_s10k', 'cube_s10k', 'ball_s10k'):\n"
+        "    pts, tets, m, kw = meshes.workload(name)\n"
+        "    mesh = api.Mesh(ctx, pts, tets)\n"
+        "    s = api.System(ctx, mesh, api.material(*m))\n"
+        "    ev, prof = s.eigs(40, -(2 * np.pi * 20.0) ** 2, 1e-6)\n"
+        "    s.close(); mesh.close()\n"
+        "    out['ev'].append([float(v).hex() for v in ev])\n"
+        "    out['idle'].append(lab.pool_stats(ctx)[1])\n"
+        "print(json.dumps(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for cap in (None, "64"):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("MH_POOL_CAP_MB", None)
+        if cap:
+            env["MH_POOL_CAP_MB"] = cap
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert runs[0]["cap"] >= 16 << 30 and runs[1]["cap"] == 64 << 20
+    assert runs[0]["ev"] == runs[1]["ev"] and runs[0]["ev"][0] == runs[0]["ev"][2]
+    assert all(i <= 64 << 20 for i in runs[1]["idle"]) and max(runs[0]["idle"]) > 64 << 20
+
+
 def test_batch_of_meshes_through_the_sharding_path(api, ctx):
     """BASELINE configs[3] in miniature on one rank: jittered boxes of the batch family, dealt, solved, packed into
     fixed-size records and unpacked; each record equals the direct solve of that mesh."""
