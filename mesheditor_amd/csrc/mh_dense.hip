@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(64) k_apply_q(const double *__restrict__ A, co
 void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m, double *z, uint32_t ldz, uint32_t ncols) {
     if (m > 768) mh_throw(MH_EINVAL, "apply_q: order %u above 768", m);
     if (!ncols || m < 2) return;
-    if (m <= 256) k_apply_q<4, 2><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
+    if (m <= 256) k_apply_q<4, 4><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
     else if (m <= 512) k_apply_q<8, 4><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
     else k_apply_q<12, 4><<<ncols, 64, 0, ctx->stream>>>(a, tau, int(m), z, int(ldz));
     KERNEL_CHECK();
