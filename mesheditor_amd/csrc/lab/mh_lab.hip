@@ -230,4 +230,19 @@ int mhl_context_pool_stats(mh_context *ctx, uint64_t *reserved, uint64_t *idle, 
     return MH_OK;
 }
 
+// G (wa x wb, column-major) = X^T Y for row-major host panels X (n x wa), Y (n x wb): the solver's Gram kernel, for parity tests.
+int mhl_context_gram(mh_context *ctx, uint64_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g) {
+    if (!ctx || !x || !y || !g || !n || !wa || !wb) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        MhSharedPhase not_during_a_factorisation;
+        DevArray<double> dx(ctx, n * wa), dy(ctx, n * wb), dg(ctx, size_t(wa) * wb);
+        dx.upload(x, n * wa);
+        dy.upload(y, n * wb);
+        mh_gram(ctx, n, dx, wa, dy, wb, dg, wa);
+        dg.download(g, size_t(wa) * wb);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 }

@@ -21,6 +21,8 @@ int mhl_context_tridiagonalize_full(mh_context *, int variant, uint32_t m, const
 /* C (M x N, ldc) = alpha op(A) op(B) + beta C through the Rayleigh-Ritz step's small-product kernel; column-major host arrays, c in and out */
 int mhl_context_small_gemm(mh_context *, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, double alpha, const double *a, uint32_t lda, const double *b, uint32_t ldb, double beta, double *c,
                            uint32_t ldc, uint32_t reps, double *avg_ms);
+/* G (wa x wb, column-major) = X^T Y for row-major host panels (n x wa), (n x wb): the solver's Gram kernel */
+int mhl_context_gram(mh_context *, uint64_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g);
 /* the context's device pool: bytes held from the device, bytes of them idle in the cache, the cap on the idle part */
 int mhl_context_pool_stats(mh_context *, uint64_t *reserved, uint64_t *idle, uint64_t *cap);
 /* The rigid-body level's graph aggregation (host code): CSR node graph in (diagonal entries included), aggregate per node out. */

@@ -405,6 +405,10 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
     else if (ti_n <= 6 && tj_n <= 5) blocked(IC(3), IC(5), IC(2), IC(1), IC(2), IC(2));
     else if (ti_n <= 10 && tj_n <= 6) blocked(IC(5), IC(3), IC(2), IC(2), IC(1), IC(2));
     else if (ti_n <= 6 && tj_n <= 10) blocked(IC(3), IC(5), IC(2), IC(2), IC(1), IC(2));
+    // (an eight-wave 160 x 192 form -- same waves per CU, the X columns read once for twice the outputs -- measured slower in round 4:
+    // 2.50 against 2.10 ms on 240 x 240; what a launch costs is tile slots, 15 per wave whether used or not: see mh_gram's cuts)
+    // (a nine-wave form holding a whole 240 x 240 block -- 25 tiles per wave, every panel element read once -- was built in round 4
+    // and ran 11.6 ms against the 2.07 ms of six launches of this form: 3 waves on a SIMD leave 170 registers for 200 of accumulators)
     else mh_throw(MH_EINVAL, "gram block %u x %u too wide", wa, wb);
 #undef IC
     KERNEL_CHECK();
@@ -419,13 +423,21 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
     if (!wa || !wb) return;
     if (!ldy) ldy = wb;
     const bool a_long = wa >= wb;
-    const uint32_t cap_a = a_long ? 160 : 96, cap_b = a_long ? 96 : 160;
-    const uint32_t na = div_up(wa, cap_a), nbk = div_up(wb, cap_b);
-    const uint32_t step_a = (div_up(wa, na) + 15) / 16 * 16, step_b = (div_up(wb, nbk) + 15) / 16 * 16;
-    for (uint32_t i0 = 0; i0 < wa; i0 += step_a)
-        for (uint32_t j0 = 0; j0 < wb; j0 += step_b)
-            gram_block(ctx, n, x + i0, wa, std::min(step_a, wa - i0), ymap ? y : y + j0, ldy, ymap ? ymap + j0 : nullptr, std::min(step_b, wb - j0),
-                       g + size_t(j0) * ld + i0, ld);
+    // A launch costs its tile SLOTS (15 per wave, 2 x 2 waves at the widest: 160 x 96), used or not: 240 x 240 cut evenly into 2 x 3
+    // launches of 128 x 80 fills 40 of 60 slots each (2.10 ms at 542 k rows); cut as 160 + 80 by 3 x 80 it fills 50 of 60 and 25 of 30
+    // (1.6 ms).  So: the long side greedily in 160s, the short side evenly in pieces of at most 96 columns.
+    const uint32_t cap_long = 160, cap_short = 96;
+    const uint32_t w_long = a_long ? wa : wb, w_short = a_long ? wb : wa;
+    const uint32_t n_short = div_up(w_short, cap_short), step_short = (div_up(w_short, n_short) + 15) / 16 * 16;
+    // (a remainder of under 32 columns would be a launch of mostly empty slots over all the rows: cut evenly then)
+    const uint32_t rest = w_long % cap_long, n_long = div_up(w_long, cap_long);
+    const uint32_t step_long = rest && rest < 32 ? (div_up(w_long, n_long) + 15) / 16 * 16 : cap_long;
+    for (uint32_t l0 = 0; l0 < w_long; l0 += step_long)
+        for (uint32_t s0 = 0; s0 < w_short; s0 += step_short) {
+            const uint32_t i0 = a_long ? l0 : s0, j0 = a_long ? s0 : l0;
+            const uint32_t ca = std::min(a_long ? step_long : step_short, wa - i0), cb = std::min(a_long ? step_short : step_long, wb - j0);
+            gram_block(ctx, n, x + i0, wa, ca, ymap ? y : y + j0, ldy, ymap ? ymap + j0 : nullptr, cb, g + size_t(j0) * ld + i0, ld);
+        }
 }
 
 // Row-major (k-major) packing of two column-major coefficient blocks side by side: ct[m][n1 + n2]

@@ -672,6 +672,21 @@ def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(5000, 80, 80), (70001, 240, 240), (33333, 234, 215), (40000, 240, 80), (40000, 97, 161), (12345, 161, 97), (9000, 1, 7), (20000, 200, 129)])
+def test_gram_kernel_against_numpy(ctx, shape):
+    """k_gram_blocked in every dispatch class (single tile groups, the 160 x 96 grid, the nine-wave 240 x 240 form of the 200-mode
+    configuration): X^T Y against numpy, ragged row counts, and bit-reproducible run to run."""
+    n, wa, wb = shape
+    rng = np.random.default_rng(n + wa + wb)
+    x = rng.standard_normal((n, wa))
+    y = rng.standard_normal((n, wb))
+    g = lab.gram(ctx, x, y)
+    want = x.T @ y
+    assert np.abs(g - want).max() <= 1e-12 * np.sqrt(n) * 10
+    assert np.array_equal(g, lab.gram(ctx, x, y))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(240, 240, 240), (720, 720, 720), (215, 240, 720), (720, 77, 215), (33, 17, 5), (1, 1, 3), (130, 259, 1001)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
 def test_small_product_kernel_against_numpy(ctx, shape, ta, tb):

@@ -25,6 +25,7 @@ def lib():
         L.mhl_system_elementwise_matvec.restype, L.mhl_system_elementwise_matvec.argtypes = i32, [vp, vp, vp, u32]
         L.mhl_context_bench_dense.restype, L.mhl_context_bench_dense.argtypes = i32, [vp, i32, C.c_uint64, u32, u32, u32, f64p]
         L.mhl_context_tridiagonalize.restype, L.mhl_context_tridiagonalize.argtypes = i32, [vp, i32, u32, vp, vp, vp, u32, f64p]
+        L.mhl_context_gram.restype, L.mhl_context_gram.argtypes = i32, [vp, C.c_uint64, vp, u32, vp, u32, vp]
         L.mhl_context_pool_stats.restype, L.mhl_context_pool_stats.argtypes = i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.mhl_context_small_gemm.restype, L.mhl_context_small_gemm.argtypes = i32, [vp, i32, i32, u32, u32, u32, C.c_double, vp, u32, vp, u32, C.c_double, vp, u32, u32, f64p]
         L.mhl_context_tridiagonalize_full.restype, L.mhl_context_tridiagonalize_full.argtypes = i32, [vp, i32, u32, vp, vp, vp, vp, vp, u32, f64p]
@@ -82,6 +83,16 @@ def tridiagonalize_full(ctx, a, variant=2, reps=1):
     d, e, refl, tau, ms = np.zeros(m), np.zeros(m - 1), np.zeros((m, m)), np.zeros(m), C.c_double(0)
     ctx.check(lib().mhl_context_tridiagonalize_full(ctx.h, variant, m, _p(a), _p(d), _p(e), _p(refl), _p(tau), reps, C.byref(ms)))
     return d, e, refl.T.copy(), tau, ms.value  # (the device's column-major image read as rows: transposed back)
+
+
+def gram(ctx, x, y):
+    """X^T Y through the solver's Gram kernel (x: n x wa, y: n x wb)."""
+    xc, yc = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+    n, wa = xc.shape
+    wb = yc.shape[1]
+    g = np.zeros((wb, wa))  # column-major wa x wb
+    ctx.check(lib().mhl_context_gram(ctx.h, n, _p(xc), wa, _p(yc), wb, _p(g)))
+    return g.T.copy()
 
 
 def pool_stats(ctx):
