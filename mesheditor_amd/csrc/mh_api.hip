@@ -139,6 +139,8 @@ int mh_context_create(int device, mh_context **out) {
         if (ctx->blas) rocblas_destroy_handle(ctx->blas);
         if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
         if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
+        if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return code;
@@ -151,6 +153,7 @@ void mh_context_destroy(mh_context *ctx) {
     if (ctx->blas) rocblas_destroy_handle(ctx->blas);
     if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

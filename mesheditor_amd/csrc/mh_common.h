@@ -132,6 +132,11 @@ struct mh_context {
         }
         return aux_stream != nullptr && blas_aux != nullptr;
     }
+    hipStream_t aux2_stream{nullptr}; // third stream: the next pivot block's inverse beside the coarse elimination's rank update (our kernel only, no library handle)
+    bool aux2_stream_ready() {
+        if (!aux2_stream && hipStreamCreateWithFlags(&aux2_stream, hipStreamNonBlocking) != hipSuccess) aux2_stream = nullptr, (void)hipGetLastError();
+        return aux2_stream != nullptr;
+    }
     rocblas_handle blas{nullptr};
     rocblas_handle blas_aux{nullptr}; // the second stream's own handle (a handle's workspace must not serve two streams at once), created with the stream
     DevicePool pool;
@@ -312,7 +317,7 @@ struct mh_system {
     // Rayleigh-Ritz step) runs beside the elimination's one-workgroup kernels.
     hipEvent_t coarse_done{nullptr};
     bool coarse_pending{false};
-    DevArray<double> coarse_ws[3];
+    DevArray<double> coarse_ws[5];
     DevArray<int> coarse_info;
     ~mh_system() {
         if (coarse_pending && coarse_done) (void)hipEventSynchronize(coarse_done);

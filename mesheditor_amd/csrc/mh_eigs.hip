@@ -53,6 +53,7 @@ std::mutex g_solve_mutex;
 //   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out),
 //                           no_sytrd_wide (orders above 256 go to the library's syevd whole: the A/B of k_sytrd_wide),
 //                           no_tridiag_wide (orders above 256: the library's divide and conquer for all pairs instead of our partial spectrum),
+//                           no_coarse_lookahead (the coarse elimination's pivot inverses in line instead of one step ahead on a third stream),
 //                           library_small_gemm (the step's order-m products through rocBLAS: the A/B of k_small_gemm)
 // and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
 // threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
@@ -64,6 +65,8 @@ struct Switches {
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_sytrd_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_sytrd_wide");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
+    bool no_coarse_lookahead = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_coarse_lookahead");
+    bool power_every_step = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "power_every_step");
     bool library_small_gemm = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "library_small_gemm");
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
@@ -952,8 +955,12 @@ double estimate_lmax(mh_context *ctx, BsrLevel &lvl, const PatchSet &ps) {
         k_dinv_mul<<<grid1(rows * w), TB, 0, ctx->stream>>>(t, lvl.dinv, v, rows, w);
         KERNEL_CHECK();
         mh_apply_patches<double>(ctx, ps, t, nullptr, w, 1.0, v, nullptr, nullptr, 0, py.get()); // v = M^-1 t with the sliver patches
-        colsumsq(ctx, v, rows, w, nrm, scratch);
-        if (it + 1 < power_its) {
+        // The columns are rescaled every fourth step only (the iterate grows by at most lmax <= ~20 per step: 1.6e5 in four), and
+        // before the last step, whose norm is the estimate: the column norms and the rescaling were 45 % of a step's 390 us, and
+        // this loop -- not the coarse elimination beside it -- is what `factorize` waits for.
+        const bool last = it + 1 == power_its, rescale = !last && (it % 4 == 3 || it + 2 == power_its || switches().power_every_step);
+        if (last || rescale) colsumsq(ctx, v, rows, w, nrm, scratch);
+        if (rescale) {
             k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
             KERNEL_CHECK();
         }
@@ -1036,20 +1043,25 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
         // solve needs no exclusive phase on the device.  The coarse solve becomes one dense product per application (2.5x
         // faster than two triangular solves at these sizes, and free of their O(n0 / 128) dependent launches).
         const uint32_t nb = 128;
-        DevArray<double> &cblk = sys->coarse_ws[0], &rblk = sys->coarse_ws[1], &pinv = sys->coarse_ws[2];
+        DevArray<double> &cblk = sys->coarse_ws[0], &rblk = sys->coarse_ws[1], &pnext = sys->coarse_ws[4];
+        DevArray<double> *pinv2[2] = {&sys->coarse_ws[2], &sys->coarse_ws[3]};
         cblk.reset(ctx, n0 * nb);
         rblk.reset(ctx, n0 * nb);
-        pinv.reset(ctx, size_t(nb) * nb);
+        pinv2[0]->reset(ctx, size_t(nb) * nb);
+        pinv2[1]->reset(ctx, size_t(nb) * nb);
+        pnext.reset(ctx, size_t(nb) * nb);
         info.zero();
         const bool side = ctx->aux_stream_ready();
         struct StreamGuard { // whatever happens below, the context leaves on its own stream
             mh_context *c;
             hipStream_t s;
+            bool swapped{false};
             ~StreamGuard() {
                 if (c->stream != s) {
                     c->stream = s;
-                    std::swap(c->blas, c->blas_aux);
+                    if (swapped) std::swap(c->blas, c->blas_aux);
                     (void)hipStreamSynchronize(c->aux_stream);
+                    if (c->aux2_stream) (void)hipStreamSynchronize(c->aux2_stream);
                 }
             }
         } guard{ctx, main_stream};
@@ -1060,19 +1072,60 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
             HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, forked, 0));
             ctx->stream = ctx->aux_stream;
             std::swap(ctx->blas, ctx->blas_aux); // the second stream's own handle
+            guard.swapped = true;
         }
+        // One step ahead: the pivot block of step k + 1 is brought up to date FIRST (a 128 x 128 x 128 product of ours into a buffer of
+        // its own) and inverted on a third stream while the rank-128 update of the whole matrix runs -- the one-workgroup inverse
+        // (117 us) and the update (131 us) were 85 % of a step's 287 us, one after the other.
+        const bool ahead = side && ctx->aux2_stream_ready() && !switches().no_coarse_lookahead;
+        hipEvent_t ev_piv[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
+        struct EventGuard {
+            hipEvent_t *a, *b;
+            ~EventGuard() {
+                for (int i = 0; i < 2; ++i) {
+                    if (a[i]) (void)hipEventDestroy(a[i]);
+                    if (b[i]) (void)hipEventDestroy(b[i]);
+                }
+            }
+        } events{ev_piv, ev_inv};
+        if (ahead)
+            for (int i = 0; i < 2; ++i) {
+                HIP_CHECK(hipEventCreateWithFlags(&ev_piv[i], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&ev_inv[i], hipEventDisableTiming));
+            }
         const double one = 1, zero = 0, mone = -1;
         const rocblas_int ld = rocblas_int(n0);
         double *a = sys->a0.get();
-        for (size_t k0 = 0; k0 < n0; k0 += nb) {
+        uint32_t step = 0;
+        for (size_t k0 = 0; k0 < n0; k0 += nb, ++step) {
             const rocblas_int w = rocblas_int(std::min<size_t>(nb, n0 - k0));
-            mh_spd_inverse_small(ctx, a + k0 * n0 + k0, uint32_t(n0), uint32_t(w), pinv, uint32_t(w), info);
+            double *pinv = pinv2[step & 1]->get();
+            if (step == 0 || !ahead) mh_spd_inverse_small(ctx, a + k0 * n0 + k0, uint32_t(n0), uint32_t(w), pinv, uint32_t(w), info);
+            else HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_inv[step & 1], 0));
             HIP_CHECK(hipMemcpyAsync(cblk, a + k0 * n0, n0 * size_t(w) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, ld, w, &one, pinv, w, a + k0, ld, &zero, rblk, w));
+            const size_t k1 = k0 + nb;
+            if (ahead && k1 < n0) {
+                const uint32_t wn = uint32_t(std::min<size_t>(nb, n0 - k1));
+                HIP_CHECK(hipMemcpy2DAsync(pnext.get(), size_t(wn) * sizeof(double), a + k1 * n0 + k1, n0 * sizeof(double), size_t(wn) * sizeof(double), wn, hipMemcpyDeviceToDevice, ctx->stream));
+                mh_small_gemm(ctx, false, false, wn, wn, uint32_t(w), -1.0, cblk.get() + k1, uint32_t(n0), rblk.get() + k1 * size_t(w), uint32_t(w), 1.0, pnext.get(), wn);
+                HIP_CHECK(hipEventRecord(ev_piv[step & 1], ctx->stream));
+                HIP_CHECK(hipStreamWaitEvent(ctx->aux2_stream, ev_piv[step & 1], 0));
+                hipStream_t elimination = ctx->stream;
+                ctx->stream = ctx->aux2_stream;
+                try {
+                    mh_spd_inverse_small(ctx, pnext.get(), wn, wn, pinv2[(step + 1) & 1]->get(), wn, info);
+                } catch (...) {
+                    ctx->stream = elimination;
+                    throw;
+                }
+                ctx->stream = elimination;
+                HIP_CHECK(hipEventRecord(ev_inv[(step + 1) & 1], ctx->aux2_stream));
+            }
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, ld, w, &mone, cblk, ld, rblk, w, &one, a, ld));
             HIP_CHECK(hipMemcpy2DAsync(a + k0, n0 * sizeof(double), rblk.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), n0, hipMemcpyDeviceToDevice, ctx->stream));
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, w, w, &mone, cblk, ld, pinv, w, &zero, a + k0 * n0, ld));
-            HIP_CHECK(hipMemcpy2DAsync(a + k0 * n0 + k0, n0 * sizeof(double), pinv.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), size_t(w), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_CHECK(hipMemcpy2DAsync(a + k0 * n0 + k0, n0 * sizeof(double), pinv, size_t(w) * sizeof(double), size_t(w) * sizeof(double), size_t(w), hipMemcpyDeviceToDevice, ctx->stream));
         }
         k_symmetrize_lower<<<grid1(n0 * n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), uint32_t(n0));
         KERNEL_CHECK();
