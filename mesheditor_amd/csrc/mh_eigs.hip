@@ -83,6 +83,7 @@ const Switches &switches() {
 }
 // Design constants (each was once a switch; the losing side of every comparison is recorded in DESIGN.md section 10)
 constexpr int kPowerIterations = 20; // spectral-bound estimate of the smoothers (12 steps left the bound 15 % low on the scan meshes -- more than the 1.1 safety factor -- and one patch-threshold setting then failed to converge; the steps run beside the coarse elimination)
+constexpr uint32_t kPrecondColumns = 256; // widest panel of one preconditioner application (the single-precision wide-load products: 64 lanes x 4)
 constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
 constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
 constexpr size_t kDenseLastResort = 12288; // unknowns up to which a solve that did not converge is redone as one dense eigensolve (2 x 1.2 GB, seconds)
@@ -1298,8 +1299,8 @@ struct BlockLobpcg {
             res_norms.resize(size_t(2) * pmax);
         }
         info.reset(ctx, 2);
-        if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, b);
-        else prec64 = std::make_unique<Precond<double>>(sys, b);
+        if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, std::min(b, kPrecondColumns));
+        else prec64 = std::make_unique<Precond<double>>(sys, std::min(b, kPrecondColumns));
         auto hd = sys->L2.dinv.to_host();
         double dmin = 1e300;
         for (double v : hd) dmin = std::min(dmin, v);
@@ -1364,6 +1365,30 @@ struct BlockLobpcg {
         return true;
     }
 
+    // z = B r for w columns.  The smoothers' wide-load products take panels of at most 256 columns (64 lanes x 4 floats): a wider block
+    // (more than ~230 wanted pairs: beyond the reference editor's 128 + margin and BASELINE's 200) goes through in column slabs,
+    // gathered into a compact panel and scattered back (two extra passes over the slab, a few per cent of the cycle's own traffic).
+    void precondition(const double *r, double *z, uint32_t w) {
+        auto one = [&](const double *rp, double *zp, uint32_t wc) {
+            if (prec32) prec32->apply(rp, zp, wc);
+            else prec64->apply(rp, zp, wc);
+        };
+        if (w <= kPrecondColumns) return one(r, z, w);
+        const uint32_t slabs = div_up(w, kPrecondColumns), step = (div_up(w, slabs) + 3u) & ~3u;
+        if (w > 1024) mh_throw(MH_EINVAL, "a block of %u columns exceeds the 1 024 the column maps cover", w);
+        DevArray<double> rs(ctx, n * step), zs(ctx, n * step);
+        const uint32_t *iota = mh_identity_map(ctx);
+        for (uint32_t c0 = 0; c0 < w; c0 += step) {
+            const uint32_t wc = std::min(step, w - c0);
+            k_gather_cols<<<grid1(n * wc), TB, 0, st>>>(r, iota + c0, rs.get(), n, w, wc);
+            KERNEL_CHECK();
+            one(rs, zs, wc);
+            k_scatter_cols<<<grid1(n * wc), TB, 0, st>>>(zs.get(), iota + c0, z, n, w, wc);
+            KERNEL_CHECK();
+        }
+        HIP_CHECK(hipStreamSynchronize(st)); // the slabs return to the pool
+    }
+
     // The initial block: seed columns (warm start), then Gaussian noise, the exact rigid-body modes, one smoothing pass;
     // M-orthonormalised and rotated into its Ritz vectors.
     void start() {
@@ -1398,8 +1423,7 @@ struct BlockLobpcg {
             {
                 mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
                 Timer tp(ctx);
-                if (prec32) prec32->apply(MX, Xn, b);
-                else prec64->apply(MX, Xn, b);
+                precondition(MX, Xn, b);
                 precond_seconds += tp.stop();
                 prof.op_applications += b;
                 HIP_CHECK(hipMemcpyAsync(X, Xn.get(), n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1502,7 +1526,7 @@ struct BlockLobpcg {
             if (prec32 && it >= 10 && h > 6 && hist_nconv[h - 7] == nconv && worst > 0.5 * hist_worst[h - 7]) {
                 if (verbose) fprintf(stderr, "[lobpcg] it %3u stagnation: switching the preconditioner to double precision\n", it);
                 prec32.reset();
-                prec64 = std::make_unique<Precond<double>>(sys, b);
+                prec64 = std::make_unique<Precond<double>>(sys, std::min(b, kPrecondColumns));
             }
         }
         return false;
@@ -1539,8 +1563,7 @@ struct BlockLobpcg {
         theta_act_d.upload(theta_act.data(), w);
         {
             Timer tp(ctx);
-            if (prec32) prec32->apply(residuals, W, w);
-            else prec64->apply(residuals, W, w);
+            precondition(residuals, W, w);
             precond_seconds += tp.stop();
             prof.op_applications += w;
         }

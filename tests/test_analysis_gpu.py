@@ -484,6 +484,26 @@ def _residuals(sysg, ev, cols):
     return res, np.abs(V.T @ MV - np.eye(len(cols))).max()
 
 
+def test_blocks_wider_than_the_smoothers_panels(api, ctx, oracle):
+    """More wanted pairs than one preconditioner panel holds (256 columns: ~230 pairs): the block goes through the smoothers in
+    column slabs, the Rayleigh-Ritz step (order 3 x 304 > 768) through the library's eigensolver.  280 pairs of a 6 912-tet plate
+    against the oracle at 1e-6, and run-to-run reproducibility."""
+    m = meshes.MATERIALS["Iron"]
+    pts, tets = meshes.kuhn_box(24, 24, 2, 0.26, 0.26, 0.012)
+    nev = 280
+    mesh = api.Mesh(ctx, pts, tets)
+    sysg = api.System(ctx, mesh, api.material(*m))
+    ev, prof = sysg.eigs(nev, SIGMA, 1e-6, max_iters=120)
+    ev2, _ = sysg.eigs(nev, SIGMA, 1e-6, max_iters=120)
+    assert len(ev) == nev and np.array_equal(ev, ev2)
+    evo, _, _ = oracle.System(pts, tets, oracle.material(*m)).eigs(nev, vectors=False)
+    elastic = evo > 1e-6 * evo[-1]
+    assert elastic.sum() == nev - 6
+    assert (np.abs(ev[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    sysg.close()
+    mesh.close()
+
+
 def test_skillet_config3_at_its_workload(api, ctx, oracle):
     """BASELINE configs[2]: the thin iron skillet plate at ~100k tets (103,788) with 200 kept modes / 215 eigenpairs --
     size-independent properties on the device result (residuals, M-orthonormality, rigid-body count, Leissa's free-plate
