@@ -253,8 +253,10 @@ class ModalResult:
 
 def residual_tolerance(cfg):
     """SolverConfig::Tolerance is Spectra's Ritz-value tolerance; a relative residual r gives an eigenvalue error ~ r^2,
-    so sqrt(tol)/10 meets it with margin (1e-5 for the default 1e-8)."""
-    return float(min(1e-4, max(1e-9, 0.1 * np.sqrt(cfg.tolerance))))
+    so sqrt(tol)/10 meets it with margin (1e-5 for the default 1e-8).  The lower clamp is 1e-8: eigenvalues at round-off already, and
+    below it a mesh with slivers sits at the rounding floor of forming A x (1e-9 never converges on the repaired scan fill;
+    tools/probe/tight_tolerance_probe.py)."""
+    return float(min(1e-4, max(1e-8, 0.1 * np.sqrt(cfg.tolerance))))
 
 
 def mesh2modes(ctx, points, tets, mat, excite_positions, baked_scale=(1.0, 1.0, 1.0), config=None, seed_basis=None, keep_basis=False, mesh=None, keep_system=False):
@@ -285,7 +287,7 @@ def mesh2modes(ctx, points, tets, mat, excite_positions, baked_scale=(1.0, 1.0, 
     keep = False
     try:
         warm = seed_basis is not None and seed_basis.shape[0] == n and seed_basis.shape[1] >= nev
-        tol = float(min(1e-2, max(1e-9, np.sqrt(cfg.warm_tolerance) * 1e-2))) if warm else residual_tolerance(cfg)
+        tol = float(min(1e-2, max(1e-8, np.sqrt(cfg.warm_tolerance) * 1e-2))) if warm else residual_tolerance(cfg)
         try:
             ev, prof = system.eigs(nev, sigma, tol, max(cfg.max_restarts, 1) * 3, seed_basis if warm else None)
         except ModalHipError as e:

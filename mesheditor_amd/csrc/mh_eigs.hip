@@ -1230,6 +1230,7 @@ struct BlockLobpcg {
     SharedPhase iterating; // released and re-taken at the top of every iteration so that a waiting factorisation gets in
     Timer t_iter;
     double precond_seconds = 0;
+    double best_worst_active = 1e300; // smallest worst relative residual of the active columns seen so far
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
     DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
@@ -1528,6 +1529,19 @@ struct BlockLobpcg {
                 prec32.reset();
                 prec64 = std::make_unique<Precond<double>>(sys, std::min(b, kPrecondColumns));
             }
+            // A tolerance below what the mesh admits (the rounding floor of forming A x on a sliver-heavy fill: 1e-9 on the repaired
+            // scan) leaves the last active columns at their floor; W then lies in span(X, P) to rounding, the Cholesky-QR spread grows
+            // and the residuals of those columns start to GROW, doubling per iteration (tools/probe/tight_tolerance_probe.py).  Say so
+            // instead of iterating into a rank failure.
+            double worst_active = 0;
+            for (uint32_t k = 0; k < nev; ++k) { // (the wanted pairs only: guard columns converge late by design)
+                const uint32_t i = order[k];
+                if (!locked[i]) worst_active = std::max(worst_active, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
+            }
+            best_worst_active = std::min(best_worst_active, worst_active);
+            if (it >= 20 && worst_active > 1e3 * best_worst_active)
+                mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged; the others sit at the rounding floor (residual %.1e and growing, best %.1e, tolerance %.1e)", nconv, nev,
+                         worst_active, best_worst_active, residual_tol);
         }
         return false;
     }

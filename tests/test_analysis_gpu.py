@@ -484,6 +484,28 @@ def _residuals(sysg, ev, cols):
     return res, np.abs(V.T @ MV - np.eye(len(cols))).max()
 
 
+def test_a_tolerance_below_the_rounding_floor_fails_cleanly(api, ctx):
+    """A residual tolerance the mesh does not admit (1e-11 on the cube: the floor of forming A x is ~1e-10 relative) ends in
+    MH_ENOTCONVERGED with a message that says so -- not in a rank failure of the search directions 40 iterations later -- and the
+    public tolerance mapping never asks for less than 1e-8 (eigenvalues at round-off), which every workload meets."""
+    from mesheditor_amd.api import ModalHipError, default_config, residual_tolerance
+    pts, tets, m, _ = meshes.workload("cube_s10k")
+    mesh = api.Mesh(ctx, pts, tets)
+    sysg = api.System(ctx, mesh, api.material(*m))
+    with pytest.raises(ModalHipError) as err:
+        sysg.eigs(65, SIGMA, 1e-11)
+    assert "rounding floor" in str(err.value) or "converged in" in str(err.value)
+    ev8, _ = sysg.eigs(65, SIGMA, 1e-8)
+    ev6, _ = sysg.eigs(65, SIGMA, 1e-6)
+    el = ev8 > 1e-6 * ev8[-1]
+    assert (np.abs(ev8[el] - ev6[el]) / ev8[el]).max() < 1e-10
+    cfg = default_config()
+    cfg.tolerance = 1e-30
+    assert residual_tolerance(cfg) == 1e-8
+    sysg.close()
+    mesh.close()
+
+
 def test_blocks_wider_than_the_smoothers_panels(api, ctx, oracle):
     """More wanted pairs than one preconditioner panel holds (256 columns: ~230 pairs): the block goes through the smoothers in
     column slabs, the Rayleigh-Ritz step (order 3 x 304 > 768) through the library's eigensolver.  280 pairs of a 6 912-tet plate
