@@ -1036,6 +1036,8 @@ uint32_t mo_result_num_modes(const mo_result *r) { return uint32_t(r->r.Modes.Fr
 uint32_t mo_result_num_positions(const mo_result *r) { return uint32_t(r->r.Modes.Positions.size()); }
 uint32_t mo_result_num_eigenpairs(const mo_result *r) { return uint32_t(r->r.Summary.Eigenvalues.size()); }
 uint32_t mo_result_num_excitations(const mo_result *r) { return uint32_t(r->r.SamplePointOfExcitation.size()); }
+// (the summary keeps its sample points also when no mode survives the band filter and Modes.Positions is empty)
+uint32_t mo_result_num_summary_points(const mo_result *r) { return uint32_t(r->r.Summary.Shapes.size()); }
 void mo_result_modes(const mo_result *r, float *freqs, float *t60s, float *shapes, float *positions, float *original_fundamental) {
     PackModes(r->r.Modes, freqs, t60s, shapes, original_fundamental);
     if (positions)

@@ -53,6 +53,7 @@ uint32_t mo_result_num_modes(const mo_result *);
 uint32_t mo_result_num_positions(const mo_result *);
 uint32_t mo_result_num_eigenpairs(const mo_result *);
 uint32_t mo_result_num_excitations(const mo_result *);
+uint32_t mo_result_num_summary_points(const mo_result *r);
 /* shapes: [position][mode][xyz]; positions: [position][xyz] */
 void mo_result_modes(const mo_result *, float *freqs, float *t60s, float *shapes, float *positions, float *original_fundamental);
 /* ModalEigenSummary: eigenvalues ascending, shapes [position][eigenpair][xyz] */

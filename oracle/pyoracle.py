@@ -84,7 +84,7 @@ def lib():
         for name in ("mo_result_free", "mo_system_free", "mo_bank_free"):
             getattr(L, name).argtypes = [vp]
             getattr(L, name).restype = None
-        for name in ("mo_result_num_modes", "mo_result_num_positions", "mo_result_num_eigenpairs", "mo_result_num_excitations",
+        for name in ("mo_result_num_modes", "mo_result_num_positions", "mo_result_num_eigenpairs", "mo_result_num_excitations", "mo_result_num_summary_points",
                      "mo_result_basis_rows", "mo_result_basis_cols", "mo_system_dofs", "mo_system_node_count", "mo_system_kept_tets",
                      "mo_bank_num_objects", "mo_bank_num_modes", "mo_bank_active_impacts"):
             getattr(L, name).argtypes = [vp]
@@ -218,7 +218,7 @@ def mesh2modes(points, tets, mat, excite_positions, baked_scale=(1.0, 1.0, 1.0),
         shapes, positions = np.zeros((npos, k, 3), np.float32), np.zeros((npos, 3), np.float32)
         orig = C.c_float(0)
         L.mo_result_modes(h, _p(freqs), _p(t60s), _p(shapes), _p(positions), C.byref(orig))
-        ev, sshapes = np.zeros(nev), np.zeros((npos if nev else 0, nev, 3), np.float32)
+        ev, sshapes = np.zeros(nev), np.zeros((L.mo_result_num_summary_points(h), nev, 3), np.float32)
         L.mo_result_summary(h, _p(ev), _p(sshapes))
         mass = C.c_double(0)
         com, inertia, quat = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(4, np.float32)

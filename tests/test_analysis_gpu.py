@@ -506,6 +506,24 @@ def test_a_tolerance_below_the_rounding_floor_fails_cleanly(api, ctx):
     mesh.close()
 
 
+def test_band_filter_that_keeps_nothing_still_returns_the_summary(api, ctx, oracle):
+    """As the oracle test of the same name: empty modes, full eigen-summary (eigenvalues at 1e-6, shapes of the same layout), same
+    mass properties and excitation map -- for a band below the spectrum and for one above the solved pairs."""
+    pts, tets = meshes.jittered_box(4, 7)
+    m = meshes.MATERIALS["Glass"]
+    ex = pts[::9].astype(np.float32)
+    for kw in (dict(max_mode_freq=10.0), dict(min_mode_freq=20000.0, max_mode_freq=1e6)):
+        ro = oracle.mesh2modes(pts, tets, oracle.material(*m), ex, config=oracle.default_config(num_modes=10, num_fem_modes=20, **kw))
+        rg = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(num_modes=10, num_fem_modes=20, **kw))
+        assert len(rg.freqs) == len(ro.freqs) == 0
+        assert len(rg.eigenvalues) == len(ro.eigenvalues) == 20
+        el = ro.eigenvalues > 1e-6 * ro.eigenvalues[-1]
+        assert (np.abs(rg.eigenvalues[el] - ro.eigenvalues[el]) / ro.eigenvalues[el]).max() < 1e-6
+        assert rg.summary_shapes.shape == ro.summary_shapes.shape
+        assert np.array_equal(rg.sample_point_of_excitation, ro.sample_point_of_excitation)
+        assert abs(rg.mass - ro.mass) <= 1e-12 * ro.mass
+
+
 def test_blocks_wider_than_the_smoothers_panels(api, ctx, oracle):
     """More wanted pairs than one preconditioner panel holds (256 columns: ~230 pairs): the block goes through the smoothers in
     column slabs, the Rayleigh-Ritz step (order 3 x 304 > 768) through the library's eigensolver.  280 pairs of a 6 912-tet plate

@@ -279,3 +279,17 @@ def test_warm_start_subspace_iteration(oracle):
     dup = np.vstack([ex[:3], ex[:3] + 1e-6])
     r = oracle.mesh2modes(pts, tets, m, dup, config=cfg)
     assert list(r.sample_point_of_excitation) == [0, 1, 2, 0, 1, 2] and len(r.positions) == 3
+
+
+def test_band_filter_that_keeps_nothing_still_returns_the_summary(oracle):
+    """mesh2modes.cpp:567-616: when no eigenpair survives [MinModeFreq, MaxModeFreq] the modes are empty but the eigen-summary keeps
+    its eigenvalues and per-sample-point shapes (the editor re-filters it without a new solve).  The binding once sized the
+    summary's shapes by the (empty) mode positions and overran the array (found by tools/probe/config_fuzz.py)."""
+    pts, tets = meshes.jittered_box(4, 7)
+    m = meshes.MATERIALS["Glass"]
+    ex = pts[::9].astype(np.float32)
+    for kw in (dict(max_mode_freq=10.0), dict(min_mode_freq=20000.0, max_mode_freq=1e6)):
+        r = oracle.mesh2modes(pts, tets, oracle.material(*m), ex, config=oracle.default_config(num_modes=10, num_fem_modes=20, **kw))
+        assert len(r.freqs) == 0 and len(r.eigenvalues) == 20
+        assert r.summary_shapes.shape[1:] == (20, 3) and r.summary_shapes.shape[0] >= 1 and np.isfinite(r.summary_shapes).all()
+        assert np.abs(r.summary_shapes).max() > 0
