@@ -419,9 +419,37 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
 
 // G (wa x wb, column-major, leading dimension ld) = X^T Y.  Blocks wider than 160 x 96 columns are cut into a grid
 // of column blocks (each a launch of the register-blocked kernel over the same rows).
+static bool gram_library_for_wide() {
+    static const bool v = !(getenv("MH_TEST") && strstr(getenv("MH_TEST"), "own_wide_gram"));
+    return v;
+}
 void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld, uint32_t ldy, const uint32_t *ymap) {
     if (!wa || !wb) return;
     if (!ldy) ldy = wb;
+    // Wide blocks (both sides >= 128 columns: the 200-mode configuration) through the vendor's batched dgemm, one batch member per row
+    // slab (split-K by hand: the output alone is four macro tiles), partials added in a fixed order by k_gram_reduce as for our own
+    // kernel.  Row-major panels are column-major transposes: G = (X^T)(Y^T)^T = dgemm(N, T) on the stored arrays.
+    if (wa >= 128 && wb >= 128 && n >= 65536 && !ymap && gram_library_for_wide()) {
+        const uint32_t slabs = 128; // (32 ... 256 slabs: 1.41 ... 1.45 ms on 240 x 240 at 542 k rows; 512: 1.54)
+        const size_t rows = n / slabs, rest = n - rows * slabs; // the first `slabs` members take `rows` rows each, one more call the rest
+        const size_t members = slabs + (rest ? 1 : 0), need = members * size_t(wa) * wb * sizeof(double);
+        if (ctx->gram_ws_bytes < need) {
+            ctx->pool.release(ctx->gram_ws);
+            ctx->gram_ws = ctx->pool.alloc(need + need / 4);
+            ctx->gram_ws_bytes = need + need / 4;
+        }
+        double *ws = static_cast<double *>(ctx->gram_ws);
+        const double one = 1, zero = 0;
+        ROCBLAS_CHECK(rocblas_dgemm_strided_batched(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, rocblas_int(wa), rocblas_int(wb), rocblas_int(rows), &one, x,
+                                                    rocblas_int(wa), rocblas_stride(rows * wa), y, rocblas_int(ldy), rocblas_stride(rows * ldy), &zero, ws, rocblas_int(wa),
+                                                    rocblas_stride(size_t(wa) * wb), rocblas_int(slabs)));
+        if (rest)
+            ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, rocblas_int(wa), rocblas_int(wb), rocblas_int(rest), &one, x + rows * slabs * wa,
+                                        rocblas_int(wa), y + rows * slabs * ldy, rocblas_int(ldy), &zero, ws + size_t(slabs) * wa * wb, rocblas_int(wa)));
+        k_gram_reduce<<<div_up(size_t(wa) * wb, 64), 1024, 0, ctx->stream>>>(ws, int(members), int(wa), int(wb), g, int(ld));
+        KERNEL_CHECK();
+        return;
+    }
     const bool a_long = wa >= wb;
     // A launch costs its tile SLOTS (15 per wave, 2 x 2 waves at the widest: 160 x 96), used or not: 240 x 240 cut evenly into 2 x 3
     // launches of 128 x 80 fills 40 of 60 slots each (2.10 ms at 542 k rows); cut as 160 + 80 by 3 x 80 it fills 50 of 60 and 25 of 30
