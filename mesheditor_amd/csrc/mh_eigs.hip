@@ -83,7 +83,7 @@ const Switches &switches() {
 }
 // Design constants (each was once a switch; the losing side of every comparison is recorded in DESIGN.md section 10)
 constexpr int kPowerIterations = 20; // spectral-bound estimate of the smoothers (12 steps left the bound 15 % low on the scan meshes -- more than the 1.1 safety factor -- and one patch-threshold setting then failed to converge; the steps run beside the coarse elimination)
-constexpr uint32_t kPrecondColumns = 256; // widest panel of one preconditioner application (the single-precision wide-load products: 64 lanes x 4)
+constexpr uint32_t kPrecondColumns = 256; // (narrower slabs measured slower on the 215-pair solves: 128 -> +2 %, 80 -> +5 %, 64 -> +9 %) // widest panel of one preconditioner application (the single-precision wide-load products: 64 lanes x 4)
 constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
 constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
 constexpr size_t kDenseLastResort = 12288; // unknowns up to which a solve that did not converge is redone as one dense eigensolve (2 x 1.2 GB, seconds)
