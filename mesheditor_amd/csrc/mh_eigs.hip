@@ -1888,6 +1888,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         // guard vectors: at least 15 (measured at S100k, nev = 65: 10 -> 23 iterations / 338 ms, 15 -> 19 / 317 ms,
         // 31 -> 15 / 338 ms), block rounded up to whole 16-column MFMA tiles
         // (every further disconnected body brings six more zero modes: the block grows by as many columns)
+        // (215 pairs: 240 columns -> 23 / 24 / 21 iterations on the three 215-pair workloads, 256 columns -> 21 / 21 / 19 but +2 ... +4 % time)
         uint32_t b = (nev + std::max(15u, nev * kGuardPercent / 100) + 6u * (sys->n_components - 1u) + 15u) / 16u * 16u;
         if (n <= 768 || n < size_t(5) * b) {
             Timer t(ctx);
