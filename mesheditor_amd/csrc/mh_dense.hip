@@ -419,17 +419,13 @@ void gram_block(mh_context *ctx, size_t n, const double *x, uint32_t ldx, uint32
 
 // G (wa x wb, column-major, leading dimension ld) = X^T Y.  Blocks wider than 160 x 96 columns are cut into a grid
 // of column blocks (each a launch of the register-blocked kernel over the same rows).
-static bool gram_library_for_wide() {
-    static const bool v = !(getenv("MH_TEST") && strstr(getenv("MH_TEST"), "own_wide_gram"));
-    return v;
-}
 void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g, uint32_t ld, uint32_t ldy, const uint32_t *ymap) {
     if (!wa || !wb) return;
     if (!ldy) ldy = wb;
     // Wide blocks (both sides >= 128 columns: the 200-mode configuration) through the vendor's batched dgemm, one batch member per row
     // slab (split-K by hand: the output alone is four macro tiles), partials added in a fixed order by k_gram_reduce as for our own
     // kernel.  Row-major panels are column-major transposes: G = (X^T)(Y^T)^T = dgemm(N, T) on the stored arrays.
-    if (wa >= 128 && wb >= 128 && n >= 65536 && !ymap && gram_library_for_wide()) {
+    if (wa >= 128 && wb >= 128 && n >= 65536 && !ymap) {
         const uint32_t slabs = 128; // (32 ... 256 slabs: 1.41 ... 1.45 ms on 240 x 240 at 542 k rows; 512: 1.54)
         const size_t rows = n / slabs, rest = n - rows * slabs; // the first `slabs` members take `rows` rows each, one more call the rest
         const size_t members = slabs + (rest ? 1 : 0), need = members * size_t(wa) * wb * sizeof(double);

@@ -50,11 +50,11 @@ std::mutex g_solve_mutex;
 //   MH_PRECOND_FP64=1       double-precision smoothers (default: single precision with double residuals between levels)
 //   MH_CYCLE=d2,d1,g,ratio  shape of the preconditioner cycle: Chebyshev degrees of the P2 and P1 smoothers, P1 cycles per
 //                           application, spectrum ratio lmax / lmin the smoothers target; 0 or missing keeps a built-in value
-//   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out),
-//                           no_sytrd_wide (orders above 256 go to the library's syevd whole: the A/B of k_sytrd_wide),
-//                           no_tridiag_wide (orders above 256: the library's divide and conquer for all pairs instead of our partial spectrum),
-//                           no_coarse_lookahead (the coarse elimination's pivot inverses in line instead of one step ahead on a third stream),
-//                           library_small_gemm (the step's order-m products through rocBLAS: the A/B of k_small_gemm)
+//   MH_TEST=...             test hooks, comma separated: sytrd_giveup (treat every multi-workgroup tridiagonalisation as timed out: the
+//                           fall-backs to the one-workgroup kernel / the library's syevd run), no_tridiag_wide (orders above 256: the
+//                           fall-back of the partial-spectrum stage -- the library's divide and conquer and ormtr -- runs)
+//   (the A/B hooks of round 4 -- wide tridiagonalisation, small products, pivot look-ahead, power-iteration norms, wide Gram -- are gone
+//   with their measurements recorded in profiles/r04_setup_ab.txt, r04_dense_kernels.txt, r04_gram_cuts.txt and DESIGN.md section 10)
 // and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
 // threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
 struct Switches {
@@ -63,11 +63,7 @@ struct Switches {
     int deg2 = 0, deg1 = 0, gamma = 0; // 0: the built-in cycle shape
     double cheb_ratio = 0.0;
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
-    bool no_sytrd_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_sytrd_wide");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
-    bool no_coarse_lookahead = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_coarse_lookahead");
-    bool power_every_step = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "power_every_step");
-    bool library_small_gemm = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "library_small_gemm");
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
             double v[4] = {0, 0, 0, 0};
@@ -576,7 +572,7 @@ void panel_trsm(mh_context *ctx, size_t n, double *wp, uint32_t w, const double 
 // on the device at these orders); anything larger goes to the library.
 void small_dgemm(mh_context *ctx, rocblas_operation ta, rocblas_operation tb, rocblas_int M, rocblas_int N, rocblas_int K, const double *alpha, const double *a, rocblas_int lda, const double *b,
                  rocblas_int ldb, const double *beta, double *c, rocblas_int ldc) {
-    if (M <= 1024 && N <= 1024 && K <= 4096 && !switches().library_small_gemm)
+    if (M <= 1024 && N <= 1024 && K <= 4096)
         mh_small_gemm(ctx, ta != rocblas_operation_none, tb != rocblas_operation_none, uint32_t(M), uint32_t(N), uint32_t(K), *alpha, a, uint32_t(lda), b, uint32_t(ldb), *beta, c, uint32_t(ldc));
     else
         ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, ta, tb, M, N, K, alpha, a, lda, b, ldb, beta, c, ldc));
@@ -724,7 +720,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         // there (8.3 of 15 ms at order 720); k_sytrd_wide does it in 4.4 ms across 48 workgroups, then the library's divide and
         // conquer on T and its back-transformation.  A give-up (see above) falls back to the library's syevd on the saved matrix.
         bool done = false;
-        if (m > 256 && m <= 768 && !switches().no_sytrd_wide) {
+        if (m > 256 && m <= 768) {
             DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
             HIP_CHECK(hipMemcpyAsync(z.get(), gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             mh_sytrd_wide(ctx, gA, m, evals, ework, tau);
@@ -959,7 +955,7 @@ double estimate_lmax(mh_context *ctx, BsrLevel &lvl, const PatchSet &ps) {
         // The columns are rescaled every fourth step only (the iterate grows by at most lmax <= ~20 per step: 1.6e5 in four), and
         // before the last step, whose norm is the estimate: the column norms and the rescaling were 45 % of a step's 390 us, and
         // this loop -- not the coarse elimination beside it -- is what `factorize` waits for.
-        const bool last = it + 1 == power_its, rescale = !last && (it % 4 == 3 || it + 2 == power_its || switches().power_every_step);
+        const bool last = it + 1 == power_its, rescale = !last && (it % 4 == 3 || it + 2 == power_its);
         if (last || rescale) colsumsq(ctx, v, rows, w, nrm, scratch);
         if (rescale) {
             k_scale_cols_inv_sqrt<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, nrm, rows, w);
@@ -1078,7 +1074,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
         // One step ahead: the pivot block of step k + 1 is brought up to date FIRST (a 128 x 128 x 128 product of ours into a buffer of
         // its own) and inverted on a third stream while the rank-128 update of the whole matrix runs -- the one-workgroup inverse
         // (117 us) and the update (131 us) were 85 % of a step's 287 us, one after the other.
-        const bool ahead = side && ctx->aux2_stream_ready() && !switches().no_coarse_lookahead;
+        const bool ahead = side && ctx->aux2_stream_ready();
         hipEvent_t ev_piv[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
         struct EventGuard {
             hipEvent_t *a, *b;
