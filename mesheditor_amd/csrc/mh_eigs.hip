@@ -1765,7 +1765,7 @@ struct BlockLobpcg {
         // the active columns) instead of being recombined from [A X, A W, A P] and [M X, M W, M P]: one pass over the matrix
         // costs less than two passes over three tall panels each, the images carry no accumulated rounding, and A P is
         // not needed at all (P^T A P comes from the small matrices, above).  M P, which the next projection needs, is
-        // still recombined -- before M X is overwritten.
+        // one product with M alone.
         {
             const uint32_t pitch = (wa + 1u) & ~1u; // 16-byte rows for the wide-load product
             if (w_implicit) { // the basis holds W, not W L^-T: every coefficient row of the W part <- L^-T row (all columns)
@@ -1782,15 +1782,10 @@ struct BlockLobpcg {
                                             rocblas_int(wp), &plus, rows_p, pitchc));
             }
             mh_combine(ctx, n, X, wa, W, w, P, wp, Ct, wa + wp_new, Xn, wa, Pn, false, b, idx_d, pitch);
-            if (wp_new && !pproj_ok) {
-                if (lazy_images && !w_implicit) { // M W_new = (M W_old) L^-T: rows [wa, wa + w) of Ct (k-major), the columns of Cp, <- L^-T rows
-                    const double unit = 1;
-                    double *rows = Ct.get() + size_t(wa) * (wa + wp_new) + wa;
-                    ROCBLAS_CHECK(rocblas_dtrmm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, rocblas_int(wp_new),
-                                                rocblas_int(w), &unit, Linv, rocblas_int(w), rows, rocblas_int(wa + wp_new), rows, rocblas_int(wa + wp_new)));
-                }
-                mh_combine(ctx, n, MX, wa, MW, w, MP, wp, Ct, wa + wp_new, nullptr, wa, MPn, false, b, idx_d, 0, nullptr, wa, wp_new);
-            }
+            // M P_new (kept for blocks wider than 128 columns: the next projection needs it) from P_new itself: one pass over M.  Until
+            // round 4 it was recombined from [M X, M W, M P] with the coefficients of P_new -- three tall panels read for one written:
+            // 215-pair solves 1.7 ... 2.8 % slower, 129-pair solves 1 ... 1.5 % (and the image carried the recombination's rounding).
+            if (wp_new && !pproj_ok) mh_spmm(ctx, sys->L2, nullptr, Pn, nullptr, sys->L2.mval, MPn, wp_new);
             if (pitch == wa) k_scatter_cols<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), idx_d, X.get(), n, b, wa);
             else k_scatter_cols_pitch<<<grid1(n * wa), TB, 0, st>>>(Xn.get(), pitch, idx_d, X.get(), n, b, wa);
             KERNEL_CHECK();
