@@ -380,6 +380,7 @@ void mh_apply_q(mh_context *ctx, const double *a, const double *tau, uint32_t m,
 bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32_t m, uint32_t k, double *w, double *z, uint32_t ldz, double *ufac,
                        double *quality, double *lam_scratch); // mh_dense.hip: k lowest eigenpairs of a tridiagonal matrix (quality: 8 doubles, lam_scratch: k)
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info); // mh_dense.hip
+void mh_potrf(mh_context *ctx, double *a, uint32_t ld, uint32_t w, int *info); // mh_dense.hip: lower Cholesky of any order without rocSOLVER (info: two ints)
 void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info); // mh_dense.hip: lower Cholesky, order <= 128, one workgroup
 bool mh_sytrd_gave_up(mh_context *ctx);
 void mh_sytrd_wide(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau); // orders up to 768, 48 workgroups over all XCDs (mh_dense.hip)

@@ -1748,12 +1748,14 @@ bool mh_tridiag_lowest_wide(mh_context *ctx, const double *d, const double *e, u
     KERNEL_CHECK();
     k_tridiag_invit<<<div_up(k, 64), 64, 0, ctx->stream>>>(d, e, int(m), int(k), w, xt, ufac);
     KERNEL_CHECK();
-    HIP_CHECK(hipMemsetAsync(info2, 0, 2 * sizeof(int), ctx->stream));
+    DevArray<int> info4_array(ctx, 4);
+    int *info4 = info4_array.get();
+    HIP_CHECK(hipMemsetAsync(info4, 0, 4 * sizeof(int), ctx->stream));
     // xt is X^T (k x m column-major).  Pass 1: xt2 = L^-1 xt; pass 2: z = xt2^T L^-T
     for (int pass = 0; pass < 2; ++pass) {
         const double *src = pass == 0 ? xt : xt2;
         mh_small_gemm(ctx, false, true, k, k, m, 1.0, src, k, src, k, 0.0, g, k);
-        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, rocblas_int(k), g, rocblas_int(k), info2 + pass));
+        mh_potrf(ctx, g, k, k, info4 + 2 * pass);
         HIP_CHECK(hipMemsetAsync(linv, 0, size_t(k) * k * sizeof(double), ctx->stream));
         ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, rocblas_int(k), g, rocblas_int(k), linv, rocblas_int(k)));
         if (pass == 0) mh_small_gemm(ctx, false, false, k, m, k, 1.0, linv, k, src, k, 0.0, xt2, k);
@@ -1762,11 +1764,11 @@ bool mh_tridiag_lowest_wide(mh_context *ctx, const double *d, const double *e, u
     HIP_CHECK(hipMemsetAsync(qual, 0, sizeof(double), ctx->stream));
     k_tridiag_residual<<<k, 256, 0, ctx->stream>>>(d, e, int(m), w, z, int(ldz), reinterpret_cast<unsigned long long *>(qual));
     KERNEL_CHECK();
-    int hinfo[2] = {0, 0};
+    int hinfo[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpyAsync(quality_host, qual, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(hinfo, info2, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(hinfo, info4, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (hinfo[0] != 0 || hinfo[1] != 0) *quality_host = std::numeric_limits<double>::quiet_NaN();
+    if (hinfo[0] != 0 || hinfo[2] != 0) *quality_host = std::numeric_limits<double>::quiet_NaN();
     return true;
 }
 
@@ -2011,6 +2013,45 @@ void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info) {
         k_potrf_panels<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
     } else k_potrf_small<<<1, 256, size_t(w) * (w + 1) * sizeof(double), ctx->stream>>>(a, int(w), info);
     KERNEL_CHECK();
+}
+
+// Lower Cholesky factor of any order in 128-column blocks, every piece a kernel of ours or a rocBLAS level-3 routine: the diagonal block
+// by k_potrf_panels, its triangular inverse by rocblas_dtrtri, the panel below and the trailing update by k_small_gemm.  It exists because
+// rocsolver_dpotrf is disturbed by work running beside it on the device (mh_eigs.hip, "Concurrency contract": wrong factors in ~10 % of
+// the calls while another stream runs the Gram kernel) -- three host threads solving 140 or 215 pairs each on their own contexts lost rank
+// or converged to perturbed eigenvalues in a third of the solves (tools/concurrent_solves.py 3 18 14 215) while blocks wider than 128
+// columns still went through it.  info[0] = 0 or the 1-based column of the first non-positive pivot; info[1] = the diagonal spread report
+// of k_potrf_panels for orders <= 128, 1 << 20 (unknown) above.  Same time as the library's at order 240 (~140 us).
+namespace {
+__global__ void k_potrf_merge_info(const int *__restrict__ block_info, int k0, int *__restrict__ info) {
+    if (info[0] == 0 && block_info[0] != 0) info[0] = k0 + block_info[0];
+    info[1] = 1 << 20;
+}
+} // namespace
+void mh_potrf(mh_context *ctx, double *a, uint32_t ld, uint32_t w, int *info) {
+    if (!w) return;
+    if (w <= 128 && ld == w) return mh_potrf_small(ctx, a, w, info);
+    constexpr uint32_t nb = 128;
+    DevArray<double> blk(ctx, size_t(nb) * nb), linv(ctx, size_t(nb) * nb), pan(ctx, size_t(w) * nb);
+    DevArray<int> binfo(ctx, 2);
+    HIP_CHECK(hipMemsetAsync(info, 0, 2 * sizeof(int), ctx->stream));
+    for (uint32_t k0 = 0; k0 < w; k0 += nb) {
+        const uint32_t wk = std::min(nb, w - k0), r = w - k0 - wk;
+        double *akk = a + size_t(k0) * ld + k0;
+        HIP_CHECK(hipMemcpy2DAsync(blk.get(), size_t(wk) * sizeof(double), akk, size_t(ld) * sizeof(double), size_t(wk) * sizeof(double), wk, hipMemcpyDeviceToDevice, ctx->stream));
+        mh_potrf_small(ctx, blk, wk, binfo);
+        k_potrf_merge_info<<<1, 1, 0, ctx->stream>>>(binfo, int(k0), info);
+        KERNEL_CHECK();
+        HIP_CHECK(hipMemcpy2DAsync(akk, size_t(ld) * sizeof(double), blk.get(), size_t(wk) * sizeof(double), size_t(wk) * sizeof(double), wk, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!r) break;
+        HIP_CHECK(hipMemsetAsync(linv, 0, size_t(wk) * wk * sizeof(double), ctx->stream));
+        ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, rocblas_int(wk), blk, rocblas_int(wk), linv, rocblas_int(wk)));
+        double *a21 = akk + wk, *a22 = a + size_t(k0 + wk) * ld + k0 + wk;
+        mh_small_gemm(ctx, false, true, r, wk, wk, 1.0, a21, ld, linv, wk, 0.0, pan, r); // L21 = A21 L11^-T
+        HIP_CHECK(hipMemcpy2DAsync(a21, size_t(ld) * sizeof(double), pan.get(), size_t(r) * sizeof(double), size_t(r) * sizeof(double), wk, hipMemcpyDeviceToDevice, ctx->stream));
+        mh_small_gemm(ctx, false, true, r, r, wk, -1.0, pan, r, pan, r, 1.0, a22, ld); // A22 -= L21 L21^T
+    }
+    // (no synchronisation: the workspaces return to the context's pool, whose blocks are only ever used on this same stream)
 }
 
 // ---- small dense products --------------------------------------------------------------------------------------

@@ -38,8 +38,14 @@ constexpr int TB = 256;
 //     diagonal-block inverses + rocBLAS dgemm), which needs no isolation -- and is faster than potrf + potri;
 //   * solves of different contexts iterate side by side.  Each iteration holds the device phase lock SHARED, as do the other
 //     entry points that launch work (assembly, nearest points, shape gathers, bank rendering);
-//   * what still goes through a rocSOLVER factorisation -- the tiny-system dense eigensolve (sygvd), and the coarse
-//     operator under MH_COARSE_ROCSOLVER=1 -- takes the lock EXCLUSIVELY after a device-wide synchronisation: it runs alone.
+//   * what still goes through a rocSOLVER factorisation -- the tiny-system dense eigensolve (sygvd) -- takes the lock
+//     EXCLUSIVELY after a device-wide synchronisation: it runs alone;
+//   * (round 4) the iteration itself calls no rocSOLVER factorisation any more: the Cholesky factors of blocks wider than 128
+//     columns went through rocsolver_dpotrf until then, and three threads solving 140 or 215 pairs each lost rank or converged
+//     to perturbed eigenvalues in a third of their solves (tools/concurrent_solves.py 3 18 14 215).  mh_potrf (mh_dense.hip)
+//     factors in 128-column blocks with our kernels and rocBLAS level 3.  What is left of rocSOLVER inside the iteration are the
+//     Rayleigh-Ritz fall-backs (stedc / ormtr after a failed residual check, syevd above order 768 or after a timed-out
+//     exchange): none of them is a Cholesky factorisation, and the soak at 280 pairs (syevd every step) is clean.
 // 2.0x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
 // MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex).
 std::mutex g_solve_mutex;
@@ -653,7 +659,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         identity = true;
     }
     if (!identity) {
-        ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, m, gM, m, info));
+        mh_potrf(ctx, gM, m, m, info);
         info.download(&hinfo, 1);
         if (hinfo != 0) return hinfo;
         ROCBLAS_CHECK(rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, m, m, &one, gM, m, gA, m));
@@ -1332,8 +1338,8 @@ struct BlockLobpcg {
                 info.download(both, 2);
                 hinfo = both[0];
                 last_spread = both[1];
-            } else {
-                ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
+            } else { // (blocked, without rocSOLVER: its potrf is disturbed by concurrent solves -- mh_potrf)
+                mh_potrf(ctx, Gs, w, w, info);
                 info.download(&hinfo, 1);
             }
         }
@@ -1727,13 +1733,8 @@ struct BlockLobpcg {
             double *Gs = G.get() + size_t(w) * w;
             int hinfo = 0;
             {
-                if (w <= 128) {
-                    mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
-                    info.download(&hinfo, 1);
-                } else {
-                    ROCBLAS_CHECK(rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, w, Gs, w, info));
-                    info.download(&hinfo, 1);
-                }
+                mh_potrf(ctx, Gs, w, w, info); // ours at every order (one workgroup up to 128 columns, 128-column blocks above)
+                info.download(&hinfo, 1);
             }
             if (hinfo != 0) {
                 wp_new = 0;

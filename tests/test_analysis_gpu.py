@@ -327,16 +327,19 @@ def test_thin_plate_converges_with_single_precision_smoothers(api, ctx):
     mesh.close()
 
 
-def test_concurrent_solves_from_several_threads(api):
+@pytest.mark.parametrize("pairs", [40, 140, 215])
+def test_concurrent_solves_from_several_threads(api, pairs):
     """The reference runs one solve job per entity, several at a time (AudioSystem.cpp:812,865).  Three host threads with
-    their own contexts solve at once: every result must equal the single-threaded one."""
+    their own contexts solve at once: every result must equal the single-threaded one, bit for bit.  140 and 215 pairs (blocks of 160
+    and 240 columns: past the one-workgroup Cholesky) lost rank or converged to perturbed values in a third of the solves until
+    round 4, through rocsolver_dpotrf -- the editor's 128 modes + margin are 143 pairs."""
     import threading
     pts, tets, m, kw = meshes.workload("cube_s10k")
     mat = api.material(*m)
     ctxs = [api.Context(0) for _ in range(3)]
     ms = [api.Mesh(c, pts, tets) for c in ctxs]
     s0 = api.System(ctxs[0], ms[0], mat)
-    ref, _ = s0.eigs(40, SIGMA, 1e-6)
+    ref, _ = s0.eigs(pairs, SIGMA, 1e-6)
     s0.close()
     out, errs = {}, []
 
@@ -344,7 +347,7 @@ def test_concurrent_solves_from_several_threads(api):
         try:
             for rep in range(3):
                 s = api.System(ctxs[i], ms[i], mat)
-                ev, _ = s.eigs(40, SIGMA, 1e-6)
+                ev, _ = s.eigs(pairs, SIGMA, 1e-6)
                 out[(i, rep)] = ev
                 s.close()
         except Exception as e:  # noqa: BLE001
@@ -355,7 +358,7 @@ def test_concurrent_solves_from_several_threads(api):
     assert not errs, errs
     assert len(out) == 9
     for ev in out.values():
-        assert np.allclose(ev[6:], ref[6:], rtol=1e-9)
+        assert np.array_equal(ev, ref)
     for c in ctxs:
         c.close()
 

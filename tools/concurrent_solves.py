@@ -1,7 +1,7 @@
 """Concurrent solves (MH_CONCURRENT_SOLVES=1): T host threads, each with its own context, solve a share of a batch of
 jittered boxes; every result is compared with the serial solve of the same mesh, and the throughput with the serial loop.
 
-    MH_CONCURRENT_SOLVES=1 python tools/concurrent_solves.py [threads] [meshes] [n]"""
+    MH_CONCURRENT_SOLVES=1 python tools/concurrent_solves.py [threads] [meshes] [n] [pairs]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,7 @@ from mesheditor_amd import api, meshes
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 17
-nev = 45
+nev = int(sys.argv[4]) if len(sys.argv) > 4 else 45  # (215: the wide Rayleigh-Ritz kernels and the library pieces beside them run concurrently)
 batch = [meshes.jittered_box(n, 1000 + i) + (meshes.MATERIALS[meshes.MATERIAL_ORDER[i % 7]],) for i in range(N)]
 ctxs = [api.Context(0) for _ in range(T)]
 
