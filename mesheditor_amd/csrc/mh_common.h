@@ -47,7 +47,7 @@ struct MhError : std::runtime_error {
 
 // Size-bucketed caching allocator: device buffers are recycled across solves so a steady-state solve performs no
 // hipMalloc/hipFree (which synchronise the device).  The cache of idle blocks is capped (MH_POOL_CAP_MB; default: the larger
-// of 16 GiB and a quarter of the device's memory): a release that takes it over the cap frees the blocks that have been idle
+// of 16 GiB and an eighth of the device's memory: 36 GB here, twice the working set of a 215-pair solve of 540 k unknowns): a release that takes it over the cap frees the blocks that have been idle
 // LONGEST first, so a long-lived process that once solved a huge mesh does not sit on that memory for ever -- and a solve
 // whose own working set is near the cap keeps it from one solve to the next (freeing the largest blocks first, as this did
 // before, threw away exactly the panels the next solve of the same mesh asks for: 1.2 s became 1.7 s for a 215-pair solve of
@@ -61,7 +61,7 @@ struct DevicePool {
     size_t cap{size_t(16) << 30};
     void set_cap_for_device(size_t device_bytes) {
         if (const char *c = getenv("MH_POOL_CAP_MB")) cap = size_t(std::max(0, atoi(c))) << 20;
-        else cap = std::max(size_t(16) << 30, device_bytes / 4);
+        else cap = std::max(size_t(16) << 30, device_bytes / 8);
     }
     static size_t round_up(size_t n) {
         if (n < 256) return 256;

@@ -420,7 +420,7 @@ def test_results_do_not_depend_on_recycled_device_memory(api, ctx):
 def test_device_pool_keeps_its_idle_cache_under_the_cap():
     """The cache of idle device blocks is capped, the longest-idle blocks leave first, and a cap far below a solve's working
     set changes nothing but the allocation traffic: two workloads alternated under MH_POOL_CAP_MB=64 reproduce the uncapped
-    eigenvalues bit for bit, with the idle bytes at or under the cap after every solve.  The default cap is a quarter of the
+    eigenvalues bit for bit, with the idle bytes at or under the cap after every solve.  The default cap is an eighth of the
     device (at least 16 GiB)."""
     import json
     import os
