@@ -27,6 +27,20 @@ __global__ void k_lab_panel_to_ref(const double *__restrict__ panel, const uint3
 }
 } // namespace
 
+namespace {
+typedef float f4_stream __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_stream_copy(const f4_stream *__restrict__ src, f4_stream *__restrict__ dst, size_t count) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_stream_read(const f4_stream *__restrict__ src, size_t count, float *__restrict__ out) {
+    f4_stream acc = {0, 0, 0, 0};
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256) acc += src[i];
+    float s = acc[0] + acc[1] + acc[2] + acc[3];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, s); // (a workgroup's four waves: the value is never read)
+}
+} // namespace
+
 extern "C" {
 // The rigid-body level's graph aggregation (host code, no device): CSR graph of a level's node blocks in, aggregate of every node
 // out; returns the aggregate count.
@@ -241,6 +255,43 @@ int mhl_context_gram(mh_context *ctx, uint64_t n, const double *x, uint32_t wa, 
         dy.upload(y, n * wb);
         mh_gram(ctx, n, dx, wa, dy, wb, dg, wa);
         dg.download(g, size_t(wa) * wb);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
+// Measured HBM ceilings of this device (SURVEY 8d asks for a measured copy-kernel ceiling beside the nominal 8 TB/s): a streaming copy
+// (bytes read + bytes written per second) and a streaming read (a sum stored once per workgroup); 16-byte accesses, grid-stride, 16
+// workgroups per CU.
+int mhl_context_bench_stream(mh_context *ctx, uint64_t bytes, uint32_t reps, double *copy_gbs, double *read_gbs) {
+    if (!ctx || !copy_gbs || !read_gbs || bytes < 4096 || !reps) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        MhSharedPhase not_during_a_factorisation;
+        const size_t count = bytes / 16;
+        const unsigned grid = unsigned(ctx->cu_count) * 16;
+        DevArray<float> a(ctx, count * 4), b(ctx, count * 4), out(ctx, grid);
+        a.zero();
+        out.zero();
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        auto timed = [&](auto &&launch) {
+            launch();
+            HIP_CHECK(hipEventRecord(e0, ctx->stream));
+            for (uint32_t r = 0; r < reps; ++r) launch();
+            HIP_CHECK(hipEventRecord(e1, ctx->stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            return double(ms) * 1e-3 / reps;
+        };
+        const double t_copy = timed([&] { k_stream_copy<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const f4_stream *>(a.get()), reinterpret_cast<f4_stream *>(b.get()), count); });
+        const double t_read = timed([&] { k_stream_read<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const f4_stream *>(a.get()), count, out.get()); });
+        KERNEL_CHECK();
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *copy_gbs = 2.0 * double(count) * 16 / t_copy / 1e9;
+        *read_gbs = double(count) * 16 / t_read / 1e9;
         return MH_OK;
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }

@@ -23,6 +23,8 @@ int mhl_context_small_gemm(mh_context *, int ta, int tb, uint32_t M, uint32_t N,
                            uint32_t ldc, uint32_t reps, double *avg_ms);
 /* G (wa x wb, column-major) = X^T Y for row-major host panels (n x wa), (n x wb): the solver's Gram kernel */
 int mhl_context_gram(mh_context *, uint64_t n, const double *x, uint32_t wa, const double *y, uint32_t wb, double *g);
+/* measured HBM ceilings of the device: a streaming copy (read + written bytes per second) and a streaming read, in GB/s */
+int mhl_context_bench_stream(mh_context *, uint64_t bytes, uint32_t reps, double *copy_gbs, double *read_gbs);
 /* the context's device pool: bytes held from the device, bytes of them idle in the cache, the cap on the idle part */
 int mhl_context_pool_stats(mh_context *, uint64_t *reserved, uint64_t *idle, uint64_t *cap);
 /* The rigid-body level's graph aggregation (host code): CSR node graph in (diagonal entries included), aggregate per node out. */

@@ -25,6 +25,7 @@ def lib():
         L.mhl_system_elementwise_matvec.restype, L.mhl_system_elementwise_matvec.argtypes = i32, [vp, vp, vp, u32]
         L.mhl_context_bench_dense.restype, L.mhl_context_bench_dense.argtypes = i32, [vp, i32, C.c_uint64, u32, u32, u32, f64p]
         L.mhl_context_tridiagonalize.restype, L.mhl_context_tridiagonalize.argtypes = i32, [vp, i32, u32, vp, vp, vp, u32, f64p]
+        L.mhl_context_bench_stream.restype, L.mhl_context_bench_stream.argtypes = i32, [vp, C.c_uint64, u32, f64p, f64p]
         L.mhl_context_gram.restype, L.mhl_context_gram.argtypes = i32, [vp, C.c_uint64, vp, u32, vp, u32, vp]
         L.mhl_context_pool_stats.restype, L.mhl_context_pool_stats.argtypes = i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.mhl_context_small_gemm.restype, L.mhl_context_small_gemm.argtypes = i32, [vp, i32, i32, u32, u32, u32, C.c_double, vp, u32, vp, u32, C.c_double, vp, u32, u32, f64p]
@@ -93,6 +94,13 @@ def gram(ctx, x, y):
     g = np.zeros((wb, wa))  # column-major wa x wb
     ctx.check(lib().mhl_context_gram(ctx.h, n, _p(xc), wa, _p(yc), wb, _p(g)))
     return g.T.copy()
+
+
+def bench_stream(ctx, nbytes=4 << 30, reps=10):
+    """(copy GB/s counting read + written bytes, read GB/s) of streaming kernels over `nbytes`: the device's measured HBM ceilings."""
+    c, r = C.c_double(0), C.c_double(0)
+    ctx.check(lib().mhl_context_bench_stream(ctx.h, nbytes, reps, C.byref(c), C.byref(r)))
+    return c.value, r.value
 
 
 def pool_stats(ctx):
