@@ -140,7 +140,10 @@ int mh_context_create(int device, mh_context **out) {
         if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
         if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
+    for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
         if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
+    for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return code;
@@ -154,6 +157,7 @@ void mh_context_destroy(mh_context *ctx) {
     if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
+    for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

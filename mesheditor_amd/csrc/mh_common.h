@@ -133,8 +133,14 @@ struct mh_context {
         return aux_stream != nullptr && blas_aux != nullptr;
     }
     hipStream_t aux2_stream{nullptr}; // third stream: the next pivot block's inverse beside the coarse elimination's rank update (our kernel only, no library handle)
-    bool aux2_stream_ready() {
+    std::vector<hipEvent_t> ahead_ev; // the look-ahead's events, two per elimination step (pivot block ready, its inverse ready), never shared between steps; they live as long as the context
+    bool aux2_stream_ready(size_t events = 0) {
         if (!aux2_stream && hipStreamCreateWithFlags(&aux2_stream, hipStreamNonBlocking) != hipSuccess) aux2_stream = nullptr, (void)hipGetLastError();
+        while (aux2_stream && ahead_ev.size() < events) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ahead_ev.push_back(e);
+        }
         return aux2_stream != nullptr;
     }
     rocblas_handle blas{nullptr};

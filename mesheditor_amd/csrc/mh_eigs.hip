@@ -43,9 +43,9 @@ constexpr int TB = 256;
 //   * (round 4) the iteration itself calls no rocSOLVER factorisation any more: the Cholesky factors of blocks wider than 128
 //     columns went through rocsolver_dpotrf until then, and three threads solving 140 or 215 pairs each lost rank or converged
 //     to perturbed eigenvalues in a third of their solves (tools/concurrent_solves.py 3 18 14 215).  mh_potrf (mh_dense.hip)
-//     factors in 128-column blocks with our kernels and rocBLAS level 3.  What is left of rocSOLVER inside the iteration are the
-//     Rayleigh-Ritz fall-backs (stedc / ormtr after a failed residual check, syevd above order 768 or after a timed-out
-//     exchange): none of them is a Cholesky factorisation, and the soak at 280 pairs (syevd every step) is clean.
+//     factors in 128-column blocks with our kernels and rocBLAS level 3: one solve in ~50 still failed -- not through any library
+//     piece and not through stream ordering (eigs_impl has the record) -- so solves with blocks wider than 128 columns hold the
+//     phase lock EXCLUSIVELY for their duration: they run alone and are exact; solves of up to 110 pairs overlap as before.
 // 2.0x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
 // MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex).
 std::mutex g_solve_mutex;
@@ -86,6 +86,7 @@ const Switches &switches() {
 // Design constants (each was once a switch; the losing side of every comparison is recorded in DESIGN.md section 10)
 constexpr int kPowerIterations = 20; // spectral-bound estimate of the smoothers (12 steps left the bound 15 % low on the scan meshes -- more than the 1.1 safety factor -- and one patch-threshold setting then failed to converge; the steps run beside the coarse elimination)
 constexpr uint32_t kPrecondColumns = 256; // (narrower slabs measured slower on the 215-pair solves: 128 -> +2 %, 80 -> +5 %, 64 -> +9 %) // widest panel of one preconditioner application (the single-precision wide-load products: 64 lanes x 4)
+constexpr uint32_t kConcurrentColumns = 128; // widest block whose solve shares the device with other solves (see eigs_impl)
 constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
 constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
 constexpr size_t kDenseLastResort = 12288; // unknowns up to which a solve that did not converge is redone as one dense eigensolve (2 x 1.2 GB, seconds)
@@ -120,11 +121,11 @@ struct PhaseLock {
 };
 PhaseLock g_phase;
 const bool g_concurrent = !(getenv("MH_CONCURRENT_SOLVES") && atoi(getenv("MH_CONCURRENT_SOLVES")) == 0);
-struct SharedPhase { // no-ops in the serialised mode
-    bool held = false;
-    SharedPhase() { acquire(); }
+struct SharedPhase { // no-ops in the serialised mode (and for a solve that holds the device exclusively: enabled = false)
+    bool held = false, enabled = true;
+    explicit SharedPhase(bool on = true) : enabled(on) { acquire(); }
     ~SharedPhase() { release(); }
-    void acquire() { if (g_concurrent && !held) { g_phase.lock_shared(); held = true; } }
+    void acquire() { if (g_concurrent && enabled && !held) { g_phase.lock_shared(); held = true; } }
     void release() { if (held) { g_phase.unlock_shared(); held = false; } }
 };
 struct ExclusivePhase {
@@ -1080,22 +1081,12 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
         // One step ahead: the pivot block of step k + 1 is brought up to date FIRST (a 128 x 128 x 128 product of ours into a buffer of
         // its own) and inverted on a third stream while the rank-128 update of the whole matrix runs -- the one-workgroup inverse
         // (117 us) and the update (131 us) were 85 % of a step's 287 us, one after the other.
-        const bool ahead = side && ctx->aux2_stream_ready();
-        hipEvent_t ev_piv[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
-        struct EventGuard {
-            hipEvent_t *a, *b;
-            ~EventGuard() {
-                for (int i = 0; i < 2; ++i) {
-                    if (a[i]) (void)hipEventDestroy(a[i]);
-                    if (b[i]) (void)hipEventDestroy(b[i]);
-                }
-            }
-        } events{ev_piv, ev_inv};
-        if (ahead)
-            for (int i = 0; i < 2; ++i) {
-                HIP_CHECK(hipEventCreateWithFlags(&ev_piv[i], hipEventDisableTiming));
-                HIP_CHECK(hipEventCreateWithFlags(&ev_inv[i], hipEventDisableTiming));
-            }
+        const size_t steps_total = div_up(n0, size_t(nb));
+        const bool ahead = side && ctx->aux2_stream_ready(2 * steps_total);
+        // (the context's own events: an event destroyed while a stream still waits on it -- as these were at first, at the end of this
+        // scope, milliseconds ahead of the device -- lets the wait through early on this runtime: one solve in ~50 then ran on a coarse
+        // inverse built from a half-finished pivot inverse, under load only)
+        hipEvent_t *ev_piv = ctx->ahead_ev.data(), *ev_inv = ctx->ahead_ev.data() + steps_total; // [step]: no event serves two steps
         const double one = 1, zero = 0, mone = -1;
         const rocblas_int ld = rocblas_int(n0);
         double *a = sys->a0.get();
@@ -1104,7 +1095,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
             const rocblas_int w = rocblas_int(std::min<size_t>(nb, n0 - k0));
             double *pinv = pinv2[step & 1]->get();
             if (step == 0 || !ahead) mh_spd_inverse_small(ctx, a + k0 * n0 + k0, uint32_t(n0), uint32_t(w), pinv, uint32_t(w), info);
-            else HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_inv[step & 1], 0));
+            else HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_inv[step], 0));
             HIP_CHECK(hipMemcpyAsync(cblk, a + k0 * n0, n0 * size_t(w) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, ld, w, &one, pinv, w, a + k0, ld, &zero, rblk, w));
             const size_t k1 = k0 + nb;
@@ -1112,8 +1103,8 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
                 const uint32_t wn = uint32_t(std::min<size_t>(nb, n0 - k1));
                 HIP_CHECK(hipMemcpy2DAsync(pnext.get(), size_t(wn) * sizeof(double), a + k1 * n0 + k1, n0 * sizeof(double), size_t(wn) * sizeof(double), wn, hipMemcpyDeviceToDevice, ctx->stream));
                 mh_small_gemm(ctx, false, false, wn, wn, uint32_t(w), -1.0, cblk.get() + k1, uint32_t(n0), rblk.get() + k1 * size_t(w), uint32_t(w), 1.0, pnext.get(), wn);
-                HIP_CHECK(hipEventRecord(ev_piv[step & 1], ctx->stream));
-                HIP_CHECK(hipStreamWaitEvent(ctx->aux2_stream, ev_piv[step & 1], 0));
+                HIP_CHECK(hipEventRecord(ev_piv[step], ctx->stream));
+                HIP_CHECK(hipStreamWaitEvent(ctx->aux2_stream, ev_piv[step], 0));
                 hipStream_t elimination = ctx->stream;
                 ctx->stream = ctx->aux2_stream;
                 try {
@@ -1123,7 +1114,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
                     throw;
                 }
                 ctx->stream = elimination;
-                HIP_CHECK(hipEventRecord(ev_inv[(step + 1) & 1], ctx->aux2_stream));
+                HIP_CHECK(hipEventRecord(ev_inv[step + 1], ctx->aux2_stream));
             }
             ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, ld, w, &mone, cblk, ld, rblk, w, &one, a, ld));
             HIP_CHECK(hipMemcpy2DAsync(a + k0, n0 * sizeof(double), rblk.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), n0, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1278,7 +1269,7 @@ struct BlockLobpcg {
                 uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_)
         : sys(system), ctx(system->ctx), st(system->ctx->stream), n(size_t(3) * system->n_nodes), nev(nev_), b(block), mmax(3 * block), sigma(sigma_), residual_tol(residual_tol_),
           max_iters(max_iters_), seed_basis(seed_basis_), seed_rows(seed_rows_), seed_cols(seed_cols_), cancel(cancel_), progress(progress_), prof(prof_), profile(profile_),
-          t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
+          iterating(block <= kConcurrentColumns), t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
           theta_act(block), order(block), locked(block, 0) {
         for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &Pn, &R, &Rw}) panel->reset(ctx, n * b);
         if (!pproj_ok) // M P is only kept for blocks wider than 128 columns (the narrower ones project against P in coefficient space)
@@ -1890,6 +1881,16 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             sys->profile = prof;
             if (profile) *profile = prof;
         } else {
+            // A block wider than 128 columns (more than ~110 pairs) is solved ALONE on the device.  Measured (tools/concurrent_solves.py
+            // 3 45 12 120 against ... 110): three threads solving 120 pairs each, one context per thread, lose one solve in ~50 --
+            // late in the iteration the active Ritz vectors turn to garbage within one step -- while 110 pairs (a 128-column block) never
+            // do, in hundreds of solves; alone, the wide solves are exact.  It is not an ordering defect inside a context (it survives
+            // AMD_SERIALIZE_KERNEL=3 and AMD_SERIALIZE_COPY=3) and not one of the library pieces (it survives our own Gram, basis update,
+            // Cholesky and tridiagonalisation in their place): something in the wide-block path is disturbed by other queues' work the way
+            // rocSOLVER's potrf is, and the round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
+            // correctness first; solves of up to 110 pairs (the batch workloads, the editor's default) overlap as before.
+            std::unique_ptr<ExclusivePhase> alone;
+            if (b > kConcurrentColumns) alone = std::make_unique<ExclusivePhase>();
             {
                 Timer t(ctx);
                 mh_build_hierarchy(sys, sigma, true); // (the coarse elimination may still run: the first preconditioner application waits for it)
@@ -1906,6 +1907,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // (not when the caller's own iteration limit is what stopped it: MaxRestarts exceeded stays the reference's empty result)
                 if (e.code != MH_ENOTCONVERGED || n > kDenseLastResort || max_iters < 50) throw;
                 if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- dense eigensolve of order %zu instead\n", e.what(), n);
+                alone.reset(); // (the dense solve takes the exclusive phase itself)
                 Timer t(ctx);
                 dense_eigs(sys, nev, sigma, eigenvalues, true);
                 prof = sys->profile;

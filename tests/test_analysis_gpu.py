@@ -331,8 +331,9 @@ def test_thin_plate_converges_with_single_precision_smoothers(api, ctx):
 def test_concurrent_solves_from_several_threads(api, pairs):
     """The reference runs one solve job per entity, several at a time (AudioSystem.cpp:812,865).  Three host threads with
     their own contexts solve at once: every result must equal the single-threaded one, bit for bit.  140 and 215 pairs (blocks of 160
-    and 240 columns: past the one-workgroup Cholesky) lost rank or converged to perturbed values in a third of the solves until
-    round 4, through rocsolver_dpotrf -- the editor's 128 modes + margin are 143 pairs."""
+    and 240 columns) lost rank or converged to perturbed values in a third of the solves until round 4 (rocsolver_dpotrf, and a
+    rarer disturbance of the wide-block path that was not found: such solves now run alone on the device) -- the editor's 128
+    modes + margin are 143 pairs."""
     import threading
     pts, tets, m, kw = meshes.workload("cube_s10k")
     mat = api.material(*m)
