@@ -1886,7 +1886,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // late in the iteration the active Ritz vectors turn to garbage within one step -- while 110 pairs (a 128-column block) never
             // do, in hundreds of solves; alone, the wide solves are exact.  It is not an ordering defect inside a context (it survives
             // AMD_SERIALIZE_KERNEL=3 and AMD_SERIALIZE_COPY=3) and not one of the library pieces (it survives our own Gram, basis update,
-            // Cholesky and tridiagonalisation in their place): something in the wide-block path is disturbed by other queues' work the way
+            // Cholesky and tridiagonalisation in their place, and the separate residual pass forced on a 128-column block stays clean): something in the wide-block path is disturbed by other queues' work the way
             // rocSOLVER's potrf is, and the round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
             // correctness first; solves of up to 110 pairs (the batch workloads, the editor's default) overlap as before.
             std::unique_ptr<ExclusivePhase> alone;
