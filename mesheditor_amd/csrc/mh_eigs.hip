@@ -1887,7 +1887,10 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // do, in hundreds of solves; alone, the wide solves are exact.  It is not an ordering defect inside a context (it survives
             // AMD_SERIALIZE_KERNEL=3 and AMD_SERIALIZE_COPY=3) and not one of the library pieces (it survives our own Gram, basis update,
             // Cholesky and tridiagonalisation in their place, and the separate residual pass forced on a 128-column block stays clean): something in the wide-block path is disturbed by other queues' work the way
-            // rocSOLVER's potrf is, and the round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
+            // rocSOLVER's potrf is -- or rather by other THREADS' host-side work: three PROCESSES solving 120 pairs at once on the same
+            // device agree bit for bit (tools/probe/multiproc_soak.py, 6 x 45 solves), so the disturbance lives inside one process (this
+            // library's host code, or the runtime's / rocBLAS's per-process state; not the hipBLASLt backend: ROCBLAS_USE_HIPBLASLT=0
+            // fails alike).  The round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
             // correctness first; solves of up to 110 pairs (the batch workloads, the editor's default) overlap as before.
             std::unique_ptr<ExclusivePhase> alone;
             if (b > kConcurrentColumns) alone = std::make_unique<ExclusivePhase>();
