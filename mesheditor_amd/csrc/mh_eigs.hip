@@ -1889,8 +1889,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // Cholesky and tridiagonalisation in their place, and the separate residual pass forced on a 128-column block stays clean): something in the wide-block path is disturbed by other queues' work the way
             // rocSOLVER's potrf is -- or rather by other THREADS' host-side work: three PROCESSES solving 120 pairs at once on the same
             // device agree bit for bit (tools/probe/multiproc_soak.py, 6 x 45 solves), so the disturbance lives inside one process (this
-            // library's host code, or the runtime's / rocBLAS's per-process state; not the hipBLASLt backend: ROCBLAS_USE_HIPBLASLT=0
-            // fails alike).  The round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
+            // library's host code, or the runtime's / rocBLAS's per-process state; not the hipBLASLt backend and not rocBLAS's workspace
+            // growth: ROCBLAS_USE_HIPBLASLT=0 and a fixed ROCBLAS_DEVICE_MEMORY_SIZE fail alike).  The round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
             // correctness first; solves of up to 110 pairs (the batch workloads, the editor's default) overlap as before.
             std::unique_ptr<ExclusivePhase> alone;
             if (b > kConcurrentColumns) alone = std::make_unique<ExclusivePhase>();
