@@ -77,7 +77,16 @@ struct DevicePool {
         return on;
     }
     std::map<void *, size_t> user_bytes; // (redzone mode) user pointer -> bytes asked for
+    static size_t farzone() { // (hunt aid) MH_TEST=farzone: every array sits in the middle of 2 x 32 MB of slack of its own, never checked
+        static const size_t z = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "farzone") ? size_t(32) << 20 : 0;
+        return z;
+    }
     void *alloc(size_t n_user) {
+        if (farzone()) {
+            char *base = static_cast<char *>(alloc_plain(n_user + 2 * farzone()));
+            user_bytes[base + farzone()] = n_user;
+            return base + farzone();
+        }
         if (redzone()) {
             char *base = static_cast<char *>(alloc_plain(n_user + 2 * RZ));
             (void)hipDeviceSynchronize();
@@ -90,6 +99,14 @@ struct DevicePool {
         return alloc_plain(n_user);
     }
     void release(void *p) {
+        if (farzone() && p) {
+            auto it = user_bytes.find(p);
+            if (it != user_bytes.end()) {
+                user_bytes.erase(it);
+                release_plain(static_cast<char *>(p) - farzone());
+                return;
+            }
+        }
         if (redzone() && p) {
             auto it = user_bytes.find(p);
             if (it != user_bytes.end()) {

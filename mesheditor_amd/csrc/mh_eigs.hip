@@ -61,7 +61,7 @@ std::mutex g_solve_mutex;
 //                           fall-back of the partial-spectrum stage -- the library's divide and conquer and ormtr -- runs)
 //   (the A/B hooks of round 4 -- wide tridiagonalisation, small products, pivot look-ahead, power-iteration norms, wide Gram -- are gone
 //   with their measurements recorded in profiles/r04_setup_ab.txt, r04_dense_kernels.txt, r04_gram_cuts.txt and DESIGN.md section 10)
-//   MH_TEST=redzone (mh_common.h): 64 KB guard zones around every pool array, checked at release
+//   MH_TEST=redzone / farzone (mh_common.h): 64 KB guard zones around every pool array, checked at release / 32 MB of unchecked slack
 // and, read elsewhere: MH_CONCURRENT_SOLVES=0 (one solve at a time), MH_AGG (aggregate size target), MH_PATCH_Q (sliver-patch
 // threshold), MH_POOL_CAP_MB (idle device-pool cap); MH_TEST also understands `poison` (NaN-filled pool allocations).
 struct Switches {
