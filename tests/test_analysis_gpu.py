@@ -364,6 +364,44 @@ def test_concurrent_solves_from_several_threads(api, pairs):
         c.close()
 
 
+def test_a_wide_solve_beside_narrow_ones(api):
+    """One thread solving 120 pairs (a block wider than 128 columns) beside two threads solving 65: until round 4 the NARROW solves
+    failed in two runs of three ("0 of 65 pairs converged"); a wide solve now holds the device phase lock exclusively.
+    Every result equals its serial one, bit for bit."""
+    import threading
+    boxes = [meshes.jittered_box(12, 1000 + i) + (meshes.MATERIALS[meshes.MATERIAL_ORDER[i % 7]],) for i in range(10)]
+
+    def solve(c, i, pairs):
+        p, t, mat = boxes[i]
+        mesh = api.Mesh(c, p, t)
+        s = api.System(c, mesh, api.material(*mat))
+        ev, _ = s.eigs(pairs, SIGMA, 1e-5)
+        s.close()
+        mesh.close()
+        return ev
+    c0 = api.Context(0)
+    ref = {pairs: [solve(c0, i, pairs) for i in range(10)] for pairs in (120, 65)}
+    bad, errs = [], []
+
+    def work(k, c):
+        pairs = 120 if k == 0 else 65
+        try:
+            for rep in range(2):
+                for i in range(10):
+                    if not np.array_equal(solve(c, i, pairs), ref[pairs][i]):
+                        bad.append((k, pairs, i))
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, pairs, repr(e)[:200]))
+    ctxs = [api.Context(0) for _ in range(3)]
+    th = [threading.Thread(target=work, args=(k, ctxs[k])) for k in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for c in ctxs + [c0]:
+        c.close()
+    assert not errs, errs
+    assert not bad, bad
+
+
 def test_solve_is_bit_reproducible(api, ctx):
     """Fixed seeds, ordered reductions, no atomics (SURVEY 8b 'Determinism'): two solves of the same mesh give the same
     bits -- eigenvalues and the gathered shapes."""
