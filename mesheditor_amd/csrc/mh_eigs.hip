@@ -1891,7 +1891,13 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // rocSOLVER's potrf is -- or rather by other THREADS' host-side work: three PROCESSES solving 120 pairs at once on the same
             // device agree bit for bit (tools/probe/multiproc_soak.py, 6 x 45 solves), so the disturbance lives inside one process (this
             // library's host code, or the runtime's / rocBLAS's per-process state; not the hipBLASLt backend and not rocBLAS's workspace
-            // growth: ROCBLAS_USE_HIPBLASLT=0 and a fixed ROCBLAS_DEVICE_MEMORY_SIZE fail alike).  The round ended before it was found.  Until it is, wide solves take the phase lock exclusively:
+            // growth: ROCBLAS_USE_HIPBLASLT=0 and a fixed ROCBLAS_DEVICE_MEMORY_SIZE fail alike).  And the victim need not be wide: ONE thread solving 120 pairs beside two threads
+            // solving 65 makes the 65-pair solves fail (tools/probe/one_wide_soak.py, four runs of six): a healthy solve loses everything in
+            // ONE step.  Not a stray write next to a pool array (MH_TEST=redzone finds nothing; 32 MB of slack around every array,
+            // MH_TEST=farzone, changes nothing).  The last experiment of the round points at the multi-workgroup tridiagonalisations: with
+            // MH_TEST=sytrd_giveup (their results discarded; the one-workgroup kernel / the library instead) the same soak is clean in 8 runs
+            // of 8 against ~4 of 8 failing -- the tagged exchange of k_sytrd_multi goes wrong beside a wide solve's kernels in a way the
+            // uneven-load tests do not provoke.  Not yet understood.  Until it is, wide solves take the phase lock exclusively:
             // correctness first; solves of up to 110 pairs (the batch workloads, the editor's default) overlap as before.
             std::unique_ptr<ExclusivePhase> alone;
             if (b > kConcurrentColumns) alone = std::make_unique<ExclusivePhase>();
