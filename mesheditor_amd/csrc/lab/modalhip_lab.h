@@ -29,6 +29,12 @@ int mhl_context_bench_stream(mh_context *, uint64_t bytes, uint32_t reps, double
 int mhl_context_pool_stats(mh_context *, uint64_t *reserved, uint64_t *idle, uint64_t *cap);
 /* The rigid-body level's graph aggregation (host code): CSR node graph in (diagonal entries included), aggregate per node out. */
 uint32_t mhl_graph_aggregates(const uint32_t *row_ptr, const uint32_t *col, uint32_t n, uint32_t target, uint32_t max_order, uint32_t *agg_of);
+/* Soak of the multi-workgroup tridiagonalisation's tagged exchange with its transport as a parameter (lab/mh_soak.hip): `launches` runs of
+ * one fixed matrix, every collected value compared with a recorded undisturbed run; out receives the deviation records. */
+int mhl_sytrd_soak(mh_context *, uint32_t transport, uint32_t m, uint32_t launches, volatile int *recorded, volatile int *go, void *out, uint64_t out_bytes);
+uint64_t mhl_sytrd_soak_bytes(void);
+/* one kind of a wide solve's work, alone, over and over on the context's stream until *stop (lab/mh_soak.hip lists the kinds) */
+int mhl_soak_aggressor(mh_context *, int kind, volatile int *stop, uint64_t *count);
 #ifdef __cplusplus
 }
 #endif

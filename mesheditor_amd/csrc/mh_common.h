@@ -52,6 +52,20 @@ struct MhError : std::runtime_error {
 // whose own working set is near the cap keeps it from one solve to the next (freeing the largest blocks first, as this did
 // before, threw away exactly the panels the next solve of the same mesh asks for: 1.2 s became 1.7 s for a 215-pair solve of
 // 540 k unknowns after any other workload had left its blocks in the cache).
+// An explicit wait for this wave's LDS stores, to be placed in front of a __syncthreads() that hipcc leaves without one.
+// Found in round 5 (tools/check_barrier_waits.py): __syncthreads() is a workgroup release fence + s_barrier, and the
+// fence's `s_waitcnt lgkmcnt(0)` is a "soft" wait that hipcc's wait-count pass (ROCm 7.2, gfx950) deletes when its scoreboard shows nothing
+// pending.  At the header of a loop whose BACK EDGE carries ds_write instructions -- and whose body holds inline asm -- the pass decided that
+// on the loop's first visit and never put the wait back: the waves of k_sytrd_multi / k_sytrd_wide reached the barrier at the top of the
+// column loop with the stores of vp, wp, xs and sq still queued.  Alone on a CU those land before any other wave's next ds_read; beside an
+// LDS-bound kernel on the same SIMDs (rocBLAS's dsymm: sixteen waves per workgroup, 32 LDS reads per 8 FMAs) the queue is long enough that
+// another wave passes the barrier and reads the previous step's values: one workgroup publishes slightly wrong numbers, nothing times out.
+// Measured with lab/mh_soak.hip beside 215-pair solves: 23-37 wrong results in 20-30 thousand launches without this wait, 0 in 120 000 with it.
+// build() runs tools/check_barrier_waits.py over every kernel's assembly: a barrier reachable with an LDS store in flight fails the build.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void mh_lds_writes_landed() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+
 struct DevicePool {
     struct Idle { void *p; unsigned long long stamp; };
     std::multimap<size_t, Idle> free_blocks;
@@ -217,6 +231,8 @@ struct mh_context {
     int *sytrd_flag{nullptr};               // set by a workgroup that gave up waiting (mh_sytrd_gave_up)
     unsigned long long *sytrd_xch_wide{nullptr}; // the same for orders 257 .. 768 (mh_sytrd_wide)
     uint32_t sytrd_epoch_wide{0};
+    uint32_t sytrd_redos{0};                // Rayleigh-Ritz steps redone by a fall-back because a workgroup of the exchange gave up (co-resident work stalled it past the poll bound); mh_profile reports the count per solve
+    unsigned long long *rr_check{nullptr};  // device word: worst sampled residual of the Rayleigh-Ritz steps' self-check (k_rr_selfcheck), double bits folded by atomicMax
     // Optional per-launch timing of the path's named kernels (measurement aid for bench.py's roofline objects): HIP
     // events on this stream around every launch of a kernel class, resolved lazily.  `work` is the class's algorithmic
     // unit: bytes for the HBM-bound classes, flops for the resonator bank.

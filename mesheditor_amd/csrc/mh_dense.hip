@@ -919,6 +919,7 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
         const unsigned tag = (epoch << 9) | unsigned(k + 1);
         const int parity = k & 1;
         const bool mine = g == k % G; // column k is this workgroup's: it reports the step's scalars and stores the reflector
+        mh_lds_writes_landed(); // (hipcc drops the barrier's own LDS wait at this loop header: see the function)
         __syncthreads(); // (1) xs, sq and the pending pair (vp, wp) are in place
         const double xnorm2 = wave_sum_lds(sq, l + 1, lane);
         const double alpha = xs[1];
@@ -1054,6 +1055,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_wide(double *__restrict__ A, int
         const unsigned tag = (epoch << 10) | unsigned(k + 1);
         const int parity = k & 1;
         const bool mine = g == k % G;
+        mh_lds_writes_landed(); // (as in k_sytrd_multi)
         __syncthreads(); // (1) xs, sq and the pending pair are in place
         const double xnorm2 = wave_sum(sq, l + 1);
         const double alpha = xs[1];

@@ -4,10 +4,12 @@
 // src/audio/mesh2modes.cpp:470,485-491; CholeskyShiftInvert.cpp) and its warm-started SubspaceIterate (:339-428)
 // by a block LOBPCG (Knyazev 2001; basis handling after Hetmaniuk & Lehoucq 2006) on the same shifted pencil
 // (A, M), A = K - sigma M, sigma = -(2 pi MinModeFreq)^2 (:460), preconditioned by one symmetric three-level cycle:
-//   level 2  P2 operator, Chebyshev-Jacobi smoothing (SpMM-bound)
-//   level 1  its exact Galerkin restriction to the corner nodes (P1 subset of P2), two cycles
-//   level 0  rigid-body modes of node aggregates, dense Cholesky (rocSOLVER potrf, rocBLAS trsm)
-// Dense tall-skinny products go through rocBLAS dgemm, the small Rayleigh-Ritz problem through rocSOLVER sygvd.
+//   level 2  P2 operator, Chebyshev-Jacobi smoothing (SpMM-bound), exact corrections on sliver patches (mh_patch.hip)
+//   level 1  its exact Galerkin restriction to the corner nodes (P1 subset of P2), gamma cycles
+//   level 0  rigid-body modes of graph-grown node aggregates; explicit inverse by our block Gauss-Jordan elimination (mh_build_hierarchy)
+// Tall-skinny products: k_gram_blocked / k_combine (fp64 MFMA, mh_dense.hip), the vendor dgemm only for blocks of >= 400 basis columns.
+// The Rayleigh-Ritz problem: our tridiagonalisation (k_sytrd_multi / k_sytrd_wide), partial spectrum by multisection + inverse iteration
+// (k_tridiag_lowest, k_tridiag_invit), one-launch back-transformation (k_apply_q); rocSOLVER only as the fall-back of a failed check.
 #include "mh_common.h"
 
 #include <algorithm>
@@ -40,12 +42,13 @@ constexpr int TB = 256;
 //     entry points that launch work (assembly, nearest points, shape gathers, bank rendering);
 //   * what still goes through a rocSOLVER factorisation -- the tiny-system dense eigensolve (sygvd) -- takes the lock
 //     EXCLUSIVELY after a device-wide synchronisation: it runs alone;
-//   * (round 4) the iteration itself calls no rocSOLVER factorisation any more: the Cholesky factors of blocks wider than 128
-//     columns went through rocsolver_dpotrf until then, and three threads solving 140 or 215 pairs each lost rank or converged
-//     to perturbed eigenvalues in a third of their solves (tools/concurrent_solves.py 3 18 14 215).  mh_potrf (mh_dense.hip)
-//     factors in 128-column blocks with our kernels and rocBLAS level 3: one solve in ~50 still failed -- not through any library
-//     piece and not through stream ordering (eigs_impl has the record) -- so solves with blocks wider than 128 columns hold the
-//     phase lock EXCLUSIVELY for their duration: they run alone and are exact; solves of up to 110 pairs overlap as before.
+//   * the iteration itself calls no rocSOLVER factorisation (round 4: mh_potrf factors blocks wider than 128 columns in 128-column blocks
+//     with our kernels and rocBLAS level 3; rocsolver_dpotrf lost rank beside other solves);
+//   * (round 5) solves of EVERY block width overlap.  Rounds 2-4 had kept blocks wider than 128 columns under the exclusive lock because
+//     other contexts' solves broke beside them; the cause was a barrier of k_sytrd_multi / k_sytrd_wide that hipcc had left without its
+//     LDS wait, exposed only beside rocBLAS's LDS-bound dsymm kernel, which only wide blocks launch (mh_common.h: mh_lds_writes_landed;
+//     DESIGN.md section 11).  The failures recorded above for rocSOLVER's potrf have the same signature (wrong only beside an LDS-heavy
+//     kernel of another stream); that library is not ours to fix, so what goes through it stays under the exclusive lock.
 // 2.0x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
 // MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex).
 std::mutex g_solve_mutex;
@@ -87,7 +90,6 @@ const Switches &switches() {
 // Design constants (each was once a switch; the losing side of every comparison is recorded in DESIGN.md section 10)
 constexpr int kPowerIterations = 20; // spectral-bound estimate of the smoothers (12 steps left the bound 15 % low on the scan meshes -- more than the 1.1 safety factor -- and one patch-threshold setting then failed to converge; the steps run beside the coarse elimination)
 constexpr uint32_t kPrecondColumns = 256; // (narrower slabs measured slower on the 215-pair solves: 128 -> +2 %, 80 -> +5 %, 64 -> +9 %) // widest panel of one preconditioner application (the single-precision wide-load products: 64 lanes x 4)
-constexpr uint32_t kConcurrentColumns = 128; // widest block whose solve shares the device with other solves (see eigs_impl)
 constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
 constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
 constexpr size_t kDenseLastResort = 12288; // unknowns up to which a solve that did not converge is redone as one dense eigensolve (2 x 1.2 GB, seconds)
@@ -615,29 +617,46 @@ __global__ void k_inverse_sqrt_series(const double *__restrict__ e, const double
     s[i] = (i % m == i / m ? 1.0 : 0.0) - 0.5 * e[i] + 0.375 * e2[i];
 }
 
-// Invariants of the tridiagonalisation Q^T A Q = T: trace and Frobenius norm.  out[0] = the larger of the two relative deviations (NaN-safe:
-// a NaN compares as a failure on the host).  One workgroup; A is the saved symmetric matrix (column-major, order m).
-__global__ void __launch_bounds__(256) k_sytrd_check(const double *__restrict__ a, uint32_t m, const double *__restrict__ d, const double *__restrict__ e, double *__restrict__ out) {
-    __shared__ double s[4][256];
-    const uint32_t tid = threadIdx.x;
-    double tra = 0, absd = 0, fa = 0, trt = 0, ft = 0;
-    for (size_t i = tid; i < size_t(m) * m; i += 256) {
-        const double v = a[i];
-        fa += v * v;
-        if (i % m == i / m) tra += v, absd += fabs(v);
-    }
+// Self-check of a whole Rayleigh-Ritz step (tridiagonalisation, reflectors, partial spectrum, back-transformation at once): for three sampled
+// pairs (first, middle, last) the residual max |A z - theta z| / (max |A z| + |theta| max |z|) against the SAVED symmetric matrix, folded into
+// one device word by atomicMax (non-negative doubles order as integers; NaN maps to the largest value).  Never read back inside the
+// iteration: the solve reads the word once at its end (BlockLobpcg::finish) and fails loudly when it is not at rounding level.
+__global__ void __launch_bounds__(256) k_rr_selfcheck(const double *__restrict__ a, uint32_t m, const double *__restrict__ z, uint32_t ldz, const double *__restrict__ theta, uint32_t ncols,
+                                                      unsigned long long *__restrict__ worst) {
+    __shared__ double zs[768], red[3][256];
+    const uint32_t tid = threadIdx.x, j = blockIdx.x == 0 ? 0 : (blockIdx.x == 1 ? ncols / 2 : ncols - 1);
+    for (uint32_t i = tid; i < m; i += 256) zs[i] = z[size_t(j) * ldz + i];
+    __syncthreads();
+    const double th = theta[j];
+    double rmax = 0, azmax = 0, zmax = 0;
+    bool nan = false;
     for (uint32_t i = tid; i < m; i += 256) {
-        trt += d[i];
-        ft += d[i] * d[i] + (i + 1 < m ? 2.0 * e[i] * e[i] : 0.0);
+        double az = 0;
+        for (uint32_t c = 0; c < m; ++c) az += a[size_t(c) * m + i] * zs[c];
+        const double r = az - th * zs[i];
+        nan = nan || !(r == r);
+        rmax = fmax(rmax, fabs(r)), azmax = fmax(azmax, fabs(az)), zmax = fmax(zmax, fabs(zs[i]));
     }
-    s[0][tid] = tra - trt; s[1][tid] = absd; s[2][tid] = fa - ft; s[3][tid] = fa;
+    red[0][tid] = nan ? INFINITY : rmax, red[1][tid] = azmax, red[2][tid] = zmax;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
-        if (tid < h)
-            for (int q = 0; q < 4; ++q) s[q][tid] += s[q][tid + h];
+        if (tid < uint32_t(h))
+            for (int q = 0; q < 3; ++q) red[q][tid] = fmax(red[q][tid], red[q][tid + h]);
         __syncthreads();
     }
-    if (tid == 0) out[0] = fmax(fabs(s[0][0]) / fmax(s[1][0], 1e-300), fabs(s[2][0]) / fmax(s[3][0], 1e-300));
+    if (tid == 0) {
+        const double rel = red[0][0] / fmax(red[1][0] + fabs(th) * red[2][0], 1e-300);
+        atomicMax(worst, (unsigned long long)__double_as_longlong(rel == rel ? rel : INFINITY));
+    }
+}
+void rr_selfcheck(mh_context *ctx, const double *saved, uint32_t m, const double *z, uint32_t ldz, const double *theta, uint32_t ncols) {
+    if (!ncols) return;
+    if (!ctx->rr_check) {
+        ctx->rr_check = static_cast<unsigned long long *>(ctx->pool.alloc(256));
+        HIP_CHECK(hipMemsetAsync(ctx->rr_check, 0, 256, ctx->stream));
+    }
+    k_rr_selfcheck<<<3, 256, 0, ctx->stream>>>(saved, m, z, ldz, theta, ncols, ctx->rr_check);
+    KERNEL_CHECK();
 }
 
 int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info, uint32_t nwant = 0) {
@@ -695,7 +714,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
     if (m >= 8 && m <= 256) {
         // syevd by parts: the tridiagonalisation (70 % of rocSOLVER's syevd at this order) in one workgroup of ours, then
         // rocSOLVER's divide and conquer on T and the back-transformation Z <- Q Z
-        DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m), check(ctx, 2);
+        DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
         const bool partial = nwant && nwant < m;
         DevArray<double> zl(ctx, partial ? size_t(m) * nwant : 0); // the first attempt's vectors: z still holds the saved matrix then
         double *zres = z.get();
@@ -707,19 +726,10 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
             if (attempt == 0) HIP_CHECK(hipMemcpyAsync(z.get(), gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             else HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             mh_sytrd_small(ctx, gA, m, evals, ework, tau, attempt == 0 ? -1 : 0); // gA is fully symmetric here (k_symmetrize_lower above / the reduction)
-            // the give-up flag travels with the next read-back of this step -- and so does a check of the result's invariants (trace,
-            // Frobenius norm against the saved matrix): the tagged exchange of the multi-workgroup kernel was seen to return garbage,
-            // without timing out, beside another context's wide-block solve (eigs_impl has the record); garbage counts as a give-up
+            // the give-up flag travels with the next read-back of this step (a workgroup stalled past the poll bound by co-resident work)
             int sytrd_gave_up = 0;
-            double sytrd_deviation = 0.0;
             const bool flagged = attempt == 0 && ctx->sytrd_flag;
-            if (flagged) {
-                HIP_CHECK(hipMemcpyAsync(&sytrd_gave_up, ctx->sytrd_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                k_sytrd_check<<<1, 256, 0, ctx->stream>>>(z.get(), m, evals, ework, check.get());
-                KERNEL_CHECK();
-                HIP_CHECK(hipMemcpyAsync(&sytrd_deviation, check.get(), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            }
-            auto garbage = [&] { return flagged && !(sytrd_deviation < 1e-9); };
+            if (flagged) HIP_CHECK(hipMemcpyAsync(&sytrd_gave_up, ctx->sytrd_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             // only the nwant lowest pairs are needed: our multisection + inverse iteration (mh_tridiag_lowest) instead of
             // the full divide and conquer, accepted when its residual check passes
             bool done = false;
@@ -731,8 +741,10 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
                     HIP_CHECK(hipMemcpyAsync(qv, wv.get() + m, sizeof(qv), hipMemcpyDeviceToHost, ctx->stream));
                     HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     if (flagged && switches().test_sytrd_giveup) sytrd_gave_up = 1;
-                    if (garbage()) sytrd_gave_up = 1;
-                    if (sytrd_gave_up) continue;
+                    if (sytrd_gave_up) {
+                        ++ctx->sytrd_redos;
+                        continue;
+                    }
                     const double quality = qv[0];
                     const bool verbose = switches().verbose;
                     if (verbose)
@@ -748,8 +760,11 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
             }
             if (!done) {
                 if (flagged) HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the flag is known before garbage could reach the library
-                if (garbage()) sytrd_gave_up = 1;
-                if (sytrd_gave_up) continue;
+                if (flagged && switches().test_sytrd_giveup) sytrd_gave_up = 1;
+                if (sytrd_gave_up) {
+                    ++ctx->sytrd_redos;
+                    continue;
+                }
                 ROCBLAS_CHECK(rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, m, evals, ework, z, m, info));
                 info.download(&hinfo, 1);
                 if (hinfo != 0) return hinfo;
@@ -757,6 +772,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
             break;
         }
         mh_apply_q(ctx, gA, tau, m, zres, m, ncols);
+        if (zres == zl.get()) rr_selfcheck(ctx, z.get(), m, zres, m, evals, ncols); // (z still holds the saved matrix on this path)
         HIP_CHECK(hipMemcpyAsync(gA, zres, size_t(m) * ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         // no synchronisation: the workspaces return to the context's pool, whose blocks are only ever used on this same stream
     } else {
@@ -765,21 +781,16 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         // conquer on T and its back-transformation.  A give-up (see above) falls back to the library's syevd on the saved matrix.
         bool done = false;
         if (m > 256 && m <= 768) {
-            DevArray<double> z(ctx, size_t(m) * m), tau(ctx, m);
-            HIP_CHECK(hipMemcpyAsync(z.get(), gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            DevArray<double> z(ctx, size_t(m) * m), saved(ctx, size_t(m) * m), tau(ctx, m);
+            HIP_CHECK(hipMemcpyAsync(saved.get(), gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             mh_sytrd_wide(ctx, gA, m, evals, ework, tau);
             int gave_up = 0;
-            double deviation = 0.0; // (the invariants of the result against the saved matrix, as for the small kernel above)
-            DevArray<double> check(ctx, 2);
             HIP_CHECK(hipMemcpyAsync(&gave_up, ctx->sytrd_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            k_sytrd_check<<<1, 256, 0, ctx->stream>>>(z.get(), m, evals, ework, check.get());
-            KERNEL_CHECK();
-            HIP_CHECK(hipMemcpyAsync(&deviation, check.get(), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if (!(deviation < 1e-9)) gave_up = 1;
             if (switches().test_sytrd_giveup) gave_up = 1;
+            if (gave_up) ++ctx->sytrd_redos;
             if (gave_up) {
-                HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_CHECK(hipMemcpyAsync(gA, saved.get(), size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             } else if (nwant && nwant < m && nwant <= 256 && !switches().no_tridiag_wide && [&] {
                            // only the nwant lowest pairs are needed: multisection, inverse iteration and Cholesky-QR (mh_tridiag_lowest_wide)
                            // instead of the full divide and conquer (stedc + ormtr: ~5 ms of library launches at order 720), accepted when
@@ -791,6 +802,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
                            if (!(quality < 1e-10)) return false;
                            HIP_CHECK(hipMemcpyAsync(evals, lam.get(), size_t(nwant) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                            mh_apply_q(ctx, gA, tau, m, z, m, nwant);
+                           rr_selfcheck(ctx, saved.get(), m, z, m, evals, nwant);
                            HIP_CHECK(hipMemcpyAsync(gA, z.get(), size_t(m) * nwant * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                            HIP_CHECK(hipStreamSynchronize(ctx->stream)); // (work and lam go back to the pool)
                            return true;
@@ -1296,7 +1308,7 @@ struct BlockLobpcg {
     int last_spread = 1 << 20;     // 16 log2(max / min diagonal of the last Cholesky factor of a unit-diagonal Gram matrix)
     bool p_needs_explicit = false; // the implicit projection against P was refused (ill-conditioned Gram matrix): caller redoes it explicitly
     uint32_t wp = 0;               // width of P
-    uint32_t iters = 0, nconv = 0;
+    uint32_t iters = 0, nconv = 0, redos_at_start = 0;
     std::vector<double> theta, rn, mn, xn, norms, theta_act, hist_worst;
     double anorm = 0;
     std::vector<uint32_t> act, order, hist_nconv;
@@ -1312,7 +1324,7 @@ struct BlockLobpcg {
                 uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_)
         : sys(system), ctx(system->ctx), st(system->ctx->stream), n(size_t(3) * system->n_nodes), nev(nev_), b(block), mmax(3 * block), sigma(sigma_), residual_tol(residual_tol_),
           max_iters(max_iters_), seed_basis(seed_basis_), seed_rows(seed_rows_), seed_cols(seed_cols_), cancel(cancel_), progress(progress_), prof(prof_), profile(profile_),
-          iterating(block <= kConcurrentColumns), t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
+          iterating(true), t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
           theta_act(block), order(block), locked(block, 0) {
         for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &Pn, &R, &Rw}) panel->reset(ctx, n * b);
         if (!pproj_ok) // M P is only kept for blocks wider than 128 columns (the narrower ones project against P in coefficient space)
@@ -1429,6 +1441,8 @@ struct BlockLobpcg {
     // The initial block: seed columns (warm start), then Gaussian noise, the exact rigid-body modes, one smoothing pass;
     // M-orthonormalised and rotated into its Ritz vectors.
     void start() {
+        redos_at_start = ctx->sytrd_redos;
+        if (ctx->rr_check) HIP_CHECK(hipMemsetAsync(ctx->rr_check, 0, sizeof(unsigned long long), st));
         k_random_panel<<<grid1(n * b), TB, 0, st>>>(X, n * b, 20260710ull);
         KERNEL_CHECK();
         warm = seed_basis && seed_rows == n && seed_cols >= nev;
@@ -1877,8 +1891,23 @@ struct BlockLobpcg {
         KERNEL_CHECK();
         HIP_CHECK(hipStreamSynchronize(st));
         prof.iterate = t_iter.stop();
+        read_health();
         sys->profile = prof;
         if (profile) *profile = prof;
+        if (!(prof.rr_selfcheck < 1e-8))
+            mh_throw(MH_EHIP, "Rayleigh-Ritz self-check failed: a step's eigenpairs leave a relative residual of %.2e against the step's own matrix", prof.rr_selfcheck);
+    }
+    // the solve's health counters: redone Rayleigh-Ritz steps and the worst sampled self-check residual (k_rr_selfcheck) since start()
+    void read_health() {
+        prof.sytrd_redos = ctx->sytrd_redos - redos_at_start;
+        prof.reserved = 0;
+        prof.rr_selfcheck = 0.0;
+        if (ctx->rr_check) {
+            unsigned long long bits = 0;
+            HIP_CHECK(hipMemcpyAsync(&bits, ctx->rr_check, sizeof(bits), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            memcpy(&prof.rr_selfcheck, &bits, sizeof(double));
+        }
     }
 
     void run(double *eigenvalues) {
@@ -1924,29 +1953,11 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             sys->profile = prof;
             if (profile) *profile = prof;
         } else {
-            // A block wider than 128 columns (more than ~110 pairs) is solved ALONE on the device.  Measured (tools/concurrent_solves.py
-            // 3 45 12 120 against ... 110): three threads solving 120 pairs each, one context per thread, lose one solve in ~50 --
-            // late in the iteration the active Ritz vectors turn to garbage within one step -- while 110 pairs (a 128-column block) never
-            // do, in hundreds of solves; alone, the wide solves are exact.  It is not an ordering defect inside a context (it survives
-            // AMD_SERIALIZE_KERNEL=3 and AMD_SERIALIZE_COPY=3) and not one of the library pieces (it survives our own Gram, basis update,
-            // Cholesky and tridiagonalisation in their place, and the separate residual pass forced on a 128-column block stays clean): something in the wide-block path is disturbed by other queues' work the way
-            // rocSOLVER's potrf is -- or rather by other THREADS' host-side work: three PROCESSES solving 120 pairs at once on the same
-            // device agree bit for bit (tools/probe/multiproc_soak.py, 6 x 45 solves), so the disturbance lives inside one process (this
-            // library's host code, or the runtime's / rocBLAS's per-process state; not the hipBLASLt backend and not rocBLAS's workspace
-            // growth: ROCBLAS_USE_HIPBLASLT=0 and a fixed ROCBLAS_DEVICE_MEMORY_SIZE fail alike).  And the victim need not be wide: ONE thread solving 120 pairs beside two threads
-            // solving 65 makes the 65-pair solves fail (tools/probe/one_wide_soak.py, four runs of six): a healthy solve loses everything in
-            // ONE step.  Not a stray write next to a pool array (MH_TEST=redzone finds nothing; 32 MB of slack around every array,
-            // MH_TEST=farzone, changes nothing).  The last experiment of the round points at the multi-workgroup tridiagonalisations: with
-            // MH_TEST=sytrd_giveup (their results discarded; the one-workgroup kernel / the library instead) the same soak is clean in 8 runs
-            // of 8 against ~4 of 8 failing -- the tagged exchange of k_sytrd_multi goes wrong beside a wide solve's kernels in a way the
-            // uneven-load tests do not provoke.  Confirmed at the very end: a check of the result's invariants (trace and Frobenius norm
-            // against the saved matrix, k_sytrd_check in rr_solve) catches the garbage -- with it, and overlap allowed, no solve fails any
-            // more (the step is redone by the one-workgroup kernel / the library, so the eigenvalues differ from the serial run in the
-            // last bits: 1e-13).  WHY the exchange returns garbage without timing out is not understood.  The check stays (any width), and
-            // wide solves still take the phase lock exclusively, which keeps results bit-identical to the serial run:
-            // correctness first; solves of up to 110 pairs (the batch workloads, the editor's default) overlap as before.
-            std::unique_ptr<ExclusivePhase> alone;
-            if (b > kConcurrentColumns) alone = std::make_unique<ExclusivePhase>();
+            // Solves of any block width share the device with other contexts' work.  (Rounds 2-4 ran blocks wider than 128 columns alone, under
+            // an exclusive process-wide lock: other contexts' solves broke beside them.  Round 5 found the cause -- not the wide path
+            // itself but what ran beside it: rocBLAS's LDS-bound dsymm kernel, which only wide blocks call, on the same CU as a workgroup
+            // of k_sytrd_multi, whose barrier at the top of the column loop hipcc had left without its LDS wait; mh_common.h:
+            // mh_lds_writes_landed, DESIGN.md section 11.  With the wait in place the lock is gone.)
             {
                 Timer t(ctx);
                 mh_build_hierarchy(sys, sigma, true); // (the coarse elimination may still run: the first preconditioner application waits for it)
@@ -1963,7 +1974,6 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 // (not when the caller's own iteration limit is what stopped it: MaxRestarts exceeded stays the reference's empty result)
                 if (e.code != MH_ENOTCONVERGED || n > kDenseLastResort || max_iters < 50) throw;
                 if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- dense eigensolve of order %zu instead\n", e.what(), n);
-                alone.reset(); // (the dense solve takes the exclusive phase itself)
                 Timer t(ctx);
                 dense_eigs(sys, nev, sigma, eigenvalues, true);
                 prof = sys->profile;
