@@ -24,7 +24,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5-6 TB/s achievable with a streaming copy
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable with a streaming copy
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X data sheet, fp64 matrix (the guide has no fp64 row)
 NEV_MAX, POS_MAX = 256, 16  # record capacity of the gather
 
 
@@ -50,7 +51,7 @@ def pmc_traffic(family="spmm_family", workload=PMC_WORKLOAD):
     those passes measured (a per-launch figure of the cube says nothing about a batch of 30k-tet meshes)."""
     if workload != PMC_WORKLOAD:
         return None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)[family]["hbm_bytes_per_launch"])
@@ -496,7 +497,7 @@ def main():
         step()
     sync(ctxs)
     dt_instrumented = time.perf_counter() - t1
-    stats = [{k: sum(c.kernel_stats(cls)[k] for c in ctxs) for k in ("launches", "total_ms", "total_bytes")} for cls in (0, 1)]
+    stats = [{k: sum(c.kernel_stats(cls)[k] for c in ctxs) for k in ("launches", "total_ms", "total_bytes")} for cls in (0, 1, 3, 4)]
     for c in ctxs:
         c.time_kernels(False)
 
@@ -540,13 +541,13 @@ def main():
         line["gathered_records"] = {"count": len(records), "words_per_record": sharding.record_length(NEV_MAX, POS_MAX),
                                     "fields": "eigenvalues, freqs, t60s, positions, shapes, mass properties, solve profile",
                                     "collective": "ncclAllGather from C++ (modal::SolveBatch)" if comm is not None else "torch.distributed all_gather (%s)" % ("gloo" if share_gpu else "nccl")}
-    spmm, asm = stats
+    spmm, asm, comb, comb_bytes = stats
     if spmm["launches"]:
         achieved = spmm["total_bytes"] / (spmm["total_ms"] * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm",
                             "kernel": "k_spmm_wide / k_spmm: BSR 3x3 SpMM of the P2 and P1 operators over n-by-w panels "
                                       "(every launch of the solve: fp32 smoother products, mixed fp64-A x fp32-panel residuals, fp64 operator products)",
-                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("spmm_family", args.workload),
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("spmm_family", args.workload), "traffic_source": "committed profile (profiles/r0N_pmc_traffic.json: separate rocprofv3 --pmc passes of this command), not measured in this run",
                             "launches": spmm["launches"], "avg_launch_us": 1e3 * spmm["total_ms"] / spmm["launches"],
                             "algorithmic_bytes_per_launch": spmm["total_bytes"] / spmm["launches"],
                             "measured_in": "%d further steps after the timed region, HIP events around every launch (%.1f ms per step with them)" % (args.steps, 1e3 * dt_instrumented / args.steps)}
@@ -556,8 +557,18 @@ def main():
                                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("assembly", args.workload),
                                      "launches": asm["launches"], "avg_launch_us": 1e3 * asm["total_ms"] / asm["launches"],
                                      "algorithmic_bytes_per_launch": asm["total_bytes"] / asm["launches"]}
+    if comb["launches"]:
+        tflops = comb["total_bytes"] / (comb["total_ms"] * 1e-3) / 1e12  # (the class's work is flops)
+        line["roofline_combine"] = {"bound": "mfma", "kernel": "k_combine: basis updates out = [X | W | P] C of the eigensolver, fp64 MFMA (v_mfma_f64_16x16x4_f64); every call of a solve",
+                                    "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                                    "launches": comb["launches"], "avg_launch_us": 1e3 * comb["total_ms"] / comb["launches"],
+                                    "algorithmic_flops_per_launch": comb["total_bytes"] / comb["launches"],
+                                    "algorithmic_bytes_per_launch": comb_bytes["total_bytes"] / max(1, comb_bytes["launches"]),
+                                    "hbm_GBps_at_that_time": comb_bytes["total_bytes"] / (comb["total_ms"] * 1e-3) / 1e9,
+                                    "ms_per_step": comb["total_ms"] / args.steps / max(1, len(ctxs)),
+                                    "peak_note": "78.6 TFLOP/s: the MI355X data sheet's fp64 matrix figure (the microarchitecture guide lists none); the device holds 2.0-2.1 GHz under these kernels, 65 TFLOP/s there"}
     if not batch:
-        line["profile"] = {k: last.profile.get(k) for k in ("assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract", "restarts", "op_applications")}
+        line["profile"] = {k: last.profile.get(k) for k in ("assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract", "restarts", "op_applications", "sytrd_redos", "rr_selfcheck")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if not batch and "roofline" in line:
             line["roofline"]["single_launch"] = operator_forms(api, ctxs[0], mesh, mat)

@@ -86,8 +86,11 @@ void mh_default_config(mh_solver_config *);
  *   MH_KERNEL_ASSEMBLY the K/M assembly kernel of the quadratic level; bytes: per tet 16 B corners + 96 B coordinates
  *                      + 40 B node ids read, 80 B per node block written
  *   MH_KERNEL_BANK     the resonator kernel (RenderObjectFast); flops: 11 per rendered mode-sample
+ *   MH_KERNEL_COMBINE  the basis updates out = [X | W | P] C of the eigensolver (k_combine, fp64 MFMA; the vendor dgemm for blocks of
+ *                      >= 400 basis columns); flops: 2 n (basis columns) (output columns) per launch.  MH_KERNEL_COMBINE_BYTES carries
+ *                      the same launches' algorithmic bytes (8 n (basis + output columns)) as its work, no time of its own.
  * Stats are the totals since the last enable: launches, summed device milliseconds, summed work. */
-enum { MH_KERNEL_SPMM = 0, MH_KERNEL_ASSEMBLY = 1, MH_KERNEL_BANK = 2, MH_KERNEL_CLASSES = 3 };
+enum { MH_KERNEL_SPMM = 0, MH_KERNEL_ASSEMBLY = 1, MH_KERNEL_BANK = 2, MH_KERNEL_COMBINE = 3, MH_KERNEL_COMBINE_BYTES = 4, MH_KERNEL_CLASSES = 5 };
 int mh_context_time_kernels(mh_context *, int enable);
 int mh_context_kernel_stats(mh_context *, uint64_t *launches, double *total_ms, double *total_bytes); /* MH_KERNEL_SPMM */
 int mh_context_kernel_class_stats(mh_context *, int kernel_class, uint64_t *launches, double *total_ms, double *total_work);

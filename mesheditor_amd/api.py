@@ -58,7 +58,7 @@ class Context:
 
     def kernel_stats(self, kernel_class=0):
         """Totals of a timed kernel class since time_kernels(True): 0 = operator products (bytes), 1 = assembly kernel (bytes),
-        2 = resonator kernel (flops)."""
+        2 = resonator kernel (flops), 3 = basis updates (flops), 4 = their algorithmic bytes (no time of its own)."""
         n, ms, by = C.c_uint64(0), C.c_double(0), C.c_double(0)
         self.check(self.L.mh_context_kernel_class_stats(self.h, kernel_class, C.byref(n), C.byref(ms), C.byref(by)))
         return {"launches": n.value, "total_ms": ms.value, "total_bytes": by.value}

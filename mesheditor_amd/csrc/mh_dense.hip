@@ -537,6 +537,9 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     // a column map on X becomes zero coefficient rows for the columns left out.
     constexpr bool wide_blas = true;
     const uint32_t m_total = wx + ww + wp;
+    // (bench.py's roofline_combine: one timed span and one work figure per call, whichever path it takes)
+    TimedLaunch timed(ctx, MH_KERNEL_COMBINE, 2.0 * double(n) * double(m_total) * double(col_count));
+    if (ctx->time_kernels) ctx->totals[MH_KERNEL_COMBINE_BYTES].work += 8.0 * double(n) * (double(m_total) + double(col_count)), ctx->totals[MH_KERNEL_COMBINE_BYTES].launches += 1;
     if (wide_blas && m_total >= 400 && col_count >= 128 && !caller_omap && out1 != x && out2 != x && n >= 65536) {
         const uint32_t px = ldx ? ldx : wx; // physical columns of the X panel
         const double *cx = ct; // coefficient rows of the X part, k-major with pitch nc

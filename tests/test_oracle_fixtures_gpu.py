@@ -63,9 +63,18 @@ def test_device_result_matches_the_committed_oracle_result(name):
     ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
     ctx = api.Context(0)
     try:
-        r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(**kw))
+        r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(**kw), keep_system=True)
+        worst_plain, dropped = r.system.residual_report()
+        r.system.close()
     finally:
         ctx.close()
+    # what the tolerance meant (VERDICT round 4, item 6 iv): a mesh without sliver patches is accepted in the plain 2-norm (report -1); one
+    # with them in the Jacobi-scaled norm, and the worst PLAIN relative residual of the returned elastic pairs is then bounded here
+    # (measured 2e-5 ... 3e-3 on the scan fixtures: the slivers' rows carry rounding noise eps ||A|| |x| in the 2-norm)
+    assert worst_plain == -1.0 or 0 < worst_plain < 1e-2, (name, worst_plain)
+    assert dropped[0] < 50 and dropped[1] < 50, dropped
+    # health of the device solve: no Rayleigh-Ritz step redone, every step's self-check at rounding level (mh_profile)
+    assert r.profile["sytrd_redos"] == 0 and r.profile["rr_selfcheck"] < 1e-10, r.profile
     ref = np.array(fx["eigenvalues"])
     assert len(r.eigenvalues) == len(ref), r.profile
     elastic = ref > 1e-6 * ref[-1]
