@@ -74,6 +74,7 @@ struct Switches {
     double cheb_ratio = 0.0;
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
+    bool no_poly_start = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_poly_start"); // (A/B hook of round 5: the cold start block as rounds 1-4 had it)
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
             double v[4] = {0, 0, 0, 0};
@@ -523,6 +524,56 @@ __global__ void k_inject_rbm(const double *__restrict__ xyz, const uint32_t *__r
         r0[3] = 0; r1[3] = -rz * on; r2[3] = ry * on; // e_x x r
         r0[4] = rz * on; r1[4] = 0; r2[4] = -rx * on; // e_y x r
         r0[5] = -ry * on; r1[5] = rx * on; r2[5] = 0; // e_z x r
+    }
+}
+// Bounding box of the nodes as six order-preserving integer keys (atomicMin / atomicMax apply): box[0..2] minima, box[3..5] maxima.
+__device__ __forceinline__ unsigned long long mh_ordered_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double mh_from_ordered_key(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+__global__ void k_bbox(const double *__restrict__ xyz, uint32_t nnodes, unsigned long long *__restrict__ box) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int a = 0; a < 3; ++a) {
+        double lo = i < nnodes ? xyz[3 * size_t(i) + a] : 1e300, hi = i < nnodes ? xyz[3 * size_t(i) + a] : -1e300;
+        for (int off = 32; off > 0; off >>= 1) lo = fmin(lo, __shfl_xor(lo, off, 64)), hi = fmax(hi, __shfl_xor(hi, off, 64));
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(box + a, mh_ordered_key(lo));
+            atomicMax(box + 3 + a, mh_ordered_key(hi));
+        }
+    }
+}
+// Smooth start vectors of a cold solve: the lowest modes of an elastic body are smooth displacement fields, so the start block holds
+// (besides the exact rigid-body modes) the six uniform-strain fields and the fields  e_k L_a(x) L_b(y) L_c(z)  in Legendre polynomials
+// over the bounding box for a host-made list of exponent triples (packed a | b << 8 | c << 16; BlockLobpcg::start orders them by total
+// degree and caps the degree along a thin axis).  Columns: strains, then per triple the three components.  One thread per node.
+__global__ void k_inject_poly(const double *__restrict__ xyz, const double *__restrict__ box, uint32_t nnodes, const uint32_t *__restrict__ triples, uint32_t ntriples,
+                              double *__restrict__ x, uint32_t b, uint32_t col0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnodes) return;
+    double t[3], L[3][7];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = box[a], hi = box[3 + a];
+        const double half = fmax(0.5 * (hi - lo), 1e-300);
+        t[a] = (xyz[3 * size_t(i) + a] - 0.5 * (hi + lo)) / half;
+        L[a][0] = 1.0, L[a][1] = t[a];
+        for (int d = 2; d < 7; ++d) L[a][d] = ((2 * d - 1) * t[a] * L[a][d - 1] - (d - 1) * L[a][d - 2]) / d;
+    }
+    double *row[3] = {x + (size_t(3) * i) * b + col0, x + (size_t(3) * i + 1) * b + col0, x + (size_t(3) * i + 2) * b + col0};
+    uint32_t col = 0;
+    auto put = [&](double v0, double v1, double v2) {
+        row[0][col] = v0, row[1][col] = v1, row[2][col] = v2;
+        ++col;
+    };
+    // uniform strains (the three rotations among the nine linear fields are rigid-body modes already)
+    put(t[0], 0, 0), put(0, t[1], 0), put(0, 0, t[2]), put(t[1], t[0], 0), put(t[2], 0, t[0]), put(0, t[2], t[1]);
+    for (uint32_t q = 0; q < ntriples; ++q) {
+        const uint32_t tr = triples[q];
+        const double v = L[0][tr & 0xff] * L[1][(tr >> 8) & 0xff] * L[2][(tr >> 16) & 0xff];
+        put(v, 0, 0), put(0, v, 0), put(0, 0, v);
     }
 }
 __global__ void k_copy_cols(const double *__restrict__ src, uint32_t wsrc, double *__restrict__ dst, uint32_t wdst, size_t rows, uint32_t ncols) {
@@ -1309,6 +1360,7 @@ struct BlockLobpcg {
     bool p_needs_explicit = false; // the implicit projection against P was refused (ill-conditioned Gram matrix): caller redoes it explicitly
     uint32_t wp = 0;               // width of P
     uint32_t iters = 0, nconv = 0, redos_at_start = 0;
+    bool poly_allowed = true; // (cleared when the polynomial start block turned out rank deficient: start() then runs once more without it)
     std::vector<double> theta, rn, mn, xn, norms, theta_act, hist_worst;
     double anorm = 0;
     std::vector<uint32_t> act, order, hist_nconv;
@@ -1467,6 +1519,44 @@ struct BlockLobpcg {
             KERNEL_CHECK();
         };
         if (seed_rigid) inject_rigid_modes();
+        // Smooth start (round 5): behind the rigid-body modes a cold block begins from low-degree polynomial displacement fields
+        // (k_inject_poly: uniform strains, then every Legendre product of total degree 2, 3, ... while whole degrees fit) instead of noise
+        // in three quarters of its columns; the last quarter stays random (what the polynomials cannot represent still has to be found).
+        // They pass through the same B M x step below.  Same iteration counts, but pairs lock earlier: 3-4 % per solve on the Kuhn cubes
+        // (interleaved A/B, profiles/r05_poly_start_ab.txt); nothing on the sphere and the ball.  Only bodies that are not thin along any
+        // axis (every extent at least a quarter of the longest) get it: on plates and shells it bought nothing -- the wanted modes there
+        // are bending modes of the walls -- and the Kuhn plate's block came out rank deficient (a few node layers through the thickness).
+        bool with_poly = !warm && seed_rigid && !switches().no_poly_start && sys->n_components == 1 && poly_allowed;
+        if (with_poly) {
+            DevArray<unsigned long long> keys(ctx, 6);
+            const unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
+            keys.upload(init, 6);
+            k_bbox<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, sys->n_nodes, keys);
+            KERNEL_CHECK();
+            unsigned long long hk[6];
+            keys.download(hk, 6);
+            double box[6], longest = 0, shortest = 1e300;
+            for (int a = 0; a < 6; ++a) {
+                const unsigned long long u = (hk[a] >> 63) ? (hk[a] & 0x7fffffffffffffffull) : ~hk[a];
+                memcpy(&box[a], &u, sizeof(double));
+            }
+            for (int a = 0; a < 3; ++a) longest = std::max(longest, box[3 + a] - box[a]), shortest = std::min(shortest, box[3 + a] - box[a]);
+            with_poly = shortest >= 0.25 * longest;
+            if (with_poly) {
+                const uint32_t room = b - n_rigid, want = room - room / 4;
+                std::vector<uint32_t> triples; // exponents packed a | b << 8 | c << 16
+                for (uint32_t deg = 2; deg <= 6 && 6 + 3 * (triples.size() + (deg + 1) * (deg + 2) / 2) <= want; ++deg)
+                    for (uint32_t a = deg + 1; a-- > 0;)
+                        for (uint32_t bb = deg - a + 1; bb-- > 0;) triples.push_back(a | bb << 8 | (deg - a - bb) << 16);
+                DevArray<double> box_d(ctx, 6);
+                DevArray<uint32_t> tri_d(ctx, std::max<size_t>(1, triples.size()));
+                box_d.upload(box, 6);
+                if (!triples.empty()) tri_d.upload(triples.data(), triples.size());
+                k_inject_poly<<<grid1(sys->n_nodes), TB, 0, st>>>(sys->node_xyz, box_d, sys->n_nodes, tri_d, uint32_t(triples.size()), X, b, n_rigid);
+                KERNEL_CHECK();
+                HIP_CHECK(hipStreamSynchronize(st)); // (the small arrays return to the pool; the uploads read stack memory)
+            }
+        }
         // A cold start begins from B M x for Gaussian noise x (one preconditioner application: the high-frequency content
         // of the noise is damped before the first Rayleigh-Ritz step), with the exact rigid-body modes put back: one
         // iteration fewer on every workload measured (18 -> 17 at S100k, 40 -> 39 on the ball, 17 -> 16 at S30k).
@@ -1482,7 +1572,15 @@ struct BlockLobpcg {
             if (seed_rigid) inject_rigid_modes();
         }
         mh_spmm(ctx, sys->L2, nullptr, X, nullptr, sys->L2.mval, MX, b);
-        if (!chol_orthonormalise(X, MX, nullptr, b)) mh_throw(MH_ENOTCONVERGED, "initial block is rank deficient");
+        if (!chol_orthonormalise(X, MX, nullptr, b)) {
+            if (with_poly) { // a body the polynomial fields are dependent on (too few node layers along an axis): the random block instead
+                if (verbose) fprintf(stderr, "[lobpcg] polynomial start block rank deficient: random block instead\n");
+                poly_allowed = false;
+                start();
+                return;
+            }
+            mh_throw(MH_ENOTCONVERGED, "initial block is rank deficient");
+        }
         mh_spmm(ctx, sys->L2, sys->L2.aval, X, AX, sys->L2.mval, MX, b);
         {
             gram(ctx, n, X, b, AX, b, gA, b);
