@@ -53,7 +53,7 @@ struct MhError : std::runtime_error {
 // before, threw away exactly the panels the next solve of the same mesh asks for: 1.2 s became 1.7 s for a 215-pair solve of
 // 540 k unknowns after any other workload had left its blocks in the cache).
 // An explicit wait for this wave's LDS stores, to be placed in front of a __syncthreads() that hipcc leaves without one.
-// Found in round 5 (DESIGN.md section 11, tools/check_barrier_waits.py): __syncthreads() is a workgroup release fence + s_barrier, and the
+// Found in round 5 (DESIGN.md section 6, tools/check_barrier_waits.py): __syncthreads() is a workgroup release fence + s_barrier, and the
 // fence's `s_waitcnt lgkmcnt(0)` is a "soft" wait that hipcc's wait-count pass (ROCm 7.2, gfx950) deletes when its scoreboard shows nothing
 // pending.  At the header of a loop whose BACK EDGE carries ds_write instructions -- and whose body holds inline asm -- the pass decided that
 // on the loop's first visit and never put the wait back: the waves of k_sytrd_multi / k_sytrd_wide reached the barrier at the top of the

@@ -47,7 +47,7 @@ constexpr int TB = 256;
 //   * (round 5) solves of EVERY block width overlap.  Rounds 2-4 had kept blocks wider than 128 columns under the exclusive lock because
 //     other contexts' solves broke beside them; the cause was a barrier of k_sytrd_multi / k_sytrd_wide that hipcc had left without its
 //     LDS wait, exposed only beside rocBLAS's LDS-bound dsymm kernel, which only wide blocks launch (mh_common.h: mh_lds_writes_landed;
-//     DESIGN.md section 11).  The failures recorded above for rocSOLVER's potrf have the same signature (wrong only beside an LDS-heavy
+//     DESIGN.md section 6).  The failures recorded above for rocSOLVER's potrf have the same signature (wrong only beside an LDS-heavy
 //     kernel of another stream); that library is not ours to fix, so what goes through it stays under the exclusive lock.
 // 2.0x the serial throughput on a batch of 30k-tet meshes with three threads, 2.5x on 4k-tet meshes with eight.
 // MH_CONCURRENT_SOLVES=0 restores one-solve-at-a-time (g_solve_mutex).
@@ -2055,7 +2055,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // an exclusive process-wide lock: other contexts' solves broke beside them.  Round 5 found the cause -- not the wide path
             // itself but what ran beside it: rocBLAS's LDS-bound dsymm kernel, which only wide blocks call, on the same CU as a workgroup
             // of k_sytrd_multi, whose barrier at the top of the column loop hipcc had left without its LDS wait; mh_common.h:
-            // mh_lds_writes_landed, DESIGN.md section 11.  With the wait in place the lock is gone.)
+            // mh_lds_writes_landed, DESIGN.md section 6.  With the wait in place the lock is gone.)
             {
                 Timer t(ctx);
                 mh_build_hierarchy(sys, sigma, true); // (the coarse elimination may still run: the first preconditioner application waits for it)

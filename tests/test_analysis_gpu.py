@@ -367,7 +367,7 @@ def test_concurrent_solves_from_several_threads(api, pairs):
 def test_a_wide_solve_beside_narrow_ones(api):
     """One thread solving 120 pairs (a block wider than 128 columns) beside two threads solving 65, OVERLAPPING: until round 4 the narrow
     solves failed in two runs of three ("0 of 65 pairs converged") and rounds 2-4 ran wide solves alone under a process-wide lock.  The
-    cause (round 5, DESIGN section 11): the barrier at the top of k_sytrd_multi's column loop had lost its LDS wait in hipcc, which shows
+    cause (round 5, DESIGN.md section 6): the barrier at the top of k_sytrd_multi's column loop had lost its LDS wait in hipcc, which shows
     only beside rocBLAS's LDS-bound dsymm kernel -- a kernel only wide blocks launch.  With the wait in place there is no lock: every
     result equals its serial one bit for bit, no Rayleigh-Ritz step was redone, every step's self-check sits at rounding level."""
     import threading

@@ -1,5 +1,5 @@
 """Every s_barrier of the product's kernels is reached with no LDS store in flight (tools/check_barrier_waits.py): the defect behind the
-round-2..4 concurrency failures was a `__syncthreads()` whose LDS wait hipcc had dropped at a loop header (DESIGN.md section 11)."""
+round-2..4 concurrency failures was a `__syncthreads()` whose LDS wait hipcc had dropped at a loop header (DESIGN.md section 6)."""
 import os
 import subprocess
 import sys

@@ -3,7 +3,7 @@
 Round 5 found hipcc (ROCm 7.2, gfx950) dropping the `s_waitcnt lgkmcnt(0)` of `__syncthreads()`'s workgroup release fence at a loop
 header whose BACK EDGE carries pending ds_write instructions: a wave then arrives at the barrier with its LDS stores still queued, the
 other waves pass the barrier and read the old values whenever that wave's LDS queue is backed up by co-resident LDS-heavy waves (the
-multi-workgroup tridiagonalisation beside rocBLAS's dsymm kernel: DESIGN.md section 11).  This walks the control-flow graph of every
+multi-workgroup tridiagonalisation beside rocBLAS's dsymm kernel: DESIGN.md section 6).  This walks the control-flow graph of every
 kernel in the given .s files (hipcc -S --cuda-device-only) with a forward "an LDS write may be pending" dataflow and reports the
 barriers reached with one.
 
