@@ -11,8 +11,9 @@
 //     border: every triangle a constraint, "inside" = what the outside cannot reach), but a recovery point on a WALL stays on it
 //     (counted in BoundarySteinerCount) and nested cavities are only understood on manifold input (parity rule); duplicate
 //     positions are rejected as "point coincides";
-//   * sliver repair changes connectivity only (edge removal, 2-3 flips: Options::RepairSlivers); no vertex smoothing, no quality
-//     refinement (the reference's Options::Quality / MaxVolume have no counterpart);
+//   * sliver repair = connectivity changes (edge removal, 2-3 flips: Options::RepairSlivers) in turn with smoothing of the ADDED points
+//     (round 4); the reference's Options::Quality / MaxVolume exist with the same meaning since round 5 (a constrained Delaunay
+//     refinement of the finished fill: RefineQuality);
 //   * tetrahedra are not the reference's: same contract, other interior (it flips and carves, this refines, re-tiles and repairs).
 // Two fills:
 //   tetra::Tetrahedralize   any closed, non-self-intersecting surface -- non-convex, non-star-shaped, any genus, nested
@@ -39,9 +40,18 @@ struct Result {
     uint32_t BoundarySteinerCount{0}; // added points left ON the surface (input triangles they refine are not boundary faces); 0 = the input triangulation is the boundary
     uint32_t SliverExchanges{0}; // edge removals and 2-3 flips the sliver repair made
     uint32_t ShellPoints{0}; // interior points added under the surface (Options::InteriorShell)
+    uint32_t QualityPoints{0}; // interior points the quality arm added (Options::Quality / MaxVolume)
     explicit operator bool() const { return Error.empty(); }
 };
 struct Options {
+    // The reference's two options (src/mesh/Tetrahedralize.h:17-27), same meaning.  Quality: interior points are inserted until every
+    // tetrahedron meets a circumradius-to-shortest-edge ratio of 2, where the fixed surface allows (a circumcentre the surface cuts off
+    // is not inserted); it gates the refinement alone -- sliver repair and the smoothing of added points run either way.  MaxVolume: any
+    // tetrahedron larger than this absolute volume (the input's own units) is split; setting it turns Quality on; 0 = unconstrained.
+    // Every point they add lies strictly inside: the boundary stays the input triangulation (src/tetrahedralize.cpp, RefineQuality).
+    bool Quality{false};
+    double MaxVolume{0};
+    size_t MaxRefinePoints{0}; // budget of the quality arm; 0 = max(20 000, 40 x the points of the fill)
     size_t MaxSteinerPoints{0}; // boundary-recovery budget; 0 = 2 x the input vertices + 4096
     bool InteriorSteiner{true}; // after the fill, move the recovery's points off the surface (every input triangle a boundary face again)
     bool RepairSlivers{true}; // connectivity-only sliver repair afterwards (the reference repairs slivers whatever its options: Tetrahedralize.h:20)

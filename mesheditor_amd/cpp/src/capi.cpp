@@ -195,19 +195,24 @@ double mhx_punch_stiffness(double inv_modulus, double area) { return PunchStiffn
 struct mhx_tets {
     tetra::Result Result;
 };
-mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner, int interior_steiner) {
+mhx_tets *mhx_tetrahedralize2(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner, int flags, double max_volume) {
     auto *h = new mhx_tets;
     try {
         std::vector<dvec3> pts(n_points);
         for (uint32_t i = 0; i < n_points; ++i) pts[i] = {points[3 * size_t(i)], points[3 * size_t(i) + 1], points[3 * size_t(i) + 2]};
         tetra::Options options;
         options.MaxSteinerPoints = size_t(max_steiner);
-        options.InteriorSteiner = (interior_steiner & 1) != 0; // bit 0: points moved off the surface, bit 1: sliver repair
-        options.RepairSlivers = (interior_steiner & 2) != 0;
-        options.InteriorShell = (interior_steiner & 4) ? tetra::Options::Shell::Never : (interior_steiner & 8) ? tetra::Options::Shell::Always : tetra::Options::Shell::WhenFlat; // bits 2, 3
+        options.InteriorSteiner = (flags & 1) != 0; // bit 0: points moved off the surface, bit 1: sliver repair
+        options.RepairSlivers = (flags & 2) != 0;
+        options.InteriorShell = (flags & 4) ? tetra::Options::Shell::Never : (flags & 8) ? tetra::Options::Shell::Always : tetra::Options::Shell::WhenFlat; // bits 2, 3
+        options.Quality = (flags & 16) != 0; // bit 4: the reference's Options::Quality; max_volume: its Options::MaxVolume
+        options.MaxVolume = max_volume;
         h->Result = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
     } catch (const std::exception &e) { h->Result.Error = e.what(); }
     return h;
+}
+mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner, int interior_steiner) {
+    return mhx_tetrahedralize2(points, n_points, triangles, n_triangles, max_steiner, interior_steiner, 0.0);
 }
 const char *mhx_tets_error(const mhx_tets *h) { return h->Result.Error.c_str(); }
 uint32_t mhx_tets_num_points(const mhx_tets *h) { return uint32_t(h->Result.Mesh.Points.size()); }

@@ -1379,6 +1379,222 @@ static uint32_t AddInteriorShell(TetMesh &mesh, uint32_t n_surface_vertices) {
     return added;
 }
 
+// The quality arm (the reference's Options::Quality / MaxVolume, src/mesh/Tetrahedralize.h:17-27): interior points are inserted until
+// every tetrahedron has a circumradius-to-shortest-edge ratio of at most `ratio_bound` (2) and a volume of at most `max_volume` (0: no
+// bound) -- "where the fixed surface allows": the point of a bad tetrahedron is its circumcentre, reached by a walk from the tetrahedron
+// that may not cross the boundary or a wall; a circumcentre the surface cuts off is not inserted (the tetrahedron stays; one that is only
+// too LARGE gets its centroid instead).  Insertion is the constrained Bowyer-Watson step on exact predicates: the cavity is what the
+// insphere test collects from the containing cell without crossing a constraint, shrunk until the point sees every face of its hull
+// from the inside, then fanned.  Every added point is strictly interior: no boundary face and no wall face is ever touched.
+// Returns the number of points added; `budget` bounds it.
+static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, double max_volume, const std::set<Tri> *walls, size_t budget) {
+    auto &P = mesh.Points;
+    auto &T = mesh.Tets;
+    struct FaceHash {
+        size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
+    };
+    std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> cells_on;
+    cells_on.reserve(T.size() * 2);
+    const auto face_of = [&](const std::array<uint32_t, 4> &v, int i) { return Sorted(v[size_t(i + 1) & 3], v[size_t(i + 2) & 3], v[size_t(i + 3) & 3]); };
+    const auto link = [&](int32_t t, bool add) {
+        for (int i = 0; i < 4; ++i) {
+            const Tri key = face_of(T[size_t(t)], i);
+            if (add) {
+                auto [it, fresh] = cells_on.try_emplace(key, std::array<int32_t, 2>{t, -1});
+                if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
+            } else {
+                auto it = cells_on.find(key);
+                if (it->second[0] == t) it->second[0] = it->second[1];
+                it->second[1] = -1;
+                if (it->second[0] < 0) cells_on.erase(it);
+            }
+        }
+    };
+    for (size_t t = 0; t < T.size(); ++t) link(int32_t(t), true);
+    std::vector<uint8_t> dead(T.size(), 0), hopeless(T.size(), 0);
+    std::vector<uint32_t> mark(T.size(), 0); // cavity membership by stamp
+    uint32_t stamp = 0;
+    // the cell across face i of cell t, or -1 at the boundary, -2 behind a wall
+    const auto across = [&](int32_t t, int i) -> int32_t {
+        const Tri key = face_of(T[size_t(t)], i);
+        if (walls && walls->count(key)) return -2;
+        const auto it = cells_on.find(key);
+        if (it == cells_on.end()) return -1;
+        return it->second[0] == t ? it->second[1] : it->second[0];
+    };
+    struct Measure { double ratio, volume; dvec3 centre; bool ok; };
+    const auto measure = [&](const std::array<uint32_t, 4> &v) {
+        const dvec3 &a = P[v[0]];
+        const dvec3 u = P[v[1]] - a, w = P[v[2]] - a, x = P[v[3]] - a;
+        const auto cross = [](const dvec3 &p, const dvec3 &q) { return dvec3{p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x}; };
+        const auto dot = [](const dvec3 &p, const dvec3 &q) { return p.x * q.x + p.y * q.y + p.z * q.z; };
+        const double det = dot(u, cross(w, x));
+        Measure m{0, std::fabs(det) / 6, a, false};
+        if (!(std::fabs(det) > 0)) return m;
+        const dvec3 num = cross(w, x) * dot(u, u) + cross(x, u) * dot(w, w) + cross(u, w) * dot(x, x);
+        const dvec3 off = num * (0.5 / det);
+        m.centre = a + off;
+        double shortest = 1e300;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                const dvec3 e = P[v[size_t(i)]] - P[v[size_t(j)]];
+                shortest = std::min(shortest, dot(e, e));
+            }
+        m.ratio = std::sqrt(dot(off, off) / shortest);
+        m.ok = std::isfinite(m.ratio);
+        return m;
+    };
+    const auto is_bad = [&](const Measure &m) { return (quality && m.ratio > ratio_bound) || (max_volume > 0 && m.volume > max_volume); };
+    uint32_t added = 0;
+    for (int pass = 0; pass < 64 && added < budget; ++pass) {
+        std::vector<std::pair<double, int32_t>> work; // worst first: the volume excess counts like a ratio
+        for (size_t t = 0; t < T.size(); ++t) {
+            if (dead[t] || hopeless[t]) continue;
+            const Measure m = measure(T[t]);
+            if (!m.ok || !is_bad(m)) continue;
+            work.emplace_back(std::max(m.ratio / ratio_bound, max_volume > 0 ? std::cbrt(m.volume / max_volume) : 0.0), int32_t(t));
+        }
+        if (work.empty()) break;
+        std::sort(work.begin(), work.end(), [](const auto &l, const auto &r) { return l.first != r.first ? l.first > r.first : l.second < r.second; });
+        uint32_t added_this_pass = 0;
+        for (const auto &[badness, t0] : work) {
+            if (added >= budget) break;
+            if (dead[size_t(t0)]) continue;
+            const Measure m = measure(T[size_t(t0)]);
+            if (!m.ok || !is_bad(m)) continue;
+            const bool too_large = max_volume > 0 && m.volume > max_volume;
+            bool inserted = false;
+            for (int attempt = 0; attempt < 2 && !inserted; ++attempt) {
+                // attempt 0: the circumcentre; attempt 1 (a tetrahedron that is too large only): its centroid, which it always contains
+                if (attempt == 1 && !too_large) break;
+                dvec3 p = m.centre;
+                if (attempt == 1) {
+                    const auto &v = T[size_t(t0)];
+                    p = (P[v[0]] + P[v[1]] + P[v[2]] + P[v[3]]) * 0.25;
+                }
+                // walk to the cell that holds p, never through the boundary or a wall
+                int32_t at = t0;
+                bool found = false;
+                for (int step = 0; step < 400 && at >= 0; ++step) {
+                    const auto cell = T[size_t(at)];
+                    int32_t next = -3;
+                    bool strictly = true;
+                    for (int k = 0; k < 4 && next == -3; ++k) {
+                        const int i = (k + step) & 3;
+                        dvec3 q[4];
+                        for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cell[size_t(j)]];
+                        const int side = exact::Orient3D(q[0], q[1], q[2], q[3]);
+                        if (side < 0) next = across(at, i);
+                        strictly = strictly && side > 0;
+                    }
+                    if (next == -3) { found = strictly; break; } // inside; on a face or an edge (not strictly): not this point
+                    at = next; // -1 / -2: the surface cuts p off
+                }
+                if (!found || at < 0) continue;
+                // cavity: insphere from the containing cell, never across a constraint; at most 512 cells (the long cells of a bare surface's
+                // Delaunay fill all hold an interior point in their circumspheres: the full cavity of an early point is most of the mesh,
+                // and a local one serves as well -- the exchanges of the sliver repair afterwards do not need a Delaunay mesh)
+                if (mark.size() < T.size()) mark.resize(T.size() + T.size() / 2, 0);
+                ++stamp;
+                std::vector<int32_t> cavity{at};
+                mark[size_t(at)] = stamp;
+                for (size_t head = 0; head < cavity.size() && cavity.size() < 512; ++head)
+                    for (int i = 0; i < 4; ++i) {
+                        const int32_t o = across(cavity[head], i);
+                        if (o < 0 || mark[size_t(o)] == stamp) continue;
+                        const auto &ov = T[size_t(o)];
+                        if (exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0) mark[size_t(o)] = stamp, cavity.push_back(o);
+                    }
+                const auto inside = [&](int32_t c) { return c >= 0 && mark[size_t(c)] == stamp; };
+                // star-shaped hull: every hull face must see p strictly from the inside; a cell whose face does not leaves the cavity
+                bool ok = true;
+                for (bool changed = true; changed && ok;) {
+                    changed = false;
+                    for (const int32_t c : cavity) {
+                        if (!inside(c)) continue;
+                        const auto &cv = T[size_t(c)];
+                        for (int i = 0; i < 4; ++i) {
+                            if (inside(across(c, i))) continue; // interior face of the cavity
+                            dvec3 q[4];
+                            for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cv[size_t(j)]];
+                            if (exact::Orient3D(q[0], q[1], q[2], q[3]) > 0) continue;
+                            if (c == at) ok = false;
+                            else mark[size_t(c)] = 0, changed = true;
+                            break;
+                        }
+                        if (!ok) break;
+                    }
+                    // the cavity must stay connected to the containing cell
+                    if (ok && changed) {
+                        ++stamp;
+                        std::vector<int32_t> reach{at};
+                        const uint32_t old = stamp - 1;
+                        mark[size_t(at)] = stamp;
+                        for (size_t head = 0; head < reach.size(); ++head)
+                            for (int i = 0; i < 4; ++i) {
+                                const int32_t o = across(reach[head], i);
+                                if (o >= 0 && mark[size_t(o)] == old) mark[size_t(o)] = stamp, reach.push_back(o);
+                            }
+                        cavity.swap(reach);
+                    }
+                }
+                if (!ok) continue;
+                std::vector<int32_t> in;
+                for (const int32_t c : cavity)
+                    if (inside(c)) in.push_back(c);
+                // not on top of a vertex of the cavity (a point that close makes an edge shorter than the ones that called for it)
+                {
+                    double nearest = 1e300, shortest = 1e300;
+                    for (const int32_t c : in)
+                        for (const uint32_t v : T[size_t(c)]) {
+                            const dvec3 e = P[v] - p;
+                            nearest = std::min(nearest, e.x * e.x + e.y * e.y + e.z * e.z);
+                        }
+                    const auto &v0 = T[size_t(t0)];
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = i + 1; j < 4; ++j) {
+                            const dvec3 e = P[v0[size_t(i)]] - P[v0[size_t(j)]];
+                            shortest = std::min(shortest, e.x * e.x + e.y * e.y + e.z * e.z);
+                        }
+                    if (attempt == 0 && nearest < shortest) continue; // no new edge shorter than the shortest edge of the tetrahedron that called for the point: the smallest edge length of the mesh never falls, so the refinement ends (the centroid of a tetrahedron that is too LARGE goes in regardless)
+                }
+                // fan the hull from p
+                const uint32_t id = uint32_t(P.size());
+                std::vector<std::array<uint32_t, 4>> fresh;
+                for (const int32_t c : in) {
+                    const auto &cv = T[size_t(c)];
+                    for (int i = 0; i < 4; ++i) {
+                        if (inside(across(c, i))) continue;
+                        std::array<uint32_t, 4> piece = cv;
+                        piece[size_t(i)] = id; // (p on the side of the vertex it replaces: the orientation stays positive)
+                        fresh.push_back(piece);
+                    }
+                }
+                P.push_back(p);
+                for (const int32_t c : in) link(c, false), dead[size_t(c)] = 1;
+                for (const auto &piece : fresh) {
+                    T.push_back(piece);
+                    dead.push_back(0);
+                    hopeless.push_back(0);
+                    link(int32_t(T.size() - 1), true);
+                }
+                ++added, ++added_this_pass;
+                inserted = true;
+            }
+            if (!inserted) hopeless[size_t(t0)] = 1; // (the surface cuts its circumcentre off: it stays as it is)
+        }
+        if (!added_this_pass) break;
+    }
+    if (added) {
+        std::vector<std::array<uint32_t, 4>> kept;
+        kept.reserve(T.size());
+        for (size_t t = 0; t < T.size(); ++t)
+            if (!dead[t]) kept.push_back(T[t]);
+        T.swap(kept);
+    }
+    return added;
+}
+
 // Vertex smoothing of the ADDED points (the reference's "vertex optimisation" runs with its sliver repair: Tetrahedralize.h:20):
 // an interior point moves towards the centroid of the vertices it is connected to, as far (1, 1/2, 1/4 of the way) as raises the
 // worst shape measure of its tetrahedra while every one of them stays positively oriented (exact).  Input vertices never move;
@@ -1748,6 +1964,20 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
             if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
             out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
         }
+        // The quality arm, when asked for (the reference's Options::Quality / MaxVolume): interior points until the radius-edge ratio is at
+        // most 2 and no tetrahedron is larger than MaxVolume, where the fixed surface allows; then the same repair and smoothing again.
+        if (options.Quality || options.MaxVolume > 0) {
+            const size_t budget = options.MaxRefinePoints ? options.MaxRefinePoints : std::max<size_t>(20000, 40 * out.Mesh.Points.size());
+            out.QualityPoints = RefineQuality(out.Mesh, true, 2.0, options.MaxVolume, keep, budget);
+            if (out.QualityPoints) {
+                for (int round = 0; round < 2; ++round) {
+                    out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                    if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
+                }
+                out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                if (options.MaxVolume > 0) out.QualityPoints += RefineQuality(out.Mesh, false, 2.0, options.MaxVolume, keep, budget); // (an exchange may have merged cells past the bound)
+            }
+        }
         // Flat cells at the surface.  A few of them (planar surface quads joined into one cell: a coarse UV sphere) each get an apex
         // underneath (BreakCaps); if the fill is still left with flat cells after that, the surface is smooth at its own resolution
         // and every surface vertex needs a vertex underneath (AddInteriorShell, from the mesh as it was before the caps).
@@ -1795,7 +2025,8 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
             std::nth_element(shapes.begin(), shapes.begin() + long(tenth), shapes.end());
             return shapes[tenth] < 0.08;
         };
-        if (manifold && (flat_at_surface(out.Mesh) > 0 || (options.InteriorShell == Options::Shell::WhenFlat && poorly_shaped(out.Mesh)))) {
+        const bool quality_arm = options.Quality || options.MaxVolume > 0; // (asked for: it stands in for the shell heuristic)
+        if (manifold && (flat_at_surface(out.Mesh) > 0 || (!quality_arm && options.InteriorShell == Options::Shell::WhenFlat && poorly_shaped(out.Mesh)))) {
             const TetMesh before = out.Mesh;
             const uint32_t exchanges_before = out.SliverExchanges;
             if (BreakCaps(out.Mesh, 1e-3)) {
@@ -1803,8 +2034,8 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
                 SmoothAddedPoints(out.Mesh, n_input, keep);
                 out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
             }
-            const bool shell = options.InteriorShell == Options::Shell::Always ||
-                               (options.InteriorShell == Options::Shell::WhenFlat && (flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size() || poorly_shaped(out.Mesh))); // > 0.5 % of the cells
+            const bool shell = !quality_arm && (options.InteriorShell == Options::Shell::Always ||
+                               (options.InteriorShell == Options::Shell::WhenFlat && (flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size() || poorly_shaped(out.Mesh)))); // > 0.5 % of the cells
             if (shell) {
                 out.Mesh = before;
                 out.SliverExchanges = exchanges_before;

@@ -10,6 +10,7 @@ def _lib():
     if not getattr(L, "_tets_bound", False):
         vp, u32 = C.c_void_p, C.c_uint32
         L.mhx_tetrahedralize.restype, L.mhx_tetrahedralize.argtypes = vp, [vp, u32, vp, u32, C.c_uint64, C.c_int]
+        L.mhx_tetrahedralize2.restype, L.mhx_tetrahedralize2.argtypes = vp, [vp, u32, vp, u32, C.c_uint64, C.c_int, C.c_double]
         L.mhx_tets_error.restype, L.mhx_tets_error.argtypes = C.c_char_p, [vp]
         for name in ("mhx_tets_num_points", "mhx_tets_num_tets", "mhx_tets_boundary_steiner"):
             getattr(L, name).restype, getattr(L, name).argtypes = u32, [vp]
@@ -20,7 +21,7 @@ def _lib():
     return L
 
 
-def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repair_slivers=True, interior_shell="when_flat"):
+def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repair_slivers=True, interior_shell="when_flat", quality=False, max_volume=0.0):
     """(points float64 [V', 3], tets uint32 [T, 4], boundary_steiner_count): input vertex i keeps index i, added points follow.
     interior_steiner (tetra::Options::InteriorSteiner): the recovery's points are moved off the surface afterwards, so that every
     input triangle is a boundary face (the count returned is what had to stay on it; 0 = the reference's contract holds).
@@ -28,12 +29,15 @@ def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repa
     reference's tetrahedraliser always does.
     interior_shell (tetra::Options::InteriorShell): "when_flat" (default: a point under every surface vertex only if the fill is left
     with flat cells at the surface), "never", "always".
+    quality / max_volume: the reference's tetra::Options::Quality / MaxVolume (src/mesh/Tetrahedralize.h:17-27): interior points until the
+    radius-edge ratio is at most 2 where the fixed surface allows / until no tetrahedron is larger than max_volume.
     Raises RuntimeError with the tetrahedraliser's message for open / self-intersecting / unrecoverable surfaces."""
     L = _lib()
     pts = np.ascontiguousarray(points, dtype=np.float64)
     tri = np.ascontiguousarray(triangles, dtype=np.uint32)
-    h = L.mhx_tetrahedralize(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner),
-                             int(bool(interior_steiner)) | (2 if repair_slivers else 0) | {"when_flat": 0, "never": 4, "always": 8}[interior_shell])
+    h = L.mhx_tetrahedralize2(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner),
+                              int(bool(interior_steiner)) | (2 if repair_slivers else 0) | {"when_flat": 0, "never": 4, "always": 8}[interior_shell] | (16 if quality else 0),
+                              float(max_volume))
     try:
         err = L.mhx_tets_error(h).decode()
         if err:

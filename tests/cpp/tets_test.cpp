@@ -108,6 +108,78 @@ std::string Validate(const Surface &s, const TetMesh &mesh, double surface_volum
 }
 } // namespace
 
+namespace {
+// circumradius over shortest edge of a tetrahedron
+double RadiusEdgeRatio(const TetMesh &mesh, const std::array<uint32_t, 4> &t) {
+    const dvec3 &a = mesh.Points[t[0]];
+    const dvec3 u = mesh.Points[t[1]] - a, v = mesh.Points[t[2]] - a, w = mesh.Points[t[3]] - a;
+    const auto cross = [](const dvec3 &p, const dvec3 &q) { return dvec3{p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x}; };
+    const auto dot = [](const dvec3 &p, const dvec3 &q) { return p.x * q.x + p.y * q.y + p.z * q.z; };
+    const double det = dot(u, cross(v, w));
+    const dvec3 off = (cross(v, w) * dot(u, u) + cross(w, u) * dot(v, v) + cross(u, v) * dot(w, w)) * (0.5 / det);
+    double shortest = 1e300;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j) {
+            const dvec3 e = mesh.Points[t[size_t(i)]] - mesh.Points[t[size_t(j)]];
+            shortest = std::min(shortest, dot(e, e));
+        }
+    return std::sqrt(dot(off, off) / shortest);
+}
+} // namespace
+
+// The reference's Options::Quality (src/mesh/Tetrahedralize.h:19-21): interior points until the radius-edge ratio is at most 2 where the
+// fixed surface allows; the surface stays exactly the input triangulation, every added point strictly inside.
+CASE(the_quality_option_refines_to_a_radius_edge_ratio_of_two_with_interior_points_only) {
+    struct Named { const char *Name; Surface S; double Volume; bool Chunky; };
+    const std::vector<Named> cases{{"cube 2 x 2 x 2, 6 quads a side", BoxSurface(2, 2, 2, 6), 8.0, true}, {"box 4 x 4 x 1, 6 quads a side", BoxSurface(4, 4, 1, 6), 16.0, false},
+                                   {"L prism", LPrism(), 7.0, false}, {"octahedron", Octahedron(), 4.0, false}};
+    for (const auto &c : cases) {
+        const auto plain = tetra::Tetrahedralize(c.S.P, c.S.T);
+        tetra::Options o;
+        o.Quality = true;
+        const auto fine = tetra::Tetrahedralize(c.S.P, c.S.T, o);
+        EXPECT_NOTE(bool(plain) && bool(fine), std::string(c.Name) + ": " + plain.Error + fine.Error);
+        if (!plain || !fine) continue;
+        EXPECT_NOTE(fine.BoundarySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
+        const auto defect = Validate(c.S, fine.Mesh, c.Volume);
+        EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
+        const auto bad = [&](const TetMesh &m) {
+            size_t n = 0;
+            for (const auto &t : m.Tets) n += RadiusEdgeRatio(m, t) > 2.0 + 1e-9;
+            return n;
+        };
+        // what is left above the bound has its circumcentre cut off by the surface: a small share of the refined mesh
+        const size_t before = bad(plain.Mesh), after = bad(fine.Mesh);
+        std::printf("        %-34s %zu -> %zu tets, ratio > 2: %zu -> %zu, %u interior points\n", c.Name, plain.Mesh.Tets.size(), fine.Mesh.Tets.size(), before, after, fine.QualityPoints);
+        // (a body the surface leaves room in: a tenth at most; a plate one or two cells thick keeps the cells that span it)
+        if (c.Chunky) EXPECT_NOTE(after * 10 <= fine.Mesh.Tets.size(), std::string(c.Name) + ": more than a tenth of the tets above the bound");
+        EXPECT_NOTE(after <= before, std::string(c.Name) + ": more tets above the bound than before");
+        if (before * 20 > plain.Mesh.Tets.size()) EXPECT_NOTE(fine.QualityPoints > 0, std::string(c.Name) + ": nothing was refined");
+        // without the option nothing changes (Tetrahedralize.h:20: "this gates refinement alone")
+        EXPECT(plain.QualityPoints == 0);
+    }
+}
+
+// Options::MaxVolume (Tetrahedralize.h:22-26): an absolute bound in the input's own units; setting it turns Quality on.
+CASE(the_max_volume_option_bounds_every_tetrahedron) {
+    const auto s = BoxSurface(2, 1, 0.5, 2);
+    for (const double bound : {0.02, 0.004}) {
+        tetra::Options o;
+        o.MaxVolume = bound;
+        const auto r = tetra::Tetrahedralize(s.P, s.T, o);
+        EXPECT_NOTE(bool(r), r.Error);
+        if (!r) continue;
+        const auto defect = Validate(s, r.Mesh, 1.0);
+        EXPECT_NOTE(defect.empty(), defect);
+        double largest = 0;
+        for (const auto &t : r.Mesh.Tets) largest = std::max(largest, Vol6(r.Mesh.Points[t[0]], r.Mesh.Points[t[1]], r.Mesh.Points[t[2]], r.Mesh.Points[t[3]]) / 6);
+        std::printf("        MaxVolume %.3g: %zu tets, largest %.3g, %u interior points\n", bound, r.Mesh.Tets.size(), largest, r.QualityPoints);
+        EXPECT(largest <= bound * (1 + 1e-12));
+        EXPECT(r.Mesh.Tets.size() >= size_t(1.0 / bound));
+        EXPECT(r.QualityPoints > 0 && r.BoundarySteinerCount == 0);
+    }
+}
+
 CASE(a_box_surface_fills_for_every_layer_count) {
     const auto s = BoxSurface(2, 1, 0.5, 3);
     for (uint32_t layers : {0u, 1u, 2u, 5u}) {

@@ -219,6 +219,39 @@ def test_tet_front_end_keeps_the_input_triangulation_as_the_boundary():
             assert boundary != given and all(max(face) < len(v) for face in boundary & given)
 
 
+def test_tet_front_end_quality_and_max_volume_options():
+    """The reference's tetra::Options::Quality / MaxVolume (src/mesh/Tetrahedralize.h:17-27) through the Python binding: a UV sphere, whose
+    default fill keeps flat cells between coplanar ring quads, comes back without any and with the surface untouched; MaxVolume bounds
+    every tetrahedron; every added point is strictly inside (the boundary is exactly the input triangulation)."""
+    from mesheditor_amd import meshes, tets
+    v, f = meshes.uv_sphere_surface(0.15, 32, 16)
+
+    def shapes(p, t):
+        q = p[t.astype(np.int64)]
+        vol6 = np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0])
+        e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+        return vol6, vol6 * np.sqrt(2) / e2 ** 1.5
+
+    def boundary_is_the_input(p, t):
+        faces = np.sort(np.concatenate([t[:, [1, 2, 3]], t[:, [0, 2, 3]], t[:, [0, 1, 3]], t[:, [0, 1, 2]]]), axis=1)
+        uniq, counts = np.unique(faces, axis=0, return_counts=True)
+        return counts.max() <= 2 and {tuple(r) for r in uniq[counts == 1]} == {tuple(sorted(r)) for r in f.tolist()}
+
+    p0, t0, _ = tets.tetrahedralize(v, f, interior_shell="never")
+    p1, t1, left1 = tets.tetrahedralize(v, f, quality=True)
+    vol0, q0 = shapes(p0, t0)
+    vol1, q1 = shapes(p1, t1)
+    assert left1 == 0 and np.array_equal(p1[: len(v)], v) and len(p1) > len(v)
+    assert vol1.min() > 0 and boundary_is_the_input(p1, t1)
+    assert (q0 < 1e-3).sum() > 0 and (q1 < 1e-3).sum() == 0, ((q0 < 1e-3).sum(), (q1 < 1e-3).sum())
+    assert abs(vol1.sum() - vol0.sum()) < 1e-12 * vol0.sum()
+    bound = vol0.sum() / 6 / 4000
+    p2, t2, left2 = tets.tetrahedralize(v, f, max_volume=bound)
+    vol2, _ = shapes(p2, t2)
+    assert left2 == 0 and vol2.min() > 0 and vol2.max() / 6 <= bound * (1 + 1e-12) and len(t2) >= 4000
+    assert boundary_is_the_input(p2, t2)
+
+
 @pytest.mark.parametrize("h,thickness,ratio", [(0.011, 0.015, 0.25), (0.011, 0.015, 0.1), (0.006, 0.008, 0.25)])
 def test_decimated_scan_surfaces_fill_with_their_triangulation_as_the_boundary(h, thickness, ratio):
     """the reference pipeline's actual input is a quadric-decimated scan (src/mesh/Tets.h:8-10 -> GenerateTets).

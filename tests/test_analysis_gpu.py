@@ -1130,3 +1130,23 @@ def test_a_small_system_that_stalls_is_redone_as_one_dense_eigensolve(oracle):
         system.close()
     finally:
         ctx.close()
+
+
+def test_a_fine_uv_sphere_solves_through_the_quality_arm(api):
+    """a fine UV sphere (96 x 48: coplanar ring quads, needle fans at the poles) filled with the reference's
+    Options::Quality -- interior points until the radius-edge ratio is 2 where the fixed surface allows, no shell heuristic -- has no
+    flat cell left and solves in at most 40 iterations (its default fill: 172 cells flat to 1e-8, 57 iterations; the 128 x 64 sphere's
+    default fill does not converge at all, with Quality: 29 iterations -- tools/probe/quality_sphere_probe.py)."""
+    from mesheditor_amd import tets as front_end
+    P, F = meshes.uv_sphere_surface(0.15, 96, 48)
+    pts, tets, left = front_end.tetrahedralize(P, F, quality=True)
+    assert left == 0
+    c = api.Context(0)
+    try:
+        m = meshes.MATERIALS["Ceramic"]
+        ex = pts[(np.arange(10) * len(P)) // 10].astype(np.float32)
+        r = api.mesh2modes(c, pts, tets, api.material(*m), ex, config=api.default_config(num_modes=50, num_fem_modes=65))
+        assert len(r.eigenvalues) == 65
+        assert r.profile["restarts"] <= 40, r.profile["restarts"]
+    finally:
+        c.close()
