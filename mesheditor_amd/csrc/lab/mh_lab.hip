@@ -138,6 +138,50 @@ int mhl_system_bench_spmm(mh_system *s, uint32_t width, uint32_t reps, double *a
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+// The single-precision smoother's fused product-and-Chebyshev step (mh_spmm_f32_cheb_step) on level 2 (P2) or 1 (P1) over an n x width
+// panel, `slabs` launches of width / slabs columns each on separate contiguous panels: does a wide block cost more per column than
+// narrow ones?  (Needs mh_build_hierarchy: the fp32 copies of the operators; a solve of the system leaves them behind.)
+int mhl_system_bench_cheb_step(mh_system *s, int level, uint32_t width, uint32_t slabs, uint32_t reps, double *avg_ms) {
+    if (!s || !avg_ms || width == 0 || slabs == 0 || width % (4 * slabs) || reps == 0 || (level != 1 && level != 2)) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const BsrLevel &lvl = level == 2 ? s->L2 : s->L1;
+        if (!lvl.aval32.get() || !lvl.dinv32.get()) mh_throw(MH_EINVAL, "bench_cheb_step: no single-precision operator (solve the system once first)");
+        const size_t n = size_t(3) * lvl.n_nodes;
+        const uint32_t wc = width / slabs;
+        std::vector<DevArray<float>> d(slabs), d2(slabs), r(slabs), x(slabs);
+        std::vector<float> h(n * wc);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = float((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
+        for (uint32_t q = 0; q < slabs; ++q) {
+            for (auto *a : {&d[q], &d2[q], &r[q], &x[q]}) {
+                a->reset(ctx, n * wc);
+                a->upload(h.data(), h.size());
+            }
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        auto run = [&] {
+            for (uint32_t q = 0; q < slabs; ++q)
+                if (!mh_spmm_f32_cheb_step(ctx, lvl, d[q], d2[q], r[q], x[q], lvl.dinv32, 0.3f, 0.1f, wc)) mh_throw(MH_EINVAL, "bench_cheb_step: width %u not served by the wide kernel", wc);
+        };
+        run();
+        run();
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t rep = 0; rep < reps; ++rep) run();
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / reps;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 int mhl_system_bench_elementwise(mh_system *s, uint32_t width, uint32_t reps, double *avg_ms) {
     if (!s || width == 0 || reps == 0 || !avg_ms) return MH_EINVAL;
     mh_context *ctx = s->ctx;

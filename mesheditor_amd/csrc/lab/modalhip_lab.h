@@ -11,6 +11,8 @@ int mhl_system_bench_spmm(mh_system *, uint32_t width, uint32_t reps, double *av
 /* The matrix-free element-by-element operator: one product in the reference's DOF order, and its timing loop. */
 int mhl_system_elementwise_matvec(mh_system *, const double *x, double *y, uint32_t width);
 int mhl_system_bench_elementwise(mh_system *, uint32_t width, uint32_t reps, double *avg_ms);
+/* The fp32 smoother's fused product-and-Chebyshev step on level 2 / 1 over an n x width panel cut into `slabs` contiguous panels. */
+int mhl_system_bench_cheb_step(mh_system *, int level, uint32_t width, uint32_t slabs, uint32_t reps, double *avg_ms);
 /* kind 0 = Gram G = X^T Y (X n x wa, Y n x wb), kind 1 = basis update Z = [X | W] C: average device time of `reps` launches. */
 int mhl_context_bench_dense(mh_context *, int kind, uint64_t n, uint32_t wa, uint32_t wb, uint32_t reps, double *avg_ms);
 /* The Rayleigh-Ritz step's Householder tridiagonalisation called directly: a (m x m, symmetric, both triangles, m <= 256) ->

@@ -18,6 +18,12 @@ struct PerDeviceOnce {
     template<typename F> void run(int device, F &&f) { std::call_once(flag[device >= 0 && device < MaxDevices ? device : 0], std::forward<F>(f)); }
 };
 
+// MH_TEST=own_gemm (A/B hook, round 5): the wide Gram blocks and basis updates of the 200-mode configuration through OUR kernels
+// (k_gram_blocked cut into 160 x 80 blocks, k_combine in 256-column chunks) instead of the vendor's dgemm -- profiles/r05_config3_gemm_ab.txt
+static bool mh_test_own_gemm() {
+    static const bool on = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "own_gemm");
+    return on;
+}
 namespace {
 constexpr int KC = 32; // rows staged per step
 
@@ -426,7 +432,7 @@ void mh_gram(mh_context *ctx, size_t n, const double *x, uint32_t wa, const doub
     // slab (split-K by hand: the output alone is four macro tiles), partials added in a fixed order by k_gram_reduce as for our own
     // kernel.  Row-major panels are column-major transposes: G = (X^T)(Y^T)^T = dgemm(N, T) on the stored arrays.
     // (below 128 columns a side the library loses to our kernel: 257 against 174 us on 80 x 80, 544 against 333 on 160 x 80 at 447 k rows)
-    if (wa >= 128 && wb >= 128 && n >= 65536 && !ymap) {
+    if (wa >= 128 && wb >= 128 && n >= 65536 && !ymap && !mh_test_own_gemm()) {
         const uint32_t slabs = 128; // (32 ... 256 slabs: 1.41 ... 1.45 ms on 240 x 240 at 542 k rows; 512: 1.54)
         const size_t rows = n / slabs, rest = n - rows * slabs; // the first `slabs` members take `rows` rows each, one more call the rest
         const size_t members = slabs + (rest ? 1 : 0), need = members * size_t(wa) * wb * sizeof(double);
@@ -540,7 +546,7 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     // (bench.py's roofline_combine: one timed span and one work figure per call, whichever path it takes)
     TimedLaunch timed(ctx, MH_KERNEL_COMBINE, 2.0 * double(n) * double(m_total) * double(col_count));
     if (ctx->time_kernels) ctx->totals[MH_KERNEL_COMBINE_BYTES].work += 8.0 * double(n) * (double(m_total) + double(col_count)), ctx->totals[MH_KERNEL_COMBINE_BYTES].launches += 1;
-    if (wide_blas && m_total >= 400 && col_count >= 128 && !caller_omap && out1 != x && out2 != x && n >= 65536) {
+    if (wide_blas && !mh_test_own_gemm() && m_total >= 400 && col_count >= 128 && !caller_omap && out1 != x && out2 != x && n >= 65536) {
         const uint32_t px = ldx ? ldx : wx; // physical columns of the X panel
         const double *cx = ct; // coefficient rows of the X part, k-major with pitch nc
         DevArray<double> ct_full;

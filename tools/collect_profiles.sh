@@ -2,7 +2,7 @@
 # Round-end evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r03
 # Writes the rocprofv3 summaries judged under profiles/ into gpurun_out/final/ (copied into profiles/ afterwards).
 # Counter passes (--pmc) run on their own, without any trace option beside them.
-R=${1:-r03}
+R=${1:-r05}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
