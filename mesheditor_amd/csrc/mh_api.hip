@@ -139,11 +139,8 @@ int mh_context_create(int device, mh_context **out) {
         if (ctx->blas) rocblas_destroy_handle(ctx->blas);
         if (ctx->blas_aux) rocblas_destroy_handle(ctx->blas_aux);
         if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
-    for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
         if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
-    for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
-        for (hipEvent_t e : ctx->ahead_ev) (void)hipEventDestroy(e);
+        for (hipEvent_t ev : ctx->ahead_ev) (void)hipEventDestroy(ev);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return code;

@@ -1330,6 +1330,7 @@ struct BlockLobpcg {
     Timer t_iter;
     double precond_seconds = 0;
     double best_worst_active = 1e300; // smallest worst relative residual of the active columns seen so far
+    int floor_strikes = 0;            // consecutive iterations in which the worst active residual sat 1e3 above it
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
     DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
@@ -1687,7 +1688,10 @@ struct BlockLobpcg {
                 if (!locked[i]) worst_active = std::max(worst_active, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
             }
             best_worst_active = std::min(best_worst_active, worst_active);
-            if (it >= 20 && worst_active > 1e3 * best_worst_active)
+            // (three iterations in a row: one step's jump is also what a guard column looks like when its Ritz value drops into the
+            // wanted range late -- a missed member of a multiplet arrives with a residual of 1e-2 .. 1e-1 beside pairs just above the tolerance)
+            floor_strikes = it >= 20 && worst_active > 1e3 * best_worst_active ? floor_strikes + 1 : 0;
+            if (floor_strikes >= 3)
                 mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged; the others sit at the rounding floor (residual %.1e and growing, best %.1e, tolerance %.1e)", nconv, nev,
                          worst_active, best_worst_active, residual_tol);
         }
