@@ -34,14 +34,14 @@ __global__ void __launch_bounds__(256) k_stream_copy(const f4_stream *__restrict
 }
 // U independent 16-byte loads in flight per lane before the first store (the one-load-per-iteration form above leaves the memory
 // system with too few bytes in flight: 4.5 TB/s against the 6.3 the device reaches); NT: non-temporal loads and stores
-template<int U, bool NT> __global__ void __launch_bounds__(256) k_stream_copy_u(const f4_stream *__restrict__ src, f4_stream *__restrict__ dst, size_t count) {
-    const size_t stride = size_t(gridDim.x) * 256;
-    for (size_t base = size_t(blockIdx.x) * 256 + threadIdx.x; base < count; base += stride * U) {
+template<int U, bool NT, int T = 256, bool NTL = NT> __global__ void __launch_bounds__(T) k_stream_copy_u(const f4_stream *__restrict__ src, f4_stream *__restrict__ dst, size_t count) {
+    const size_t stride = size_t(gridDim.x) * T;
+    for (size_t base = size_t(blockIdx.x) * T + threadIdx.x; base < count; base += stride * U) {
         f4_stream v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t i = base + size_t(u) * stride;
-            if (i < count) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+            if (i < count) v[u] = NTL ? __builtin_nontemporal_load(src + i) : src[i];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -371,13 +371,19 @@ int mhl_context_bench_stream(mh_context *ctx, uint64_t bytes, uint32_t reps, dou
         double t_copy = 1e30, t_read = 1e30;
         const f4_stream *src = reinterpret_cast<const f4_stream *>(a.get());
         f4_stream *dst = reinterpret_cast<f4_stream *>(b.get());
-        for (unsigned per_cu : {8u, 16u, 32u}) {
+        for (unsigned per_cu : {4u, 8u, 16u, 32u}) {
             const unsigned g = std::min(grid, unsigned(ctx->cu_count) * per_cu);
             t_copy = std::min(t_copy, timed([&] { k_stream_copy<<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
             t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<4, false><<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
             t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<8, false><<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
             t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<4, true><<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
             t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<8, true><<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
+            t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<16, false><<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
+            t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<16, true><<<g, 256, 0, ctx->stream>>>(src, dst, count); }));
+            t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<8, true, 256, false><<<g, 256, 0, ctx->stream>>>(src, dst, count); })); // non-temporal stores only
+            t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<8, false, 1024><<<g / 4 + 1, 1024, 0, ctx->stream>>>(src, dst, count); }));
+            t_copy = std::min(t_copy, timed([&] { k_stream_copy_u<4, true, 1024><<<g / 4 + 1, 1024, 0, ctx->stream>>>(src, dst, count); }));
+            t_copy = std::min(t_copy, timed([&] { (void)hipMemcpyAsync(dst, src, count * 16, hipMemcpyDeviceToDevice, ctx->stream); })); // the runtime's own copy
             t_read = std::min(t_read, timed([&] { k_stream_read<<<g, 256, 0, ctx->stream>>>(src, count, out.get()); }));
             t_read = std::min(t_read, timed([&] { k_stream_read_u<4, false><<<g, 256, 0, ctx->stream>>>(src, count, out.get()); }));
             t_read = std::min(t_read, timed([&] { k_stream_read_u<8, false><<<g, 256, 0, ctx->stream>>>(src, count, out.get()); }));
