@@ -710,7 +710,8 @@ void rr_selfcheck(mh_context *ctx, const double *saved, uint32_t m, const double
     KERNEL_CHECK();
 }
 
-int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info, uint32_t nwant = 0) {
+int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals, double *ework, DevArray<int> &info, uint32_t nwant = 0, bool gm_is_identity = false,
+             std::vector<double> *host_evals = nullptr) { // host_evals: receives the nwant lowest eigenvalues when the partial-spectrum path delivered them (they travel with its quality read-back: no second synchronisation for them); left empty otherwise
     // nwant: only the nwant lowest pairs are needed (the active Ritz vectors): lets the tridiagonal stage compute a partial spectrum
     const double one = 1, zero = 0;
     int hinfo = 0;
@@ -719,8 +720,8 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
     // The basis is built M-orthonormal (X and P by construction, W by projection + Cholesky-QR), so gM is the identity
     // up to the orthogonalisation error.  When that error is below 1e-11 the pencil is solved as a standard problem:
     // no Cholesky reduction (potrf + three trsm, ~1.2 ms of a ~4 ms solve at order 225).  Otherwise the full reduction.
-    bool identity = false, series = false;
-    {
+    bool identity = gm_is_identity, series = false; // (gm_is_identity: every block of gM was SET by the caller, none measured: no defect to look for, no read-back)
+    if (!identity) {
         static_assert(sizeof(unsigned long long) == sizeof(double), "defect word");
         unsigned long long *defect = reinterpret_cast<unsigned long long *>(ework);
         HIP_CHECK(hipMemsetAsync(defect, 0, sizeof(unsigned long long), ctx->stream));
@@ -789,7 +790,9 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
                 double *zout = attempt == 0 ? zl.get() : z.get();
                 if (mh_tridiag_lowest(ctx, evals, ework, m, nwant, wv, zout, m, ufac, wv.get() + m, wv.get() + m + 8)) {
                     double qv[5] = {1, 0, 0, 0, 0};
+                    std::vector<double> lam_host(host_evals ? nwant : 0);
                     HIP_CHECK(hipMemcpyAsync(qv, wv.get() + m, sizeof(qv), hipMemcpyDeviceToHost, ctx->stream));
+                    if (host_evals) HIP_CHECK(hipMemcpyAsync(lam_host.data(), wv.get(), size_t(nwant) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                     HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     if (flagged && switches().test_sytrd_giveup) sytrd_gave_up = 1;
                     if (sytrd_gave_up) {
@@ -802,6 +805,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
                         fprintf(stderr, "[rr] tridiagonal m %u lowest %u: residual / ||T|| %.2e; us: multisection %.0f, inverse iteration %.0f, Gram-Schmidt %.0f, output %.0f\n", m,
                                 nwant, quality, qv[1] * 0.01, qv[2] * 0.01, qv[3] * 0.01, qv[4] * 0.01);
                     if (quality < 1e-10) {
+                        if (host_evals) host_evals->swap(lam_host);
                         HIP_CHECK(hipMemcpyAsync(evals, wv.get(), size_t(nwant) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                         zres = zout;
                         ncols = nwant;
@@ -1338,6 +1342,7 @@ struct BlockLobpcg {
     // The residuals of the active columns as the image product's epilogue leaves them (mh_spmm_mapped): compact panel of pitch
     // res_pitch for the columns res_act, per-node norm partials, the reduced norms [2][res_pitch]
     DevArray<double> Rr, res_partial, res_blocks, res_norms_d;
+    std::vector<double> rr_evals; // the Rayleigh-Ritz step's eigenvalues when rr_solve read them back itself
     std::vector<uint32_t> res_act, res_pos; // (res_pos: a member so that its asynchronous upload never outlives it)
     std::vector<double> res_norms;
     uint32_t res_pitch = 0;
@@ -1852,13 +1857,15 @@ struct BlockLobpcg {
             KERNEL_CHECK();
             HIP_CHECK(hipMemcpyAsync(gA0, gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
             HIP_CHECK(hipMemcpyAsync(gM0, gM, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, st));
-            const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info, wa);
+            rr_evals.clear();
+            const int hinfo = rr_solve(ctx, gA, gM, m, evals, ework, info, wa, gm_identity, &rr_evals);
             if (hinfo == 0) break;
             if (attempt == 1 || wp == 0) mh_throw(MH_ENOTCONVERGED, "Rayleigh-Ritz failed at iteration %u (info %d)", it, hinfo);
             wp = 0; // drop the previous directions and retry on [X W]
             m = wa + w;
         }
-        evals.download(theta_act.data(), wa); // ascending Ritz values into the (ascending) active slots
+        if (rr_evals.size() == wa) std::copy(rr_evals.begin(), rr_evals.end(), theta_act.begin()); // (came back with the step's quality word)
+        else evals.download(theta_act.data(), wa); // ascending Ritz values into the (ascending) active slots
         for (uint32_t k = 0; k < wa; ++k) theta[act[k]] = theta_act[k];
     }
 
