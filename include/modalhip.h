@@ -116,6 +116,15 @@ int mh_system_export_blocks(const mh_system *, uint32_t *row_node, uint32_t *col
  * which = 3 / 4: the same shifted product as the preconditioner's smoothers form it -- single-precision values and panel
  * (3), double-precision values over a single-precision panel (4, width % 4 == 0) -- so those kernels can be checked too. */
 int mh_system_matvec(mh_system *, int which, const double *x, double *y, uint32_t width);
+/* The reference's shift-invert operator as an OPERATION (src/audio/CholeskyShiftInvert.h:11-30: set_shift + perform_op / solve_panel):
+ * x = (K - sigma M)^-1 b for `width` right-hand sides, b and x column-major n x width in the reference's DOF order.  There is no
+ * factorisation here: the panel is solved by preconditioned conjugate gradients (the eigensolver's three-level cycle as the
+ * preconditioner) to a relative residual `rel_tol` per column (0 = 1e-11), at most `max_iters` steps (0 = 200).  sigma must be negative
+ * (MH_EFACTOR otherwise: the reference's "Modal shift-invert factorization failed.", CholeskyShiftInvert.cpp:44).  *iterations and
+ * *worst_relative_residual (nullable) report the solve.  The hierarchy of the shift is built on first use and kept with the system, as
+ * set_shift keeps its factor.  mh_eigs is the fast path to the eigenpairs; this exists for callers that drive their own Lanczos. */
+int mh_system_shift_invert(mh_system *, double sigma, const double *b, double *x, uint32_t width, double rel_tol, uint32_t max_iters, uint32_t *iterations,
+                           double *worst_relative_residual);
 
 /* The nearest tet point to each excitation position, first minimum wins (mesh2modes.cpp:626-636). */
 int mh_nearest_points(mh_context *, const mh_mesh *, uint32_t n, const float *positions_xyz, uint32_t *nearest);

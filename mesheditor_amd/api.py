@@ -139,6 +139,17 @@ class System:
         Mn = sp.coo_matrix((m, (r, c)), shape=(self.node_count, self.node_count)).tocsr()
         return K, sp.kron(Mn, sp.identity(3), format="csr")
 
+    def shift_invert(self, b, sigma=-(2 * np.pi * 20.0) ** 2, rel_tol=1e-11, max_iters=200):
+        """x = (K - sigma M)^-1 b (the reference's CholeskyShiftInvert::perform_op / solve_panel), columns in the reference's DOF order;
+        returns (x, iterations, worst relative residual)."""
+        b = np.asfortranarray(b, dtype=np.float64)
+        if b.ndim == 1:
+            b = b[:, None]
+        x = np.zeros_like(b, order="F")
+        its, worst = C.c_uint32(0), C.c_double(0)
+        self.ctx.check(self.ctx.L.mh_system_shift_invert(self.h, sigma, _p(b), _p(x), b.shape[1], rel_tol, max_iters, C.byref(its), C.byref(worst)))
+        return x, its.value, worst.value
+
     def matvec(self, which, x):
         x = np.asfortranarray(np.atleast_2d(np.asarray(x, dtype=np.float64).T).T if np.ndim(x) == 1 else x, dtype=np.float64)
         if x.ndim == 1:

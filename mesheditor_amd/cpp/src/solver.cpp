@@ -1,5 +1,6 @@
 // modal::mesh2modes over libmodalhip (reference orchestration: src/audio/mesh2modes.cpp:605-658 and :441-512).
 #include "modal/solver.hpp"
+#include "modal/shift_invert.hpp"
 
 #include "modalhip.h"
 
@@ -227,3 +228,49 @@ ModalResult mesh2modes(const TetMesh &tets, const AcousticMaterialProperties &ma
     return result;
 }
 } // namespace modal
+
+// ---- the shift-invert operator concept (src/audio/CholeskyShiftInvert.h:11-30) over the device path -----------------------------------
+struct CholeskyShiftInvert::Device {
+    Handles h;
+};
+
+CholeskyShiftInvert::CholeskyShiftInvert(const TetMesh &mesh, const AcousticMaterialProperties &material, double &factorize_seconds, double &solve_seconds)
+    : FactorizeSeconds(factorize_seconds), SolveSeconds(solve_seconds), Dev(std::make_unique<Device>()) {
+    mh_context *ctx = t_context.get();
+    const auto *xyz = reinterpret_cast<const double *>(mesh.Points.data());
+    const auto *corners = reinterpret_cast<const uint32_t *>(mesh.Tets.data());
+    if (mh_mesh_create(ctx, uint32_t(mesh.Points.size()), xyz, uint32_t(mesh.Tets.size()), corners, &Dev->h.mesh) != MH_OK)
+        throw std::runtime_error(std::string("modalhip: ") + mh_last_error(ctx));
+    const mh_material mat = ToC(material);
+    if (mh_assemble(ctx, Dev->h.mesh, &mat, &Dev->h.sys) != MH_OK) throw std::runtime_error(std::string("modalhip: ") + mh_last_error(ctx));
+    uint32_t n = 0, node_count = 0, kept_tets = 0;
+    uint64_t node_blocks = 0;
+    mh_system_dims(Dev->h.sys, &n, &node_count, &kept_tets, &node_blocks);
+    Order = std::ptrdiff_t(n);
+}
+
+CholeskyShiftInvert::~CholeskyShiftInvert() = default;
+
+void CholeskyShiftInvert::set_shift(const Scalar &sigma) {
+    // K is positive semidefinite and M positive definite: K - sigma M is positive definite exactly for sigma < 0 (CholeskyShiftInvert.h:9-10)
+    if (!(sigma < 0)) throw std::runtime_error("Modal shift-invert factorization failed.");
+    const auto start = std::chrono::steady_clock::now();
+    Sigma = sigma;
+    Shifted = true;
+    // the hierarchy of the shift is built by the first solve and kept with the system: run one (a zero right-hand side costs no iteration)
+    std::vector<double> zero(size_t(Order), 0.0), out(size_t(Order), 0.0);
+    if (mh_system_shift_invert(Dev->h.sys, Sigma, zero.data(), out.data(), 1, Tolerance, 1, nullptr, nullptr) != MH_OK)
+        throw std::runtime_error("Modal shift-invert factorization failed.");
+    FactorizeSeconds += Since(start);
+}
+
+void CholeskyShiftInvert::solve_panel(const Scalar *b_in, Scalar *x_out, int width) const {
+    if (!Shifted) throw std::runtime_error("CholeskyShiftInvert: set_shift was not called");
+    if (width <= 0) return;
+    const auto start = std::chrono::steady_clock::now();
+    if (mh_system_shift_invert(Dev->h.sys, Sigma, b_in, x_out, uint32_t(width), Tolerance, 0, &LastIterations, &LastResidual) != MH_OK)
+        throw std::runtime_error(std::string("modalhip: ") + mh_last_error(t_context.get()));
+    SolveSeconds += Since(start);
+}
+
+void CholeskyShiftInvert::perform_op(const Scalar *x_in, Scalar *y_out) const { solve_panel(x_in, y_out, 1); }

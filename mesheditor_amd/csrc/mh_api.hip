@@ -312,6 +312,36 @@ int mh_system_matvec(mh_system *s, int which, const double *x, double *y, uint32
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+int mh_system_shift_invert(mh_system *s, double sigma, const double *b, double *x, uint32_t width, double rel_tol, uint32_t max_iters, uint32_t *iterations, double *worst_relative_residual) {
+    if (!s || !b || !x || width == 0) return MH_EINVAL;
+    mh_context *ctx = s->ctx;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = size_t(3) * s->n_nodes;
+        if (!(rel_tol > 0)) rel_tol = 1e-11;
+        if (!max_iters) max_iters = 200;
+        uint32_t its = 0;
+        double worst = 0;
+        // (slabs of 64 columns: the preconditioner's panels are sized by the slab)
+        for (uint32_t c0 = 0; c0 < width; c0 += 64) {
+            const uint32_t wc = std::min(64u, width - c0);
+            DevArray<double> ref(ctx, n * wc), bp(ctx, n * wc), xp(ctx, n * wc);
+            ref.upload(b + size_t(c0) * n, n * wc);
+            k_ref_to_panel<<<div_up(n * wc, TB), TB, 0, ctx->stream>>>(ref, s->perm, s->n_nodes, wc, bp);
+            KERNEL_CHECK();
+            double slab_worst = 0;
+            its = std::max(its, mh_shift_invert_panel(s, sigma, bp, xp, wc, rel_tol, max_iters, &slab_worst));
+            worst = std::max(worst, slab_worst);
+            k_panel_to_ref<double><<<div_up(n * wc, TB), TB, 0, ctx->stream>>>(xp, s->perm, s->n_nodes, wc, wc, ref.get());
+            KERNEL_CHECK();
+            ref.download(x + size_t(c0) * n, n * wc);
+        }
+        if (iterations) *iterations = its;
+        if (worst_relative_residual) *worst_relative_residual = worst;
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 int mh_nearest_points(mh_context *ctx, const mh_mesh *mesh, uint32_t n, const float *positions_xyz, uint32_t *nearest) {
     if (!ctx || !mesh || (n && (!positions_xyz || !nearest))) return MH_EINVAL;
     if (n == 0) return MH_OK;

@@ -441,7 +441,9 @@ struct MhSharedPhase {
 std::mutex &mh_solve_mutex(); // mh_eigs.hip: one eigensolve (or Gram benchmark) at a time per process, see there
 void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &mat, mh_system *sys); // mh_pipeline.hip
 void mh_build_hierarchy(mh_system *sys, double sigma, bool defer = false);
-void mh_finish_hierarchy(mh_system *sys); // no-op unless a deferred elimination is pending // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
+void mh_finish_hierarchy(mh_system *sys);
+uint32_t mh_shift_invert_panel(mh_system *sys, double sigma, const double *b, double *x, uint32_t w, double rel_tol, uint32_t max_iters, double *worst_rel); // mh_eigs.hip: x = (K - sigma M)^-1 b by preconditioned CG
+ // no-op unless a deferred elimination is pending // mh_pipeline.hip: A = K - sigma M on both levels, dense coarse factor
 uint32_t mh_graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col, uint32_t n, uint32_t target, uint32_t max_order, std::vector<uint32_t> &agg_of); // mh_pipeline.hip
 void mh_select_patches(mh_system *sys, float threshold);                                  // mh_patch.hip: elements whose shape measure is below the threshold
 void mh_build_patch_inverses(mh_context *ctx, const BsrLevel &lvl, PatchSet &ps);         // mh_patch.hip: (A_ee)^-1 of every patch from lvl.aval

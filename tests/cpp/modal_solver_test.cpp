@@ -3,7 +3,9 @@
 // JobMonitor, warm start through SolveReuse, RescaleModes on a material edit.
 #include "harness.hpp"
 
+#include <audio/CholeskyShiftInvert.h>
 #include <audio/mesh2modes.h>
+#include <modalhip.h> // (the C ABI's product of the shifted operator: the check of the operator below)
 #include <mesh/TetMesh.h>
 
 #include <algorithm>
@@ -177,6 +179,61 @@ CASE(warm_start_and_rescale_agree_with_a_cold_solve) {
     auto other_nu = ceramic;
     other_nu.PoissonRatio = 0.3;
     EXPECT(!modal::RescaleModes(cold.Summary, cold.Modes, other_nu).has_value());
+}
+
+// The reference's shift-invert operator concept (src/audio/CholeskyShiftInvert.h:11-30) over the device path: rows / cols / set_shift /
+// perform_op / solve_panel with the reference's argument meaning; (K - sigma M) applied to what it returns gives the input back; a panel
+// solve agrees with its columns solved one by one; the operator is symmetric; a non-negative shift throws the reference's error.
+CASE(the_shift_invert_operator_concept_over_the_device_path) {
+    const auto mesh = GridTets(Beam{0.12, 0.08, 0.05, {}}, 6, 4, 3);
+    const auto &ceramic = materials::acoustic::Ceramic.Properties;
+    double factorize = 0, solve = 0;
+    CholeskyShiftInvert op(mesh, ceramic, factorize, solve);
+    const auto n = size_t(op.rows());
+    EXPECT(op.rows() == op.cols() && n > 3 * mesh.Points.size()); // (quadratic elements: corner and midside nodes)
+    bool threw = false;
+    try {
+        op.set_shift(1.0);
+    } catch (const std::runtime_error &e) { threw = std::string(e.what()) == "Modal shift-invert factorization failed."; }
+    EXPECT(threw);
+    const double sigma = -15791.367041742974; // -(2 pi 20 Hz)^2, the reference's default shift (mesh2modes.cpp:460)
+    op.set_shift(sigma);
+    EXPECT(factorize > 0);
+    std::vector<double> b(3 * n), x(3 * n), one(n);
+    uint64_t st = 0x2545F4914F6CDD1Dull;
+    for (auto &v : b) {
+        st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+        v = double(st >> 11) / 9007199254740992.0 - 0.5;
+    }
+    op.solve_panel(b.data(), x.data(), 3);
+    EXPECT(op.LastIterations > 0 && op.LastResidual < 1e-8 && solve > 0);
+    // (K - sigma M) x = b through the C ABI's own product on a second system of the same mesh
+    {
+        mh_context *ctx = nullptr;
+        mh_mesh *dm = nullptr;
+        mh_system *ds = nullptr;
+        EXPECT(mh_context_create(0, &ctx) == MH_OK);
+        const mh_material mat{ceramic.Density, ceramic.YoungModulus, ceramic.PoissonRatio, ceramic.Alpha, ceramic.Beta};
+        EXPECT(mh_mesh_create(ctx, uint32_t(mesh.Points.size()), reinterpret_cast<const double *>(mesh.Points.data()), uint32_t(mesh.Tets.size()),
+                              reinterpret_cast<const uint32_t *>(mesh.Tets.data()), &dm) == MH_OK);
+        EXPECT(mh_assemble(ctx, dm, &mat, &ds) == MH_OK);
+        std::vector<double> back(3 * n);
+        EXPECT(mh_system_matvec(ds, 2, x.data(), back.data(), 3) == MH_OK);
+        double worst = 0, scale = 0;
+        for (size_t i = 0; i < 3 * n; ++i) worst = std::max(worst, std::fabs(back[i] - b[i])), scale = std::max(scale, std::fabs(b[i]));
+        EXPECT(worst < 1e-7 * scale);
+        mh_system_destroy(ds);
+        mh_mesh_destroy(dm);
+        mh_context_destroy(ctx);
+    }
+    // one column at a time gives the panel's columns; the operator is symmetric: b0 . op(b1) = b1 . op(b0)
+    op.perform_op(b.data() + n, one.data());
+    double diff = 0, size = 0;
+    for (size_t i = 0; i < n; ++i) diff = std::max(diff, std::fabs(one[i] - x[n + i])), size = std::max(size, std::fabs(x[n + i]));
+    EXPECT(diff < 1e-7 * size);
+    double s01 = 0, s10 = 0;
+    for (size_t i = 0; i < n; ++i) s01 += b[i] * x[n + i], s10 += b[n + i] * x[i];
+    EXPECT(check::near(s01, s10, 1e-7));
 }
 
 int main() { return check::run_all(); }

@@ -1150,3 +1150,29 @@ def test_a_fine_uv_sphere_solves_through_the_quality_arm(api):
         assert r.profile["restarts"] <= 40, r.profile["restarts"]
     finally:
         c.close()
+
+
+def test_the_shift_invert_operator_as_an_operation(api, ctx):
+    """SURVEY 8a row A8's interface (src/audio/CholeskyShiftInvert.h:11-30: set_shift, perform_op, solve_panel): x = (K - sigma M)^-1 b through the
+    C ABI (preconditioned conjugate gradients on the device: there is no factorisation) against a sparse direct solve of the exported
+    matrices -- one vector, a panel wider than one slab, another shift -- and the reference's error for a non-negative shift."""
+    import scipy.sparse.linalg as spla
+    pts, tets, m, _ = meshes.workload("cube_small")
+    mesh = api.Mesh(ctx, pts, tets)
+    s = api.System(ctx, mesh, api.material(*m))
+    K, M = s.to_scipy()
+    rng = np.random.default_rng(5)
+    for sigma, width in ((SIGMA, 1), (SIGMA, 70), (-4.0e6, 3)):
+        A = (K - sigma * M).tocsc()
+        lu = spla.splu(A)
+        b = rng.standard_normal((s.n, width))
+        x, its, worst = s.shift_invert(b, sigma)
+        ref = lu.solve(b)
+        assert 0 < its <= 200 and worst < 1e-8, (its, worst)  # (asked 1e-11; the floor is eps ||A|| ||x|| / ||b||: the rigid-body components of x are large at this small shift)
+        err = np.abs(x - ref).max(axis=0) / np.abs(ref).max(axis=0)
+        assert err.max() < 1e-8, (sigma, width, err.max())  # (the residual is at 1e-11; the solution carries the condition number on top)
+        assert np.abs(A @ x - b).max() < 1e-9 * np.abs(b).max() * 10
+    with pytest.raises(api.ModalHipError):
+        s.shift_invert(rng.standard_normal(s.n), 1.0)
+    s.close()
+    mesh.close()
