@@ -178,6 +178,24 @@ std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &c
     const size_t slots = *std::max_element(share.begin(), share.end()); // every rank sends the same count: the largest share
     // [slot][1 + reclen]: word 0 says whether the slot is used
     std::vector<double> send(slots * (reclen + 1), 0.0);
+    // The gather's device buffers are taken BEFORE the solves: a rank that cannot have them fails here, at once, not after minutes of
+    // solving -- and once it has them nothing between here and the collective allocates on the device outside the solves' own pools,
+    // so a rank whose solves all fail still joins with failed records.  (A rank that fails HERE aborts the communicator; RCCL's abort is
+    // local, the peers learn of it through their watchdog: an aborted communicator must be recreated on every rank.)
+    const size_t count = slots * (reclen + 1);
+    double *d_send{}, *d_recv{};
+    if (count) {
+        try {
+            Check(hipSetDevice(comm.Device()), "hipSetDevice");
+            Check(hipMalloc(reinterpret_cast<void **>(&d_send), count * sizeof(double)), "hipMalloc");
+            Check(hipMalloc(reinterpret_cast<void **>(&d_recv), size_t(world) * count * sizeof(double)), "hipMalloc");
+        } catch (...) {
+            comm.Abort();
+            if (d_send) (void)hipFree(d_send);
+            if (d_recv) (void)hipFree(d_recv);
+            throw;
+        }
+    }
     std::atomic<size_t> next{0};
     const uint32_t workers = std::max<uint32_t>(1, std::min<uint32_t>(options.ThreadsPerDevice, uint32_t(std::max<size_t>(mine.size(), 1))));
     // Nothing a worker does may keep this rank from the collective: whatever is thrown (by the device selection, a solve, the
@@ -213,21 +231,16 @@ std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &c
         work();
         for (auto &t : pool) t.join();
     }
-    // the one collective: every rank's slots, on the device, over RCCL.  A rank that cannot stage its records (no memory, a
-    // failed copy) cannot join; it aborts the communicator so that the others' watchdogs fire at once instead of after the timeout.
-    const size_t count = slots * (reclen + 1);
+    // the one collective: every rank's slots, on the device, over RCCL
     std::vector<double> all(size_t(world) * count, 0.0);
     if (count) {
-        double *d_send{}, *d_recv{};
         try {
             Check(hipSetDevice(comm.Device()), "hipSetDevice");
-            Check(hipMalloc(reinterpret_cast<void **>(&d_send), count * sizeof(double)), "hipMalloc");
-            Check(hipMalloc(reinterpret_cast<void **>(&d_recv), size_t(world) * count * sizeof(double)), "hipMalloc");
             Check(hipMemcpy(d_send, send.data(), count * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
-        } catch (...) {
+        } catch (...) { // (a failed copy into memory we hold: the device is gone -- nothing to join with)
             comm.Abort();
-            if (d_send) (void)hipFree(d_send);
-            if (d_recv) (void)hipFree(d_recv);
+            (void)hipFree(d_send);
+            (void)hipFree(d_recv);
             throw;
         }
         try {
