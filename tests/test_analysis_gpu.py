@@ -1176,3 +1176,36 @@ def test_the_shift_invert_operator_as_an_operation(api, ctx):
         s.shift_invert(rng.standard_normal(s.n), 1.0)
     s.close()
     mesh.close()
+
+
+def test_the_polynomial_start_block_changes_the_path_not_the_answer(api, ctx):
+    """The cold start block from low-degree polynomial displacement fields (round 5; chunky bodies only) against the random block of rounds
+    1-4 (MH_TEST=no_poly_start, read once per process: a fresh interpreter): same eigenvalues to 1e-9, iteration counts within two; and a
+    thin plate, which does not get the polynomial block, solves exactly as without the option."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from mesheditor_amd import api, meshes\n"
+            "ctx = api.Context(0); out = {}\n"
+            "for name in ('cube_s10k', 'bar_thin'):\n"
+            "    pts, tets, m, kw = meshes.workload(name)\n"
+            "    mesh = api.Mesh(ctx, pts, tets); s = api.System(ctx, mesh, api.material(*m))\n"
+            "    ev, prof = s.eigs(65, residual_tol=1e-5); out[name] = [ev.tolist(), prof['restarts']]\n"
+            "print('RESULT ' + json.dumps(out))\n") % root
+    env = dict(os.environ, MH_TEST="no_poly_start")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plain = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for name in ("cube_s10k", "bar_thin"):
+        pts, tets, m, kw = meshes.workload(name)
+        mesh = api.Mesh(ctx, pts, tets)
+        s = api.System(ctx, mesh, api.material(*m))
+        ev, prof = s.eigs(65, residual_tol=1e-5)
+        s.close()
+        mesh.close()
+        ref, its = np.array(plain[name][0]), plain[name][1]
+        if name == "bar_thin":  # (thin along y and z: no polynomial block -- the same solve bit for bit)
+            assert np.array_equal(ev, ref) and prof["restarts"] == its
+        else:
+            elastic = ref > 1e-6 * ref[-1]
+            assert np.abs(ev[elastic] / ref[elastic] - 1).max() < 1e-9
+            assert abs(prof["restarts"] - its) <= 2, (prof["restarts"], its)
