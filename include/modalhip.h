@@ -69,6 +69,9 @@ typedef struct {
     float center_of_mass[3], inertia_diagonal[3], inertia_orientation_wxyz[4];
 } mh_mass_props;
 
+/* sizeof(mh_profile), sizeof(mh_solver_config), sizeof(mh_material), sizeof(mh_mass_props) as this library was built: a binding checks its own
+ * struct images against them (needs no GPU) */
+void mh_abi_struct_sizes(uint32_t out[4]);
 int mh_context_create(int device, mh_context **out);
 void mh_context_destroy(mh_context *);
 const char *mh_last_error(const mh_context *);

@@ -65,6 +65,7 @@ def lib():
         "mh_assemble": (i32, [vp, vp, C.POINTER(Material), pp]), "mh_system_destroy": (None, [vp]),
         "mh_system_dims": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]),
         "mh_system_element_nodes": (i32, [vp, vp]), "mh_system_export_blocks": (i32, [vp, vp, vp, vp, vp]),
+        "mh_abi_struct_sizes": (None, [vp]),
         "mh_system_matvec": (i32, [vp, i32, vp, vp, u32]),
         "mh_system_shift_invert": (i32, [vp, C.c_double, vp, vp, u32, C.c_double, u32, C.POINTER(u32), C.POINTER(C.c_double)]),
         "mh_nearest_points": (i32, [vp, vp, u32, vp, vp]),

@@ -109,6 +109,10 @@ template<typename T> static int export_vectors(const mh_system *s, uint32_t n_co
 }
 
 extern "C" {
+void mh_abi_struct_sizes(uint32_t out[4]) {
+    if (!out) return;
+    out[0] = uint32_t(sizeof(mh_profile)), out[1] = uint32_t(sizeof(mh_solver_config)), out[2] = uint32_t(sizeof(mh_material)), out[3] = uint32_t(sizeof(mh_mass_props));
+}
 int mh_context_create(int device, mh_context **out) {
     if (!out) return MH_EINVAL;
     *out = nullptr;

@@ -33,6 +33,15 @@ def test_library_exports_every_declared_symbol(core):
     assert not [n for n in declared if "bench" in n or "tridiagonalize" in n or "elementwise" in n]
 
 
+def test_the_bindings_struct_images_match_the_library(core):
+    """The ctypes images of the boundary's structs have the sizes the library was built with (mh_abi_struct_sizes; no GPU needed): a field
+    added on one side only -- round 5 added two to mh_profile -- would otherwise read garbage silently."""
+    L = core.lib()
+    sizes = (C.c_uint32 * 4)()
+    L.mh_abi_struct_sizes(sizes)
+    assert list(sizes) == [C.sizeof(core.Profile), C.sizeof(core.SolverConfig), C.sizeof(core.Material), C.sizeof(core.MassProps)], list(sizes)
+
+
 def test_lab_library_is_separate_from_the_product(core):
     """libmodalhip_lab.so (timing loops, kernel variants called directly, the matrix-free operator) exports what its own header
     declares; the product library exports none of it."""
