@@ -669,7 +669,7 @@ __global__ void k_inverse_sqrt_series(const double *__restrict__ e, const double
 }
 
 // Self-check of a whole Rayleigh-Ritz step (tridiagonalisation, reflectors, partial spectrum, back-transformation at once): for three sampled
-// pairs (first, middle, last) the residual max |A z - theta z| / (max |A z| + |theta| max |z|) against the SAVED symmetric matrix, folded into
+// pairs (first, middle, last) the residual max |A z - theta z| / (max_i sum_c |a_ic z_c| + |theta| max |z|) against the SAVED symmetric matrix, folded into
 // one device word by atomicMax (non-negative doubles order as integers; NaN maps to the largest value).  Never read back inside the
 // iteration: the solve reads the word once at its end (BlockLobpcg::finish) and fails loudly when it is not at rounding level.
 __global__ void __launch_bounds__(256) k_rr_selfcheck(const double *__restrict__ a, uint32_t m, const double *__restrict__ z, uint32_t ldz, const double *__restrict__ theta, uint32_t ncols,
@@ -682,11 +682,14 @@ __global__ void __launch_bounds__(256) k_rr_selfcheck(const double *__restrict__
     double rmax = 0, azmax = 0, zmax = 0;
     bool nan = false;
     for (uint32_t i = tid; i < m; i += 256) {
-        double az = 0;
-        for (uint32_t c = 0; c < m; ++c) az += a[size_t(c) * m + i] * zs[c];
+        double az = 0, abs_az = 0; // abs_az = sum_c |a_ic| |z_c|: the scale rounding errors of the step's arithmetic live on (a pair far below
+        for (uint32_t c = 0; c < m; ++c) { // ||A|| -- the rigid-body pairs beside a random start block -- carries an absolute error of eps ||A||)
+            const double t = a[size_t(c) * m + i] * zs[c];
+            az += t, abs_az += fabs(t);
+        }
         const double r = az - th * zs[i];
         nan = nan || !(r == r);
-        rmax = fmax(rmax, fabs(r)), azmax = fmax(azmax, fabs(az)), zmax = fmax(zmax, fabs(zs[i]));
+        rmax = fmax(rmax, fabs(r)), azmax = fmax(azmax, abs_az), zmax = fmax(zmax, fabs(zs[i]));
     }
     red[0][tid] = nan ? INFINITY : rmax, red[1][tid] = azmax, red[2][tid] = zmax;
     __syncthreads();
@@ -1591,6 +1594,8 @@ struct BlockLobpcg {
         {
             gram(ctx, n, X, b, AX, b, gA, b);
             gram(ctx, n, X, b, MX, b, gM, b);
+            // (the library's divide and conquer here: every pair of a start block's matrix, whose spectrum spans |sigma| .. ||A|| -- our partial-spectrum
+            // kernels, accepted at a residual of 1e-10 ||T||, left the small pairs at 1e-8 .. 1e-7 in the step's self-check: measured in round 5)
             const int hinfo = rr_solve(ctx, gA, gM, b, evals, ework, info);
             if (hinfo != 0) mh_throw(MH_ENOTCONVERGED, "initial Rayleigh-Ritz failed (info %d)", hinfo);
             panel_mul(ctx, n, X, b, gA, b, Xn, b, 1.0, 0.0);

@@ -415,7 +415,7 @@ def test_a_wide_solve_beside_narrow_ones(api):
     assert not bad, bad
     assert overlapped[0] > 0  # (wide solves started while narrow ones were in flight: nothing serialises them any more)
     assert all(r == 0 for r, _ in health), health
-    assert max(q for _, q in health) < 1e-9, max(q for _, q in health)
+    assert max(q for _, q in health) < 1e-10, max(q for _, q in health)
 
 
 def test_the_exchange_kernel_beside_wide_solves_soak(api):
