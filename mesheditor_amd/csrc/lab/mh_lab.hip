@@ -250,7 +250,7 @@ int mhl_context_tridiagonalize(mh_context *ctx, int variant, uint32_t m, const d
 
 // variant 2: the wide kernel (orders up to 768).  reflectors (m x m, LAPACK's lower storage) and tau (m) are returned when asked for.
 int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, const double *a, double *d, double *e, double *reflectors, double *tau, uint32_t reps, double *avg_ms) {
-    if (!ctx || !a || !d || !e || m < 2 || variant < 0 || variant > 2 || m > (variant == 2 ? 768u : 256u)) return MH_EINVAL;
+    if (!ctx || !a || !d || !e || m < 2 || variant < 0 || variant > 3 || m > (variant == 2 ? 768u : 256u)) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
         MhSharedPhase not_during_a_factorisation; // (no process-wide lock: calls on different contexts are meant to overlap)

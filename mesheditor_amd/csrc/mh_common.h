@@ -64,6 +64,40 @@ struct MhError : std::runtime_error {
 // build() runs tools/check_barrier_waits.py over every kernel's assembly: a barrier reachable with an LDS store in flight fails the build.
 #if defined(__HIPCC__)
 __device__ __forceinline__ void mh_lds_writes_landed() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Sums across lanes on the vector ALU's data-parallel primitives (DPP).  __shfl_xor compiles to ds_bpermute, which goes through the LDS
+// pipeline: about a hundred cycles per stage behind the other waves' LDS traffic, six stages for a wave -- the longest serial stretch of
+// a Householder column in every tridiagonalisation kernel here (measured with cycle stamps, tools/probe/sytrd_regs_probe.py).  A DPP move
+// is an ordinary ALU instruction.  Every lane receives the same bits (each stage adds the same two numbers on both sides).
+template <int CTRL> __device__ __forceinline__ double mh_dpp_move(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int MH_DPP_QUAD_XOR1 = 0xB1, MH_DPP_QUAD_XOR2 = 0x4E, MH_DPP_ROW_HALF_MIRROR = 0x141, MH_DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ double mh_quad_sum(double x) { // over each aligned group of four lanes
+    x += mh_dpp_move<MH_DPP_QUAD_XOR1>(x);
+    x += mh_dpp_move<MH_DPP_QUAD_XOR2>(x);
+    return x;
+}
+__device__ __forceinline__ double mh_row_sum(double x) { // over each aligned group of sixteen lanes
+    x = mh_quad_sum(x);
+    x += mh_dpp_move<MH_DPP_ROW_HALF_MIRROR>(x); // (quads already uniform: the mirror pairs each quad with the other one of its half)
+    x += mh_dpp_move<MH_DPP_ROW_MIRROR>(x);
+    return x;
+}
+__device__ __forceinline__ double mh_lane_value(double x, int lane) { // lane: the same in every lane
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ double mh_wave_sum(double x) { // over the 64 lanes
+    x = mh_row_sum(x);
+    return (mh_lane_value(x, 0) + mh_lane_value(x, 16)) + (mh_lane_value(x, 32) + mh_lane_value(x, 48));
+}
+__device__ __forceinline__ double mh_half_wave_sum(double x) { // over lanes 0-31 and over lanes 32-63
+    x = mh_row_sum(x);
+    const double low = mh_lane_value(x, 0) + mh_lane_value(x, 16), high = mh_lane_value(x, 32) + mh_lane_value(x, 48);
+    return (threadIdx.x & 32) ? high : low;
+}
 #endif
 
 struct DevicePool {

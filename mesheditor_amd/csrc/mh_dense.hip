@@ -684,8 +684,7 @@ __device__ inline double wave_sum_lds(const double *buf, int count, int lane) {
         const int i = lane + 64 * q;
         s += i < count ? buf[i] : 0.0;
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    return s;
+    return mh_wave_sum(s); // (DPP, not ds_bpermute: see mh_common.h)
 }
 
 __global__ void __launch_bounds__(1024) k_sytrd_small(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
@@ -850,6 +849,235 @@ __global__ void __launch_bounds__(MH_SYTRD_THREADS) k_sytrd_small_fused(double *
     }
 }
 
+// ---- the same reduction on ONE CU with the matrix in REGISTERS (round 5) ---------------------------------------------------------
+// The lower triangle of a symmetric matrix of order <= 256 is 263 KB: it fits the register file of one CU (eight waves x 256 registers).
+// Thread (ti, tj) = (tid & 31, tid >> 5) of 512 holds the entries (ti + 32 a, tj + 16 b), b <= 2 a + 1, of a 256 x 256 frame with the
+// matrix at its END (row r at position r + 256 - m, so that what is left of the matrix always ends with the last block); the 32 x 32
+// blocks on the diagonal (b = 2 a, 2 a + 1) are held in full, both triangles.  Nothing of the matrix moves during the reduction.  Per
+// column k, three barriers:
+//   (P) every thread multiplies its entries by v both ways (an entry (r, c) of a block below the diagonal gives a_rc v_c to p_r and
+//       a_rc v_r to p_c; a diagonal block, held in full, only the former); the parts go to LDS by tj / by ti;
+//   (R) two threads per row add them in that order: p = tau A v;
+//   (U) every wave forms p . v, every thread w = p - (tau / 2)(p . v) v at its rows and columns and applies A -= v w^T + w v^T to its
+//       entries; the half-wave that holds column k + 1 first works out that column alone, its reflector (norm by DPP sums, one sqrt, two
+//       divisions) and publishes v for the next column while the other waves are still updating.
+// No exchange between workgroups, no co-residency assumption, sums in a fixed order (bit-reproducible).  The sixteen columns a column
+// lies in are a template parameter: "has the reduction left this block behind" is decided by the compiler.  The barriers fence LDS ONLY:
+// the stores to global memory (d, e, tau, the reflector columns -- nothing in the kernel reads them back) are never waited for.
+namespace {
+constexpr int REGS_RA = 8, REGS_CB = 16; // row blocks of 32, column blocks of 16
+__device__ __forceinline__ void regs_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    mh_lds_writes_landed(); // (the compiler has been seen to drop this wait at a loop header: see mh_common.h)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#ifdef MH_REGS_STAMPS
+__device__ unsigned long long g_regs_stamps[8];
+#define REGS_STAMP(i) do { const unsigned long long now_ = clock64(); acc_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define REGS_STAMP(i) do { } while (0)
+#endif
+struct RegsShared {
+    double vs[2][256], part[16][258], partc[32][257], ps[256], scal[2]; // (row lengths chosen against LDS bank conflicts: partc is written down its columns)
+};
+struct RegsOut {
+    double *__restrict__ A, *__restrict__ D, *__restrict__ E, *__restrict__ TAU;
+    int m, off;
+};
+using RegsMatrix = double[REGS_RA][REGS_CB];
+// The half-wave tj == kn % 16 that holds column kn (column block BN): the column as the update of column kn - 1 leaves it (UPDATE; the
+// registers are updated with everybody else's afterwards, to the same bits or not: the column is not read from them again), its
+// reflector, and v, tau for the next column into the other LDS buffer.
+template <int BN, bool UPDATE>
+__device__ __forceinline__ void regs_next_reflector(const RegsMatrix &val, RegsShared &sh, const RegsOut &out, int kn, int ti, int tj, const double (&vr)[REGS_RA],
+                                                    const double (&vc)[REGS_CB], double half) {
+    constexpr int AN = BN / 2;
+    const int k2 = kn + 1;
+    __builtin_amdgcn_s_setprio(3); // (the one serial stretch of a column: ahead of the wave it shares its SIMD with)
+    double x[REGS_RA], sq = 0.0, wc = 0.0;
+    if (UPDATE) wc = sh.ps[tj + 16 * BN] - half * vc[BN];
+#pragma unroll
+    for (int a = AN; a < REGS_RA; ++a) {
+        const int r = ti + 32 * a;
+        double t = val[a][BN];
+        if (UPDATE) {
+            const double wr = sh.ps[r] - half * vr[a];
+            t -= vr[a] * wc;
+            t -= wr * vc[BN];
+        }
+        x[a] = t;
+        sq += r > k2 ? t * t : 0.0;
+        if (r == kn) out.D[kn - out.off] = t;
+    }
+    const int base = __builtin_amdgcn_readfirstlane(threadIdx.x & 32);
+    sq = mh_row_sum(sq);
+    sq = mh_lane_value(sq, base) + mh_lane_value(sq, base + 16);
+    double alpha = x[AN]; // row k2 = kn + 1 lies in row block AN or the next one, at lane k2 % 32 of this half-wave
+    if constexpr (AN + 1 < REGS_RA) alpha = (k2 >> 5) == AN ? x[AN] : x[AN + 1];
+    alpha = mh_lane_value(alpha, base + (k2 & 31));
+    double tau = 0.0, beta = alpha, scale = 0.0;
+    if (sq > 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + sq), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    double *vnext = sh.vs[k2 & 1];
+    const size_t column = size_t(kn - out.off) * out.m;
+#pragma unroll
+    for (int a = AN & ~1; a < REGS_RA; ++a) { // (from an even block: the dot product p . v reads whole pairs of blocks)
+        const int r = ti + 32 * a;
+        double v = 0.0;
+        if (a >= AN) {
+            v = r == k2 ? 1.0 : (r > k2 ? x[a] * scale : 0.0);
+            if (r > kn) out.A[column + (r - out.off)] = r == k2 ? beta : v; // the subdiagonal entry, then the reflector tail (LAPACK's lower storage)
+        }
+        vnext[r] = v;
+    }
+    if (ti == 0) sh.scal[k2 & 1] = tau, out.E[kn - out.off] = beta, out.TAU[kn - out.off] = tau;
+    __builtin_amdgcn_s_setprio(0);
+}
+// The columns at the positions 16 B ... 16 B + 15.
+template <int B>
+__device__ __forceinline__ void regs_block_columns(RegsMatrix &val, RegsShared &sh, const RegsOut &out, int tid, int ti, int tj, int lane
+#ifdef MH_REGS_STAMPS
+                                                   , unsigned long long (&acc_)[7]
+#endif
+) {
+    constexpr int BA = B / 2; // the first live row block
+    const int k_begin = max(16 * B, out.off), k_end = min(16 * B + 16, 255);
+#ifdef MH_REGS_STAMPS
+    unsigned long long last_ = clock64();
+#endif
+    for (int k = k_begin; k < k_end; ++k) {
+        const int k1 = k + 1;
+        const double *v = sh.vs[k1 & 1];
+        const double tau = sh.scal[k1 & 1];
+        // (P) p = A22 v
+        double vr[REGS_RA], vc[REGS_CB];
+#pragma unroll
+        for (int a = BA; a < REGS_RA; ++a) vr[a] = v[ti + 32 * a];
+#pragma unroll
+        for (int b = B; b < REGS_CB; ++b) vc[b] = v[tj + 16 * b];
+#pragma unroll
+        for (int a = BA; a < REGS_RA; ++a) {
+            double pr = 0.0;
+#pragma unroll
+            for (int b = B; b <= 2 * a + 1; ++b) pr += val[a][b] * vc[b];
+            sh.part[tj][ti + 32 * a] = pr;
+        }
+#pragma unroll
+        for (int b = B; b < REGS_CB - 2; ++b) {
+            double pc = 0.0;
+#pragma unroll
+            for (int a = b / 2 + 1; a < REGS_RA; ++a) pc += val[a][b] * vr[a];
+            sh.partc[ti][tj + 16 * b] = pc;
+        }
+        REGS_STAMP(0);
+        regs_barrier();
+        REGS_STAMP(1);
+        // (R) p_r = tau (the row parts by tj, then the column parts by ti, in order): two threads per row, eight + sixteen parts each
+        {
+            const int r = tid >> 1, q = tid & 1;
+            if (r >= 16 * B) { // (live rows; the column parts of a column block left behind are not written any more)
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += sh.part[8 * q + j][r];
+                if (r < 32 * (REGS_RA - 1)) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) t += sh.partc[16 * q + j][r];
+                }
+                t += mh_dpp_move<MH_DPP_QUAD_XOR1>(t);
+                if (q == 0) sh.ps[r] = tau * t;
+            }
+        }
+        REGS_STAMP(2);
+        regs_barrier();
+        REGS_STAMP(3);
+        // (U) w = p - (tau / 2) (p . v) v at this thread's rows and columns; A22 -= v w^T + w v^T on its entries, one term per sweep
+        double pv = 0.0;
+#pragma unroll
+        for (int q = BA / 2; q < 4; ++q) pv += sh.ps[lane + 64 * q] * v[lane + 64 * q]; // (rows 64 (BA / 2) ... 32 BA - 1, if any: ps from an earlier column, times v = 0)
+        pv = mh_wave_sum(pv);
+        const double half = 0.5 * tau * pv;
+        if (tj == (k1 & 15) && k1 < 255) { // column k + 1 first, by its holders: the next reflector is under way while the others update
+            if ((k & 15) < 15) regs_next_reflector<B, true>(val, sh, out, k1, ti, tj, vr, vc, half);
+            else if constexpr (B + 1 < REGS_CB) regs_next_reflector<B + 1, true>(val, sh, out, k1, ti, tj, vr, vc, half);
+        }
+        REGS_STAMP(4);
+#pragma unroll
+        for (int b = B; b < REGS_CB; ++b) {
+            const double wc = sh.ps[tj + 16 * b] - half * vc[b];
+#pragma unroll
+            for (int a = b / 2; a < REGS_RA; ++a) val[a][b] -= vr[a] * wc;
+        }
+#pragma unroll
+        for (int a = BA; a < REGS_RA; ++a) {
+            const double wr = sh.ps[ti + 32 * a] - half * vr[a];
+#pragma unroll
+            for (int b = B; b <= 2 * a + 1; ++b) val[a][b] -= wr * vc[b];
+        }
+        REGS_STAMP(5);
+        regs_barrier();
+        REGS_STAMP(6);
+    }
+}
+#ifdef MH_REGS_STAMPS
+#define REGS_ACC , acc_
+#else
+#define REGS_ACC
+#endif
+template <int B> __device__ __forceinline__ void regs_from_block(RegsMatrix &val, RegsShared &sh, const RegsOut &out, int tid, int ti, int tj, int lane
+#ifdef MH_REGS_STAMPS
+                                                                 , unsigned long long (&acc_)[7]
+#endif
+) {
+    if (out.off < 16 * B + 16) regs_block_columns<B>(val, sh, out, tid, ti, tj, lane REGS_ACC);
+    if constexpr (B + 1 < REGS_CB) regs_from_block<B + 1>(val, sh, out, tid, ti, tj, lane REGS_ACC);
+}
+template <int B> __device__ __forceinline__ void regs_first_reflector(const RegsMatrix &val, RegsShared &sh, const RegsOut &out, int ti, int tj) {
+    const double none_r[REGS_RA] = {}, none_c[REGS_CB] = {};
+    if ((out.off >> 4) == B) regs_next_reflector<B, false>(val, sh, out, out.off, ti, tj, none_r, none_c, 0.0);
+    else if constexpr (B + 1 < REGS_CB) regs_first_reflector<B + 1>(val, sh, out, ti, tj);
+}
+__global__ void __launch_bounds__(512) k_sytrd_regs(double *__restrict__ A, int m, double *__restrict__ D, double *__restrict__ E, double *__restrict__ TAU) {
+    __shared__ RegsShared sh;
+    const int tid = threadIdx.x, ti = tid & 31, tj = tid >> 5, lane = tid & 63, off = 256 - m;
+    const RegsOut out{A, D, E, TAU, m, off};
+#ifdef MH_REGS_STAMPS
+    unsigned long long acc_[7] = {};
+#endif
+    RegsMatrix val; // val[a][b], b <= 2 a + 1: position (ti + 32 a, tj + 16 b) of the frame
+#pragma unroll
+    for (int a = 0; a < REGS_RA; ++a)
+#pragma unroll
+        for (int b = 0; b < REGS_CB; ++b)
+            if (b <= 2 * a + 1) {
+                const int r = ti + 32 * a - off, c = tj + 16 * b - off;
+                val[a][b] = (r >= 0 && c >= 0) ? (r >= c ? A[size_t(c) * m + r] : A[size_t(r) * m + c]) : 0.0; // (the lower triangle is the input; zero outside the matrix: no guards in the sweeps)
+            }
+    if (tid < 256) sh.ps[tid] = 0.0, sh.vs[0][tid] = 0.0, sh.vs[1][tid] = 0.0;
+    regs_barrier();
+    if (tj == (off & 15) && off < 255) regs_first_reflector<0>(val, sh, out, ti, tj); // from the matrix as it is
+    regs_barrier();
+    regs_from_block<0>(val, sh, out, tid, ti, tj, lane REGS_ACC);
+    if (tid == 511) D[m - 1] = val[REGS_RA - 1][REGS_CB - 1], TAU[m - 1] = 0.0; // the last diagonal entry: position (255, 255)
+#ifdef MH_REGS_STAMPS
+    if (tid == 0)
+        for (int i = 0; i < 7; ++i) g_regs_stamps[i] += acc_[i];
+#endif
+}
+#ifdef MH_REGS_STAMPS
+} // namespace
+extern "C" int mh_debug_regs_stamps(unsigned long long *out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_regs_stamps), sizeof(g_regs_stamps));
+    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_regs_stamps), z, sizeof(z)); }
+    return 0;
+}
+namespace {
+#endif
+} // namespace
+
 // ---- the same reduction on SEVERAL CUs ---------------------------------------------------------------------------
 // The one-workgroup kernel streams the trailing block from L2 twice per column through one CU's memory path (~60 GB/s:
 // 4 us per column, 0.9 ms at m = 230 -- the largest single kernel of a solve).  Here G workgroups hold the matrix in
@@ -975,7 +1203,7 @@ template<int G> __global__ void __launch_bounds__(256) k_sytrd_multi(double *__r
                 acc += aa * v[r];
                 if (cl == k + 1) publish_tagged(slot(parity, 1, r), aa, tag);
             }
-            for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+            acc = mh_row_sum(acc);
             if (t16 == 0) publish_tagged(slot(parity, 0, cl), acc, tag);
         }
         double pr = 0.0, xn = 0.0;
@@ -1041,7 +1269,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_wide(double *__restrict__ A, int
     auto wave_sum = [&](const double *buf, int count) { // every wave for itself, fixed order
         double s_ = 0.0;
         for (int i = lane; i < count; i += 64) s_ += buf[i];
-        for (int off = 32; off > 0; off >>= 1) s_ += __shfl_xor(s_, off, 64);
+        s_ = mh_wave_sum(s_);
         return s_;
     };
     const int cl = g + wave * G; // this wave's column in the sweep
@@ -1101,7 +1329,7 @@ __global__ void __launch_bounds__(1024) k_sytrd_wide(double *__restrict__ A, int
                 acc += aa * v[r];
                 if (cl == k + 1) publish_tagged(slot(parity, 1, r), aa, tag);
             }
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            acc = mh_wave_sum(acc);
             if (lane == 0) publish_tagged(slot(parity, 0, cl), acc, tag);
         }
         double pr = 0.0, xn = 0.0;
@@ -1165,9 +1393,14 @@ void mh_sytrd_wide(mh_context *ctx, double *a, uint32_t m, double *d, double *e,
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant) {
     if (m < 1 || m > 256) mh_throw(MH_EINVAL, "sytrd_small: order %u outside 1..256", m);
     constexpr bool fused = true;
-    // several workgroups from order 64 up (measured: 287 against 363 us at 96, 861 against 1 812 us at 222); MH_SYTRD_MULTI=0: always one
-    constexpr bool multi_default = true;
-    const bool multi = variant < 0 ? (multi_default && m >= 64) : variant == 1;
+    // Default since round 5: the register-resident one-CU kernel (variant 3) at every order -- 43 / 95 / 407 / 506 us at 32 / 64 / 222 / 256
+    // against 94 / 172 / 741 / 890 us of the better of the other two (one workgroup with the matrix in LDS below 64, sixteen workgroups
+    // with a tagged exchange per column from there: profiles/r05_sytrd_regs.txt).  MH_TEST=sytrd_multi: the round-4 choice, for A/B runs.
+    static const bool old_default = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_multi");
+    static const bool one_group = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_fused");
+    if (variant < 0 && one_group) variant = 0;
+    if (variant < 0 && !old_default) variant = 3;
+    const bool multi = variant < 0 ? m >= 64 : variant == 1;
     // the give-up flag belongs to THIS call: a timeout of an earlier launch (co-resident work stalling a workgroup) must not
     // condemn every later reduction on the context (the one-workgroup kernels never raise it)
     if (ctx->sytrd_flag) HIP_CHECK(hipMemsetAsync(ctx->sytrd_flag, 0, sizeof(int), ctx->stream));
@@ -1185,7 +1418,8 @@ void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e
         ctx->sytrd_flag = reinterpret_cast<int *>(ctx->sytrd_xch + words);
         HIP_CHECK(hipMemsetAsync(ctx->sytrd_flag, 0, sizeof(int), ctx->stream));
         k_sytrd_multi<G><<<8 * G, 256, 0, ctx->stream>>>(a, int(m), d, e, tau, ctx->sytrd_xch, ctx->sytrd_epoch, ctx->sytrd_flag);
-    } else if (fused) k_sytrd_small_fused<<<1, MH_SYTRD_THREADS, 0, ctx->stream>>>(a, int(m), d, e, tau);
+    } else if (variant == 3) k_sytrd_regs<<<1, 512, 0, ctx->stream>>>(a, int(m), d, e, tau);
+    else if (fused) k_sytrd_small_fused<<<1, MH_SYTRD_THREADS, 0, ctx->stream>>>(a, int(m), d, e, tau);
     else k_sytrd_small<<<1, 1024, 0, ctx->stream>>>(a, int(m), d, e, tau);
     KERNEL_CHECK();
 }
@@ -1229,7 +1463,7 @@ __global__ void __launch_bounds__(64) k_apply_q(const double *__restrict__ A, co
             double dot = 0;
 #pragma unroll
             for (int q = 0; q < Q; ++q) dot += v[u][q] * z[q];
-            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            dot = mh_wave_sum(dot);
             const double t = tk[u] * dot;
 #pragma unroll
             for (int q = 0; q < Q; ++q) z[q] -= t * v[u][q];
@@ -1669,9 +1903,8 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
 #pragma unroll 8
                     for (int i = part; i < m; i += 8) s += X[i * k + a] * X[i * k + j];
                 }
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                s += __shfl_xor(s, 4, 64);
+                s = mh_quad_sum(s);
+                s += mh_dpp_move<MH_DPP_ROW_HALF_MIRROR>(s); // (eight lanes)
                 if (a < j && part == 0) coef[a] = s * my_inv2;
             }
             __syncthreads();
@@ -1683,8 +1916,7 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
 #pragma unroll 8
                     for (int a = part; a < j; a += 4) s += coef[a] * X[i * k + a];
                 }
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
+                s = mh_quad_sum(s);
                 if (part == 0) {
                     double v = 0.0;
                     if (i < m) {

@@ -1652,7 +1652,13 @@ struct BlockLobpcg {
             const bool near_shift = std::abs(theta[i]) < 10.0 * std::abs(sigma);
             // (Jacobi-scaled norms: the rounding floor of (A x)_i is eps lmax(D^-1 A) D_ii |x|, i.e. eps lmax ||x||_D in the D^-1 norm)
             const double floor_norm = scaled_norms ? sys->L2.lmax * std::sqrt(xn[i]) : anorm * std::sqrt(xn[i]);
-            const bool ok = rel < residual_tol || (near_shift && std::sqrt(rn[i]) < 50 * 2.2e-16 * floor_norm);
+            // The factor: forming (A x)_i rounds to gamma_k sum_j |a_ij| |x_j| with k the row length (~100-250 entries of a P2 row), against
+            // eps ||A|| ||x|| here.  The EXACT rigid-body vectors of the start block measure 37 ... 96 times eps ||A|| ||x|| on the quality-refined
+            // 96 x 48 sphere (||A|| = 2e16 from one sliver; tol |sigma| lies 3e-4 / 1e-5 = 30 times BELOW that floor there); with 50 (rounds
+            // 1-4) whether those pairs ever locked was decided by the rounding of the Rayleigh-Ritz step: 32 iterations with one
+            // tridiagonalisation kernel, no convergence with the other two (tools/probe/sphere_iters_probe.py, profiles/r05_rigid_floor.txt).
+            // A pair accepted here has an eigenvector error of 256 eps ||A|| / (lambda_7 - sigma) ~ 1e-7 at worst and an eigenvalue error of its square.
+            const bool ok = rel < residual_tol || (near_shift && std::sqrt(rn[i]) < 256 * 2.2e-16 * floor_norm);
             if (ok) locked[i] = 1;
             if (!locked[i]) act.push_back(i);
         }

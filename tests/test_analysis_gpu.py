@@ -756,6 +756,111 @@ def test_small_tridiagonalisation_keeps_the_spectrum(ctx, variant, m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m", [2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 96, 100, 127, 128, 129, 160, 193, 222, 224, 225, 240, 241, 255, 256])
+def test_register_resident_tridiagonalisation_returns_t_and_its_reflectors(ctx, m):
+    """k_sytrd_regs (the default of the Rayleigh-Ritz step up to order 256 since round 5: one CU, the matrix in its registers at the
+    END of a 256 x 256 frame, sixteen-column blocks as template parameters -- hence the orders either side of every multiple of 16
+    and 32): T has A's spectrum, the reflectors left in the lower triangle with tau rebuild a Q with Q^T A Q = T, the UPPER triangle
+    of the input is never read, and the output is reproducible run to run."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    rng = np.random.default_rng(3000 + m)
+    q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    lam = np.sort(rng.uniform(1.0, 1e4, m))
+    lam[:3] = lam[min(3, m - 1)]
+    a = (q * lam) @ q.T
+    a = 0.5 * (a + a.T)
+    poisoned = np.tril(a) + np.triu(np.full((m, m), np.nan), 1)  # (column-major on the device: what the kernel must read is this matrix's upper triangle)
+    d, e, refl, tau, _ = lab.tridiagonalize_full(ctx, poisoned.T.copy(), variant=3)
+    assert np.isfinite(d).all() and np.isfinite(e).all()
+    assert np.max(np.abs(eigvalsh_tridiagonal(d, e) - np.linalg.eigvalsh(a))) <= 1e-12 * lam[-1] * m
+    qq = np.eye(m)
+    for k in range(m - 2, -1, -1):
+        v = np.zeros(m)
+        v[k + 1] = 1.0
+        v[k + 2:] = refl[k + 2:, k]
+        qq -= tau[k] * np.outer(v, v @ qq)
+    t = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    assert np.abs(qq.T @ a @ qq - t).max() <= 1e-13 * lam[-1] * m
+    assert tau[m - 1] == 0.0 and np.all((tau[:m - 1] >= 0.0) & (tau[:m - 1] <= 2.0))
+    d2, e2, refl2, tau2, _ = lab.tridiagonalize_full(ctx, poisoned.T.copy(), variant=3)
+    assert np.array_equal(d, d2) and np.array_equal(e, e2) and np.array_equal(tau, tau2) and np.array_equal(refl, refl2, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_the_rigid_body_pairs_lock_whatever_the_rounding_of_the_rayleigh_ritz_step():
+    """Round 5: on the quality-refined 96 x 48 sphere (one sliver: ||A|| = 2e16) tol |sigma| lies thirty times below the rounding
+    floor of forming A x, so the six rigid-body pairs can only be accepted by the floor clause of the convergence test.  With the
+    clause at 50 eps ||A|| ||x|| the EXACT rigid-body vectors of the start block measured 37 ... 96: whether they ever locked hung on
+    the rounding of the Rayleigh-Ritz step -- 32 iterations with the multi-workgroup tridiagonalisation, no convergence with the
+    one-workgroup or the register-resident kernel.  The same solve under each of the three kernels must now converge, in the same
+    number of iterations give or take two, to the same elastic eigenvalues."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from mesheditor_amd import api, meshes, tets\n"
+            "P, F = meshes.uv_sphere_surface(0.15, 96, 48); pts, cells, left = tets.tetrahedralize(P, F, quality=True)\n"
+            "ctx = api.Context(0); mesh = api.Mesh(ctx, pts, cells); s = api.System(ctx, mesh, api.material(*meshes.MATERIALS['Ceramic']))\n"
+            "ev, prof = s.eigs(65, residual_tol=1e-5)\n"
+            "print('RESULT ' + json.dumps([ev.tolist(), prof['restarts'], prof['rr_selfcheck']]))\n") % root
+    runs = {}
+    for kernel in ("sytrd_fused", "sytrd_multi", "registers"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MH_TEST=kernel), timeout=900)
+        assert r.returncode == 0, (kernel, r.stderr[-2000:])
+        runs[kernel] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    ref = np.array(runs["registers"][0])
+    for kernel, (ev, its, check) in runs.items():
+        assert its <= 30 and abs(its - runs["registers"][1]) <= 2, (kernel, its, runs["registers"][1])
+        assert check < 1e-10, (kernel, check)
+        assert np.abs(np.array(ev)[6:] / ref[6:] - 1).max() < 1e-5, kernel  # (each within the residual tolerance of the exact value; 6e-9 on the separated ones)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_tridiagonalisation_of_a_captured_rayleigh_ritz_matrix(ctx, variant):
+    """tests/golden/rr_matrix_order80.bin: the first Rayleigh-Ritz matrix of the quality-refined 96 x 48 sphere's solve (captured
+    from this library in round 5) -- six rigid-body values at 1.579e4 = -sigma, the elastic ones from 3.2e9, the search directions' up to
+    5.6e13.  Every kernel must return T with A's spectrum to eps ||A|| and reflectors with Q^T A Q = T: the values at 1.579e4 are what
+    the solver's convergence test for the rigid-body pairs sees."""
+    import struct
+    from pathlib import Path
+    from scipy.linalg import eigvalsh_tridiagonal
+    raw = (Path(__file__).parent / "golden" / "rr_matrix_order80.bin").read_bytes()
+    m = struct.unpack("I", raw[:4])[0]
+    a = np.frombuffer(raw[4:], dtype=np.float64).reshape(m, m)
+    a = 0.5 * (a + a.T)
+    want = np.linalg.eigvalsh(a)
+    assert 1.5e4 < want[0] < 1.6e4 and want[6] > 3e9 and want[-1] > 5e13
+    d, e, refl, tau, _ = lab.tridiagonalize_full(ctx, a, variant=variant)
+    assert np.abs(eigvalsh_tridiagonal(d, e) - want).max() <= 1e-14 * want[-1]
+    q = np.eye(m)
+    for k in range(m - 2, -1, -1):
+        v = np.zeros(m)
+        v[k + 1] = 1.0
+        v[k + 2:] = refl[k + 2:, k]
+        q -= tau[k] * np.outer(v, v @ q)
+    t = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    assert np.abs(q.T @ a @ q - t).max() <= 1e-14 * want[-1]
+
+
+@pytest.mark.gpu
+def test_register_resident_tridiagonalisation_of_special_matrices(ctx):
+    """Columns that are already reduced (tau = 0, the subdiagonal entry kept with its sign), a diagonal matrix, a zero matrix."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    for m in (5, 40, 130):
+        t0 = np.diag(np.arange(1.0, m + 1)) + np.diag(-np.ones(m - 1), 1) + np.diag(-np.ones(m - 1), -1)
+        d, e, _, tau, _ = lab.tridiagonalize_full(ctx, t0, variant=3)
+        assert np.array_equal(d, np.diag(t0)) and np.array_equal(e, np.diag(t0, -1)) and not tau.any()
+        d, e, _, tau, _ = lab.tridiagonalize_full(ctx, np.diag(np.arange(1.0, m + 1)), variant=3)
+        assert np.array_equal(d, np.arange(1.0, m + 1)) and not e.any() and not tau.any()
+        d, e, _, tau, _ = lab.tridiagonalize_full(ctx, np.zeros((m, m)), variant=3)
+        assert not d.any() and not e.any() and not tau.any()
+        rng = np.random.default_rng(m)
+        b = rng.standard_normal((m, m)) * 1e-150  # tiny entries: the norm must not underflow to an identity reflector silently
+        a = b + b.T
+        d, e, _, _, _ = lab.tridiagonalize_full(ctx, a, variant=3)
+        assert np.max(np.abs(eigvalsh_tridiagonal(d, e) - np.linalg.eigvalsh(a))) <= 1e-12 * np.abs(a).max() * m
+
+
+@pytest.mark.gpu
 def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
     """The tagged-value exchange between the workgroups of k_sytrd_multi must not depend on timing: four host threads (one
     context each) reduce matrices of different orders over and over while a fifth keeps the device busy with operator
