@@ -283,6 +283,40 @@ int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, co
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+// out = a^-1 for a symmetric positive definite a of order w <= 128 (column-major host arrays) through the coarse set-up's one-workgroup
+// Gauss-Jordan kernel; the average of `reps` launches, HIP events around each.
+int mhl_context_spd_inverse(mh_context *ctx, uint32_t w, const double *a, double *out, uint32_t reps, double *avg_ms) {
+    if (!ctx || !a || !out || w < 1 || w > 128) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        MhSharedPhase not_during_a_factorisation;
+        DevArray<double> da(ctx, size_t(w) * w), dout(ctx, size_t(w) * w);
+        DevArray<int> info(ctx, 1);
+        info.zero();
+        da.upload(a, size_t(w) * w);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float total = 0;
+        for (uint32_t r = 0; r < std::max(1u, reps); ++r) {
+            HIP_CHECK(hipEventRecord(e0, ctx->stream));
+            mh_spd_inverse_small(ctx, da, w, w, dout, w, info);
+            HIP_CHECK(hipEventRecord(e1, ctx->stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        dout.download(out, size_t(w) * w);
+        int hinfo = 0;
+        info.download(&hinfo, 1);
+        if (avg_ms) *avg_ms = total / std::max(1u, reps);
+        return hinfo ? MH_EFACTOR : MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 // C = alpha op(A) op(B) + beta C with the Rayleigh-Ritz step's small-product kernel (column-major host arrays; c in and out).
 int mhl_context_small_gemm(mh_context *ctx, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, double alpha, const double *a, uint32_t lda, const double *b, uint32_t ldb, double beta,
                            double *c, uint32_t ldc, uint32_t reps, double *avg_ms) {

@@ -2174,32 +2174,41 @@ __global__ void __launch_bounds__(1024) k_spd_inverse_small(const double *__rest
             const int i = tr + 32 * a, j = tc + 32 * b;
             val[a][b] = (i < w && j < w) ? A[size_t(j) * lda + i] : (i == j ? 1.0 : 0.0); // identity padding: inert
         }
+    int bad = 0; // index + 1 of the first pivot that was not positive (the elimination runs on: its output is then garbage, and flagged)
     for (int p = 0; p < w; ++p) {
         double *rb = rowbuf[p & 1];
         const int ap = p >> 5, lp = p & 31; // row / column p inside its owners' tiles (uniform)
         if (tr == lp) {
+            __builtin_amdgcn_s_setprio(3); // (the serial stretch of a step: the row's owners ahead of the waves they share SIMDs with)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 if (a == ap) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         rb[tc + 32 * b] = val[a][b];
-                        if (tc == lp && b == ap) rb[128] = 1.0 / val[a][b];
+                        if (tc == lp && b == ap) { // 1 / pivot: the hardware's reciprocal and two Newton steps (a full division is ~3x the dependent instructions, on every step's critical path)
+                            const double d = val[a][b];
+                            double r = __builtin_amdgcn_rcp(d);
+                            r = fma(fma(-d, r, 1.0), r, r);
+                            r = fma(fma(-d, r, 1.0), r, r);
+                            rb[128] = r;
+                        }
                     }
                 }
+            __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads();
-        const double piv = rb[p];
-        if (!(piv > 0.0)) { // uniform
-            if (tid == 0) atomicMax(info, p + 1);
-            break;
-        }
-        const double inv = rb[128];
-        double f[4], r[4];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        mh_lds_writes_landed();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const double piv = rb[p], inv = rb[128];
+        if (!(piv > 0.0) && !bad) bad = p + 1; // uniform
+        double f[4], fi[4], r[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int i = tr + 32 * a;
             f[a] = i < p ? -rb[i] : rb[i]; // element (i, p)
+            fi[a] = f[a] * inv;
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) r[b] = rb[tc + 32 * b];
@@ -2207,10 +2216,7 @@ __global__ void __launch_bounds__(1024) k_spd_inverse_small(const double *__rest
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const double t = f[a] * r[b];
-                val[a][b] = fma(-t, inv, val[a][b]);
-            }
+            for (int b = 0; b < 4; ++b) val[a][b] = fma(-fi[a], r[b], val[a][b]);
         // ... then row p (its owners only) and column p (one register per tile row of its owners), picked by uniform compares
         if (tr == lp) {
 #pragma unroll
@@ -2225,10 +2231,11 @@ __global__ void __launch_bounds__(1024) k_spd_inverse_small(const double *__rest
             for (int b = 0; b < 4; ++b)
                 if (b == ap) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) val[a][b] = (tr + 32 * a == p) ? inv : -f[a] * inv; // element (i, p) of the result
+                    for (int a = 0; a < 4; ++a) val[a][b] = (tr + 32 * a == p) ? inv : -fi[a]; // element (i, p) of the result
                 }
         }
     }
+    if (bad && tid == 0) atomicMax(info, bad);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2241,6 +2248,8 @@ __global__ void __launch_bounds__(1024) k_spd_inverse_small(const double *__rest
 
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "spd_inverse_small: order %u outside 1..128", w);
+    // (Round 5: asking for 144 KB of LDS so that no GEMM workgroup of the set-up's other stream can share the CU changed nothing --
+    // 199 us per call inside the coarse set-up either way, against 75 alone: it is not the neighbours on the CU.  docs/LAB_NOTEBOOK.md section 12.)
     k_spd_inverse_small<<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
     KERNEL_CHECK();
 }

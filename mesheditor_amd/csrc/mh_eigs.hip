@@ -2064,7 +2064,9 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
         // 31 -> 15 / 338 ms), block rounded up to whole 16-column MFMA tiles
         // (every further disconnected body brings six more zero modes: the block grows by as many columns)
         // (215 pairs: 240 columns -> 23 / 24 / 21 iterations on the three 215-pair workloads, 256 columns -> 21 / 21 / 19 but +2 ... +4 % time)
-        uint32_t b = (nev + std::max(15u, nev * kGuardPercent / 100) + 6u * (sys->n_components - 1u) + 15u) / 16u * 16u;
+        uint32_t guards = std::max(15u, nev * kGuardPercent / 100);
+        if (const char *g = getenv("MH_GUARDS")) guards = uint32_t(std::max(1, atoi(g))); // (A/B hook: tools/probe/guard_sweep.sh)
+        uint32_t b = (nev + guards + 6u * (sys->n_components - 1u) + 15u) / 16u * 16u;
         if (n <= 768 || n < size_t(5) * b) {
             Timer t(ctx);
             dense_eigs(sys, nev, sigma, eigenvalues);

@@ -415,7 +415,7 @@ def test_a_wide_solve_beside_narrow_ones(api):
     assert not bad, bad
     assert overlapped[0] > 0  # (wide solves started while narrow ones were in flight: nothing serialises them any more)
     assert all(r == 0 for r, _ in health), health
-    assert max(q for _, q in health) < 1e-10, max(q for _, q in health)
+    assert max(q for _, q in health) < 1e-9, max(q for _, q in health)  # (1e-13 ... 1e-10 over these sixty solves, by the rounding of the step; the solve itself fails at 1e-8)
 
 
 def test_the_exchange_kernel_beside_wide_solves_soak(api):
@@ -556,7 +556,8 @@ def _residuals(sysg, ev, cols):
 
 
 def test_a_tolerance_below_the_rounding_floor_fails_cleanly(api, ctx):
-    """A residual tolerance the mesh does not admit (1e-11 on the cube: the floor of forming A x is ~1e-10 relative) ends in
+    """A residual tolerance the mesh does not admit (1e-13 on the cube: the floor of forming A x is 1e-11 ... 1e-10 relative -- 1e-11 itself,
+    asked for here until round 5, is met or not by the rounding of the coarse inverse since the rigid-body pairs lock at once) ends in
     MH_ENOTCONVERGED with a message that says so -- not in a rank failure of the search directions 40 iterations later -- and the
     public tolerance mapping never asks for less than 1e-8 (eigenvalues at round-off), which every workload meets."""
     from mesheditor_amd.api import ModalHipError, default_config, residual_tolerance
@@ -564,7 +565,7 @@ def test_a_tolerance_below_the_rounding_floor_fails_cleanly(api, ctx):
     mesh = api.Mesh(ctx, pts, tets)
     sysg = api.System(ctx, mesh, api.material(*m))
     with pytest.raises(ModalHipError) as err:
-        sysg.eigs(65, SIGMA, 1e-11)
+        sysg.eigs(65, SIGMA, 1e-13)
     assert "rounding floor" in str(err.value) or "converged in" in str(err.value)
     ev8, _ = sysg.eigs(65, SIGMA, 1e-8)
     ev6, _ = sysg.eigs(65, SIGMA, 1e-6)
@@ -809,7 +810,7 @@ def test_the_rigid_body_pairs_lock_whatever_the_rounding_of_the_rayleigh_ritz_st
     ref = np.array(runs["registers"][0])
     for kernel, (ev, its, check) in runs.items():
         assert its <= 30 and abs(its - runs["registers"][1]) <= 2, (kernel, its, runs["registers"][1])
-        assert check < 1e-10, (kernel, check)
+        assert check < 1e-9, (kernel, check)
         assert np.abs(np.array(ev)[6:] / ref[6:] - 1).max() < 1e-5, kernel  # (each within the residual tolerance of the exact value; 6e-9 on the separated ones)
 
 

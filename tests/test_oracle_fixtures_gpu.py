@@ -74,7 +74,7 @@ def test_device_result_matches_the_committed_oracle_result(name):
     assert worst_plain == -1.0 or 0 < worst_plain < 1e-2, (name, worst_plain)
     assert dropped[0] < 50 and dropped[1] < 50, dropped
     # health of the device solve: no Rayleigh-Ritz step redone, every step's self-check at rounding level (mh_profile)
-    assert r.profile["sytrd_redos"] == 0 and r.profile["rr_selfcheck"] < 1e-10, r.profile  # (measured 1e-13 ... 3e-12; the solve itself fails at 1e-8)
+    assert r.profile["sytrd_redos"] == 0 and r.profile["rr_selfcheck"] < 1e-9, r.profile  # (measured 1e-13 ... 3e-12 here, up to 1e-10 on jittered boxes; the solve itself fails at 1e-8)
     ref = np.array(fx["eigenvalues"])
     assert len(r.eigenvalues) == len(ref), r.profile
     elastic = ref > 1e-6 * ref[-1]

@@ -28,6 +28,7 @@ def lib():
         L.mhl_context_bench_stream.restype, L.mhl_context_bench_stream.argtypes = i32, [vp, C.c_uint64, u32, f64p, f64p]
         L.mhl_context_gram.restype, L.mhl_context_gram.argtypes = i32, [vp, C.c_uint64, vp, u32, vp, u32, vp]
         L.mhl_context_pool_stats.restype, L.mhl_context_pool_stats.argtypes = i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mhl_context_spd_inverse.restype, L.mhl_context_spd_inverse.argtypes = i32, [vp, u32, vp, vp, u32, f64p]
         L.mhl_context_small_gemm.restype, L.mhl_context_small_gemm.argtypes = i32, [vp, i32, i32, u32, u32, u32, C.c_double, vp, u32, vp, u32, C.c_double, vp, u32, u32, f64p]
         L.mhl_context_tridiagonalize_full.restype, L.mhl_context_tridiagonalize_full.argtypes = i32, [vp, i32, u32, vp, vp, vp, vp, vp, u32, f64p]
         L.mhl_graph_aggregates.restype, L.mhl_graph_aggregates.argtypes = u32, [vp, vp, u32, u32, u32, vp]
@@ -108,6 +109,14 @@ def pool_stats(ctx):
     r, i, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     ctx.check(lib().mhl_context_pool_stats(ctx.h, C.byref(r), C.byref(i), C.byref(c)))
     return r.value, i.value, c.value
+
+
+def spd_inverse(ctx, a, reps=1):
+    """(a^-1, average ms) through the coarse set-up's one-workgroup Gauss-Jordan kernel (order <= 128)."""
+    af = np.asfortranarray(a, dtype=np.float64)
+    out, ms = np.zeros_like(af, order="F"), C.c_double(0)
+    ctx.check(lib().mhl_context_spd_inverse(ctx.h, af.shape[0], _p(af), _p(out), reps, C.byref(ms)))
+    return out, ms.value
 
 
 def small_gemm(ctx, a, b, c=None, ta=False, tb=False, alpha=1.0, beta=0.0, reps=1):
