@@ -244,6 +244,7 @@ struct mh_context {
     hipStream_t aux2_stream{nullptr}; // third stream: the next pivot block's inverse beside the coarse elimination's rank update (our kernel only, no library handle)
     std::vector<hipEvent_t> ahead_ev; // the look-ahead's events, two per elimination step (pivot block ready, its inverse ready), never shared between steps; they live as long as the context
     bool aux2_stream_ready(size_t events = 0) {
+        // (a stream of the highest priority for the pivot inverses changed nothing: round 5, notebook section 12)
         if (!aux2_stream && hipStreamCreateWithFlags(&aux2_stream, hipStreamNonBlocking) != hipSuccess) aux2_stream = nullptr, (void)hipGetLastError();
         while (aux2_stream && ahead_ev.size() < events) {
             hipEvent_t e = nullptr;

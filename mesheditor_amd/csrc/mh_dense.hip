@@ -2248,8 +2248,10 @@ __global__ void __launch_bounds__(1024) k_spd_inverse_small(const double *__rest
 
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info) {
     if (w < 1 || w > 128) mh_throw(MH_EINVAL, "spd_inverse_small: order %u outside 1..128", w);
-    // (Round 5: asking for 144 KB of LDS so that no GEMM workgroup of the set-up's other stream can share the CU changed nothing --
-    // 199 us per call inside the coarse set-up either way, against 75 alone: it is not the neighbours on the CU.  docs/LAB_NOTEBOOK.md section 12.)
+    // (Round 5, docs/LAB_NOTEBOOK.md section 12: inside the coarse set-up the elimination loop runs 115-136 us instead of 87 because waves of
+    // the main stream's device-filling products share its SIMDs -- they need no LDS, so reserving LDS kept nobody out; claiming the whole
+    // register file (128 instead of 96 registers) does, but the workgroup then waits as long for an EMPTY CU as it gained: 160 us per call in
+    // the trace either way, and the set-up's step is bound by the rank-128 update beside it, not by this kernel.)
     k_spd_inverse_small<<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
     KERNEL_CHECK();
 }
