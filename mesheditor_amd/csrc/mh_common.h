@@ -93,6 +93,31 @@ __device__ __forceinline__ double mh_wave_sum(double x) { // over the 64 lanes
     x = mh_row_sum(x);
     return (mh_lane_value(x, 0) + mh_lane_value(x, 16)) + (mh_lane_value(x, 32) + mh_lane_value(x, 48));
 }
+// 1 / x and (sqrt x, 1 / sqrt x) from the hardware's estimates (v_rcp_f64, v_rsq_f64: ~26 bits) and two Newton / Goldschmidt steps: a dozen
+// dependent instructions where the IEEE division and square root sequences take thirty to forty each.  For the serial stretches of the
+// one-workgroup dense kernels (a pivot, a Householder reflector, a Cholesky column per step), where that latency is the step's time.
+// Within an ulp or two of the correctly rounded values; outside 1e-290 < |x| < 1e290 the IEEE operations are used (a uniform branch there).
+__device__ __forceinline__ double mh_fast_rcp(double x) {
+    if (!(fabs(x) > 1e-290 && fabs(x) < 1e290)) return 1.0 / x;
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ void mh_fast_sqrt_rsqrt(double x, double &root, double &inverse_root) { // x > 0
+    if (!(x > 1e-290 && x < 1e290)) {
+        root = sqrt(x), inverse_root = 1.0 / root;
+        return;
+    }
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r; // g -> sqrt x, h -> 1 / (2 sqrt x)
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g), h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g), h = fma(h, e, h);
+    g = fma(fma(-g, g, x), h, g); // one more correction of the root from its residual x - g^2
+    root = g, inverse_root = 2.0 * h;
+}
 __device__ __forceinline__ double mh_half_wave_sum(double x) { // over lanes 0-31 and over lanes 32-63
     x = mh_row_sum(x);
     const double low = mh_lane_value(x, 0) + mh_lane_value(x, 16), high = mh_lane_value(x, 32) + mh_lane_value(x, 48);

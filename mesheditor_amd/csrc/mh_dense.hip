@@ -918,9 +918,11 @@ __device__ __forceinline__ void regs_next_reflector(const RegsMatrix &val, RegsS
     alpha = mh_lane_value(alpha, base + (k2 & 31));
     double tau = 0.0, beta = alpha, scale = 0.0;
     if (sq > 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + sq), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
+        double norm, inverse_norm;
+        mh_fast_sqrt_rsqrt(fma(alpha, alpha, sq), norm, inverse_norm);
+        beta = -copysign(norm, alpha);
+        tau = fma(alpha, copysign(inverse_norm, alpha), 1.0); // (beta - alpha) / beta = 1 - alpha / beta = 1 + |alpha| / norm
+        scale = mh_fast_rcp(alpha - beta);
     }
     double *vnext = sh.vs[k2 & 1];
     const size_t column = size_t(kn - out.off) * out.m;
@@ -1824,17 +1826,21 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
                 const double sb = e[i], nd = d[i + 1] - lj, ns = i + 2 < m ? e[i + 1] : 0.0;
                 double rn = X[(i + 1) * k + j];
                 double u0, u1, u2;
+                // (u0 holds the RECIPROCAL of the pivot: the elimination needs it anyway, and the back substitution then has no division in its
+                // chain; the reciprocal by the hardware estimate and Newton steps -- one per row, each waiting for the previous row's)
                 if (fabs(cd) >= fabs(sb)) {
                     if (fabs(cd) < tiny) cd = copysign(tiny, cd);
-                    const double mult = sb / cd;
-                    u0 = cd; u1 = cs; u2 = 0.0;
+                    u0 = mh_fast_rcp(cd);
+                    const double mult = sb * u0;
+                    u1 = cs; u2 = 0.0;
                     cd = nd - mult * cs;
                     cs = ns;
                     rn -= mult * ri;
                     X[i * k + j] = ri;
                 } else {
-                    const double mult = cd / sb;
-                    u0 = sb; u1 = nd; u2 = ns;
+                    u0 = mh_fast_rcp(sb);
+                    const double mult = cd * u0;
+                    u1 = nd; u2 = ns;
                     cd = cs - mult * nd;
                     cs = -mult * ns;
                     const double t = ri;
@@ -1864,7 +1870,7 @@ __global__ void __launch_bounds__(1024) k_tridiag_lowest(const double *__restric
                 for (int q = 0; q < 8; ++q) {
                     const int i = i0 - q;
                     if (i < 0) break;
-                    const double y = (X[i * k + j] - u[q][1] * y1 - u[q][2] * y2) / u[q][0];
+                    const double y = (X[i * k + j] - u[q][1] * y1 - u[q][2] * y2) * u[q][0];
                     X[i * k + j] = y;
                     nrm += y * y;
                     y2 = y1;
@@ -2084,8 +2090,9 @@ __global__ void __launch_bounds__(256) k_potrf_panels(double *__restrict__ A, in
         for (int q = 0; q < NB; ++q) {
             const double akk = blk[q][q];
             if (!(akk > 0.0) && !fail) fail = k0 + q + 1;
-            const double d = sqrt(akk);
-            inv[q] = 1.0 / d;
+            double d = 1.0;
+            inv[q] = 1.0;
+            if (akk > 0.0) mh_fast_sqrt_rsqrt(akk, d, inv[q]); // (eight of these in a row, every one waiting for the previous column's update: the panel's time)
             blk[q][q] = d;
 #pragma unroll
             for (int p = q + 1; p < NB; ++p) blk[p][q] *= inv[q];
