@@ -283,6 +283,25 @@ int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, co
     } catch (const std::exception &e) { return mh_guard(ctx, e); }
 }
 
+// The Cholesky-QR step's one-launch kernel: l <- diag(1 / dscale) chol(a) (lower, zeros above), linv <- l^-1; info[0] = 0 or the failing column,
+// info[1] = the diagonal spread report.  Column-major host arrays of order w <= 128.
+int mhl_context_potrf_inverse(mh_context *ctx, uint32_t w, const double *a, const double *dscale, double *l, double *linv, int *info2) {
+    if (!ctx || !a || !dscale || !l || !linv || !info2 || w < 1 || w > 128) return MH_EINVAL;
+    try {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        MhSharedPhase not_during_a_factorisation;
+        DevArray<double> da(ctx, size_t(w) * w), dd(ctx, w), dl(ctx, size_t(w) * w);
+        DevArray<int> info(ctx, 2);
+        da.upload(a, size_t(w) * w);
+        dd.upload(dscale, w);
+        mh_potrf_small_inverse(ctx, da, w, info, dd, dl);
+        da.download(l, size_t(w) * w);
+        dl.download(linv, size_t(w) * w);
+        info.download(info2, 2);
+        return MH_OK;
+    } catch (const std::exception &e) { return mh_guard(ctx, e); }
+}
+
 // out = a^-1 for a symmetric positive definite a of order w <= 128 (column-major host arrays) through the coarse set-up's one-workgroup
 // Gauss-Jordan kernel; the average of `reps` launches, HIP events around each.
 int mhl_context_spd_inverse(mh_context *ctx, uint32_t w, const double *a, double *out, uint32_t reps, double *avg_ms) {

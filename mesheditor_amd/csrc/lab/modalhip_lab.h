@@ -21,6 +21,7 @@ int mhl_context_tridiagonalize(mh_context *, int variant, uint32_t m, const doub
 /* the same with the reflectors (m x m, LAPACK's lower storage) and tau returned; variant 2 = the wide kernel, orders up to 768 */
 int mhl_context_tridiagonalize_full(mh_context *, int variant, uint32_t m, const double *a, double *d, double *e, double *reflectors, double *tau, uint32_t reps, double *avg_ms);
 /* C (M x N, ldc) = alpha op(A) op(B) + beta C through the Rayleigh-Ritz step's small-product kernel; column-major host arrays, c in and out */
+int mhl_context_potrf_inverse(mh_context *, uint32_t w, const double *a, const double *dscale, double *l, double *linv, int *info2);
 int mhl_context_spd_inverse(mh_context *, uint32_t w, const double *a, double *out, uint32_t reps, double *avg_ms);
 int mhl_context_small_gemm(mh_context *, int ta, int tb, uint32_t M, uint32_t N, uint32_t K, double alpha, const double *a, uint32_t lda, const double *b, uint32_t ldb, double beta, double *c,
                            uint32_t ldc, uint32_t reps, double *avg_ms);

@@ -527,6 +527,7 @@ bool mh_tridiag_lowest(mh_context *ctx, const double *d, const double *e, uint32
 void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32_t w, double *out, uint32_t ldo, int *info); // mh_dense.hip
 void mh_potrf(mh_context *ctx, double *a, uint32_t ld, uint32_t w, int *info); // mh_dense.hip: lower Cholesky of any order without rocSOLVER (info: two ints)
 void mh_potrf_small(mh_context *ctx, double *a, uint32_t w, int *info); // mh_dense.hip: lower Cholesky, order <= 128, one workgroup
+void mh_potrf_small_inverse(mh_context *ctx, double *a, uint32_t w, int *info, const double *dscale, double *linv); // the same, then a <- diag(1 / dscale) a and linv <- a^-1, one launch
 bool mh_sytrd_gave_up(mh_context *ctx);
 void mh_sytrd_wide(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau); // orders up to 768, 48 workgroups over all XCDs (mh_dense.hip)
 void mh_sytrd_small(mh_context *ctx, double *a, uint32_t m, double *d, double *e, double *tau, int variant = -1); // variant: -1 = the process default, 0 = one workgroup, 1 = several; mh_dense.hip: A (column-major, ld m, symmetric, full) -> D, E, tau, reflectors

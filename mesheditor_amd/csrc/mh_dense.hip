@@ -2072,7 +2072,13 @@ __global__ void __launch_bounds__(256) k_potrf_small(double *__restrict__ A, int
 // it, then the trailing triangle takes the panel's eight rank-1 updates one after the other.  Every entry goes through
 // exactly the operations of the column-by-column kernel in the same order: the two produce the same bits.
 namespace {
-__global__ void __launch_bounds__(256) k_potrf_panels(double *__restrict__ A, int w, int *__restrict__ info) {
+// With linv: the Cholesky-QR step of the search directions in ONE launch -- factor, L <- diag(1 / dscale) L (k_unscale_chol's rule), and
+// linv = L^-1 (full w x w, zeros above the diagonal) by a blocked in-place inversion in LDS, eight columns per step from the last block to
+// the first: the 8 x 8 diagonal block is inverted in registers by every thread, the panel below becomes -T (P D^-1) with T the inverse
+// of the trailing block already in place (two threads per row, alternate columns).  Replaces the chain potrf, unscale, memset, the
+// library's trtri (three to five launches of its own): ~130 us of launches and gaps per Cholesky-QR, two per iteration.
+__global__ void __launch_bounds__(256) k_potrf_panels(double *__restrict__ A, int w, int *__restrict__ info, const double *__restrict__ dscale = nullptr,
+                                                      double *__restrict__ linv = nullptr) {
     constexpr int NB = 8;
     extern __shared__ __attribute__((aligned(16))) double L[]; // w x w, column-major, pitch w + 1 (bank spread)
     const int tid = threadIdx.x, pitch = w + 1;
@@ -2145,15 +2151,111 @@ __global__ void __launch_bounds__(256) k_potrf_panels(double *__restrict__ A, in
         __syncthreads();
     }
     __syncthreads();
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int j = idx / w, i = idx % w;
-        if (i >= j) A[idx] = L[j * pitch + i]; // the strictly upper part keeps the input, as potrf
-    }
     if (tid == 0) {
         info[0] = fail;
         double lo = 1.7976931348623157e308, hi = 0;
         for (int k = 0; k < w; ++k) { const double v = L[k * pitch + k]; lo = fmin(lo, v); hi = fmax(hi, v); }
         info[1] = fail || !(lo > 0) ? 1 << 20 : int(16.0 * log2(hi / lo)); // as k_potrf_small
+    }
+    if (!linv) {
+        for (int idx = tid; idx < w * w; idx += 256) {
+            const int j = idx / w, i = idx % w;
+            if (i >= j) A[idx] = L[j * pitch + i]; // the strictly upper part keeps the input, as potrf
+        }
+        return;
+    }
+    __syncthreads(); // (thread 0 has read the diagonal)
+    // L <- diag(1 / dscale) L, out to A with zeros above the diagonal (k_unscale_chol)
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int j = idx / w, i = idx % w;
+        double v = 0.0;
+        if (i >= j) {
+            const double d = dscale[i];
+            v = d > 0 ? L[j * pitch + i] / d : (i == j ? 1.0 : 0.0);
+            L[j * pitch + i] = v;
+        }
+        A[idx] = v;
+    }
+    __syncthreads();
+    if (fail) return; // uniform
+    double *scr = L + size_t(w) * pitch; // 8 values per panel row: the second half of a row's sum
+    for (int kb = (w + NB - 1) / NB - 1; kb >= 0; --kb) {
+        const int k0 = kb * NB, nb = min(NB, w - k0), r0 = k0 + nb, rem = w - r0;
+        // inverse of the diagonal block, by every thread (lower triangle, identity padding)
+        double dm[NB][NB], di[NB][NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int pr = q; pr < NB; ++pr) dm[pr][q] = (pr < nb) ? L[(k0 + q) * pitch + k0 + pr] : (pr == q ? 1.0 : 0.0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) di[q][q] = mh_fast_rcp(dm[q][q]);
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int pr = q + 1; pr < NB; ++pr) {
+                double t = 0.0;
+#pragma unroll
+                for (int u = q; u < pr; ++u) t += dm[pr][u] * di[u][q];
+                di[pr][q] = -di[pr][pr] * t;
+            }
+        // Y = P D^-1, a row per thread, in place
+        if (tid < rem) {
+            const int i = r0 + tid;
+            double pv[NB], y[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) pv[q] = q < nb ? L[(k0 + q) * pitch + i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                y[q] = 0.0;
+#pragma unroll
+                for (int pr = q; pr < NB; ++pr) y[q] += pv[pr] * di[pr][q];
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (q < nb) L[(k0 + q) * pitch + i] = y[q];
+        }
+        __syncthreads();
+        // X = -T Y: two threads per row, alternate columns of T
+        const int row = tid & 127, half = tid >> 7;
+        double acc[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) acc[q] = 0.0;
+        if (row < rem) {
+            const int i = r0 + row;
+            for (int k = r0 + half; k <= i; k += 2) {
+                const double t = L[k * pitch + i];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) acc[q] += t * L[(k0 + q) * pitch + k]; // (columns beyond nb of a last, short block: the next block's, times a result never stored)
+            }
+            if (half) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) scr[row * NB + q] = acc[q];
+            }
+        }
+        __syncthreads();
+        if (row < rem && !half) {
+            const int i = r0 + row;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (q < nb) L[(k0 + q) * pitch + i] = -(acc[q] + scr[row * NB + q]);
+        }
+        if (tid < NB * NB) {
+            const int q = tid / NB, pr = tid % NB;
+            if (pr >= q && pr < nb) {
+                double val = 0.0;
+#pragma unroll
+                for (int qq = 0; qq < NB; ++qq)
+#pragma unroll
+                    for (int pp = qq; pp < NB; ++pp)
+                        if (qq == q && pp == pr) val = di[pp][qq];
+                L[(k0 + q) * pitch + k0 + pr] = val;
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int j = idx / w, i = idx % w;
+        linv[idx] = i >= j ? L[j * pitch + i] : 0.0;
     }
 }
 } // namespace
@@ -2260,6 +2362,15 @@ void mh_spd_inverse_small(mh_context *ctx, const double *a, uint32_t lda, uint32
     // register file (128 instead of 96 registers) does, but the workgroup then waits as long for an EMPTY CU as it gained: 160 us per call in
     // the trace either way, and the set-up's step is bound by the rank-128 update beside it, not by this kernel.)
     k_spd_inverse_small<<<1, 1024, 0, ctx->stream>>>(a, int(lda), int(w), out, int(ldo), info);
+    KERNEL_CHECK();
+}
+
+// Factor, unscale and invert in one launch (k_potrf_panels with linv): a <- diag(1 / dscale) chol(a) (zeros above the diagonal), linv <- its inverse.
+void mh_potrf_small_inverse(mh_context *ctx, double *a, uint32_t w, int *info, const double *dscale, double *linv) {
+    if (w < 1 || w > 128) mh_throw(MH_EINVAL, "potrf_small_inverse: order %u outside 1..128", w);
+    static PerDeviceOnce attr;
+    attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_panels), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });
+    k_potrf_panels<<<1, 256, (size_t(w) * (w + 1) + size_t(8) * w) * sizeof(double), ctx->stream>>>(a, int(w), info, dscale, linv);
     KERNEL_CHECK();
 }
 

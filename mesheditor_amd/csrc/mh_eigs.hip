@@ -8,7 +8,7 @@
 //   level 1  its exact Galerkin restriction to the corner nodes (P1 subset of P2), gamma cycles
 //   level 0  rigid-body modes of graph-grown node aggregates; explicit inverse by our block Gauss-Jordan elimination (mh_build_hierarchy)
 // Tall-skinny products: k_gram_blocked / k_combine (fp64 MFMA, mh_dense.hip), the vendor dgemm only for blocks of >= 400 basis columns.
-// The Rayleigh-Ritz problem: our tridiagonalisation (k_sytrd_multi / k_sytrd_wide), partial spectrum by multisection + inverse iteration
+// The Rayleigh-Ritz problem: our tridiagonalisation (k_sytrd_regs up to order 256, k_sytrd_wide above), partial spectrum by multisection + inverse iteration
 // (k_tridiag_lowest, k_tridiag_invit), one-launch back-transformation (k_apply_q); rocSOLVER only as the fall-back of a failed check.
 #include "mh_common.h"
 
@@ -1437,10 +1437,16 @@ struct BlockLobpcg {
         KERNEL_CHECK();
         double *Gs = G.get() + size_t(w) * w;
         int hinfo = 0;
+        bool fused_inverse = false; // Gs already unscaled and Linv already formed (orders <= 128)
         {
             last_spread = 1 << 20;
             if (w <= 128) {
-                mh_potrf_small(ctx, Gs, w, info); // one workgroup of ours (rocSOLVER potf2: ~100 us at these orders)
+                // one workgroup of ours: factor, unscale and invert in one launch (round 5; before: potrf, unscale, memset and the library's
+                // trtri -- six to eight launches, ~130 us with their gaps, twice per iteration); MH_TEST=potrf_chain: the old chain
+                static const bool chain = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "potrf_chain");
+                fused_inverse = !chain;
+                if (fused_inverse) mh_potrf_small_inverse(ctx, Gs, w, info, dscale, Linv);
+                else mh_potrf_small(ctx, Gs, w, info);
                 int both[2] = {0, 0};
                 info.download(both, 2);
                 hinfo = both[0];
@@ -1456,8 +1462,10 @@ struct BlockLobpcg {
             return true;
         }
         if (hinfo != 0) return false;
-        k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
-        KERNEL_CHECK();
+        if (!fused_inverse) {
+            k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
+            KERNEL_CHECK();
+        }
         if (w > 256) {
             panel_trsm(ctx, n, V, w, Gs, w);
             if (MV) panel_trsm(ctx, n, MV, w, Gs, w);
@@ -1465,8 +1473,10 @@ struct BlockLobpcg {
         } else {
             // V <- V L^-T through the explicit small inverse and the MFMA basis-update kernel (in place: a workgroup
             // reads its rows before it writes them): L^-1 column-major IS the k-major coefficient matrix of V L^-T
-            HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
-            ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
+            if (!fused_inverse) {
+                HIP_CHECK(hipMemsetAsync(Linv, 0, size_t(w) * w * sizeof(double), st));
+                ROCBLAS_CHECK(rocblas_dtrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, w, Gs, w, Linv, w));
+            }
             w_implicit = allow_implicit && !transform_images && last_spread < 16 * 8;
             if (!w_implicit) mh_combine(ctx, n, V, w, nullptr, 0, nullptr, 0, Linv, w, V, w, nullptr);
             if (MV && transform_images) mh_combine(ctx, n, MV, w, nullptr, 0, nullptr, 0, Linv, w, MV, w, nullptr);

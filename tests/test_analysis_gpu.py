@@ -788,6 +788,38 @@ def test_register_resident_tridiagonalisation_returns_t_and_its_reflectors(ctx, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w", [1, 2, 5, 7, 8, 9, 16, 17, 63, 64, 74, 80, 121, 127, 128])
+def test_cholesky_qr_factor_and_inverse_in_one_launch(ctx, w):
+    """k_potrf_panels with its inverse stage (round 5: the search directions' Cholesky-QR step was potrf, unscale, memset and the
+    library's trtri): L = diag(1 / d) chol(G) with zeros above the diagonal, L^-1 to rounding, the conditioning report, a row with d = 0
+    turned into an identity row, and a matrix that is not positive definite reported by its column with nothing inverted."""
+    rng = np.random.default_rng(4000 + w)
+    b = rng.standard_normal((w + 5, w))
+    d = rng.uniform(0.5, 2.0, w)
+    g = b.T @ b
+    g = g / np.sqrt(np.outer(np.diag(g), np.diag(g)))  # unit diagonal, as k_scale_gram leaves it
+    l, linv, info = lab.potrf_inverse(ctx, g, d)
+    want = np.linalg.cholesky(g) / d[:, None]
+    assert info[0] == 0 and info[1] < 1 << 20
+    assert np.abs(l - want).max() <= 1e-13 * np.abs(want).max() and not np.triu(l, 1).any()
+    assert not np.triu(linv, 1).any()
+    assert np.abs(linv @ want - np.eye(w)).max() <= 1e-12 * np.linalg.cond(want)
+    if w >= 3:
+        d0 = d.copy()
+        d0[w // 2] = 0.0
+        l0, linv0, info0 = lab.potrf_inverse(ctx, g, d0)
+        want0 = want.copy()
+        want0[w // 2] = 0.0
+        want0[w // 2, w // 2] = 1.0
+        assert info0[0] == 0 and np.abs(l0 - want0).max() <= 1e-13 * np.abs(want0).max()
+        assert np.abs(linv0 @ want0 - np.eye(w)).max() <= 1e-12 * np.linalg.cond(want0)
+        bad = g.copy()
+        bad[w // 2, w // 2] = -1.0
+        _, _, info_bad = lab.potrf_inverse(ctx, bad, d)
+        assert info_bad[0] == w // 2 + 1
+
+
+@pytest.mark.gpu
 def test_the_rigid_body_pairs_lock_whatever_the_rounding_of_the_rayleigh_ritz_step():
     """Round 5: on the quality-refined 96 x 48 sphere (one sliver: ||A|| = 2e16) tol |sigma| lies thirty times below the rounding
     floor of forming A x, so the six rigid-body pairs can only be accepted by the floor clause of the convergence test.  With the
@@ -1039,7 +1071,9 @@ def test_a_timed_out_tridiagonalisation_falls_back_without_changing_the_answer()
         "print(json.dumps(out))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = []
-    for hook in ("", "sytrd_giveup", "no_tridiag_wide"):  # (the third: the partial-spectrum stage above order 256 takes its fall-back, stedc + ormtr)
+    # (the third: the partial-spectrum stage above order 256 takes its fall-back, stedc + ormtr; the fourth: up to order 256 the default kernel
+    # since round 5 is the one-CU k_sytrd_regs, which cannot time out -- sytrd_multi selects the exchanging kernel there, so that ITS fall-back runs)
+    for hook in ("", "sytrd_giveup", "no_tridiag_wide", "sytrd_multi sytrd_giveup"):
         env = dict(os.environ, MH_TEST=hook, PYTHONPATH=root)
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert p.returncode == 0, p.stderr[-2000:]

@@ -28,6 +28,7 @@ def lib():
         L.mhl_context_bench_stream.restype, L.mhl_context_bench_stream.argtypes = i32, [vp, C.c_uint64, u32, f64p, f64p]
         L.mhl_context_gram.restype, L.mhl_context_gram.argtypes = i32, [vp, C.c_uint64, vp, u32, vp, u32, vp]
         L.mhl_context_pool_stats.restype, L.mhl_context_pool_stats.argtypes = i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mhl_context_potrf_inverse.restype, L.mhl_context_potrf_inverse.argtypes = i32, [vp, u32, vp, vp, vp, vp, vp]
         L.mhl_context_spd_inverse.restype, L.mhl_context_spd_inverse.argtypes = i32, [vp, u32, vp, vp, u32, f64p]
         L.mhl_context_small_gemm.restype, L.mhl_context_small_gemm.argtypes = i32, [vp, i32, i32, u32, u32, u32, C.c_double, vp, u32, vp, u32, C.c_double, vp, u32, u32, f64p]
         L.mhl_context_tridiagonalize_full.restype, L.mhl_context_tridiagonalize_full.argtypes = i32, [vp, i32, u32, vp, vp, vp, vp, vp, u32, f64p]
@@ -109,6 +110,15 @@ def pool_stats(ctx):
     r, i, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     ctx.check(lib().mhl_context_pool_stats(ctx.h, C.byref(r), C.byref(i), C.byref(c)))
     return r.value, i.value, c.value
+
+
+def potrf_inverse(ctx, a, dscale):
+    """(L, L^-1, info[2]) of the Cholesky-QR step's one-launch kernel: L = diag(1 / dscale) chol(a) (rows with dscale <= 0: identity rows)."""
+    af = np.asfortranarray(a, dtype=np.float64)
+    d = np.ascontiguousarray(dscale, dtype=np.float64)
+    l, linv, info = np.zeros_like(af, order="F"), np.zeros_like(af, order="F"), np.zeros(2, np.int32)
+    ctx.check(lib().mhl_context_potrf_inverse(ctx.h, af.shape[0], _p(af), _p(d), _p(l), _p(linv), _p(info)))
+    return l, linv, info
 
 
 def spd_inverse(ctx, a, reps=1):
