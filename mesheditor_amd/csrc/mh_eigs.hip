@@ -1341,6 +1341,7 @@ struct BlockLobpcg {
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
     DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
+    DevArray<double> Linv_p, T1p2; // the conjugate directions' own triangular inverse (Linv belongs to W until the basis update) and the product's output
     DevArray<uint32_t> idx_d, pos_d;
     // The residuals of the active columns as the image product's epilogue leaves them (mh_spmm_mapped): compact panel of pitch
     // res_pitch for the columns res_act, per-node norm partials, the reduced norms [2][res_pitch]
@@ -1392,6 +1393,8 @@ struct BlockLobpcg {
             for (DevArray<double> *panel : {&MP, &MPn}) panel->reset(ctx, n * b);
         for (DevArray<double> *small : {&gA, &gM, &gM0, &gA0}) small->reset(ctx, size_t(mmax) * mmax);
         for (DevArray<double> *small : {&App, &H, &H2, &Linv, &Hp, &Up, &Vp, &T1p}) small->reset(ctx, size_t(b) * b);
+        Linv_p.reset(ctx, size_t(b) * b);
+        T1p2.reset(ctx, size_t(mmax) * b);
         for (DevArray<double> *small : {&Cp, &T1}) small->reset(ctx, size_t(mmax) * b);
         for (DevArray<double> *small : {&evals, &ework}) small->reset(ctx, mmax);
         for (DevArray<double> *small : {&dscale, &theta_d, &rn_d, &mn_d, &theta_act_d}) small->reset(ctx, b);
@@ -1910,12 +1913,21 @@ struct BlockLobpcg {
         {
             double *Gs = G.get() + size_t(w) * w;
             int hinfo = 0;
+            // Up to 128 columns: factor, unscale and invert in one launch, then Cp <- Cp L^-T as one small product (round 5; before: potrf,
+            // unscale and the library's trsm, which is a trtri and several GEMM launches of its own -- a dozen launches on the serial path of
+            // every iteration).  MH_TEST=potrf_chain: the old chain.
+            static const bool chain = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "potrf_chain");
+            const bool fused = w <= 128 && !chain;
             {
-                mh_potrf(ctx, Gs, w, w, info); // ours at every order (one workgroup up to 128 columns, 128-column blocks above)
+                if (fused) mh_potrf_small_inverse(ctx, Gs, w, info, dscale, Linv_p);
+                else mh_potrf(ctx, Gs, w, w, info); // ours at every order (one workgroup up to 128 columns, 128-column blocks above)
                 info.download(&hinfo, 1);
             }
             if (hinfo != 0) {
                 wp_new = 0;
+            } else if (fused) {
+                mh_small_gemm(ctx, false, true, m, w, w, 1.0, Cp, m, Linv_p, w, 0.0, T1p2, m);
+                HIP_CHECK(hipMemcpyAsync(Cp, T1p2, size_t(m) * w * sizeof(double), hipMemcpyDeviceToDevice, st));
             } else {
                 k_unscale_chol<<<grid1(size_t(w) * w), TB, 0, st>>>(Gs, w, w, dscale);
                 KERNEL_CHECK();
