@@ -894,10 +894,12 @@ def test_register_resident_tridiagonalisation_of_special_matrices(ctx):
 
 
 @pytest.mark.gpu
-def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
+@pytest.mark.parametrize("variant", [1, 3])
+def test_multi_workgroup_tridiagonalisation_under_uneven_load(api, variant):
     """The tagged-value exchange between the workgroups of k_sytrd_multi must not depend on timing: four host threads (one
     context each) reduce matrices of different orders over and over while a fifth keeps the device busy with operator
-    products; every result must equal, bit for bit, the one the same context produced alone."""
+    products; every result must equal, bit for bit, the one the same context produced alone.  The same for the one-CU
+    register-resident kernel (variant 3, the default since round 5): nothing to exchange, but co-resident work on its CU's neighbours."""
     import threading
     rng = np.random.default_rng(77)
     orders = [64, 131, 200, 240]
@@ -906,7 +908,7 @@ def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
         a = rng.standard_normal((m, m))
         mats.append(a + a.T + 2 * m * np.eye(m))
     ctxs = [api.Context(0) for _ in orders]
-    alone = [lab.tridiagonalize(c, a, variant=1)[:2] for c, a in zip(ctxs, mats)]
+    alone = [lab.tridiagonalize(c, a, variant=variant)[:2] for c, a in zip(ctxs, mats)]
     busy_ctx = api.Context(0)
     p, t, mat, _ = meshes.workload("cube_s10k")
     system = api.System(busy_ctx, api.Mesh(busy_ctx, p, t), api.material(*mat))
@@ -923,7 +925,7 @@ def test_multi_workgroup_tridiagonalisation_under_uneven_load(api):
     def work(i):
         try:
             for rep in range(120):
-                d, e, _ = lab.tridiagonalize(ctxs[i], mats[i], variant=1)
+                d, e, _ = lab.tridiagonalize(ctxs[i], mats[i], variant=variant)
                 if not (np.array_equal(d, alone[i][0]) and np.array_equal(e, alone[i][1])):
                     bad.append((orders[i], rep))
         except Exception as e:  # noqa: BLE001
