@@ -934,10 +934,20 @@ template<typename T> struct Precond {
         x0_partial.reset(ctx, n0 * w * COARSE_SLICES);
         patch_y.reset(ctx, std::max(size_t(s->patches2.n_patches) * 30, size_t(s->patches1.n_patches) * 12) * w);
         const Switches &sw = switches();
-        if (s->patches2.n_patches) { // a mesh with slivers: the P1 space represents its smooth error poorly (measured two-grid bound, exact
-            deg2 = 5;                // coarse solve, 30k-tet skillet scan: condition 34 with two steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax]).
-            ratio = 60.0;            // With the patches scaled by their overlap (mh_patch.hip) five steps over [lmax/60, lmax] are the measured best on the
-        }                            // four scan workloads: 24 / 26 / 40 / 40 iterations (4 over lmax/30: 26 / 33 / 44 / 48)
+        // The longer smoother (five steps over [lmax / 60, lmax]) for
+        //  * a mesh with slivers: the P1 space represents its smooth error poorly (measured two-grid bound, exact coarse solve, 30k-tet skillet
+        //    scan: condition 34 with two steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax]); with the patches scaled by their overlap
+        //    (mh_patch.hip) five steps over [lmax/60, lmax] are the measured best on the four scan workloads: 24 / 26 / 40 / 40 iterations
+        //    (4 over lmax/30: 26 / 33 / 44 / 48);
+        //  * a SURFACE-DOMINATED body (round 5): fewer than 4.5 tetrahedra per mesh point (a bulk fill has 5-6.7; a plate two cells thick 3.9, a
+        //    UV sphere's fill 4.2, the reference's test bars 2.4-3.7).  Measured with MH_CYCLE (profiles/r05_cycle_by_body.txt): the 215-pair Kuhn
+        //    plate 860 -> 674 ms (22 -> 17 iterations), the 48 x 24 UV sphere 64 -> 53 ms (28 -> 21), the thin bar 24 -> 19 ms (15 -> 11); the
+        //    Kuhn cubes lose with it (26^3: 134 -> 158 ms, 17^3: 56 -> 61, 12^3 at 4.72 tetrahedra per point: 34 -> 35) and keep the short one.
+        const bool surface_dominated = s->kept_tets < 4.5 * s->n_points;
+        if (s->patches2.n_patches || surface_dominated) {
+            deg2 = 5;
+            ratio = 60.0;
+        }
         if (sw.deg2 > 0) deg2 = sw.deg2;
         if (sw.deg1 > 0) deg1 = sw.deg1;
         if (sw.gamma > 0) gamma = sw.gamma;
