@@ -820,6 +820,27 @@ def test_cholesky_qr_factor_and_inverse_in_one_launch(ctx, w):
 
 
 @pytest.mark.gpu
+def test_surface_dominated_bodies_get_the_longer_smoother(api, ctx):
+    """Round 5 (profiles/r05_cycle_by_body.txt): a body with fewer than 4.5 tetrahedra per mesh point -- a plate, a bar, the fill of a UV
+    sphere -- is preconditioned with the cycle of the sliver-patch meshes (P2 Chebyshev degree 5 over [lmax / 60, lmax]): the UV-sphere
+    primitive of BASELINE's config 2 took 28 iterations with the cubes' cycle and takes 21, the reference's thin test bar 15 -> 11; a
+    Kuhn cube (4.7 and more tetrahedra per point) keeps the short smoother and its count."""
+    counts = {}
+    for name in ("uvsphere_s10k", "bar_thin", "cube_s10k"):
+        pts, tets, m, kw = meshes.workload(name)
+        mesh = api.Mesh(ctx, pts, tets)
+        s = api.System(ctx, mesh, api.material(*m))
+        ev, prof = s.eigs(min(65, kw.get("num_fem_modes", 65)), SIGMA, 1e-5)
+        counts[name] = (prof["restarts"], len(tets) / len(pts))
+        s.close()
+        mesh.close()
+    assert counts["uvsphere_s10k"][1] < 4.5 and counts["bar_thin"][1] < 4.5 and counts["cube_s10k"][1] > 4.5
+    assert counts["uvsphere_s10k"][0] <= 24, counts
+    assert counts["bar_thin"][0] <= 13, counts
+    assert counts["cube_s10k"][0] <= 17, counts
+
+
+@pytest.mark.gpu
 def test_the_rigid_body_pairs_lock_whatever_the_rounding_of_the_rayleigh_ritz_step():
     """Round 5: on the quality-refined 96 x 48 sphere (one sliver: ||A|| = 2e16) tol |sigma| lies thirty times below the rounding
     floor of forming A x, so the six rigid-body pairs can only be accepted by the floor clause of the convergence test.  With the
