@@ -71,16 +71,17 @@ struct Switches {
     bool verbose = getenv("MH_VERBOSE") != nullptr;
     bool fp32_prec = !(getenv("MH_PRECOND_FP64") && atoi(getenv("MH_PRECOND_FP64")) != 0);
     int deg2 = 0, deg1 = 0, gamma = 0; // 0: the built-in cycle shape
-    double cheb_ratio = 0.0;
+    double cheb_ratio = 0.0, cheb_ratio1 = 0.0; // (ratio1: the P1 level's own interval, optional fifth value of MH_CYCLE)
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
     bool no_poly_start = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_poly_start"); // (A/B hook of round 5: the cold start block as rounds 1-4 had it)
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
-            double v[4] = {0, 0, 0, 0};
-            sscanf(c, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]);
+            double v[5] = {0, 0, 0, 0, 0};
+            sscanf(c, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]);
             deg2 = std::max(0, int(v[0])), deg1 = std::max(0, int(v[1])), gamma = std::max(0, int(v[2]));
             cheb_ratio = v[3];
+            cheb_ratio1 = v[4];
         }
     }
 };
@@ -911,7 +912,7 @@ template<typename T> struct Precond {
     mh_context *ctx;
     uint32_t wmax;
     int deg2{2}, deg1{5}, gamma{3}; // measured at S100k: deg1 3 -> 4 saves one to two iterations for 1 ms of P1-level work; 4 -> 5 (with the graph-grown aggregates) one more for 0.5 ms
-    double ratio{8.0};
+    double ratio{8.0}, ratio1{0.0}; // ratio1 > 0: the P1 level's own interval [lmax / ratio1, lmax]
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
     DevArray<double> r0, x0, x0_partial;
     static constexpr uint32_t COARSE_SLICES = 8;
@@ -952,6 +953,7 @@ template<typename T> struct Precond {
         if (sw.deg1 > 0) deg1 = sw.deg1;
         if (sw.gamma > 0) gamma = sw.gamma;
         if (sw.cheb_ratio > 0) ratio = std::max(1.5, sw.cheb_ratio);
+        if (sw.cheb_ratio1 > 0) ratio1 = std::max(1.5, sw.cheb_ratio1);
     }
     void spmm(const BsrLevel &lvl, const T *x, T *y, uint32_t w) {
         if constexpr (kDouble) mh_spmm(ctx, lvl, lvl.aval, x, y, nullptr, nullptr, w);
@@ -966,7 +968,7 @@ template<typename T> struct Precond {
     void cheb(const BsrLevel &lvl, int deg, const T *b, T *x, bool zero_init, T *r, T *d, T *t, uint32_t w, double *z_out = nullptr, uint32_t w_out = 0,
               const double *b_src = nullptr, uint32_t w_src = 0, T *b_copy = nullptr) { // b_src: (single-precision cycle) convert the right-hand side on the way
         const size_t rows = size_t(3) * lvl.n_nodes;
-        const double lmax = lvl.lmax, lmin = lvl.lmax / ratio;
+        const double lmax = lvl.lmax, lmin = lvl.lmax / (lvl.id == 1 && ratio1 > 0 ? ratio1 : ratio);
         const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig = theta / delta;
         double rho = 1.0 / sig;
         const T *dinv = dinv_of(lvl);
