@@ -948,11 +948,16 @@ template<typename T> struct Precond {
         if (s->patches2.n_patches || surface_dominated) {
             deg2 = 5;
             ratio = 60.0;
+        } else {
+            // the short P2 smoother's interval is [lmax / 8, lmax]; the P1 level's five steps do better over [lmax / 40, lmax] (round 5, fifth value of
+            // MH_CYCLE: Kuhn cubes of 12^3 / 17^3 / 26^3 cells 34.5 -> 33.3 / 56.0 -> 55.0 / 132.7 -> 131.5 ms, the batch of 64 boxes 1.65 -> 1.61 s;
+            // lmax / 4: +5 %, lmax / 100: +1 ... +5 %)
+            ratio1 = 40.0;
         }
         if (sw.deg2 > 0) deg2 = sw.deg2;
         if (sw.deg1 > 0) deg1 = sw.deg1;
         if (sw.gamma > 0) gamma = sw.gamma;
-        if (sw.cheb_ratio > 0) ratio = std::max(1.5, sw.cheb_ratio);
+        if (sw.cheb_ratio > 0) ratio = std::max(1.5, sw.cheb_ratio), ratio1 = 0.0; // (a given ratio holds for both levels unless a fifth value follows)
         if (sw.cheb_ratio1 > 0) ratio1 = std::max(1.5, sw.cheb_ratio1);
     }
     void spmm(const BsrLevel &lvl, const T *x, T *y, uint32_t w) {

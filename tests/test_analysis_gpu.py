@@ -1371,4 +1371,4 @@ def test_the_polynomial_start_block_changes_the_path_not_the_answer(api, ctx):
         else:
             elastic = ref > 1e-6 * ref[-1]
             assert np.abs(ev[elastic] / ref[elastic] - 1).max() < 1e-9
-            assert abs(prof["restarts"] - its) <= 2, (prof["restarts"], its)
+            assert -4 <= prof["restarts"] - its <= 1, (prof["restarts"], its)  # (14 against 17 since the P1 level's own smoothing interval: the polynomial block may only help)
