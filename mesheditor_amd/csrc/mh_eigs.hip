@@ -911,7 +911,7 @@ template<typename T> struct Precond {
     mh_system *sys;
     mh_context *ctx;
     uint32_t wmax;
-    int deg2{2}, deg1{5}, gamma{3}; // measured at S100k: deg1 3 -> 4 saves one to two iterations for 1 ms of P1-level work; 4 -> 5 (with the graph-grown aggregates) one more for 0.5 ms
+    int deg2{2}, deg1{5}, gamma{3}; // (the constructor picks the cycle shape by the kind of mesh)
     double ratio{8.0}, ratio1{0.0}; // ratio1 > 0: the P1 level's own interval [lmax / ratio1, lmax]
     DevArray<T> rin, z2, d2, t2, r2, r1, x1, d1, t1, rr1;
     DevArray<double> r0, x0, x0_partial;
@@ -935,24 +935,31 @@ template<typename T> struct Precond {
         x0_partial.reset(ctx, n0 * w * COARSE_SLICES);
         patch_y.reset(ctx, std::max(size_t(s->patches2.n_patches) * 30, size_t(s->patches1.n_patches) * 12) * w);
         const Switches &sw = switches();
-        // The longer smoother (five steps over [lmax / 60, lmax]) for
-        //  * a mesh with slivers: the P1 space represents its smooth error poorly (measured two-grid bound, exact coarse solve, 30k-tet skillet
-        //    scan: condition 34 with two steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax]); with the patches scaled by their overlap
-        //    (mh_patch.hip) five steps over [lmax/60, lmax] are the measured best on the four scan workloads: 24 / 26 / 40 / 40 iterations
-        //    (4 over lmax/30: 26 / 33 / 44 / 48);
-        //  * a SURFACE-DOMINATED body (round 5): fewer than 4.5 tetrahedra per mesh point (a bulk fill has 5-6.7; a plate two cells thick 3.9, a
-        //    UV sphere's fill 4.2, the reference's test bars 2.4-3.7).  Measured with MH_CYCLE (profiles/r05_cycle_by_body.txt): the 215-pair Kuhn
-        //    plate 860 -> 674 ms (22 -> 17 iterations), the 48 x 24 UV sphere 64 -> 53 ms (28 -> 21), the thin bar 24 -> 19 ms (15 -> 11); the
-        //    Kuhn cubes lose with it (26^3: 134 -> 158 ms, 17^3: 56 -> 61, 12^3 at 4.72 tetrahedra per point: 34 -> 35) and keep the short one.
+        // Three cycle shapes, each the measured best of its class (round 5; MH_CYCLE = deg2, deg1, gamma, ratio[, ratio1] overrides; profiles/r05_cycle_by_body.txt):
+        //  * a mesh with SLIVER PATCHES: P2 Chebyshev degree 5 over [lmax / 60, lmax], three P1 cycles of degree 5 over the same ratio.  The P1 space
+        //    represents the smooth error of such a mesh poorly (measured two-grid bound, exact coarse solve, 30k-tet skillet scan: condition 34 with two
+        //    steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax]); with the patches scaled by their overlap (mh_patch.hip) five steps over
+        //    [lmax/60, lmax] are the measured best on the four scan workloads: 24 / 26 / 40 / 40 iterations (4 over lmax/30: 26 / 33 / 44 / 48).  One long
+        //    P1 sequence instead of three cycles gains ~5 % on the repaired scans and the ball and LOSES 9 % on the unrepaired 95k-tet scan: kept at three.
+        //  * a SURFACE-DOMINATED body without patches -- fewer than 4.5 tetrahedra per mesh point (a bulk fill has 5-6.7; a plate two cells thick 3.9,
+        //    a UV sphere's fill 4.2, the reference's test bars 2.4-3.7): the same long P2 smoother (the 215-pair Kuhn plate 860 -> 674 ms, 22 -> 17
+        //    iterations; the 48 x 24 UV sphere 64 -> 53 ms, 28 -> 21; the thin bar 24 -> 19 ms), and ONE P1 cycle of degree 16 over [lmax / 250, lmax]
+        //    instead of three of degree 5 (plate 674 -> 643 ms, sphere 54 -> 50.5).
+        //  * a BULK body (Kuhn cubes, jittered boxes): the short P2 smoother (degree 2 over [lmax / 8, lmax]: the long one costs 8-18 % there) and one
+        //    P1 cycle of degree 12 over [lmax / 100, lmax] instead of three of degree 5 over [lmax / 8, lmax]: the P1 level's launches are latency-bound
+        //    (~25 us each whatever the size) and one long sequence over a wide interval smooths better than three short ones around the coarse solve --
+        //    26^3 / 17^3 / 12^3 cubes 133.0 -> 122.3 / 54.7 -> 49.8 / 32.8 -> 31.4 ms, the batch of 64 boxes 1.65 -> 1.54 s (with [lmax / 8, lmax] the
+        //    same single cycle LOSES 10 %: the interval is what makes it work).
         const bool surface_dominated = s->kept_tets < 4.5 * s->n_points;
-        if (s->patches2.n_patches || surface_dominated) {
+        if (s->patches2.n_patches) {
             deg2 = 5;
             ratio = 60.0;
+        } else if (surface_dominated) {
+            deg2 = 5;
+            ratio = 60.0;
+            deg1 = 16, gamma = 1, ratio1 = 250.0;
         } else {
-            // the short P2 smoother's interval is [lmax / 8, lmax]; the P1 level's five steps do better over [lmax / 40, lmax] (round 5, fifth value of
-            // MH_CYCLE: Kuhn cubes of 12^3 / 17^3 / 26^3 cells 34.5 -> 33.3 / 56.0 -> 55.0 / 132.7 -> 131.5 ms, the batch of 64 boxes 1.65 -> 1.61 s;
-            // lmax / 4: +5 %, lmax / 100: +1 ... +5 %)
-            ratio1 = 40.0;
+            deg1 = 12, gamma = 1, ratio1 = 100.0;
         }
         if (sw.deg2 > 0) deg2 = sw.deg2;
         if (sw.deg1 > 0) deg1 = sw.deg1;
