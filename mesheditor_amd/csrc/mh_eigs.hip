@@ -954,6 +954,9 @@ template<typename T> struct Precond {
         if (s->patches2.n_patches) {
             deg2 = 5;
             ratio = 60.0;
+            // blocks wider than 128 columns (the 215-pair configuration): the single long P1 cycle wins on patch meshes too -- config3_s30k / _s100k
+            // 464 -> 446 / 1 897 -> 1 817 ms, their repaired fills 388 -> 369 / 1 093 -> 1 039 -- while 65-pair solves of the 100k-tet scans lose 6-8 % with it
+            if (w_in > 128) deg1 = 16, gamma = 1, ratio1 = 250.0;
         } else if (surface_dominated) {
             deg2 = 5;
             ratio = 60.0;
