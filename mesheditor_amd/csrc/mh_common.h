@@ -423,6 +423,7 @@ struct mh_system {
     double plain_residual{-1.0}; // last solve: worst 2-norm relative residual of the returned elastic pairs when they were accepted in the Jacobi-scaled norm, else -1
     mh_material material{};
     uint32_t n_points{0}, kept_tets{0}, n_nodes{0}, n_edges{0};
+    bool lmax_widened{false}; // a solve stalled and was redone with the smoothers' spectral bounds widened by a quarter (mh_eigs.hip, eigs_impl)
     DevArray<double> points; // copy of mesh points (P1 node coordinates), reference numbering
     DevArray<uint32_t> elem_nodes_ref; // kept_tets x 10, reference numbering
     DevArray<uint32_t> elem_nodes; // kept_tets x 10, internal numbering

@@ -820,6 +820,37 @@ def test_cholesky_qr_factor_and_inverse_in_one_launch(ctx, w):
 
 
 @pytest.mark.gpu
+def test_a_spectral_bound_that_falls_short_is_widened_and_the_solve_redone():
+    """The smoothers' Chebyshev intervals end at 1.1 x a power-iteration estimate of lmax(D^-1 A).  MH_TEST=lmax_low puts the bound 12 % lower
+    -- below the spectrum's end, as an estimate that has not converged would: the long P1 sequences (degree 12-16 since round 5) then amplify
+    the top of the spectrum and the iteration stalls.  The solve must notice (ENOTCONVERGED inside), widen both bounds by a quarter, run
+    again and return the same eigenvalues as the normal run; a second solve of the same system starts with the wider bounds."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from mesheditor_amd import api, meshes\n"
+            "ctx = api.Context(0); out = {}\n"
+            "for name in ('cube_s10k', 'uvsphere_s10k'):\n"
+            "    pts, tets, m, kw = meshes.workload(name)\n"
+            "    mesh = api.Mesh(ctx, pts, tets); s = api.System(ctx, mesh, api.material(*m))\n"
+            "    ev, prof = s.eigs(65, residual_tol=1e-5); ev2, prof2 = s.eigs(65, residual_tol=1e-5)\n"
+            "    out[name] = [ev.tolist(), prof['restarts'], ev2.tolist(), prof2['restarts']]\n"
+            "print('RESULT ' + json.dumps(out))\n") % root
+    runs = {}
+    for hook in ("", "lmax_low"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MH_TEST=hook, MH_VERBOSE="1"), timeout=900)
+        assert r.returncode == 0, (hook, r.stderr[-2000:])
+        runs[hook] = (json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]), r.stderr)
+    assert "spectral bounds widened" not in runs[""][1]
+    assert runs["lmax_low"][1].count("spectral bounds widened") == 2  # (once per system: the second solve of each starts wide)
+    for name in ("cube_s10k", "uvsphere_s10k"):
+        ref, its, ref2, its2 = runs[""][0][name]
+        ev, its_low, ev2, its_low2 = runs["lmax_low"][0][name]
+        el = np.array(ref) > 1e-6 * ref[-1]
+        assert np.abs(np.array(ev)[el] / np.array(ref)[el] - 1).max() < 1e-8 and np.abs(np.array(ev2)[el] / np.array(ref)[el] - 1).max() < 1e-8
+        assert its_low <= its + 6 and its_low2 <= its + 6, (name, its, its_low, its_low2)  # (1.1 x 0.88 x 1.25 = 1.21 x the estimate: a slightly wider interval than the normal run's)
+
+
+@pytest.mark.gpu
 def test_surface_dominated_bodies_get_the_longer_smoother(api, ctx):
     """Round 5 (profiles/r05_cycle_by_body.txt): a body with fewer than 4.5 tetrahedra per mesh point -- a plate, a bar, the fill of a UV
     sphere -- is preconditioned with the cycle of the sliver-patch meshes (P2 Chebyshev degree 5 over [lmax / 60, lmax]): the UV-sphere
