@@ -936,11 +936,10 @@ template<typename T> struct Precond {
         patch_y.reset(ctx, std::max(size_t(s->patches2.n_patches) * 30, size_t(s->patches1.n_patches) * 12) * w);
         const Switches &sw = switches();
         // Three cycle shapes, each the measured best of its class (round 5; MH_CYCLE = deg2, deg1, gamma, ratio[, ratio1] overrides; profiles/r05_cycle_by_body.txt):
-        //  * a mesh with SLIVER PATCHES: P2 Chebyshev degree 5 over [lmax / 60, lmax], three P1 cycles of degree 5 over the same ratio.  The P1 space
+        //  * a mesh with SLIVER PATCHES: P2 Chebyshev degree 5 over [lmax / 60, lmax]; P1: see below (three cycles of degree 5 over the same ratio until the end of round 5).  The P1 space
         //    represents the smooth error of such a mesh poorly (measured two-grid bound, exact coarse solve, 30k-tet skillet scan: condition 34 with two
         //    steps over [lmax/8, lmax], 12 with four over [lmax/30, lmax]); with the patches scaled by their overlap (mh_patch.hip) five steps over
-        //    [lmax/60, lmax] are the measured best on the four scan workloads: 24 / 26 / 40 / 40 iterations (4 over lmax/30: 26 / 33 / 44 / 48).  One long
-        //    P1 sequence instead of three cycles gains ~5 % on the repaired scans and the ball and LOSES 9 % on the unrepaired 95k-tet scan: kept at three.
+        //    [lmax/60, lmax] are the measured best on the four scan workloads: 24 / 26 / 40 / 40 iterations (4 over lmax/30: 26 / 33 / 44 / 48).
         //  * a SURFACE-DOMINATED body without patches -- fewer than 4.5 tetrahedra per mesh point (a bulk fill has 5-6.7; a plate two cells thick 3.9,
         //    a UV sphere's fill 4.2, the reference's test bars 2.4-3.7): the same long P2 smoother (the 215-pair Kuhn plate 860 -> 674 ms, 22 -> 17
         //    iterations; the 48 x 24 UV sphere 64 -> 53 ms, 28 -> 21; the thin bar 24 -> 19 ms), and ONE P1 cycle of degree 16 over [lmax / 250, lmax]
@@ -954,9 +953,11 @@ template<typename T> struct Precond {
         if (s->patches2.n_patches) {
             deg2 = 5;
             ratio = 60.0;
-            // blocks wider than 128 columns (the 215-pair configuration): the single long P1 cycle wins on patch meshes too -- config3_s30k / _s100k
-            // 464 -> 446 / 1 897 -> 1 817 ms, their repaired fills 388 -> 369 / 1 093 -> 1 039 -- while 65-pair solves of the 100k-tet scans lose 6-8 % with it
-            if (w_in > 128) deg1 = 16, gamma = 1, ratio1 = 250.0;
+            // one P1 cycle of degree 28 over [lmax / 800, lmax]: the single cycle of degree 16 over lmax / 250 that suits the patch-free bodies lost 6-8 % on
+            // the 65-pair solves of the 100k-tet scans (and won 4-5 % on the 215-pair ones); longer and wider it is level with the three short cycles or
+            // ahead on all nine patch workloads -- scan_s100k_repaired 336 -> 317 ms, config3_s100k_repaired 1 093 -> 1 007, config3_s30k 464 -> 438, the
+            // unrepaired scan_s100k 570 -> 579, ball and 30k-tet scans within 1 %
+            deg1 = 28, gamma = 1, ratio1 = 800.0;
         } else if (surface_dominated) {
             deg2 = 5;
             ratio = 60.0;
