@@ -957,7 +957,10 @@ template<typename T> struct Precond {
             // the 65-pair solves of the 100k-tet scans (and won 4-5 % on the 215-pair ones); longer and wider it is level with the three short cycles or
             // ahead on all nine patch workloads -- scan_s100k_repaired 336 -> 317 ms, config3_s100k_repaired 1 093 -> 1 007, config3_s30k 464 -> 438, the
             // unrepaired scan_s100k 570 -> 579, ball and 30k-tet scans within 1 %
-            deg1 = 28, gamma = 1, ratio1 = 800.0;
+            // -- except the fills DENSE in patches at blocks up to 128 columns (unrepaired scans with and without interior points, 9-28 patches per
+            // thousand tetrahedra: 65-pair solves +2 ... +8 % with it; the repaired fills have 0.3-0.5 per thousand), which keep three cycles of degree 5
+            const bool few_patches = uint64_t(s->patches2.n_patches) * 500 < s->kept_tets;
+            if (w_in > 128 || few_patches) deg1 = 28, gamma = 1, ratio1 = 800.0;
         } else if (surface_dominated) {
             deg2 = 5;
             ratio = 60.0;
