@@ -194,6 +194,7 @@ double mhx_punch_stiffness(double inv_modulus, double area) { return PunchStiffn
 // ---- tet-generation front end (modal/tets.hpp): surface in, tet mesh out; host code only -----------------------------------
 struct mhx_tets {
     tetra::Result Result;
+    std::string Error;
 };
 mhx_tets *mhx_tetrahedralize2(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner, int flags, double max_volume) {
     auto *h = new mhx_tets;
@@ -207,17 +208,25 @@ mhx_tets *mhx_tetrahedralize2(const double *points, uint32_t n_points, const uin
         options.InteriorShell = (flags & 4) ? tetra::Options::Shell::Never : (flags & 8) ? tetra::Options::Shell::Always : tetra::Options::Shell::WhenFlat; // bits 2, 3
         options.Quality = (flags & 16) != 0; // bit 4: the reference's Options::Quality; max_volume: its Options::MaxVolume
         options.MaxVolume = max_volume;
-        h->Result = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
-    } catch (const std::exception &e) { h->Result.Error = e.what(); }
+        auto filled = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
+        if (filled) h->Result = std::move(*filled);
+        else h->Error = filled.error();
+    } catch (const std::exception &e) { h->Error = e.what(); }
     return h;
 }
 mhx_tets *mhx_tetrahedralize(const double *points, uint32_t n_points, const uint32_t *triangles, uint32_t n_triangles, uint64_t max_steiner, int interior_steiner) {
     return mhx_tetrahedralize2(points, n_points, triangles, n_triangles, max_steiner, interior_steiner, 0.0);
 }
-const char *mhx_tets_error(const mhx_tets *h) { return h->Result.Error.c_str(); }
+const char *mhx_tets_error(const mhx_tets *h) { return h->Error.c_str(); }
 uint32_t mhx_tets_num_points(const mhx_tets *h) { return uint32_t(h->Result.Mesh.Points.size()); }
 uint32_t mhx_tets_num_tets(const mhx_tets *h) { return uint32_t(h->Result.Mesh.Tets.size()); }
-uint32_t mhx_tets_boundary_steiner(const mhx_tets *h) { return h->Result.BoundarySteinerCount; }
+uint32_t mhx_tets_boundary_steiner(const mhx_tets *h) { return h->Result.Profile.BdrySteinerCount; }
+// tetra::Profile as 16 doubles: the seven stage times, then the counters in declaration order (TetCount ... Builds), then the interior points by origin
+void mhx_tets_profile(const mhx_tets *h, double *out) {
+    const auto &p = h->Result.Profile;
+    const double v[] = {p.DelaunaySeconds, p.RecoverSeconds, p.CarveSeconds, p.RefineSeconds, p.SegmentSeconds, p.FaceSeconds, p.SuppressSeconds, double(p.TetCount), double(p.SteinerCount), double(p.DelaunayTetCount), double(p.BdrySteinerCount), double(p.VolSteinerCount), double(p.FlipCount), double(p.SplitCount), double(p.MissingEdgeCount), double(p.MissingFaceCount), double(p.Builds), double(p.ShellPointCount), double(p.QualityPointCount), double(p.FlatCellPointCount), double(p.SliverExchangeCount)};
+    for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); ++i) out[i] = v[i];
+}
 void mhx_tets_copy(const mhx_tets *h, double *points, uint32_t *tets) {
     for (size_t i = 0; i < h->Result.Mesh.Points.size(); ++i)
         for (int k = 0; k < 3; ++k) points[3 * i + k] = h->Result.Mesh.Points[i][k];

@@ -40,8 +40,11 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <map>
 #include <queue>
@@ -50,6 +53,16 @@
 
 namespace tetra {
 namespace {
+// One attempt's outcome (internal): the mesh or an error, and the counters that become tetra::Profile.
+struct Attempt {
+    TetMesh Mesh;
+    std::string Error; // empty on success
+    uint32_t BoundarySteinerCount{0}; // added points left ON the surface (input triangles they refine are not boundary faces)
+    uint32_t SliverExchanges{0}; // edge removals and 2-3 flips the sliver repair made
+    uint32_t ShellPoints{0}, QualityPoints{0}, FlatCellPoints{0}; // interior points by origin
+    tetra::Profile Profile; // seconds and recovery counters, filled as the stages run
+    explicit operator bool() const { return Error.empty(); }
+};
 using Tri = std::array<uint32_t, 3>;
 Tri Sorted(uint32_t a, uint32_t b, uint32_t c) {
     Tri t{a, b, c};
@@ -1122,6 +1135,8 @@ static uint32_t BreakCaps(TetMesh &mesh, double flat) {
         return lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0;
     };
     uint32_t added = 0;
+    static const bool dbg = std::getenv("MH_TET_DEBUG") != nullptr;
+    size_t why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int pass = 0; pass < 4; ++pass) {
         std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> faces;
         faces.reserve(T.size() * 2);
@@ -1144,7 +1159,8 @@ static uint32_t BreakCaps(TetMesh &mesh, double flat) {
             bool open[4];
             int n_open = 0;
             for (int i = 0; i < 4; ++i) n_open += (open[i] = across(int32_t(t), tet[size_t(i + 1) & 3], tet[size_t(i + 2) & 3], tet[size_t(i + 3) & 3]) < 0);
-            if (n_open == 0) continue; // (an interior sliver split at an edge only breeds more of them: those are the exchanges' business)
+            ++why[0];
+            if (n_open == 0) { ++why[1]; continue; } // (an interior sliver split at an edge only breeds more of them: those are the exchanges' business)
             // the edges of the cell that lie on none of its boundary faces: for a cap the quad's other diagonal; for a flat cell on one
             // boundary face (a pole fan's triangle and a fourth ring point) the three edges at its fourth vertex
             bool done = false;
@@ -1174,7 +1190,7 @@ static uint32_t BreakCaps(TetMesh &mesh, double flat) {
                         from = to, to = beyond, cell = next;
                         if (cell == int32_t(t)) { closed = true; break; }
                     }
-                    if (!closed || !clean) continue;
+                    if (!closed || !clean) { ++why[closed ? 3 : 2]; continue; }
                     // away from the flat cell: from the middle of {b, d} towards the ring's vertices that are not the cell's
                     const dvec3 mid = (P[b] + P[d]) * 0.5;
                     dvec3 inner{0, 0, 0};
@@ -1241,9 +1257,12 @@ static uint32_t BreakCaps(TetMesh &mesh, double flat) {
                         }
                         ++broken;
                         done = true;
-                    }
+                    } else ++why[4];
                 }
+            if (!done) ++why[5];
         }
+        if (dbg) std::fprintf(stderr, "BreakCaps pass %d: flat %zu interior %zu ring-open %zu ring-unclean %zu no-position %zu unbroken %zu broken %u\n", pass, why[0], why[1], why[2], why[3], why[4], why[5], broken);
+        for (auto &w : why) w = 0;
         if (!broken) break;
         added += broken;
         std::vector<std::array<uint32_t, 4>> kept;
@@ -1306,6 +1325,7 @@ static uint32_t AddInteriorShell(TetMesh &mesh, uint32_t n_surface_vertices) {
                 if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
             } else {
                 auto it = cells_on.find(key);
+                if (it == cells_on.end()) continue;
                 if (it->second[0] == t) it->second[0] = it->second[1];
                 it->second[1] = -1;
                 if (it->second[0] < 0) cells_on.erase(it);
@@ -1379,49 +1399,189 @@ static uint32_t AddInteriorShell(TetMesh &mesh, uint32_t n_surface_vertices) {
     return added;
 }
 
+// Point insertion into a finished fill: the constrained Bowyer-Watson step on exact predicates, shared by the quality arm (RefineQuality)
+// and the flat-cell pass (BreakFlatCells).  The cavity is what the insphere test collects from the containing cell without crossing the
+// boundary or a wall, shrunk until the point sees every face of its hull strictly from the inside, then fanned.  Every point inserted is
+// strictly interior: no boundary face and no wall face is ever touched.
+class FillEditor {
+public:
+    struct FaceHash {
+        size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
+    };
+    FillEditor(TetMesh &mesh, const std::set<Tri> *walls) : P(mesh.Points), T(mesh.Tets), Walls(walls), Dead(mesh.Tets.size(), 0), Mark(mesh.Tets.size(), 0) {
+        CellsOn.reserve(T.size() * 2);
+        for (size_t t = 0; t < T.size(); ++t) Link(int32_t(t), true);
+    }
+    static Tri FaceOf(const std::array<uint32_t, 4> &v, int i) { return Sorted(v[size_t(i + 1) & 3], v[size_t(i + 2) & 3], v[size_t(i + 3) & 3]); }
+    // the cell across face i of cell t, or -1 at the boundary, -2 behind a wall
+    int32_t Across(int32_t t, int i) const {
+        const Tri key = FaceOf(T[size_t(t)], i);
+        if (Walls && Walls->count(key)) return -2;
+        const auto it = CellsOn.find(key);
+        if (it == CellsOn.end()) return -1;
+        return it->second[0] == t ? it->second[1] : it->second[0];
+    }
+    bool IsDead(size_t t) const { return Dead[t] != 0; }
+    // the cell that holds p strictly inside, by a walk from `from` that never crosses the boundary or a wall; -1: the surface cuts p
+    // off, or p lies on a face or an edge (not this point)
+    int32_t Locate(const dvec3 &p, int32_t from) const {
+        int32_t at = from;
+        for (int step = 0; step < 400 && at >= 0; ++step) {
+            const auto cell = T[size_t(at)];
+            int32_t next = -3;
+            bool strictly = true;
+            for (int k = 0; k < 4 && next == -3; ++k) {
+                const int i = (k + step) & 3;
+                dvec3 q[4];
+                for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cell[size_t(j)]];
+                const int side = exact::Orient3D(q[0], q[1], q[2], q[3]);
+                if (side < 0) next = Across(at, i);
+                strictly = strictly && side > 0;
+            }
+            if (next == -3) return strictly ? at : -1;
+            at = next;
+        }
+        return -1;
+    }
+    // The cavity of p around the cell `at` that holds it: insphere from the containing cell, never across a constraint; at most 512 cells
+    // (the long cells of a bare surface's Delaunay fill all hold an interior point in their circumspheres: the full cavity of an early
+    // point is most of the mesh, and a local one serves as well -- the exchanges of the sliver repair afterwards do not need a Delaunay
+    // mesh).  Returns the cells to be replaced; empty when the containing cell itself cannot see p through one of its hull faces.
+    std::vector<int32_t> Cavity(const dvec3 &p, int32_t at) {
+        if (Mark.size() < T.size()) Mark.resize(T.size() + T.size() / 2, 0);
+        ++Stamp;
+        std::vector<int32_t> cavity{at};
+        Mark[size_t(at)] = Stamp;
+        for (size_t head = 0; head < cavity.size() && cavity.size() < 512; ++head)
+            for (int i = 0; i < 4; ++i) {
+                const int32_t o = Across(cavity[head], i);
+                if (o < 0 || Mark[size_t(o)] == Stamp) continue;
+                const auto &ov = T[size_t(o)];
+                if (exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0) Mark[size_t(o)] = Stamp, cavity.push_back(o);
+            }
+        // star-shaped hull: every hull face must see p strictly from the inside; a cell whose face does not leaves the cavity
+        bool ok = true;
+        for (bool changed = true; changed && ok;) {
+            changed = false;
+            for (const int32_t c : cavity) {
+                if (!Inside(c)) continue;
+                const auto &cv = T[size_t(c)];
+                for (int i = 0; i < 4; ++i) {
+                    if (Inside(Across(c, i))) continue; // interior face of the cavity
+                    dvec3 q[4];
+                    for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cv[size_t(j)]];
+                    if (exact::Orient3D(q[0], q[1], q[2], q[3]) > 0) continue;
+                    if (c == at) ok = false;
+                    else Mark[size_t(c)] = 0, changed = true;
+                    break;
+                }
+                if (!ok) break;
+            }
+            // the cavity must stay connected to the containing cell
+            if (ok && changed) {
+                ++Stamp;
+                std::vector<int32_t> reach{at};
+                const uint32_t old = Stamp - 1;
+                Mark[size_t(at)] = Stamp;
+                for (size_t head = 0; head < reach.size(); ++head)
+                    for (int i = 0; i < 4; ++i) {
+                        const int32_t o = Across(reach[head], i);
+                        if (o >= 0 && Mark[size_t(o)] == old) Mark[size_t(o)] = Stamp, reach.push_back(o);
+                    }
+                cavity.swap(reach);
+            }
+        }
+        std::vector<int32_t> in;
+        if (!ok) return in;
+        for (const int32_t c : cavity)
+            if (Inside(c)) in.push_back(c);
+        return in;
+    }
+    // the cells that fanning the cavity (as returned by Cavity, still marked) from a new point would make; the point's id is P.size()
+    std::vector<std::array<uint32_t, 4>> Fan(const std::vector<int32_t> &in) const {
+        const uint32_t id = uint32_t(P.size());
+        std::vector<std::array<uint32_t, 4>> fresh;
+        for (const int32_t c : in) {
+            const auto &cv = T[size_t(c)];
+            for (int i = 0; i < 4; ++i) {
+                if (Inside(Across(c, i))) continue;
+                std::array<uint32_t, 4> piece = cv;
+                piece[size_t(i)] = id; // (p on the side of the vertex it replaces: the orientation stays positive)
+                fresh.push_back(piece);
+            }
+        }
+        return fresh;
+    }
+    // replaces the cavity by the fan; returns the index of the first new cell
+    size_t Commit(const dvec3 &p, const std::vector<int32_t> &in, const std::vector<std::array<uint32_t, 4>> &fresh) {
+        P.push_back(p);
+        for (const int32_t c : in) Link(c, false), Dead[size_t(c)] = 1;
+        const size_t first = T.size();
+        for (const auto &piece : fresh) {
+            T.push_back(piece);
+            Dead.push_back(0);
+            Link(int32_t(T.size() - 1), true);
+        }
+        return first;
+    }
+    void Compact() {
+        std::vector<std::array<uint32_t, 4>> kept;
+        kept.reserve(T.size());
+        for (size_t t = 0; t < T.size(); ++t)
+            if (!Dead[t]) kept.push_back(T[t]);
+        T.swap(kept);
+    }
+    std::vector<dvec3> &P;
+    std::vector<std::array<uint32_t, 4>> &T;
+
+private:
+    bool Inside(int32_t c) const { return c >= 0 && Mark[size_t(c)] == Stamp; }
+    void Link(int32_t t, bool add) {
+        for (int i = 0; i < 4; ++i) {
+            const Tri key = FaceOf(T[size_t(t)], i);
+            if (add) {
+                auto [it, fresh] = CellsOn.try_emplace(key, std::array<int32_t, 2>{t, -1});
+                if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
+            } else {
+                auto it = CellsOn.find(key);
+                if (it == CellsOn.end()) continue;
+                if (it->second[0] == t) it->second[0] = it->second[1];
+                it->second[1] = -1;
+                if (it->second[0] < 0) CellsOn.erase(it);
+            }
+        }
+    }
+    const std::set<Tri> *Walls;
+    std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> CellsOn;
+    std::vector<uint8_t> Dead;
+    std::vector<uint32_t> Mark; // cavity membership by stamp
+    uint32_t Stamp{0};
+};
+
+static double ShapeOf(const std::vector<dvec3> &P, const std::array<uint32_t, 4> &t, const dvec3 *fresh = nullptr) {
+    const auto at = [&](uint32_t v) -> const dvec3 & { return v < P.size() ? P[v] : *fresh; };
+    const dvec3 u = at(t[1]) - at(t[0]), v = at(t[2]) - at(t[0]), w = at(t[3]) - at(t[0]);
+    const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+    double l2 = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j) {
+            const dvec3 e = at(t[size_t(i)]) - at(t[size_t(j)]);
+            l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+        }
+    const double lrms = std::sqrt(l2 / 6);
+    return lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0;
+}
+
 // The quality arm (the reference's Options::Quality / MaxVolume, src/mesh/Tetrahedralize.h:17-27): interior points are inserted until
 // every tetrahedron has a circumradius-to-shortest-edge ratio of at most `ratio_bound` (2) and a volume of at most `max_volume` (0: no
 // bound) -- "where the fixed surface allows": the point of a bad tetrahedron is its circumcentre, reached by a walk from the tetrahedron
 // that may not cross the boundary or a wall; a circumcentre the surface cuts off is not inserted (the tetrahedron stays; one that is only
-// too LARGE gets its centroid instead).  Insertion is the constrained Bowyer-Watson step on exact predicates: the cavity is what the
-// insphere test collects from the containing cell without crossing a constraint, shrunk until the point sees every face of its hull
-// from the inside, then fanned.  Every added point is strictly interior: no boundary face and no wall face is ever touched.
-// Returns the number of points added; `budget` bounds it.
+// too LARGE gets its centroid instead).  Insertion: FillEditor.  Returns the number of points added; `budget` bounds it.
 static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, double max_volume, const std::set<Tri> *walls, size_t budget) {
+    FillEditor ed(mesh, walls);
     auto &P = mesh.Points;
     auto &T = mesh.Tets;
-    struct FaceHash {
-        size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
-    };
-    std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> cells_on;
-    cells_on.reserve(T.size() * 2);
-    const auto face_of = [&](const std::array<uint32_t, 4> &v, int i) { return Sorted(v[size_t(i + 1) & 3], v[size_t(i + 2) & 3], v[size_t(i + 3) & 3]); };
-    const auto link = [&](int32_t t, bool add) {
-        for (int i = 0; i < 4; ++i) {
-            const Tri key = face_of(T[size_t(t)], i);
-            if (add) {
-                auto [it, fresh] = cells_on.try_emplace(key, std::array<int32_t, 2>{t, -1});
-                if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
-            } else {
-                auto it = cells_on.find(key);
-                if (it->second[0] == t) it->second[0] = it->second[1];
-                it->second[1] = -1;
-                if (it->second[0] < 0) cells_on.erase(it);
-            }
-        }
-    };
-    for (size_t t = 0; t < T.size(); ++t) link(int32_t(t), true);
-    std::vector<uint8_t> dead(T.size(), 0), hopeless(T.size(), 0);
-    std::vector<uint32_t> mark(T.size(), 0); // cavity membership by stamp
-    uint32_t stamp = 0;
-    // the cell across face i of cell t, or -1 at the boundary, -2 behind a wall
-    const auto across = [&](int32_t t, int i) -> int32_t {
-        const Tri key = face_of(T[size_t(t)], i);
-        if (walls && walls->count(key)) return -2;
-        const auto it = cells_on.find(key);
-        if (it == cells_on.end()) return -1;
-        return it->second[0] == t ? it->second[1] : it->second[0];
-    };
+    std::vector<uint8_t> hopeless(T.size(), 0);
     struct Measure { double ratio, volume; dvec3 centre; bool ok; };
     const auto measure = [&](const std::array<uint32_t, 4> &v) {
         const dvec3 &a = P[v[0]];
@@ -1449,7 +1609,7 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
     for (int pass = 0; pass < 64 && added < budget; ++pass) {
         std::vector<std::pair<double, int32_t>> work; // worst first: the volume excess counts like a ratio
         for (size_t t = 0; t < T.size(); ++t) {
-            if (dead[t] || hopeless[t]) continue;
+            if (ed.IsDead(t) || hopeless[t]) continue;
             const Measure m = measure(T[t]);
             if (!m.ok || !is_bad(m)) continue;
             work.emplace_back(std::max(m.ratio / ratio_bound, max_volume > 0 ? std::cbrt(m.volume / max_volume) : 0.0), int32_t(t));
@@ -1459,7 +1619,7 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
         uint32_t added_this_pass = 0;
         for (const auto &[badness, t0] : work) {
             if (added >= budget) break;
-            if (dead[size_t(t0)]) continue;
+            if (ed.IsDead(size_t(t0))) continue;
             const Measure m = measure(T[size_t(t0)]);
             if (!m.ok || !is_bad(m)) continue;
             const bool too_large = max_volume > 0 && m.volume > max_volume;
@@ -1472,76 +1632,10 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
                     const auto &v = T[size_t(t0)];
                     p = (P[v[0]] + P[v[1]] + P[v[2]] + P[v[3]]) * 0.25;
                 }
-                // walk to the cell that holds p, never through the boundary or a wall
-                int32_t at = t0;
-                bool found = false;
-                for (int step = 0; step < 400 && at >= 0; ++step) {
-                    const auto cell = T[size_t(at)];
-                    int32_t next = -3;
-                    bool strictly = true;
-                    for (int k = 0; k < 4 && next == -3; ++k) {
-                        const int i = (k + step) & 3;
-                        dvec3 q[4];
-                        for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cell[size_t(j)]];
-                        const int side = exact::Orient3D(q[0], q[1], q[2], q[3]);
-                        if (side < 0) next = across(at, i);
-                        strictly = strictly && side > 0;
-                    }
-                    if (next == -3) { found = strictly; break; } // inside; on a face or an edge (not strictly): not this point
-                    at = next; // -1 / -2: the surface cuts p off
-                }
-                if (!found || at < 0) continue;
-                // cavity: insphere from the containing cell, never across a constraint; at most 512 cells (the long cells of a bare surface's
-                // Delaunay fill all hold an interior point in their circumspheres: the full cavity of an early point is most of the mesh,
-                // and a local one serves as well -- the exchanges of the sliver repair afterwards do not need a Delaunay mesh)
-                if (mark.size() < T.size()) mark.resize(T.size() + T.size() / 2, 0);
-                ++stamp;
-                std::vector<int32_t> cavity{at};
-                mark[size_t(at)] = stamp;
-                for (size_t head = 0; head < cavity.size() && cavity.size() < 512; ++head)
-                    for (int i = 0; i < 4; ++i) {
-                        const int32_t o = across(cavity[head], i);
-                        if (o < 0 || mark[size_t(o)] == stamp) continue;
-                        const auto &ov = T[size_t(o)];
-                        if (exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0) mark[size_t(o)] = stamp, cavity.push_back(o);
-                    }
-                const auto inside = [&](int32_t c) { return c >= 0 && mark[size_t(c)] == stamp; };
-                // star-shaped hull: every hull face must see p strictly from the inside; a cell whose face does not leaves the cavity
-                bool ok = true;
-                for (bool changed = true; changed && ok;) {
-                    changed = false;
-                    for (const int32_t c : cavity) {
-                        if (!inside(c)) continue;
-                        const auto &cv = T[size_t(c)];
-                        for (int i = 0; i < 4; ++i) {
-                            if (inside(across(c, i))) continue; // interior face of the cavity
-                            dvec3 q[4];
-                            for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cv[size_t(j)]];
-                            if (exact::Orient3D(q[0], q[1], q[2], q[3]) > 0) continue;
-                            if (c == at) ok = false;
-                            else mark[size_t(c)] = 0, changed = true;
-                            break;
-                        }
-                        if (!ok) break;
-                    }
-                    // the cavity must stay connected to the containing cell
-                    if (ok && changed) {
-                        ++stamp;
-                        std::vector<int32_t> reach{at};
-                        const uint32_t old = stamp - 1;
-                        mark[size_t(at)] = stamp;
-                        for (size_t head = 0; head < reach.size(); ++head)
-                            for (int i = 0; i < 4; ++i) {
-                                const int32_t o = across(reach[head], i);
-                                if (o >= 0 && mark[size_t(o)] == old) mark[size_t(o)] = stamp, reach.push_back(o);
-                            }
-                        cavity.swap(reach);
-                    }
-                }
-                if (!ok) continue;
-                std::vector<int32_t> in;
-                for (const int32_t c : cavity)
-                    if (inside(c)) in.push_back(c);
+                const int32_t at = ed.Locate(p, t0);
+                if (at < 0) continue; // the surface cuts p off
+                const std::vector<int32_t> in = ed.Cavity(p, at);
+                if (in.empty()) continue;
                 // not on top of a vertex of the cavity (a point that close makes an edge shorter than the ones that called for it)
                 {
                     double nearest = 1e300, shortest = 1e300;
@@ -1558,26 +1652,9 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
                         }
                     if (attempt == 0 && nearest < shortest) continue; // no new edge shorter than the shortest edge of the tetrahedron that called for the point: the smallest edge length of the mesh never falls, so the refinement ends (the centroid of a tetrahedron that is too LARGE goes in regardless)
                 }
-                // fan the hull from p
-                const uint32_t id = uint32_t(P.size());
-                std::vector<std::array<uint32_t, 4>> fresh;
-                for (const int32_t c : in) {
-                    const auto &cv = T[size_t(c)];
-                    for (int i = 0; i < 4; ++i) {
-                        if (inside(across(c, i))) continue;
-                        std::array<uint32_t, 4> piece = cv;
-                        piece[size_t(i)] = id; // (p on the side of the vertex it replaces: the orientation stays positive)
-                        fresh.push_back(piece);
-                    }
-                }
-                P.push_back(p);
-                for (const int32_t c : in) link(c, false), dead[size_t(c)] = 1;
-                for (const auto &piece : fresh) {
-                    T.push_back(piece);
-                    dead.push_back(0);
-                    hopeless.push_back(0);
-                    link(int32_t(T.size() - 1), true);
-                }
+                const auto fresh = ed.Fan(in);
+                ed.Commit(p, in, fresh);
+                hopeless.resize(T.size(), 0);
                 ++added, ++added_this_pass;
                 inserted = true;
             }
@@ -1585,13 +1662,117 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
         }
         if (!added_this_pass) break;
     }
-    if (added) {
-        std::vector<std::array<uint32_t, 4>> kept;
-        kept.reserve(T.size());
+    if (added) ed.Compact();
+    return added;
+}
+
+// Flat cells that the exchanges, the caps' apexes and the shell have left (the reference repairs slivers and optimises vertices "either
+// way", src/mesh/Tetrahedralize.h:19-20; a cell flat to 1e-9 inflates ||K|| by as much and no iterative eigensolver converges on it): the
+// quality arm run LOCALLY.  Every cell with a shape measure below `floor` gets a point beside it -- under its boundary face(s) when it has
+// any (a cap on a surface quad, a pole fan's triangle with a ring point), otherwise off its own plane on either side -- at a distance of
+// the order of its edges, inserted by the constrained Bowyer-Watson step (FillEditor): the flat cell's circumsphere is huge, so it and its
+// flat neighbours fall into the cavity together and are replaced by cells of the new point's height.  A position is taken only when the
+// flat cell goes and the WORST cell of the fan is better than the worst cell it replaces; the best of the candidate positions wins.
+// Points are strictly interior; the boundary and the walls are untouched.  Returns the number of points added.
+static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> *walls, size_t budget) {
+    FillEditor ed(mesh, walls);
+    auto &P = mesh.Points;
+    auto &T = mesh.Tets;
+    const auto cross = [](const dvec3 &p, const dvec3 &q) { return dvec3{p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x}; };
+    const auto dot = [](const dvec3 &p, const dvec3 &q) { return p.x * q.x + p.y * q.y + p.z * q.z; };
+    uint32_t added = 0;
+    for (int pass = 0; pass < 6 && added < budget; ++pass) {
+        std::vector<std::pair<double, int32_t>> work; // flattest first
         for (size_t t = 0; t < T.size(); ++t)
-            if (!dead[t]) kept.push_back(T[t]);
-        T.swap(kept);
+            if (!ed.IsDead(t)) {
+                const double q = ShapeOf(P, T[t]);
+                if (q < floor) work.emplace_back(q, int32_t(t));
+            }
+        if (work.empty()) break;
+        std::sort(work.begin(), work.end());
+        uint32_t added_this_pass = 0;
+        for (const auto &[q0, t0] : work) {
+            if (added >= budget) break;
+            if (ed.IsDead(size_t(t0))) continue;
+            const auto cell = T[size_t(t0)];
+            // candidate positions
+            std::vector<dvec3> candidates;
+            double l2 = 0;
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j) {
+                    const dvec3 e = P[cell[size_t(i)]] - P[cell[size_t(j)]];
+                    l2 += dot(e, e);
+                }
+            const double lrms = std::sqrt(l2 / 6);
+            const dvec3 centroid = (P[cell[0]] + P[cell[1]] + P[cell[2]] + P[cell[3]]) * 0.25;
+            // the cell's own plane: the normal of its largest face
+            dvec3 normal{0, 0, 0};
+            double largest = -1;
+            bool open[4];
+            int n_open = 0;
+            for (int i = 0; i < 4; ++i) {
+                const dvec3 &a = P[cell[size_t(i + 1) & 3]], &b = P[cell[size_t(i + 2) & 3]], &c = P[cell[size_t(i + 3) & 3]];
+                const dvec3 n = cross(b - a, c - a);
+                const double area2 = dot(n, n);
+                if (area2 > largest) largest = area2, normal = n;
+                n_open += (open[i] = ed.Across(t0, i) == -1);
+            }
+            if (!(largest > 0)) continue;
+            normal = normal * (1.0 / std::sqrt(largest));
+            if (n_open > 0) {
+                // inwards = the mean of the boundary faces' normals on the cell's side.  The cell is flat, so which side its fourth vertex is
+                // on is asked of the exact predicate, not of a rounded dot product.
+                dvec3 inward{0, 0, 0};
+                for (int i = 0; i < 4; ++i) {
+                    if (!open[i]) continue;
+                    const dvec3 &a = P[cell[size_t(i + 1) & 3]], &b = P[cell[size_t(i + 2) & 3]], &c = P[cell[size_t(i + 3) & 3]];
+                    dvec3 n = cross(b - a, c - a);
+                    const double nl = std::sqrt(dot(n, n));
+                    if (!(nl > 0)) continue;
+                    n = n * (1.0 / nl);
+                    const dvec3 probe = (a + b + c) * (1.0 / 3) + n * lrms;
+                    if (exact::Orient3D(a, b, c, probe) != exact::Orient3D(a, b, c, P[cell[size_t(i)]])) n = n * -1.0;
+                    inward = inward + n;
+                }
+                const double il = std::sqrt(dot(inward, inward));
+                if (il > 0) {
+                    inward = inward * (1.0 / il);
+                    for (const double depth : {0.45, 0.3, 0.65, 0.2, 0.9, 0.12}) candidates.push_back(centroid + inward * (depth * lrms));
+                }
+            }
+            for (const double depth : {0.45, 0.3, 0.65, 0.2, 0.9}) {
+                candidates.push_back(centroid + normal * (depth * lrms));
+                candidates.push_back(centroid - normal * (depth * lrms));
+            }
+            // the worst cell around: what the insertion must beat
+            double best_gain = 0;
+            dvec3 best_p{0, 0, 0};
+            std::vector<int32_t> best_in;
+            std::vector<std::array<uint32_t, 4>> best_fresh;
+            for (const dvec3 &p : candidates) {
+                const int32_t at = ed.Locate(p, t0);
+                if (at < 0) continue;
+                const std::vector<int32_t> in = ed.Cavity(p, at);
+                if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) continue;
+                double worst_old = 1e300, worst_new = 1e300;
+                for (const int32_t c : in) worst_old = std::min(worst_old, ShapeOf(P, T[size_t(c)]));
+                const auto fresh = ed.Fan(in);
+                for (const auto &piece : fresh) worst_new = std::min(worst_new, ShapeOf(P, piece, &p));
+                if (!(worst_new > worst_old)) continue;
+                const double gain = worst_new;
+                if (gain > best_gain) best_gain = gain, best_p = p, best_in = in, best_fresh = fresh;
+                if (worst_new >= 0.05) break; // (good enough: the repair and the smoothing follow)
+            }
+            if (best_gain > 0) {
+                // (Cavity's marks belong to the LAST candidate: commit needs only the lists)
+                ed.Commit(best_p, best_in, best_fresh);
+                ++added, ++added_this_pass;
+            }
+        }
+        if (std::getenv("MH_TET_DEBUG")) std::fprintf(stderr, "BreakFlatCells pass %d: %zu below %.0e (flattest %.1e), %u points\n", pass, work.size(), floor, work.front().first, added_this_pass);
+        if (!added_this_pass) break;
     }
+    if (added) ed.Compact();
     return added;
 }
 
@@ -1690,8 +1871,11 @@ static uint32_t SmoothAddedPoints(TetMesh &mesh, uint32_t n_input, const std::se
 
 // One attempt.  `constrained`: no point is added; what the Delaunay tetrahedralisation of the vertices lacks is forced in by
 // re-tiling the cells it cuts through (DelaunayMesh::ConstrainEdge / ConstrainFace).
-static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options, bool constrained) {
-    Result out;
+static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options, bool constrained) {
+    Attempt out;
+    using Clock = std::chrono::steady_clock;
+    const auto seconds_since = [](Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
+    auto stage_start = Clock::now();
     const uint32_t n_input = uint32_t(points.size());
     if (triangle_indices.size() < 12 || triangle_indices.size() % 3) return out.Error = "a closed surface needs at least four triangles (three indices each)", out;
     std::vector<Tri> surface; // current surface triangles (refined as recovery proceeds), winding as given
@@ -1747,6 +1931,14 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
         for (const uint32_t i : order)
             if (!dt.Insert(i)) return out.Error = "Delaunay insertion failed: " + dt.Error, out;
     }
+    for (const auto &cell : dt.Cells) {
+        if (!cell.Alive) continue;
+        bool hull = true;
+        for (const uint32_t v : cell.V) hull = hull && !(v >= shell0 && v < first_steiner);
+        out.Profile.DelaunayTetCount += hull;
+    }
+    out.Profile.DelaunaySeconds = seconds_since(stage_start);
+    stage_start = Clock::now();
 
     // 2. boundary recovery by refinement, one split at a time: a split can knock neighbouring constraints out of the mesh (and
     //    make queued ones present again), so everything near the new point is re-examined before anything else is cut
@@ -1826,8 +2018,12 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
         const Tri tri = surface[t];
         int cut = -1;
         bool flipped = false;
+        const auto item_start = Clock::now();
+        bool face_work = false;
+        const auto account = [&] { (face_work ? out.Profile.FaceSeconds : out.Profile.SegmentSeconds) += seconds_since(item_start); };
         for (int e = 0; e < 3 && cut < 0 && !flipped; ++e)
             if (!dt.HasEdge(tri[e], tri[(e + 1) % 3])) {
+                ++out.Profile.MissingEdgeCount;
                 // first without a point: on degenerate input another Delaunay tetrahedralisation may hold the edge
                 // (between input vertices only: the recovery's own points sit exactly in the planes of the triangles they split, where
                 // a coplanar crossing is the rule and the search behind it costs more than the bisection it would save)
@@ -1837,23 +2033,31 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
                 else cut = e; // (constrained: a point on the edge, inserted by splitting the cells that hold it)
             }
         if (flipped) { // look at the triangle again, and at everything around the exchanged cells
+            ++out.Profile.FlipCount;
             requeue_near(dt.Touched);
             if (!queued[t]) queued[t] = 1, pending.push_back(t);
+            account();
             continue;
         }
         if (cut < 0 && constrained && !dt.HasFace(tri[0], tri[1], tri[2])) {
+            face_work = true;
+            ++out.Profile.MissingFaceCount;
             if (dt.ConstrainFace(tri[0], tri[1], tri[2], is_surface_edge, is_surface_face)) {
+                ++out.Profile.FlipCount;
                 requeue_near(dt.Touched);
                 if (!queued[t]) queued[t] = 1, pending.push_back(t);
+                account();
                 continue;
             }
         }
         if (cut < 0 && !dt.HasFace(tri[0], tri[1], tri[2])) { // edges present, face absent: cut the longest edge
+            if (!face_work) ++out.Profile.MissingFaceCount;
+            face_work = true;
             cut = 0;
             for (int e = 1; e < 3; ++e)
                 if (length2(tri[e], tri[(e + 1) % 3]) > length2(tri[cut], tri[(cut + 1) % 3])) cut = e;
         }
-        if (cut < 0) continue;
+        if (cut < 0) { account(); continue; }
         if (dt.Points.size() - first_steiner >= steiner_cap)
             return out.Error = "boundary recovery did not converge (surface self-intersects or has very sharp wedges)", out;
         // Longest-edge propagation (Rivara): bisecting an arbitrary edge of a triangle makes thinner and thinner pieces, whose
@@ -1882,7 +2086,11 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
         const bool same = EdgeKey(cu, cv) == EdgeKey(tri[cut], tri[(cut + 1) % 3]);
         if (!split(cu, cv)) return out.Error = "Delaunay insertion of a boundary point failed: " + dt.Error, out;
         if (!same && alive[t] && !queued[t]) queued[t] = 1, pending.push_back(t);
+        account();
     }
+    out.Profile.SplitCount = uint32_t(split_edge.size());
+    out.Profile.RecoverSeconds = seconds_since(stage_start);
+    stage_start = Clock::now();
     {
         std::vector<Tri> live;
         for (uint32_t t = 0; t < surface.size(); ++t)
@@ -1949,9 +2157,15 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
         out.Mesh.Tets.push_back({final_id(cell.V[0]), final_id(cell.V[1]), final_id(cell.V[2]), final_id(cell.V[3])});
     }
     if (out.Mesh.Tets.empty()) return out.Error = "surface encloses no volume", out;
+    out.Profile.CarveSeconds = seconds_since(stage_start);
+    stage_start = Clock::now();
+    const auto refine_start = stage_start; // everything from here on is the last stage
     if (options.InteriorSteiner && out.BoundarySteinerCount) {
         for (auto &e : split_edge) e = {final_id(e[0]), final_id(e[1])};
+        const uint32_t on_surface = out.BoundarySteinerCount;
         out.BoundarySteinerCount = LiftBoundaryPoints(out.Mesh, n_input, split_edge);
+        out.Profile.VolSteinerCount = on_surface - out.BoundarySteinerCount;
+        out.Profile.SuppressSeconds = seconds_since(stage_start);
     }
     if (options.RepairSlivers) {
         std::set<Tri> walls; // non-manifold input: the surface pieces that ended up between two tetrahedra
@@ -1975,7 +2189,7 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
                     if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
                 }
                 out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
-                if (options.MaxVolume > 0) out.QualityPoints += RefineQuality(out.Mesh, false, 2.0, options.MaxVolume, keep, budget); // (an exchange may have merged cells past the bound)
+                if (options.MaxVolume > 0 && out.QualityPoints < budget) out.QualityPoints += RefineQuality(out.Mesh, false, 2.0, options.MaxVolume, keep, budget - out.QualityPoints); // (an exchange may have merged cells past the bound; what is left of the budget)
             }
         }
         // Flat cells at the surface.  A few of them (planar surface quads joined into one cell: a coarse UV sphere) each get an apex
@@ -2034,8 +2248,8 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
                 SmoothAddedPoints(out.Mesh, n_input, keep);
                 out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
             }
-            const bool shell = !quality_arm && (options.InteriorShell == Options::Shell::Always ||
-                               (options.InteriorShell == Options::Shell::WhenFlat && (flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size() || poorly_shaped(out.Mesh)))); // > 0.5 % of the cells
+            const bool shell = options.InteriorShell == Options::Shell::Always || // (asked for explicitly: also beside the quality arm)
+                               (!quality_arm && options.InteriorShell == Options::Shell::WhenFlat && (flat_at_surface(out.Mesh) * 200 > out.Mesh.Tets.size() || poorly_shaped(out.Mesh))); // > 0.5 % of the cells
             if (shell) {
                 out.Mesh = before;
                 out.SliverExchanges = exchanges_before;
@@ -2059,23 +2273,67 @@ static Result TetrahedralizeOnce(std::span<const dvec3> points, std::span<const 
             }
             out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
         }
+        // Whatever is still flat after all that (needle quads at a fine UV sphere's poles, cells between three points of one ring): the
+        // quality arm run locally, then the repair and the smoothing again -- until no cell is below the floor or a round adds nothing.
+        // The reference's repair and vertex optimisation run whatever its options (Tetrahedralize.h:19-20); so does this.
+        const auto worst_shape = [&](const TetMesh &m) {
+            double worst = 1e300;
+            for (const auto &t : m.Tets) worst = std::min(worst, ShapeOf(m.Points, t));
+            return worst;
+        };
+        constexpr double kShapeFloor = 1e-2; // cells below it are worked on; what the pass guarantees where it succeeds is 1e-3 (tests)
+        for (int round = 0; round < 4 && worst_shape(out.Mesh) < kShapeFloor; ++round) {
+            const uint32_t points = BreakFlatCells(out.Mesh, kShapeFloor, keep, std::max<size_t>(4096, out.Mesh.Points.size() / 4));
+            if (!points) break;
+            out.FlatCellPoints += points;
+            for (int sweep = 0; sweep < 2; ++sweep) {
+                out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+                if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
+            }
+            out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+        }
     }
+    out.Profile.RefineSeconds = seconds_since(refine_start);
     return out;
 }
 
 // Conforming Delaunay first (well-shaped cells, what every surface of round 3 goes through); a surface whose refinement runs away
 // -- coarse triangles on a thin wall, needle fans: quadric-decimated scans -- is filled by the constrained recovery instead.
-Result Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options) {
-    Result conforming = TetrahedralizeOnce(points, triangle_indices, options, false);
+static Attempt TetrahedralizeAttempts(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, const Options &options) {
+    Attempt conforming = TetrahedralizeOnce(points, triangle_indices, options, false);
+    conforming.Profile.Builds = 1;
     if (options.MaxSteinerPoints) return conforming; // (an explicit budget asks for the refinement alone)
     if (conforming && (conforming.BoundarySteinerCount == 0 || !options.InteriorSteiner)) return conforming;
     if (!conforming && conforming.Error.find("did not converge") == std::string::npos) return conforming;
     // the refinement ran away, or left points on the surface that could not be moved inside: the constrained recovery adds a point
     // only where no tiling exists without one
-    Result constrained = TetrahedralizeOnce(points, triangle_indices, options, true);
-    if (constrained && (!conforming || constrained.BoundarySteinerCount < conforming.BoundarySteinerCount)) return constrained;
-    if (conforming) return conforming;
+    Attempt constrained = TetrahedralizeOnce(points, triangle_indices, options, true);
+    const auto both = [](Attempt &kept, const Attempt &other) { // the seconds of both attempts were spent
+        auto &p = kept.Profile;
+        const auto &o = other.Profile;
+        p.DelaunaySeconds += o.DelaunaySeconds, p.RecoverSeconds += o.RecoverSeconds, p.CarveSeconds += o.CarveSeconds, p.RefineSeconds += o.RefineSeconds;
+        p.SegmentSeconds += o.SegmentSeconds, p.FaceSeconds += o.FaceSeconds, p.SuppressSeconds += o.SuppressSeconds;
+        p.Builds = 2;
+    };
+    if (constrained && (!conforming || constrained.BoundarySteinerCount < conforming.BoundarySteinerCount)) return both(constrained, conforming), constrained;
+    if (conforming) return both(conforming, constrained), conforming;
     conforming.Error += "; " + constrained.Error;
     return conforming;
+}
+
+// Conforming Delaunay first (well-shaped cells, what every surface of round 3 goes through); a surface whose refinement runs away
+// -- coarse triangles on a thin wall, needle fans: quadric-decimated scans -- is filled by the constrained recovery instead.
+Expected<Result> Tetrahedralize(std::span<const dvec3> points, std::span<const uint32_t> triangle_indices, Options options) {
+    Attempt done = TetrahedralizeAttempts(points, triangle_indices, options);
+    if (!done) return modal_compat::unexpected<std::string>(std::move(done.Error));
+    Result out{std::move(done.Mesh), done.Profile};
+    auto &p = out.Profile;
+    p.TetCount = uint32_t(out.Mesh.Tets.size());
+    p.SteinerCount = uint32_t(out.Mesh.Points.size() - points.size());
+    p.BdrySteinerCount = done.BoundarySteinerCount;
+    p.FlipCount += done.SliverExchanges;
+    p.SliverExchangeCount = done.SliverExchanges;
+    p.ShellPointCount = done.ShellPoints, p.QualityPointCount = done.QualityPoints, p.FlatCellPointCount = done.FlatCellPoints;
+    return out;
 }
 } // namespace tetra

@@ -17,22 +17,23 @@ double SignedVolume6(const dvec3 &a, const dvec3 &b, const dvec3 &c, const dvec3
 } // namespace
 
 namespace tetra {
-Result FillStarShaped(std::span<const dvec3> points, std::span<const uint32_t> tris, uint32_t layers) {
+Expected<Result> FillStarShaped(std::span<const dvec3> points, std::span<const uint32_t> tris, uint32_t layers) {
     Result out;
+    const auto fail = [](const char *why) { return modal_compat::unexpected<std::string>(std::string(why)); };
     const size_t nv = points.size(), nt = tris.size() / 3;
-    if (nv < 4 || nt < 4 || tris.size() % 3 != 0) return {{}, "the surface needs at least four vertices and four triangles"};
+    if (nv < 4 || nt < 4 || tris.size() % 3 != 0) return fail("the surface needs at least four vertices and four triangles");
     for (const auto i : tris)
-        if (i >= nv) return {{}, "triangle index out of range"};
+        if (i >= nv) return fail("triangle index out of range");
     // closed and manifold: every undirected edge belongs to exactly two triangles
     std::map<std::pair<uint32_t, uint32_t>, int> edges;
     for (size_t t = 0; t < nt; ++t)
         for (int e = 0; e < 3; ++e) {
             const uint32_t a = tris[3 * t + e], b = tris[3 * t + (e + 1) % 3];
-            if (a == b) return {{}, "degenerate triangle"};
+            if (a == b) return fail("degenerate triangle");
             ++edges[{std::min(a, b), std::max(a, b)}];
         }
     for (const auto &[edge, count] : edges)
-        if (count != 2) return {{}, count == 1 ? "the surface is open (an edge with a single triangle)" : "non-manifold edge: this fill needs a simple closed surface"};
+        if (count != 2) return fail(count == 1 ? "the surface is open (an edge with a single triangle)" : "non-manifold edge: this fill needs a simple closed surface");
     // centroid of the referenced vertices
     std::vector<uint8_t> used(nv, 0);
     for (const auto i : tris) used[i] = 1;
@@ -50,7 +51,7 @@ Result FillStarShaped(std::span<const dvec3> points, std::span<const uint32_t> t
     for (size_t t = 0; t < nt; ++t) {
         std::array<uint32_t, 3> f{tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
         const double vol = SignedVolume6(points[f[0]], points[f[1]], points[f[2]], c);
-        if (std::abs(vol) <= 1e-12 * scale * scale * scale) return {{}, "the surface is not star-shaped about its centroid (a triangle is seen edge-on)"};
+        if (std::abs(vol) <= 1e-12 * scale * scale * scale) return fail("the surface is not star-shaped about its centroid (a triangle is seen edge-on)");
         if (vol < 0) { std::swap(f[1], f[2]); ++flipped; }
         oriented[t] = f;
     }
@@ -61,7 +62,7 @@ Result FillStarShaped(std::span<const dvec3> points, std::span<const uint32_t> t
         for (const auto &f : oriented)
             for (int e = 0; e < 3; ++e) ++directed[{f[e], f[(e + 1) % 3]}];
         for (const auto &[edge, count] : directed)
-            if (count != 1 || !directed.count({edge.second, edge.first})) return {{}, "the surface is not star-shaped about its centroid"};
+            if (count != 1 || !directed.count({edge.second, edge.first})) return fail("the surface is not star-shaped about its centroid");
     }
     (void)flipped;
     // vertices: shell 0 = the input (same indices), shells 1..layers shrunk towards the centroid, then the centroid
@@ -92,6 +93,9 @@ Result FillStarShaped(std::span<const dvec3> points, std::span<const uint32_t> t
         const uint32_t in = uint32_t(layers * nv);
         add(in + f[0], in + f[1], in + f[2], centre);
     }
+    out.Profile.TetCount = uint32_t(mesh.Tets.size());
+    out.Profile.SteinerCount = uint32_t(mesh.Points.size() - nv);
+    out.Profile.Builds = 1;
     return out;
 }
 } // namespace tetra
@@ -104,14 +108,14 @@ std::vector<dvec3> Widened(const std::vector<vec3> &positions) {
 }
 } // namespace
 
-tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, const tetra::Options &options) {
+tetra::Expected<tetra::Result> GenerateTets(std::vector<vec3> positions, std::vector<uint32_t> triangle_indices, tetra::Options options) {
     return tetra::Tetrahedralize(Widened(positions), triangle_indices, options);
 }
 
-tetra::Result GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, uint32_t layers) {
+tetra::Expected<tetra::Result> GenerateTets(const std::vector<vec3> &positions, const std::vector<uint32_t> &triangle_indices, uint32_t layers) {
     const auto points = Widened(positions);
     auto layered = tetra::FillStarShaped(points, triangle_indices, layers);
-    if (layered || layered.Error.find("star-shaped") == std::string::npos) return layered;
+    if (layered || layered.error().find("star-shaped") == std::string::npos) return layered;
     return tetra::Tetrahedralize(points, triangle_indices); // not star-shaped: the general fill
 }
 

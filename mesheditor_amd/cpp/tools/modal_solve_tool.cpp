@@ -1,9 +1,9 @@
 // Solve a tetrahedral mesh's modal model on the MI355X and print it as JSON on stdout: the fields of the reference's
 // MeshEditorModalSolve (tests/ModalSolveTool.cpp:101-123 -- frequencies, decayRates, positions, mode-major shapes,
 // indices, mass, centerOfMass, inertiaDiagonal), which its sample generator shells out to.  The reference tool starts
-// from a surface .obj and tetrahedralises it; here an .obj is filled by tetra::FillStarShaped (star-shaped solids only,
+// from a surface .obj and tetrahedralises it; here an .obj is filled the same way (GenerateTets,
 // modal/tets.hpp) and its vertices are the excitation positions, or the tet mesh is given directly:
-//   modal_solve <mesh.obj> [--layers k] [options]
+//   modal_solve <mesh.obj> [--quality | --layers k] [options]   general fill (tetra::Tetrahedralize), or the layered fill of a star-shaped surface
 //   modal_solve <mesh.tet> [options]        text file: "V T", V lines "x y z", T lines "a b c d" (positively oriented)
 //   modal_solve --kuhn lx ly lz nx ny nz [--origin x y z] [options]
 //   --young E --poisson v --density rho --alpha a --beta b   material (SI)
@@ -172,12 +172,15 @@ std::optional<SolveInput> ReadInput(const CommandLine &cl) {
             std::fprintf(stderr, "Failed to load mesh: %s\n", path.data());
             return std::nullopt;
         }
-        auto filled = GenerateTets(surface->Positions, surface->TriangleIndices, uint32_t(cl.Number("--layers", 2)));
+        // as the reference's tool (tests/ModalSolveTool.cpp:72): the general fill, --quality = tetra::Options::Quality; with --layers k the
+        // layered fill of a star-shaped surface instead
+        auto filled = cl.Find("--layers") ? GenerateTets(surface->Positions, surface->TriangleIndices, uint32_t(cl.Number("--layers", 2)))
+                                          : GenerateTets(surface->Positions, surface->TriangleIndices, {.Quality = cl.Find("--quality").has_value()});
         if (!filled) {
-            std::fprintf(stderr, "Tetrahedralization failed: %s\n", filled.Error.c_str());
+            std::fprintf(stderr, "Tetrahedralization failed: %s\n", filled.error().c_str());
             return std::nullopt;
         }
-        in.Mesh = std::move(filled.Mesh);
+        in.Mesh = std::move(filled->Mesh);
         in.Excite = std::move(surface->Positions);
         in.Triangles = std::move(surface->TriangleIndices);
         return in;

@@ -14,6 +14,7 @@
 #include <set>
 
 namespace {
+template <class R> std::string ErrorOf(const R &r) { return r ? std::string() : r.error(); } // (error() without an error is a precondition violation)
 double Vol6(const dvec3 &a, const dvec3 &b, const dvec3 &c, const dvec3 &d) {
     const dvec3 u = b - a, v = c - a, w = d - a;
     return u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x);
@@ -138,10 +139,10 @@ CASE(the_quality_option_refines_to_a_radius_edge_ratio_of_two_with_interior_poin
         tetra::Options o;
         o.Quality = true;
         const auto fine = tetra::Tetrahedralize(c.S.P, c.S.T, o);
-        EXPECT_NOTE(bool(plain) && bool(fine), std::string(c.Name) + ": " + plain.Error + fine.Error);
+        EXPECT_NOTE(bool(plain) && bool(fine), std::string(c.Name) + ": " + ErrorOf(plain) + ErrorOf(fine));
         if (!plain || !fine) continue;
-        EXPECT_NOTE(fine.BoundarySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
-        const auto defect = Validate(c.S, fine.Mesh, c.Volume);
+        EXPECT_NOTE(fine->Profile.BdrySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
+        const auto defect = Validate(c.S, fine->Mesh, c.Volume);
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
         const auto bad = [&](const TetMesh &m) {
             size_t n = 0;
@@ -149,14 +150,14 @@ CASE(the_quality_option_refines_to_a_radius_edge_ratio_of_two_with_interior_poin
             return n;
         };
         // what is left above the bound has its circumcentre cut off by the surface: a small share of the refined mesh
-        const size_t before = bad(plain.Mesh), after = bad(fine.Mesh);
-        std::printf("        %-34s %zu -> %zu tets, ratio > 2: %zu -> %zu, %u interior points\n", c.Name, plain.Mesh.Tets.size(), fine.Mesh.Tets.size(), before, after, fine.QualityPoints);
+        const size_t before = bad(plain->Mesh), after = bad(fine->Mesh);
+        std::printf("        %-34s %zu -> %zu tets, ratio > 2: %zu -> %zu, %u interior points\n", c.Name, plain->Mesh.Tets.size(), fine->Mesh.Tets.size(), before, after, fine->Profile.QualityPointCount);
         // (a body the surface leaves room in: a tenth at most; a plate one or two cells thick keeps the cells that span it)
-        if (c.Chunky) EXPECT_NOTE(after * 10 <= fine.Mesh.Tets.size(), std::string(c.Name) + ": more than a tenth of the tets above the bound");
+        if (c.Chunky) EXPECT_NOTE(after * 10 <= fine->Mesh.Tets.size(), std::string(c.Name) + ": more than a tenth of the tets above the bound");
         EXPECT_NOTE(after <= before, std::string(c.Name) + ": more tets above the bound than before");
-        if (before * 20 > plain.Mesh.Tets.size()) EXPECT_NOTE(fine.QualityPoints > 0, std::string(c.Name) + ": nothing was refined");
+        if (before * 20 > plain->Mesh.Tets.size()) EXPECT_NOTE(fine->Profile.QualityPointCount > 0, std::string(c.Name) + ": nothing was refined");
         // without the option nothing changes (Tetrahedralize.h:20: "this gates refinement alone")
-        EXPECT(plain.QualityPoints == 0);
+        EXPECT(plain->Profile.QualityPointCount == 0);
     }
 }
 
@@ -167,16 +168,16 @@ CASE(the_max_volume_option_bounds_every_tetrahedron) {
         tetra::Options o;
         o.MaxVolume = bound;
         const auto r = tetra::Tetrahedralize(s.P, s.T, o);
-        EXPECT_NOTE(bool(r), r.Error);
+        EXPECT_NOTE(bool(r), ErrorOf(r));
         if (!r) continue;
-        const auto defect = Validate(s, r.Mesh, 1.0);
+        const auto defect = Validate(s, r->Mesh, 1.0);
         EXPECT_NOTE(defect.empty(), defect);
         double largest = 0;
-        for (const auto &t : r.Mesh.Tets) largest = std::max(largest, Vol6(r.Mesh.Points[t[0]], r.Mesh.Points[t[1]], r.Mesh.Points[t[2]], r.Mesh.Points[t[3]]) / 6);
-        std::printf("        MaxVolume %.3g: %zu tets, largest %.3g, %u interior points\n", bound, r.Mesh.Tets.size(), largest, r.QualityPoints);
+        for (const auto &t : r->Mesh.Tets) largest = std::max(largest, Vol6(r->Mesh.Points[t[0]], r->Mesh.Points[t[1]], r->Mesh.Points[t[2]], r->Mesh.Points[t[3]]) / 6);
+        std::printf("        MaxVolume %.3g: %zu tets, largest %.3g, %u interior points\n", bound, r->Mesh.Tets.size(), largest, r->Profile.QualityPointCount);
         EXPECT(largest <= bound * (1 + 1e-12));
-        EXPECT(r.Mesh.Tets.size() >= size_t(1.0 / bound));
-        EXPECT(r.QualityPoints > 0 && r.BoundarySteinerCount == 0);
+        EXPECT(r->Mesh.Tets.size() >= size_t(1.0 / bound));
+        EXPECT(r->Profile.QualityPointCount > 0 && r->Profile.BdrySteinerCount == 0);
     }
 }
 
@@ -184,10 +185,10 @@ CASE(a_box_surface_fills_for_every_layer_count) {
     const auto s = BoxSurface(2, 1, 0.5, 3);
     for (uint32_t layers : {0u, 1u, 2u, 5u}) {
         const auto r = tetra::FillStarShaped(s.P, s.T, layers);
-        EXPECT_NOTE(bool(r), r.Error);
-        EXPECT(r.Mesh.Tets.size() == (s.T.size() / 3) * (3 * layers + 1));
-        EXPECT(r.Mesh.Points.size() == s.P.size() * (layers + 1) + 1);
-        const auto defect = Validate(s, r.Mesh, 1.0);
+        EXPECT_NOTE(bool(r), ErrorOf(r));
+        EXPECT(r->Mesh.Tets.size() == (s.T.size() / 3) * (3 * layers + 1));
+        EXPECT(r->Mesh.Points.size() == s.P.size() * (layers + 1) + 1);
+        const auto defect = Validate(s, r->Mesh, 1.0);
         EXPECT_NOTE(defect.empty(), defect);
     }
 }
@@ -195,8 +196,8 @@ CASE(a_box_surface_fills_for_every_layer_count) {
 CASE(an_octahedron_fills) {
     const auto s = Octahedron();
     const auto r = tetra::FillStarShaped(s.P, s.T, 2);
-    EXPECT_NOTE(bool(r), r.Error);
-    const auto defect = Validate(s, r.Mesh, 8 * (1 * 1.5 * 2) / 6);
+    EXPECT_NOTE(bool(r), ErrorOf(r));
+    const auto defect = Validate(s, r->Mesh, 8 * (1 * 1.5 * 2) / 6);
     EXPECT_NOTE(defect.empty(), defect);
 }
 
@@ -204,11 +205,11 @@ CASE(unsuitable_surfaces_return_an_error) {
     auto open = BoxSurface(1, 1, 1, 2);
     open.T.resize(open.T.size() - 3);
     EXPECT(!tetra::FillStarShaped(open.P, open.T));
-    EXPECT(tetra::FillStarShaped(open.P, open.T).Error.find("open") != std::string::npos);
+    EXPECT(tetra::FillStarShaped(open.P, open.T).error().find("open") != std::string::npos);
     const auto bent = LPrism();
     const auto r = tetra::FillStarShaped(bent.P, bent.T);
     EXPECT(!r);
-    EXPECT(r.Error.find("star-shaped") != std::string::npos);
+    EXPECT(ErrorOf(r).find("star-shaped") != std::string::npos);
     auto bad = BoxSurface(1, 1, 1, 1);
     bad.T[0] = 99;
     EXPECT(!tetra::FillStarShaped(bad.P, bad.T));
@@ -445,27 +446,27 @@ CASE(non_star_shaped_and_higher_genus_surfaces_fill) {
                         {"hollow ball", hollow}};
     for (const auto &c : cases) {
         const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
-        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + ErrorOf(r));
         if (!r) continue;
-        const auto defect = ValidateGeneral(c.S, r.Mesh);
+        const auto defect = ValidateGeneral(c.S, r->Mesh);
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
         // the recovery's points were taken off the surface again: the boundary IS the input triangulation
-        EXPECT_NOTE(r.BoundarySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
-        const auto contract = InputSurfaceIsTheBoundary(c.S, r.Mesh);
+        EXPECT_NOTE(r->Profile.BdrySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
+        const auto contract = InputSurfaceIsTheBoundary(c.S, r->Mesh);
         EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
         tetra::Options on_surface;
         on_surface.InteriorSteiner = false;
         const auto refined = tetra::Tetrahedralize(c.S.P, c.S.T, on_surface);
         std::printf("%12s: %zu surface triangles -> %zu tets, %zu added points (%u of them on the surface before they were moved inside)\n", c.Name, c.S.T.size() / 3,
-                    r.Mesh.Tets.size(), r.Mesh.Points.size() - c.S.P.size(), refined ? refined.BoundarySteinerCount : 0u);
+                    r->Mesh.Tets.size(), r->Mesh.Points.size() - c.S.P.size(), refined ? refined->Profile.BdrySteinerCount : 0u);
     }
     // the star-shaped filler refuses the bracket, the layered front end falls through to the general fill
     const Surface bent = LPrism();
     std::vector<vec3> as_float;
     for (const auto &p : bent.P) as_float.emplace_back(float(p.x), float(p.y), float(p.z));
     const auto r = GenerateTets(as_float, bent.T, 2);
-    EXPECT_NOTE(bool(r), r.Error);
-    EXPECT(ValidateGeneral(bent, r.Mesh).empty());
+    EXPECT_NOTE(bool(r), ErrorOf(r));
+    EXPECT(ValidateGeneral(bent, r->Mesh).empty());
 }
 
 // Sliver repair and vertex smoothing (Options::RepairSlivers, on by default as in the reference: src/mesh/Tetrahedralize.h:20):
@@ -494,20 +495,20 @@ CASE(sliver_repair_keeps_the_mesh_valid_and_removes_most_slivers) {
         tetra::Options plain;
         plain.RepairSlivers = false;
         const auto before = tetra::Tetrahedralize(c.S.P, c.S.T, plain), after = tetra::Tetrahedralize(c.S.P, c.S.T);
-        EXPECT_NOTE(bool(before) && bool(after), std::string(c.Name) + ": " + before.Error + after.Error);
+        EXPECT_NOTE(bool(before) && bool(after), std::string(c.Name) + ": " + ErrorOf(before) + ErrorOf(after));
         if (!before || !after) continue;
-        const auto defect = ValidateGeneral(c.S, after.Mesh);
+        const auto defect = ValidateGeneral(c.S, after->Mesh);
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
-        const auto contract = InputSurfaceIsTheBoundary(c.S, after.Mesh);
+        const auto contract = InputSurfaceIsTheBoundary(c.S, after->Mesh);
         EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
-        EXPECT(after.Mesh.Points.size() >= before.Mesh.Points.size() && after.SliverExchanges > 0); // (a flat cell on two surface triangles gets a point underneath)
+        EXPECT(after->Mesh.Points.size() >= before->Mesh.Points.size() && after->Profile.SliverExchangeCount > 0); // (a flat cell on two surface triangles gets a point underneath)
         double v_before = 0, v_after = 0;
         size_t flat_before = 0, flat_after = 0;
-        for (const auto &t : before.Mesh.Tets) v_before += Vol6(before.Mesh.Points[t[0]], before.Mesh.Points[t[1]], before.Mesh.Points[t[2]], before.Mesh.Points[t[3]]), flat_before += shape(before.Mesh, t) < 0.05;
-        for (const auto &t : after.Mesh.Tets) v_after += Vol6(after.Mesh.Points[t[0]], after.Mesh.Points[t[1]], after.Mesh.Points[t[2]], after.Mesh.Points[t[3]]), flat_after += shape(after.Mesh, t) < 0.05;
+        for (const auto &t : before->Mesh.Tets) v_before += Vol6(before->Mesh.Points[t[0]], before->Mesh.Points[t[1]], before->Mesh.Points[t[2]], before->Mesh.Points[t[3]]), flat_before += shape(before->Mesh, t) < 0.05;
+        for (const auto &t : after->Mesh.Tets) v_after += Vol6(after->Mesh.Points[t[0]], after->Mesh.Points[t[1]], after->Mesh.Points[t[2]], after->Mesh.Points[t[3]]), flat_after += shape(after->Mesh, t) < 0.05;
         EXPECT(check::near(v_after, v_before, 1e-12));
         EXPECT_NOTE(2 * flat_after <= flat_before, std::string(c.Name) + ": tetrahedra with shape < 0.05: " + std::to_string(flat_before) + " -> " + std::to_string(flat_after));
-        std::printf("%18s: shape < 0.05: %zu of %zu tets -> %zu of %zu, %u exchanges\n", c.Name, flat_before, before.Mesh.Tets.size(), flat_after, after.Mesh.Tets.size(), after.SliverExchanges);
+        std::printf("%18s: shape < 0.05: %zu of %zu tets -> %zu of %zu, %u exchanges\n", c.Name, flat_before, before->Mesh.Tets.size(), flat_after, after->Mesh.Tets.size(), after->Profile.SliverExchangeCount);
     }
 }
 
@@ -552,15 +553,15 @@ CASE(one_cell_thick_grid_bodies_fill_without_any_added_point) {
     const Named cases[]{{"box 12x3x1", SlabSurface(12, 3, 1, 0.12, 0.03, 0.01), 36}, {"platform 12x1x12", SlabSurface(12, 1, 12, 0.3, 0.03, 0.3), 144}, {"rod 1x1x9", SlabSurface(1, 1, 9, 0.01, 0.01, 0.2), 9}};
     for (const auto &c : cases) {
         const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
-        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + ErrorOf(r));
         if (!r) continue;
-        EXPECT_NOTE(r.Mesh.Points.size() == c.S.P.size(), std::string(c.Name) + ": points were added");
-        EXPECT(r.Mesh.Tets.size() == 6 * c.Cells); // (parallel diagonals on opposite faces rule the five-tet tiling out)
-        const auto defect = ValidateGeneral(c.S, r.Mesh, true);
+        EXPECT_NOTE(r->Mesh.Points.size() == c.S.P.size(), std::string(c.Name) + ": points were added");
+        EXPECT(r->Mesh.Tets.size() == 6 * c.Cells); // (parallel diagonals on opposite faces rule the five-tet tiling out)
+        const auto defect = ValidateGeneral(c.S, r->Mesh, true);
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
-        const auto contract = InputSurfaceIsTheBoundary(c.S, r.Mesh);
+        const auto contract = InputSurfaceIsTheBoundary(c.S, r->Mesh);
         EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
-        std::printf("%18s: %zu surface triangles -> %zu tets, %zu added points\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(), r.Mesh.Points.size() - c.S.P.size());
+        std::printf("%18s: %zu surface triangles -> %zu tets, %zu added points\n", c.Name, c.S.T.size() / 3, r->Mesh.Tets.size(), r->Mesh.Points.size() - c.S.P.size());
     }
 }
 
@@ -577,25 +578,25 @@ CASE(degenerate_and_noisy_point_sets_fill) {
                         {"20k sphere", IcoSphere(5, 0.01, 11), true}};
     for (const auto &c : cases) {
         const auto r = tetra::Tetrahedralize(c.S.P, c.S.T);
-        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + ErrorOf(r));
         if (!r) continue;
-        const auto defect = ValidateGeneral(c.S, r.Mesh, c.Oriented);
+        const auto defect = ValidateGeneral(c.S, r->Mesh, c.Oriented);
         EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
         if (!c.Oriented) { // a box: the volume is known even though the test surface winds every other quad the wrong way
             double v6 = 0;
-            for (const auto &t : r.Mesh.Tets) v6 += Vol6(r.Mesh.Points[t[0]], r.Mesh.Points[t[1]], r.Mesh.Points[t[2]], r.Mesh.Points[t[3]]);
+            for (const auto &t : r->Mesh.Tets) v6 += Vol6(r->Mesh.Points[t[0]], r->Mesh.Points[t[1]], r->Mesh.Points[t[2]], r->Mesh.Points[t[3]]);
             double lo[3]{1e300, 1e300, 1e300}, hi[3]{-1e300, -1e300, -1e300};
             for (const auto &p : c.S.P)
                 for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], p[d]), hi[d] = std::max(hi[d], p[d]);
             EXPECT(check::near(v6 / 6, (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]), 1e-12));
         }
-        EXPECT_NOTE(r.BoundarySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
+        EXPECT_NOTE(r->Profile.BdrySteinerCount == 0, std::string(c.Name) + ": points left on the surface");
         if (c.Oriented) { // (the boxes' test surfaces wind every other quad the wrong way; their triangles are checked all the same)
-            const auto contract = InputSurfaceIsTheBoundary(c.S, r.Mesh);
+            const auto contract = InputSurfaceIsTheBoundary(c.S, r->Mesh);
             EXPECT_NOTE(contract.empty(), std::string(c.Name) + ": " + contract);
         }
-        std::printf("%12s: %zu surface triangles -> %zu tets, %zu added points, %u left on the surface\n", c.Name, c.S.T.size() / 3, r.Mesh.Tets.size(),
-                    r.Mesh.Points.size() - c.S.P.size(), r.BoundarySteinerCount);
+        std::printf("%12s: %zu surface triangles -> %zu tets, %zu added points, %u left on the surface\n", c.Name, c.S.T.size() / 3, r->Mesh.Tets.size(),
+                    r->Mesh.Points.size() - c.S.P.size(), r->Profile.BdrySteinerCount);
     }
 }
 
@@ -646,10 +647,10 @@ CASE(simplify_surface_keeps_a_closed_manifold_and_its_shape) {
         Surface coarse;
         for (const auto &p : pos) coarse.P.push_back(dvec3(p));
         coarse.T = tri;
-        const auto r = c.Fill ? tetra::Tetrahedralize(coarse.P, coarse.T) : tetra::Result{};
-        if (c.Fill) EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + r.Error);
+        const auto r = c.Fill ? tetra::Tetrahedralize(coarse.P, coarse.T) : tetra::Expected<tetra::Result>{};
+        if (c.Fill) EXPECT_NOTE(bool(r), std::string(c.Name) + ": " + ErrorOf(r));
         if (c.Fill && r) {
-            const auto defect = ValidateGeneral(coarse, r.Mesh, true);
+            const auto defect = ValidateGeneral(coarse, r->Mesh, true);
             EXPECT_NOTE(defect.empty(), std::string(c.Name) + ": " + defect);
         }
         std::printf("%12s: %zu -> %zu triangles, volume %.4f -> %.4f\n", c.Name, nt0, nt, v0, volume(pos, tri));
@@ -678,12 +679,12 @@ CASE(internal_walls_are_kept_as_faces_between_tetrahedra) {
     s.P.push_back({0.5, 0.5, 0.4});
     s.T.insert(s.T.end(), {ids.at({0, 1, 0}), ids.at({1, 1, 0}), apex});
     const auto r = tetra::Tetrahedralize(s.P, s.T);
-    EXPECT_NOTE(bool(r), r.Error);
+    EXPECT_NOTE(bool(r), ErrorOf(r));
     if (!r) return;
     std::map<std::array<uint32_t, 3>, int> count;
     double v6 = 0;
-    for (const auto &t : r.Mesh.Tets) {
-        const double v = Vol6(r.Mesh.Points[t[0]], r.Mesh.Points[t[1]], r.Mesh.Points[t[2]], r.Mesh.Points[t[3]]);
+    for (const auto &t : r->Mesh.Tets) {
+        const double v = Vol6(r->Mesh.Points[t[0]], r->Mesh.Points[t[1]], r->Mesh.Points[t[2]], r->Mesh.Points[t[3]]);
         EXPECT(v > 0);
         v6 += v;
         for (int i = 0; i < 4; ++i) {
@@ -701,20 +702,20 @@ CASE(internal_walls_are_kept_as_faces_between_tetrahedra) {
         if (it != count.end() && it->second == (t < outer_triangles ? 1 : 2)) ++kept; // (a wall piece refined by recovery points would not be found whole)
     }
     std::printf("box with a bulkhead and a fin: %zu triangles (%zu outer), %zu tets, %zu added points, %zu input triangles are faces as given\n", s.T.size() / 3,
-                outer_triangles, r.Mesh.Tets.size(), r.Mesh.Points.size() - s.P.size(), kept);
+                outer_triangles, r->Mesh.Tets.size(), r->Mesh.Points.size() - s.P.size(), kept);
     EXPECT(kept == s.T.size() / 3);
     // an outer surface with a hole leaks: the flood from outside reaches everything
     Surface open = BoxSurface(1, 1, 1, 2);
     open.T.resize(open.T.size() - 3);
     const auto leak = tetra::Tetrahedralize(open.P, open.T);
-    EXPECT(!leak && leak.Error.find("open") != std::string::npos);
+    EXPECT(!leak && ErrorOf(leak).find("open") != std::string::npos);
 }
 
 CASE(the_general_fill_reports_unsuitable_surfaces) {
     auto open = BoxSurface(1, 1, 1, 2);
     open.T.resize(open.T.size() - 3);
     const auto r = tetra::Tetrahedralize(open.P, open.T);
-    EXPECT(!r && r.Error.find("open") != std::string::npos);
+    EXPECT(!r && ErrorOf(r).find("open") != std::string::npos);
     auto bad = BoxSurface(1, 1, 1, 1);
     bad.T[0] = 99;
     EXPECT(!tetra::Tetrahedralize(bad.P, bad.T));
@@ -725,7 +726,7 @@ CASE(the_general_fill_reports_unsuitable_surfaces) {
     for (auto &p : other.P) p = {p.x + 0.5, p.y + 0.25, p.z + 0.125};
     Append(crossed, other);
     const auto x = tetra::Tetrahedralize(crossed.P, crossed.T);
-    EXPECT(!x || !x.Mesh.Tets.empty());
+    EXPECT(!x || !x->Mesh.Tets.empty());
 }
 
 CASE(an_obj_file_loads_welded_and_fanned) {
@@ -742,11 +743,11 @@ CASE(an_obj_file_loads_welded_and_fanned) {
     EXPECT(obj->Positions.size() == 8);
     EXPECT(obj->TriangleIndices.size() == 36);
     const auto r = GenerateTets(obj->Positions, obj->TriangleIndices, 1);
-    EXPECT_NOTE(bool(r), r.Error);
+    EXPECT_NOTE(bool(r), ErrorOf(r));
     Surface s;
     for (const auto &p : obj->Positions) s.P.push_back({p.x, p.y, p.z});
     s.T = obj->TriangleIndices;
-    const auto defect = Validate(s, r.Mesh, 1.0);
+    const auto defect = Validate(s, r->Mesh, 1.0);
     EXPECT_NOTE(defect.empty(), defect);
     EXPECT(!LoadObj("/nonexistent/file.obj"));
 }
