@@ -273,12 +273,13 @@ def config3_rows(api, ctx):
     return scan_like_rows(api, ctx, names=("config3_s30k", "config3_s100k", "config3_s30k_repaired", "config3_s100k_repaired", "skillet_s100k"), reps=1)
 
 
-def batch64_pass(api, device, threads=3):
+def batch64_pass(api, device, threads=3, scans=False):
     """BASELINE config 4 on the GPU(s) of this run's first rank: the 64 jittered 29k-tet boxes solved by `threads` host threads
-    (one context each), one pass after a warm-up solve; N = 1 here -- the multi-GPU form is `--workload batch64 --gpus N`."""
+    (one context each), one pass after a warm-up solve; N = 1 here -- the multi-GPU form is `--workload batch64 --gpus N`.
+    scans: the same with 64 jittered scan-like thin-walled fills (RealImpact's shape) instead of Kuhn boxes."""
     from mesheditor_amd import sharding
     try:
-        items = batch_meshes()
+        items = batch_scan_meshes() if scans else batch_meshes()
         ctxs = [api.Context(device) for _ in range(threads)]
         ex_of = [m[0][:: len(m[0]) // 10][:10].astype(np.float32) for m in items]
 
@@ -292,7 +293,9 @@ def batch64_pass(api, device, threads=3):
         dt = time.perf_counter() - t0
         [c.close() for c in ctxs]
         pairs = sum(len(r["eigenvalues"]) for r in recs)
-        return {"workload": "64 jittered Kuhn boxes of %d tets, 7 materials cycled, 45 eigenpairs each, mesh upload included" % len(items[0][1]), "n_gpus": 1,
+        what = ("64 jittered scan-like thin-walled fills (8 skillet scan surfaces through the front end's default options, stretched by U(0.8, 1.25) per axis) of %d-%d tets"
+                % (min(len(m[1]) for m in items), max(len(m[1]) for m in items))) if scans else "64 jittered Kuhn boxes of %d tets" % len(items[0][1])
+        return {"workload": what + ", 7 materials cycled, 45 eigenpairs each, mesh upload included", "n_gpus": 1,
                 "threads_per_gpu": threads, "seconds": dt, "eigenpairs_per_s": pairs / dt, "meshes_per_s": len(items) / dt,
                 "iterations_mean": float(np.mean([r["iterations"] for r in recs]))}
     except Exception as e:  # noqa: BLE001
@@ -345,6 +348,17 @@ def batch_meshes(count=64, n=17):
     out = []
     for i in range(count):
         p, t = meshes.jittered_box(n, 1000 + i)
+        out.append((p, t, meshes.MATERIALS[meshes.MATERIAL_ORDER[i % len(meshes.MATERIAL_ORDER)]], {"num_modes": 30, "num_fem_modes": 45}))
+    return out
+
+
+def batch_scan_meshes(count=64):
+    """config 4's batch on RealImpact's SHAPE -- `count` jittered scan-like thin-walled fills of ~30k tets
+    (meshes.jittered_scan), materials cycled, 45 eigenpairs."""
+    from mesheditor_amd import meshes
+    out = []
+    for i in range(count):
+        p, t = meshes.jittered_scan(i)
         out.append((p, t, meshes.MATERIALS[meshes.MATERIAL_ORDER[i % len(meshes.MATERIAL_ORDER)]], {"num_modes": 30, "num_fem_modes": 45}))
     return out
 
@@ -585,8 +599,22 @@ def main():
             line["scan_like"] = scan_like_rows(api, ctxs[0])
             line["config3"] = config3_rows(api, ctxs[0])
             line["batch64"] = batch64_pass(api, device)
-        line["cpu_baseline"] = cpu_baseline()
-        line["cpu_baseline_metric_mesh"] = cpu_baseline_metric_mesh("cube_s100k" if batch else args.workload)
+            line["batch64_scan"] = batch64_pass(api, device, scans=True)
+        # The CPU partner of `value`, timed LIVE on this box's host cores on the metric's own mesh (round 6; ~150 s on the 16 cores the GPU
+        # box grants: the driver gives the bench 1 800 s).  The 10k-tet sample of rounds 1-5 (one thread and the team) stays as
+        # cpu_baseline_small; MH_BENCH_CPU_SAMPLE=1 puts it back as the main row for a quick run.
+        small = cpu_baseline()
+        if os.environ.get("MH_BENCH_CPU_SAMPLE") == "1":
+            line["cpu_baseline"] = small
+            line["cpu_baseline_metric_mesh"] = cpu_baseline_metric_mesh("cube_s100k" if batch else args.workload)
+        else:
+            live = cpu_baseline_metric_mesh_live("cube_s100k" if batch else args.workload)
+            live["sample"] = "%s: %d tets / %d DOF, %d eigenpairs, whole mesh2modes path -- the metric's own mesh, timed live on this box in this run (%.0f s)" % (
+                live["workload"], live["mesh"]["tets"], live["mesh"]["dof"], live["eigenpairs"], live["seconds"])
+            live["host_cores"] = live["host"]["cores_available"]
+            line["cpu_baseline"] = live
+            line["cpu_baseline_small"] = small
+            line["cpu_baseline_metric_mesh"] = live  # (the key of rounds 4-5: the same record)
         bank = bank_metric()
         line["resonator_bank"] = bank
         if isinstance(bank.get("all_live"), dict):

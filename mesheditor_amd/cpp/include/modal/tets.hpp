@@ -55,6 +55,11 @@ struct Options {
     // The reference's default fill adds no such points (its quality arm does): a fill with a shell has more points than the reference's.
     enum class Shell { Never, WhenFlat, Always };
     Shell InteriorShell{Shell::WhenFlat};
+    // With RepairSlivers: whatever cell every other repair leaves with a shape measure below 1e-2 gets an interior point beside it (the
+    // quality arm run locally, src/tetrahedralize.cpp: BreakFlatCells) -- no fill leaves here with a cell flat to 1e-9, whatever the other
+    // options (round 6; the reference's repair and vertex optimisation run "either way", Tetrahedralize.h:19-20).  Off: for tests that
+    // want such a mesh (a caller's own TetMesh need not be well shaped).
+    bool BreakFlatCells{true};
 };
 // Wall-clock seconds per stage, with size and effort counters: the reference's tetra::Profile (src/mesh/Tetrahedralize.h:29-44), field
 // for field, filled with what the corresponding stage of THIS fill did (the bench prints them: tests/ModalSolverBench.cpp:297-327).

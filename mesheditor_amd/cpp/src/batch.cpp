@@ -183,18 +183,23 @@ std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &c
     // so a rank whose solves all fail still joins with failed records.  (A rank that fails HERE aborts the communicator; RCCL's abort is
     // local, the peers learn of it through their watchdog: an aborted communicator must be recreated on every rank.)
     const size_t count = slots * (reclen + 1);
-    double *d_send{}, *d_recv{};
+    // Owned from here to the end of the function, whatever is thrown in between (a thread that cannot start, a host allocation): freed on
+    // every path; and a throw before the collective aborts the communicator, so that the peers' watchdogs fire instead of their waiting.
+    struct DeviceBuffer {
+        double *Ptr{};
+        ~DeviceBuffer() { if (Ptr) (void)hipFree(Ptr); }
+    } d_send, d_recv;
+    struct AbortUnlessJoined {
+        BatchComm &Comm;
+        bool Joined{false};
+        ~AbortUnlessJoined() { if (!Joined) Comm.Abort(); }
+    } joining{comm};
+    // the gather's host buffer too, before the solves: nothing between the solves and the collective allocates
+    std::vector<double> all(size_t(world) * count, 0.0);
     if (count) {
-        try {
-            Check(hipSetDevice(comm.Device()), "hipSetDevice");
-            Check(hipMalloc(reinterpret_cast<void **>(&d_send), count * sizeof(double)), "hipMalloc");
-            Check(hipMalloc(reinterpret_cast<void **>(&d_recv), size_t(world) * count * sizeof(double)), "hipMalloc");
-        } catch (...) {
-            comm.Abort();
-            if (d_send) (void)hipFree(d_send);
-            if (d_recv) (void)hipFree(d_recv);
-            throw;
-        }
+        Check(hipSetDevice(comm.Device()), "hipSetDevice");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_send.Ptr), count * sizeof(double)), "hipMalloc");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_recv.Ptr), size_t(world) * count * sizeof(double)), "hipMalloc");
     }
     std::atomic<size_t> next{0};
     const uint32_t workers = std::max<uint32_t>(1, std::min<uint32_t>(options.ThreadsPerDevice, uint32_t(std::max<size_t>(mine.size(), 1))));
@@ -227,34 +232,23 @@ std::vector<double> SolveBatchRaw(std::span<const BatchItem> items, BatchComm &c
     };
     {
         std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < workers; ++t) pool.emplace_back(work);
+        try {
+            for (uint32_t t = 1; t < workers; ++t) pool.emplace_back(work);
+        } catch (...) { // (std::system_error: no more threads) -- the ones that started and this one do the work
+        }
         work();
         for (auto &t : pool) t.join();
     }
     // the one collective: every rank's slots, on the device, over RCCL
-    std::vector<double> all(size_t(world) * count, 0.0);
     if (count) {
-        try {
-            Check(hipSetDevice(comm.Device()), "hipSetDevice");
-            Check(hipMemcpy(d_send, send.data(), count * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
-        } catch (...) { // (a failed copy into memory we hold: the device is gone -- nothing to join with)
-            comm.Abort();
-            (void)hipFree(d_send);
-            (void)hipFree(d_recv);
-            throw;
-        }
-        try {
-            comm.AllGather(d_send, d_recv, count);
-            comm.Synchronize(options.GatherTimeoutSeconds);
-            Check(hipMemcpy(all.data(), d_recv, all.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
-        } catch (...) {
-            (void)hipFree(d_send);
-            (void)hipFree(d_recv);
-            throw;
-        }
-        (void)hipFree(d_send);
-        (void)hipFree(d_recv);
+        Check(hipSetDevice(comm.Device()), "hipSetDevice");
+        Check(hipMemcpy(d_send.Ptr, send.data(), count * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"); // (a failed copy into memory we hold: the device is gone -- nothing to join with: abort)
+        joining.Joined = true; // from here the collective itself reports what goes wrong (its watchdog aborts)
+        comm.AllGather(d_send.Ptr, d_recv.Ptr, count);
+        comm.Synchronize(options.GatherTimeoutSeconds);
+        Check(hipMemcpy(all.data(), d_recv.Ptr, all.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
     }
+    joining.Joined = true;
     std::vector<double> out(n * reclen, 0.0);
     std::vector<uint8_t> seen(n, 0);
     for (size_t s = 0; s < size_t(world) * slots; ++s) {

@@ -208,6 +208,7 @@ mhx_tets *mhx_tetrahedralize2(const double *points, uint32_t n_points, const uin
         options.InteriorShell = (flags & 4) ? tetra::Options::Shell::Never : (flags & 8) ? tetra::Options::Shell::Always : tetra::Options::Shell::WhenFlat; // bits 2, 3
         options.Quality = (flags & 16) != 0; // bit 4: the reference's Options::Quality; max_volume: its Options::MaxVolume
         options.MaxVolume = max_volume;
+        options.BreakFlatCells = (flags & 32) == 0; // bit 5: leave flat cells as the other repairs leave them (tests)
         auto filled = tetra::Tetrahedralize(pts, std::span<const uint32_t>(triangles, size_t(n_triangles) * 3), options);
         if (filled) h->Result = std::move(*filled);
         else h->Error = filled.error();

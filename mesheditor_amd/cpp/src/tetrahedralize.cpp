@@ -2282,7 +2282,7 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
             return worst;
         };
         constexpr double kShapeFloor = 1e-2; // cells below it are worked on; what the pass guarantees where it succeeds is 1e-3 (tests)
-        for (int round = 0; round < 4 && worst_shape(out.Mesh) < kShapeFloor; ++round) {
+        for (int round = 0; round < 4 && options.BreakFlatCells && worst_shape(out.Mesh) < kShapeFloor; ++round) {
             const uint32_t points = BreakFlatCells(out.Mesh, kShapeFloor, keep, std::max<size_t>(4096, out.Mesh.Points.size() / 4));
             if (!points) break;
             out.FlatCellPoints += points;

@@ -253,7 +253,7 @@ int mhl_context_tridiagonalize_full(mh_context *ctx, int variant, uint32_t m, co
     if (!ctx || !a || !d || !e || m < 2 || variant < 0 || variant > 3 || m > (variant == 2 ? 768u : 256u)) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation; // (no process-wide lock: calls on different contexts are meant to overlap)
+        MhSharedPhase not_during_a_factorisation(ctx->device); // (no process-wide lock: calls on different contexts are meant to overlap)
         DevArray<double> da(ctx, size_t(m) * m), work(ctx, size_t(m) * m), dd(ctx, m), de(ctx, m), dtau(ctx, m);
         da.upload(a, size_t(m) * m);
         hipEvent_t e0, e1;
@@ -289,7 +289,7 @@ int mhl_context_potrf_inverse(mh_context *ctx, uint32_t w, const double *a, cons
     if (!ctx || !a || !dscale || !l || !linv || !info2 || w < 1 || w > 128) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         DevArray<double> da(ctx, size_t(w) * w), dd(ctx, w), dl(ctx, size_t(w) * w);
         DevArray<int> info(ctx, 2);
         da.upload(a, size_t(w) * w);
@@ -308,7 +308,7 @@ int mhl_context_spd_inverse(mh_context *ctx, uint32_t w, const double *a, double
     if (!ctx || !a || !out || w < 1 || w > 128) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         DevArray<double> da(ctx, size_t(w) * w), dout(ctx, size_t(w) * w);
         DevArray<int> info(ctx, 1);
         info.zero();
@@ -342,7 +342,7 @@ int mhl_context_small_gemm(mh_context *ctx, int ta, int tb, uint32_t M, uint32_t
     if (!ctx || !a || !b || !c || !M || !N || !K || lda < (ta ? K : M) || ldb < (tb ? N : K) || ldc < M) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         const size_t na = size_t(lda) * (ta ? M : K), nb = size_t(ldb) * (tb ? K : N), nc = size_t(ldc) * N;
         DevArray<double> da(ctx, na), db(ctx, nb), dc(ctx, nc), work(ctx, nc);
         da.upload(a, na);
@@ -384,7 +384,7 @@ int mhl_context_gram(mh_context *ctx, uint64_t n, const double *x, uint32_t wa, 
     if (!ctx || !x || !y || !g || !n || !wa || !wb) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         DevArray<double> dx(ctx, n * wa), dy(ctx, n * wb), dg(ctx, size_t(wa) * wb);
         dx.upload(x, n * wa);
         dy.upload(y, n * wb);
@@ -401,7 +401,7 @@ int mhl_context_bench_stream(mh_context *ctx, uint64_t bytes, uint32_t reps, dou
     if (!ctx || !copy_gbs || !read_gbs || bytes < 4096 || !reps) return MH_EINVAL;
     try {
         HIP_CHECK(hipSetDevice(ctx->device));
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         const size_t count = bytes / 16;
         const unsigned grid = unsigned(ctx->cu_count) * 32;
         DevArray<float> a(ctx, count * 4), b(ctx, count * 4), out(ctx, grid);

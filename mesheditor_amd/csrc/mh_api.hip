@@ -202,7 +202,7 @@ int mh_mesh_create(mh_context *ctx, uint32_t n_points, const double *points_xyz,
     if (!ctx || !out || (n_points && !points_xyz) || (n_tets && !tets)) return MH_EINVAL;
     *out = nullptr;
     try {
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         HIP_CHECK(hipSetDevice(ctx->device));
         for (size_t i = 0; i < size_t(n_tets) * 4; ++i)
             if (tets[i] >= n_points) mh_throw(MH_EINVAL, "tet %zu references point %u of %u", i / 4, tets[i], n_points);
@@ -225,7 +225,7 @@ int mh_assemble(mh_context *ctx, const mh_mesh *mesh, const mh_material *materia
     if (!ctx || !mesh || !material || !out) return MH_EINVAL;
     *out = nullptr;
     try {
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         HIP_CHECK(hipSetDevice(ctx->device));
         auto sys = std::make_unique<mh_system>();
         hipEvent_t e0, e1;
@@ -350,7 +350,7 @@ int mh_nearest_points(mh_context *ctx, const mh_mesh *mesh, uint32_t n, const fl
     if (!ctx || !mesh || (n && (!positions_xyz || !nearest))) return MH_EINVAL;
     if (n == 0) return MH_OK;
     try {
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         HIP_CHECK(hipSetDevice(ctx->device));
         DevArray<float> pos(ctx, size_t(n) * 3);
         DevArray<uint32_t> out(ctx, n);
@@ -367,7 +367,7 @@ int mh_system_gather_shapes(const mh_system *s, uint32_t n_nodes, const uint32_t
     if (!s || !nodes || !shapes) return MH_EINVAL;
     mh_context *ctx = s->ctx;
     try {
-        MhSharedPhase not_during_a_factorisation;
+        MhSharedPhase not_during_a_factorisation(ctx->device);
         HIP_CHECK(hipSetDevice(ctx->device));
         if (n_cols > s->evec_cols) mh_throw(MH_EINVAL, "%u columns requested, %u solved", n_cols, s->evec_cols);
         for (uint32_t i = 0; i < n_nodes; ++i)

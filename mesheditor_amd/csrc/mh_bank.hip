@@ -789,7 +789,7 @@ int mh_bank_render(mh_bank *bank, uint32_t frames, float click_gain, uint32_t n_
     if (n_renderers && deal_offset[n_renderers] && (!deal_objects || !render_count || !tuned_count || !object_energy || !object_live || !object_silenced)) return MH_EINVAL;
     if (frames == 0) return MH_OK;
     try {
-        MhSharedPhase not_during_a_factorisation; // a solve's dense coarse factorisation runs alone on the device (mh_eigs.hip)
+        MhSharedPhase not_during_a_factorisation(bank->ctx->device); // a solve's dense coarse factorisation runs alone on the device (mh_eigs.hip)
         HIP_CHECK(hipSetDevice(bank->ctx->device));
         if (bank->dbl) render_impl(*bank->d, frames, click_gain, n_impacts, impacts, n_renderers, deal_offset, deal_objects, render_count, tuned_count, out_gain, listener_gain, out, object_energy, object_live, object_silenced, object_modal_energy);
         else render_impl(*bank->f, frames, click_gain, n_impacts, impacts, n_renderers, deal_offset, deal_objects, render_count, tuned_count, out_gain, listener_gain, out, object_energy, object_live, object_silenced, object_modal_energy);

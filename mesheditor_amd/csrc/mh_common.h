@@ -291,6 +291,7 @@ struct mh_context {
     int *sytrd_flag{nullptr};               // set by a workgroup that gave up waiting (mh_sytrd_gave_up)
     unsigned long long *sytrd_xch_wide{nullptr}; // the same for orders 257 .. 768 (mh_sytrd_wide)
     uint32_t sytrd_epoch_wide{0};
+    bool exchange_disabled{false};          // set after a failed Rayleigh-Ritz self-check: orders 257-768 then go to the library's syevd instead of the tagged-exchange kernel (k_sytrd_wide), and the solve is redone once
     uint32_t sytrd_redos{0};                // Rayleigh-Ritz steps redone by a fall-back because a workgroup of the exchange gave up (co-resident work stalled it past the poll bound); mh_profile reports the count per solve
     unsigned long long *rr_check{nullptr};  // device word: worst sampled residual of the Rayleigh-Ritz steps' self-check (k_rr_selfcheck), double bits folded by atomicMax
     // Optional per-launch timing of the path's named kernels (measurement aid for bench.py's roofline objects): HIP
@@ -415,6 +416,23 @@ struct PatchSet {
     DevArray<int> dropped;                         // [0]: patches whose block was not safely positive definite (they contribute nothing), [1]: one of them + 1
     DevArray<float> inv32;
     DevArray<uint32_t> touched, t_ptr, t_patch, t_local; // nodes in some patch; per touched node its (patch, local node) entries, CSR
+    // CLUSTERS (round 6): badly shaped elements that share nodes (a pole fan's needles, stacked caps: connected components of the bad
+    // elements, two or more of them) get ONE exact inverse on the union of their nodes instead of overlapping element patches -- measured
+    // on a 96 x 48 UV sphere's fill with 172 cells flat to 1e-8 (two-grid bound, exact P1 level; tools/proto/cluster_patches.py): condition
+    // number 786 with the weighted element patches, 339 / 124 / 75 with clusters cut at 64 / 128 / 256 nodes, 9 with whole clusters (818 nodes);
+    // a well-shaped sphere: 5.  Node sets are pairwise disjoint (a component larger than the cap is cut into node-disjoint pieces).
+    uint32_t n_clusters{0}, cluster_rows{0}, cluster_tiles{0}; // clusters; the sum of their orders 3 n_c; 64-row tiles over all of them
+    uint32_t n_bad_elements{0};                                   // elements below the shape threshold, in element patches and clusters together
+    uint32_t largest_cluster{0};                                  // nodes of the largest one
+    std::vector<uint32_t> h_cluster_ptr;                          // host copy of the row offsets (n_clusters + 1), in rows (3 per node)
+    DevArray<uint32_t> cluster_row;                               // cluster_rows: the level's dof row (3 node + k) of every cluster row
+    DevArray<uint32_t> cluster_ptr;                               // n_clusters + 1: first row of each cluster in cluster_row
+    DevArray<uint64_t> cluster_inv_ptr;                           // n_clusters + 1: offset of each cluster's inverse (order^2 values, row-major)
+    DevArray<uint32_t> tile_cluster, tile_row0;                   // per 64-row tile: its cluster and first row within it
+    DevArray<double> cinv64;
+    DevArray<float> cinv32;
+    bool any() const { return n_patches || n_clusters; }
+    size_t scratch_rows() const { return size_t(n_patches) * 3 * npe + cluster_rows; } // rows of the work panel mh_apply_patches needs
 };
 
 struct mh_system {
@@ -491,11 +509,12 @@ inline int mh_guard(mh_context *ctx, const std::exception &e) {
 inline unsigned div_up(size_t a, size_t b) { return unsigned((a + b - 1) / b); }
 
 // ---- stage entry points implemented across the .hip files ----
-void mh_phase_shared_lock();   // mh_eigs.hip: MH_CONCURRENT_SOLVES -- device work of other entry points keeps out of an exclusive
-void mh_phase_shared_unlock(); // factorisation phase (no-ops in the default, serialised mode)
+void mh_phase_shared_lock(int device);   // mh_eigs.hip: device work of other entry points keeps out of an exclusive factorisation phase
+void mh_phase_shared_unlock(int device); // ON THE SAME DEVICE (one lock per device; no-ops with MH_CONCURRENT_SOLVES=0)
 struct MhSharedPhase {
-    MhSharedPhase() { mh_phase_shared_lock(); }
-    ~MhSharedPhase() { mh_phase_shared_unlock(); }
+    const int device;
+    explicit MhSharedPhase(int dev) : device(dev) { mh_phase_shared_lock(device); }
+    ~MhSharedPhase() { mh_phase_shared_unlock(device); }
     MhSharedPhase(const MhSharedPhase &) = delete;
     MhSharedPhase &operator=(const MhSharedPhase &) = delete;
 };
@@ -508,7 +527,7 @@ uint32_t mh_shift_invert_panel(mh_system *sys, double sigma, const double *b, do
 uint32_t mh_graph_aggregates(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col, uint32_t n, uint32_t target, uint32_t max_order, std::vector<uint32_t> &agg_of); // mh_pipeline.hip
 void mh_select_patches(mh_system *sys, float threshold);                                  // mh_patch.hip: elements whose shape measure is below the threshold
 void mh_build_patch_inverses(mh_context *ctx, const BsrLevel &lvl, PatchSet &ps);         // mh_patch.hip: (A_ee)^-1 of every patch from lvl.aval
-// d += s, x += s (either may be null) or z (double, pitch wz) += s with s = coef * sum_e R_e^T (A_ee)^-1 R_e (in - minus); scratch: n_patches x 3 npe x w
+// d += s, x += s (either may be null) or z (double, pitch wz) += s with s = coef * sum_e R_e^T (A_ee)^-1 R_e (in - minus), e over element patches and clusters; scratch: ps.scratch_rows() x w
 template<typename T>
 void mh_apply_patches(mh_context *ctx, const PatchSet &ps, const T *in, const T *minus, uint32_t w, T coef, T *d, T *x, double *z, uint32_t wz, T *scratch);
 // y (n x w row-major, ld = w) = A x with A given by 9-value blocks; optionally y2 = M x from the scalar blocks.

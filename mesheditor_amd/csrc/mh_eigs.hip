@@ -74,6 +74,7 @@ struct Switches {
     double cheb_ratio = 0.0, cheb_ratio1 = 0.0; // (ratio1: the P1 level's own interval, optional fifth value of MH_CYCLE)
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
+    bool test_selfcheck_fail = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "selfcheck_fail"); // the first solve's Rayleigh-Ritz self-check reports a failure
     bool no_poly_start = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_poly_start"); // (A/B hook of round 5: the cold start block as rounds 1-4 had it)
     Switches() {
         if (const char *c = getenv("MH_CYCLE")) {
@@ -94,6 +95,7 @@ constexpr int kPowerIterations = 20; // spectral-bound estimate of the smoothers
 constexpr uint32_t kPrecondColumns = 256; // (narrower slabs measured slower on the 215-pair solves: 128 -> +2 %, 80 -> +5 %, 64 -> +9 %) // widest panel of one preconditioner application (the single-precision wide-load products: 64 lanes x 4)
 constexpr uint32_t kSkipP = 4;       // no conjugate directions in the first iterations of a cold start
 constexpr uint32_t kGuardPercent = 10; // guard vectors: max(15, 10 % of the wanted pairs)
+constexpr float kFlatShape = 1e-4f; // element shape measure below which a mesh counts as having flat cells: double-precision smoothers from the start
 constexpr size_t kDenseLastResort = 12288; // unknowns up to which a solve that did not converge is redone as one dense eigensolve (2 x 1.2 GB, seconds)
 
 // readers-writer lock with writer priority (glibc's shared_mutex prefers readers: iterating solves would starve a factorisation)
@@ -124,25 +126,33 @@ struct PhaseLock {
         cv.notify_all();
     }
 };
-PhaseLock g_phase;
+// One lock per DEVICE (round 6): what a factorisation must be alone with is its own GPU's queue -- a tiny dense solve on GPU 0 has no
+// business stalling the solves of GPUs 1-7 of the same process (modal::SolveBatch with several devices per process; one process per GPU
+// never sees more than one).  hipDeviceSynchronize below drains the current device only, which is the one locked.
+constexpr int kMaxDevices = 64;
+PhaseLock g_phase_of_device[kMaxDevices];
+PhaseLock &phase_of(int device) { return g_phase_of_device[unsigned(device) % kMaxDevices]; }
 const bool g_concurrent = !(getenv("MH_CONCURRENT_SOLVES") && atoi(getenv("MH_CONCURRENT_SOLVES")) == 0);
 struct SharedPhase { // no-ops in the serialised mode (and for a solve that holds the device exclusively: enabled = false)
+    PhaseLock &phase;
     bool held = false, enabled = true;
-    explicit SharedPhase(bool on = true) : enabled(on) { acquire(); }
+    explicit SharedPhase(int device, bool on = true) : phase(phase_of(device)), enabled(on) { acquire(); }
     ~SharedPhase() { release(); }
-    void acquire() { if (g_concurrent && enabled && !held) { g_phase.lock_shared(); held = true; } }
-    void release() { if (held) { g_phase.unlock_shared(); held = false; } }
+    void acquire() { if (g_concurrent && enabled && !held) { phase.lock_shared(); held = true; } }
+    void release() { if (held) { phase.unlock_shared(); held = false; } }
 };
 struct ExclusivePhase {
+    PhaseLock &phase;
     bool held = false;
-    ExclusivePhase() {
+    explicit ExclusivePhase(int device) : phase(phase_of(device)) {
         if (g_concurrent) {
-            g_phase.lock();
+            phase.lock();
             held = true;
-            (void)hipDeviceSynchronize(); // everything the iterating solves had queued has drained: the device is ours
+            (void)hipSetDevice(device);
+            (void)hipDeviceSynchronize(); // everything the iterating solves had queued ON THIS DEVICE has drained: it is ours
         }
     }
-    ~ExclusivePhase() { if (held) g_phase.unlock(); }
+    ~ExclusivePhase() { if (held) phase.unlock(); }
 };
 
 struct Timer {
@@ -839,7 +849,7 @@ int rr_solve(mh_context *ctx, double *gA, double *gM, uint32_t m, double *evals,
         // there (8.3 of 15 ms at order 720); k_sytrd_wide does it in 4.4 ms across 48 workgroups, then the library's divide and
         // conquer on T and its back-transformation.  A give-up (see above) falls back to the library's syevd on the saved matrix.
         bool done = false;
-        if (m > 256 && m <= 768) {
+        if (m > 256 && m <= 768 && !ctx->exchange_disabled) {
             DevArray<double> z(ctx, size_t(m) * m), saved(ctx, size_t(m) * m), tau(ctx, m);
             HIP_CHECK(hipMemcpyAsync(saved.get(), gA, size_t(m) * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             mh_sytrd_wide(ctx, gA, m, evals, ework, tau);
@@ -933,7 +943,7 @@ template<typename T> struct Precond {
         r0.reset(ctx, n0 * w);
         x0.reset(ctx, n0 * w);
         x0_partial.reset(ctx, n0 * w * COARSE_SLICES);
-        patch_y.reset(ctx, std::max(size_t(s->patches2.n_patches) * 30, size_t(s->patches1.n_patches) * 12) * w);
+        patch_y.reset(ctx, std::max(s->patches2.scratch_rows(), s->patches1.scratch_rows()) * w);
         const Switches &sw = switches();
         // Three cycle shapes, each the measured best of its class (round 5; MH_CYCLE = deg2, deg1, gamma, ratio[, ratio1] overrides; profiles/r05_cycle_by_body.txt):
         //  * a mesh with SLIVER PATCHES: P2 Chebyshev degree 5 over [lmax / 60, lmax]; P1: see below (three cycles of degree 5 over the same ratio until the end of round 5).  The P1 space
@@ -950,7 +960,7 @@ template<typename T> struct Precond {
         //    26^3 / 17^3 / 12^3 cubes 133.0 -> 122.3 / 54.7 -> 49.8 / 32.8 -> 31.4 ms, the batch of 64 boxes 1.65 -> 1.54 s (with [lmax / 8, lmax] the
         //    same single cycle LOSES 10 %: the interval is what makes it work).
         const bool surface_dominated = s->kept_tets < 4.5 * s->n_points;
-        if (s->patches2.n_patches) {
+        if (s->patches2.any()) {
             deg2 = 5;
             ratio = 60.0;
             // one P1 cycle of degree 28 over [lmax / 800, lmax]: the single cycle of degree 16 over lmax / 250 that suits the patch-free bodies lost 6-8 % on
@@ -959,7 +969,7 @@ template<typename T> struct Precond {
             // unrepaired scan_s100k 570 -> 579, ball and 30k-tet scans within 1 %
             // -- except the fills DENSE in patches at blocks up to 128 columns (unrepaired scans with and without interior points, 9-28 patches per
             // thousand tetrahedra: 65-pair solves +2 ... +8 % with it; the repaired fills have 0.3-0.5 per thousand), which keep three cycles of degree 5
-            const bool few_patches = uint64_t(s->patches2.n_patches) * 500 < s->kept_tets;
+            const bool few_patches = uint64_t(s->patches2.n_bad_elements) * 500 < s->kept_tets;
             if (w_in > 128 || few_patches) deg1 = 28, gamma = 1, ratio1 = 800.0;
         } else if (surface_dominated) {
             deg2 = 5;
@@ -1091,7 +1101,7 @@ template<typename T> struct Precond {
 double estimate_lmax(mh_context *ctx, BsrLevel &lvl, const PatchSet &ps) {
     const uint32_t w = 8;
     const size_t rows = size_t(3) * lvl.n_nodes;
-    DevArray<double> v(ctx, rows * w), t(ctx, rows * w), nrm(ctx, w), scratch, py(ctx, size_t(ps.n_patches) * 3 * ps.npe * w);
+    DevArray<double> v(ctx, rows * w), t(ctx, rows * w), nrm(ctx, w), scratch, py(ctx, ps.scratch_rows() * w);
     k_random_panel<<<grid1(rows * w), TB, 0, ctx->stream>>>(v, rows * w, 0x5eedull);
     KERNEL_CHECK();
     colsumsq(ctx, v, rows, w, nrm, scratch);
@@ -1135,12 +1145,12 @@ void mh_finish_hierarchy(mh_system *sys) {
     sys->coarse_info.download(&hinfo, 1); // (on the main stream, i.e. after the elimination)
     for (auto &ws : sys->coarse_ws) ws.reset(ctx, 0);
     for (PatchSet *ps : {&sys->patches2, &sys->patches1}) { // sliver patches that were dropped (block not safely positive definite)
-        if (!ps->n_patches || !ps->dropped.count) continue;
+        if (!ps->any() || !ps->dropped.count) continue;
         int dropped[2] = {0, 0};
         ps->dropped.download(dropped, 2);
         sys->dropped_patches[ps->npe == 10 ? 0 : 1] = uint32_t(dropped[0]);
         if (dropped[0] && switches().verbose)
-            fprintf(stderr, "[lobpcg] %d of %u sliver patches of the %s level dropped (e.g. patch %d): their nodes keep the diagonal scaling only\n", dropped[0], ps->n_patches,
+            fprintf(stderr, "[lobpcg] %d of %u + %u sliver patches / clusters of the %s level dropped (e.g. patch %d; clusters count from 1000000): their nodes keep the diagonal scaling only\n", dropped[0], ps->n_patches, ps->n_clusters,
                     ps->npe == 10 ? "P2" : "P1", dropped[1] - 1);
     }
     if (hinfo != 0) {
@@ -1322,7 +1332,7 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues,
     k_bsr_to_dense<<<grid1(lvl.n_nodes), TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, lvl.mval, lvl.n_nodes, a, m);
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ExclusivePhase alone_on_the_device;
+    ExclusivePhase alone_on_the_device(ctx->device);
     double *lhs = inverse ? m.get() : a.get(), *rhs = inverse ? a.get() : m.get(); // (vectors come back in lhs)
     ROCBLAS_CHECK(rocsolver_dsygvd(ctx->blas, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_lower, rocblas_int(n), lhs, rocblas_int(n), rhs, rocblas_int(n), d, e, info));
     int hinfo = 0;
@@ -1375,6 +1385,8 @@ struct BlockLobpcg {
     Timer t_iter;
     double precond_seconds = 0;
     double best_worst_active = 1e300; // smallest worst relative residual of the active columns seen so far
+    double restart_best = 1e300, last_worst_active = 0; // the same since the last restart; the previous iteration's
+    uint32_t growth_run = 0, restarts = 0, drop_p_until = 0; // iterations of growth in a row; restarts made; no conjugate directions before this iteration
     int floor_strikes = 0;            // consecutive iterations in which the worst active residual sat 1e3 above it
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
@@ -1424,7 +1436,7 @@ struct BlockLobpcg {
                 uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_)
         : sys(system), ctx(system->ctx), st(system->ctx->stream), n(size_t(3) * system->n_nodes), nev(nev_), b(block), mmax(3 * block), sigma(sigma_), residual_tol(residual_tol_),
           max_iters(max_iters_), seed_basis(seed_basis_), seed_rows(seed_rows_), seed_cols(seed_cols_), cancel(cancel_), progress(progress_), prof(prof_), profile(profile_),
-          iterating(true), t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.n_patches > 0), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
+          iterating(system->ctx->device, true), t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.any()), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
           theta_act(block), order(block), locked(block, 0) {
         for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &Pn, &R, &Rw}) panel->reset(ctx, n * b);
         if (!pproj_ok) // M P is only kept for blocks wider than 128 columns (the narrower ones project against P in coefficient space)
@@ -1450,7 +1462,10 @@ struct BlockLobpcg {
             res_norms.resize(size_t(2) * pmax);
         }
         info.reset(ctx, 2);
-        if (fp32_prec) prec32 = std::make_unique<Precond<float>>(sys, std::min(b, kPrecondColumns));
+        // Single-precision smoothers unless the mesh has FLAT cells (round 6): an element of shape 1e-9 puts entries 1e9 times its neighbours'
+        // into the operator, and the residuals of its rows -- differences of such entries -- have no correct digit in fp32; the clusters'
+        // inverses (condition number ~ 1 / shape) then turn that noise into the iterate.  Such a mesh starts in double precision.
+        if (fp32_prec && !(sys->worst_quality < kFlatShape)) prec32 = std::make_unique<Precond<float>>(sys, std::min(b, kPrecondColumns));
         else prec64 = std::make_unique<Precond<double>>(sys, std::min(b, kPrecondColumns));
         auto hd = sys->L2.dinv.to_host();
         double dmin = 1e300;
@@ -1722,7 +1737,7 @@ struct BlockLobpcg {
         if (verbose) {
             double worst = 0;
             for (uint32_t k = 0; k < nev; ++k) { const uint32_t i = order[k]; worst = std::max(worst, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i]))); }
-            if (it == 0) fprintf(stderr, "[lobpcg] ||A|| <= %.3e, sliver patches %u (worst element shape %.2e), aggregates %u, lmax %.4f / %.4f\n", anorm, sys->patches2.n_patches, double(sys->worst_quality), sys->n_agg, sys->L2.lmax, sys->L1.lmax);
+            if (it == 0) fprintf(stderr, "[lobpcg] ||A|| <= %.3e, sliver patches %u + %u clusters (largest %u nodes; worst element shape %.2e), aggregates %u, lmax %.4f / %.4f\n", anorm, sys->patches2.n_patches, sys->patches2.n_clusters, sys->patches2.largest_cluster, double(sys->worst_quality), sys->n_agg, sys->L2.lmax, sys->L1.lmax);
             fprintf(stderr, "[lobpcg] it %3u conv %3u/%u active %zu wp %u worst %.2e  floor-ratio[0..7]:", it, nconv, nev, act.size(), wp, worst);
             for (uint32_t i = 0; i < std::min(8u, b); ++i) fprintf(stderr, " %.1f", xn[i] > 0 ? std::sqrt(rn[i]) / (2.2e-16 * (scaled_norms ? sys->L2.lmax : anorm) * std::sqrt(xn[i])) : 0.0);
             fprintf(stderr, "  theta0 %.6e\n", theta[0]);
@@ -1755,6 +1770,20 @@ struct BlockLobpcg {
                 if (!locked[i]) worst_active = std::max(worst_active, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
             }
             best_worst_active = std::min(best_worst_active, worst_active);
+            // ... and before it comes to that: residuals of the active columns that have GROWN for two iterations running, to four times their best,
+            // with nothing newly converged, are the onset of that loss of rank -- on a mesh with flat cells (||A|| / theta ~ 1e8 and up) it sets in long
+            // before the wanted pairs are done (128 x 64 UV sphere with 346 cells flat to 5e-10: 57 of 65 pairs at iteration 60, residuals then 9e-5
+            // -> 1e-3 -> 1e+1 in twenty iterations).  The cure is the textbook one: drop the conjugate directions for two iterations (a restart on
+            // [X W]) and measure growth afresh; at most eight times per solve.
+            growth_run = (h > 1 && worst_active > last_worst_active && hist_nconv[h - 2] == nconv) ? growth_run + 1 : 0;
+            last_worst_active = worst_active;
+            if (it >= 12 && growth_run >= 2 && worst_active > 4 * restart_best && restarts < 8) {
+                if (verbose) fprintf(stderr, "[lobpcg] it %3u residuals growing (%.1e from %.1e): two iterations without conjugate directions\n", it, worst_active, restart_best);
+                drop_p_until = it + 2;
+                ++restarts;
+                growth_run = 0;
+                restart_best = worst_active;
+            } else restart_best = std::min(restart_best, worst_active);
             // (three iterations in a row: one step's jump is also what a guard column looks like when its Ritz value drops into the
             // wanted range late -- a missed member of a multiplet arrives with a residual of 1e-2 .. 1e-1 beside pairs just above the tolerance)
             floor_strikes = it >= 20 && worst_active > 1e3 * best_worst_active ? floor_strikes + 1 : 0;
@@ -1977,6 +2006,7 @@ struct BlockLobpcg {
         // count is the same without it (18 and 18 at S100k) -- and an iteration on [X W] costs a third less
         // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
         if (!warm && it < kSkipP && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
+        if (it < drop_p_until) wp_new = 0; // (a restart: converged_or_locked saw the residuals grow)
         if (wp_new) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
             small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m);
             small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new);
@@ -2074,6 +2104,7 @@ struct BlockLobpcg {
         read_health();
         sys->profile = prof;
         if (profile) *profile = prof;
+        if (switches().test_selfcheck_fail && !ctx->exchange_disabled) prof.rr_selfcheck = 1.0; // (test hook: the redo in eigs_impl)
         if (!(prof.rr_selfcheck < 1e-8))
             mh_throw(MH_EHIP, "Rayleigh-Ritz self-check failed: a step's eigenpairs leave a relative residual of %.2e against the step's own matrix", prof.rr_selfcheck);
     }
@@ -2148,8 +2179,22 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             if (progress) *progress = 0.3f;
             try {
                 try {
-                    BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
-                    solver.run(eigenvalues);
+                    try {
+                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
+                        solver.run(eigenvalues);
+                    } catch (const MhError &e) {
+                        // A Rayleigh-Ritz step whose eigenpairs do not fit the step's own matrix (k_rr_selfcheck: sampled per step, read once at
+                        // the end) means a dense kernel delivered wrong numbers -- in rounds 2-4 the tagged exchange beside an LDS-bound
+                        // neighbour.  Rather than hand the caller MH_EHIP after a whole solve's time: once more with the
+                        // exchange kernel out of the path (orders 257-768 go to the library's syevd); the context remembers.
+                        if (e.code != MH_EHIP || !strstr(e.what(), "self-check") || ctx->exchange_disabled) throw;
+                        if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- once more without the exchange kernels\n", e.what());
+                        ctx->exchange_disabled = true;
+                        prof = sys->profile;
+                        prof.dofs = uint32_t(n);
+                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
+                        solver.run(eigenvalues);
+                    }
                 } catch (const MhError &e) {
                     // A Chebyshev smoother whose interval ends below lmax(D^-1 A) amplifies the top of the spectrum instead of damping it -- by
                     // T_deg(1 + 2 x overshoot): twelve-fold per smoothing at degree 16 for 2 %.  The bound is a power-iteration estimate times 1.1
@@ -2229,7 +2274,9 @@ uint32_t mh_shift_invert_panel(mh_system *sys, double sigma, const double *b, do
     const size_t n = size_t(3) * sys->n_nodes;
     if (!(sigma < 0)) mh_throw(MH_EFACTOR, "shift-invert: the shift must be negative (K - sigma M positive definite)");
     if (w == 0 || w > 64) mh_throw(MH_EINVAL, "shift-invert panel: %u columns outside 1..64", w);
-    SharedPhase solving;
+    std::unique_lock<std::mutex> one_solve_at_a_time(g_solve_mutex, std::defer_lock); // MH_CONCURRENT_SOLVES=0 serialises this entry point like mh_eigs
+    if (!g_concurrent) one_solve_at_a_time.lock();
+    SharedPhase solving(ctx->device);
     mh_build_hierarchy(sys, sigma); // (finished: the coarse inverse is waited for)
     Precond<double> prec(sys, w);
     DevArray<double> r(ctx, n * w), z(ctx, n * w), p(ctx, n * w), ap(ctx, n * w), rz(ctx, w), rz_new(ctx, w), pap(ctx, w), rn(ctx, w), scratch;
@@ -2288,15 +2335,25 @@ uint32_t mh_shift_invert_panel(mh_system *sys, double sigma, const double *b, do
             HIP_CHECK(hipMemcpyAsync(rz.get(), rz_new.get(), w * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
     }
+    // what is reported and judged is the TRUE residual of the x that is returned, not the one a restart began with (the inner loop may
+    // have ended on max_iters, or the sixth restart may just have finished)
+    mh_spmm(ctx, sys->L2, sys->L2.aval, x, ap, nullptr, nullptr, w);
+    HIP_CHECK(hipMemcpyAsync(r.get(), ap.get(), n * w * sizeof(double), hipMemcpyDeviceToDevice, st));
+    k_axpy_panel<<<grid1(n * w), TB, 0, st>>>(r, b, n * w);
+    KERNEL_CHECK();
+    dot(r, r, rn);
+    rn.download(rnh.data(), w);
+    worst = worst_of();
     if (worst_rel) *worst_rel = worst;
+    // accepted: the tolerance asked for, or -- where eps ||A|| ||x|| / ||b|| lies above it (a direct solve's residual too) -- 1e-8
     if (!(worst <= std::max(rel_tol, 1e-8))) mh_throw(MH_ENOTCONVERGED, "shift-invert: relative residual %.2e after %u iterations (asked %.1e)", worst, it, rel_tol);
     HIP_CHECK(hipStreamSynchronize(st));
     return it;
 }
 
 std::mutex &mh_solve_mutex() { return g_solve_mutex; }
-void mh_phase_shared_lock() { if (g_concurrent) g_phase.lock_shared(); }
-void mh_phase_shared_unlock() { if (g_concurrent) g_phase.unlock_shared(); }
+void mh_phase_shared_lock(int device) { if (g_concurrent) phase_of(device).lock_shared(); }
+void mh_phase_shared_unlock(int device) { if (g_concurrent) phase_of(device).unlock_shared(); }
 
 extern "C" int mh_eigs(mh_system *sys, uint32_t nev, double sigma, double residual_tol, uint32_t max_iters, const float *seed_basis, uint32_t seed_rows,
                        uint32_t seed_cols, const volatile unsigned char *cancel, volatile float *progress, double *eigenvalues, mh_profile *profile) {

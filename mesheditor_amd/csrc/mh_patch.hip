@@ -18,6 +18,14 @@
 
 namespace {
 constexpr int TB = 256;
+struct PerDeviceOnce { // hipFuncSetAttribute once per (kernel, device)
+    std::mutex m;
+    bool done[64] = {};
+    template<typename F> void run(int device, F &&f) {
+        std::lock_guard<std::mutex> l(m);
+        if (!done[unsigned(device) % 64]) f(), done[unsigned(device) % 64] = true;
+    }
+};
 
 __global__ void k_element_quality(const double *__restrict__ pts, const uint32_t *__restrict__ elem_ref, uint32_t stride, uint32_t nt, float *__restrict__ q, float threshold,
                                   uint32_t *__restrict__ summary) {
@@ -157,6 +165,160 @@ __global__ void k_patch_gather(const T *__restrict__ y, uint32_t w, const uint32
     if (x) x[row * w + c] += s;
     if (z && c < wz) z[row * wz + c] += double(s);
 }
+// ---- clusters: one exact inverse on the union of the nodes of badly shaped elements that hang together (PatchSet, mh_common.h) ----
+// The principal submatrix of the level's operator on a cluster's rows, dense row-major of order N = rows of the cluster: one thread per
+// pair of nodes (binary search of the BSR row), blockIdx.x = cluster, the pairs strided over blockIdx.y.
+__global__ void k_cluster_block(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ aval, const uint32_t *__restrict__ crow,
+                                const uint32_t *__restrict__ cptr, const uint64_t *__restrict__ iptr, double *__restrict__ out) {
+    const uint32_t c = blockIdx.x, r0 = cptr[c], N = cptr[c + 1] - r0, nn = N / 3;
+    double *a = out + iptr[c];
+    for (uint64_t pair = uint64_t(blockIdx.y) * blockDim.x + threadIdx.x; pair < uint64_t(nn) * nn; pair += uint64_t(gridDim.y) * blockDim.x) {
+        const uint32_t ia = uint32_t(pair / nn), ib = uint32_t(pair % nn);
+        const uint32_t r = crow[r0 + 3 * ia] / 3, cc = crow[r0 + 3 * ib] / 3;
+        uint32_t lo = row_ptr[r], hi = row_ptr[r + 1];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (col[mid] < cc) lo = mid + 1;
+            else hi = mid;
+        }
+        const bool found = lo < row_ptr[r + 1] && col[lo] == cc;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) a[size_t(3 * ia + i) * N + 3 * ib + j] = found ? aval[9 * size_t(lo) + 3 * i + j] : 0.0;
+    }
+}
+
+// Clusters of order <= 128: Gauss-Jordan in LDS, one workgroup each (as k_patch_inverse, order at run time); `list` = the clusters of this launch.
+__global__ void __launch_bounds__(128) k_cluster_inverse_lds(const uint32_t *__restrict__ list, const uint32_t *__restrict__ cptr, const uint64_t *__restrict__ iptr, double *__restrict__ inv,
+                                                           int *__restrict__ info) {
+    extern __shared__ double lds_a[];
+    const uint32_t c = list[blockIdx.x];
+    const int N = int(cptr[c + 1] - cptr[c]), LD = N + 1, tid = threadIdx.x;
+    double *g = inv + iptr[c];
+    for (int e = tid; e < N * N; e += 128) lds_a[(e / N) * LD + e % N] = g[e];
+    __shared__ double floor_;
+    __syncthreads();
+    if (tid == 0) {
+        double dmax = 0;
+        for (int k = 0; k < N; ++k) dmax = fmax(dmax, lds_a[k * LD + k]);
+        floor_ = 1e-13 * dmax;
+    }
+    __syncthreads();
+    const double floor = floor_;
+    bool bad = false;
+    for (int k = 0; k < N; ++k) {
+        const double piv = lds_a[k * LD + k];
+        if (!(piv > floor)) bad = true;
+        const double d = 1.0 / piv;
+        __syncthreads();
+        if (tid < N && tid != k) lds_a[k * LD + tid] *= d;
+        __syncthreads();
+        if (tid < N && tid != k) {
+            const double f = lds_a[tid * LD + k];
+            for (int j = 0; j < N; ++j)
+                if (j != k) lds_a[tid * LD + j] -= f * lds_a[k * LD + j];
+            lds_a[tid * LD + k] = -f * d;
+        }
+        if (tid == k) lds_a[k * LD + k] = d;
+        __syncthreads();
+    }
+    if (bad && tid == 0) {
+        atomicAdd(info, 1);
+        atomicMax(info + 1, int(c) + 1000001); // (cluster ids are reported above a million: told apart from element patches)
+    }
+    for (int e = tid; e < N * N; e += 128) g[e] = bad ? 0.0 : lds_a[(e / N) * LD + e % N];
+}
+
+// y_c = inv_c (R_c v), v = in - (minus ? minus : 0): 64 x 64 output tiles, K in slices of 32 through LDS, 4 x 4 values per thread.
+template<typename T>
+__global__ void __launch_bounds__(256) k_cluster_apply(const T *__restrict__ in, const T *__restrict__ minus, uint32_t w, const uint32_t *__restrict__ crow, const uint32_t *__restrict__ cptr,
+                                                      const uint64_t *__restrict__ iptr, const uint32_t *__restrict__ tile_cluster, const uint32_t *__restrict__ tile_row0,
+                                                      const T *__restrict__ inv, T *__restrict__ y) {
+    constexpr int KT = 32;
+    __shared__ T s_inv[64][KT + 1];
+    __shared__ T s_v[KT][64 + 1];
+    const uint32_t c = tile_cluster[blockIdx.x], row0 = tile_row0[blockIdx.x], r0 = cptr[c], N = cptr[c + 1] - r0, col0 = blockIdx.y * 64;
+    const T *m = inv + iptr[c];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    T acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    for (uint32_t k0 = 0; k0 < N; k0 += KT) {
+        for (int e = tid; e < 64 * KT; e += 256) {
+            const uint32_t r = row0 + e / KT, k = k0 + e % KT;
+            s_inv[e / KT][e % KT] = (r < N && k < N) ? m[size_t(r) * N + k] : T(0);
+        }
+        for (int e = tid; e < KT * 64; e += 256) {
+            const uint32_t k = k0 + e / 64, cc = col0 + e % 64;
+            T v = 0;
+            if (k < N && cc < w) {
+                const size_t o = size_t(crow[r0 + k]) * w + cc;
+                v = minus ? in[o] - minus[o] : in[o];
+            }
+            s_v[e / 64][e % 64] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < KT; ++k) {
+            T a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = s_inv[ty * 4 + i][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = s_v[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t r = row0 + ty * 4 + i;
+        if (r >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cc = col0 + tx * 4 + j;
+            if (cc < w) y[size_t(r0 + r) * w + cc] = acc[i][j];
+        }
+    }
+}
+
+// the clusters' rows are pairwise distinct: s = coef * y goes straight to its row; d += s, x += s (either may be null), or z (double, pitch wz) += s
+template<typename T>
+__global__ void k_cluster_scatter(const T *__restrict__ y, uint32_t w, const uint32_t *__restrict__ crow, uint32_t nrows, T coef, T *__restrict__ d, T *__restrict__ x, double *__restrict__ z,
+                                  uint32_t wz) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(nrows) * w) return;
+    const uint32_t c = uint32_t(i % w);
+    const size_t row = crow[i / w];
+    const T s = coef * y[i];
+    if (d) d[row * w + c] += s;
+    if (x) x[row * w + c] += s;
+    if (z && c < wz) z[row * wz + c] += double(s);
+}
+
+__global__ void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, size_t count) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = float(in[i]);
+}
+__global__ void k_copy_block(const double *__restrict__ in, uint32_t ldi, double *__restrict__ out, uint32_t ldo, uint32_t rows, uint32_t cols) { // out[r][c] = in[r][c] (column-major, lds as given)
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(rows) * cols) return;
+    const size_t c = i / rows, r = i % rows;
+    out[c * ldo + r] = in[c * ldi + r];
+}
+__global__ void k_symmetrize(double *__restrict__ a, uint32_t n) { // both triangles = their mean
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(n) * n) return;
+    const size_t r = i / n, c = i % n;
+    if (c < r) {
+        const double v = 0.5 * (a[r * n + c] + a[c * n + r]);
+        a[r * n + c] = v;
+        a[c * n + r] = v;
+    }
+}
 } // namespace
 
 // Shape measure of every kept element; the elements below `threshold` become the patch list of both levels (host: a few
@@ -195,13 +357,55 @@ void mh_select_patches(mh_system *sys, float threshold) {
     // scan workloads (iterations, surface-refined / interior fills at 30k and 95k tets): unscaled 27 / 39 / 44 / 54; exponent -1
     // 26 / 40 / 54 / 57; -0.5 26 / 34 / 45 / 50; -0.35 26 / 33 / 44 / 48; a greedy independent set of patches instead 29 / 45 / 77 / 76.
     constexpr double overlap_exponent = -0.35;
-    const auto fill = [&](PatchSet &ps, const std::vector<uint32_t> &elem, uint32_t npe) {
-        const uint32_t np = uint32_t(bad.size());
+    // Connected components of the bad elements (two of them hang together when they share a P2 node).  A component of ONE element stays an
+    // element patch (30 x 30 / 12 x 12, the kernels above); a component of two or more -- a pole fan's needles, caps stacked on one another, the
+    // slivers along a scan's sharp rim -- becomes a CLUSTER: one exact inverse on the union of its nodes (PatchSet, mh_common.h).
+    // Clusters are for meshes with FLAT cells (worst shape below 1e-4): there they turn "no convergence" into the iteration count of a well-shaped
+    // mesh (96 x 48 UV sphere's fill with 172 cells flat to 1e-8: 54 -> 23 iterations).  On the scan fills (worst shape ~1e-3, slivers strung along
+    // the rims in components of up to 163 elements) they save 4-7 iterations of 41 and cost twice the time in dense products: element patches
+    // there, as before.  MH_CLUSTERS=1 forces them, =0 forbids.
+    static const int cluster_switch = getenv("MH_CLUSTERS") ? atoi(getenv("MH_CLUSTERS")) : -1;
+    const bool use_clusters = cluster_switch == 1 || (cluster_switch != 0 && sys->worst_quality < 1e-4f);
+    static const uint32_t cluster_cap = getenv("MH_CLUSTER_CAP") ? uint32_t(std::max(16, atoi(getenv("MH_CLUSTER_CAP")))) : 2048u; // nodes: an inverse of order 6 144 at most
+    std::vector<uint32_t> comp(bad.size());
+    {
+        std::vector<uint32_t> parent(bad.size());
+        for (uint32_t k = 0; k < bad.size(); ++k) parent[k] = k;
+        const auto find = [&](uint32_t a) {
+            while (parent[a] != a) a = parent[a] = parent[parent[a]];
+            return a;
+        };
+        std::vector<int32_t> owner(sys->n_nodes, -1);
+        for (uint32_t k = 0; k < bad.size(); ++k)
+            for (uint32_t a = 0; a < 10; ++a) {
+                const uint32_t v = en[size_t(bad[k]) * 10 + a];
+                if (owner[v] < 0) owner[v] = int32_t(k);
+                else {
+                    const uint32_t ra = find(uint32_t(owner[v])), rb = find(k);
+                    if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb); // (the root is the component's first element: deterministic)
+                }
+            }
+        for (uint32_t k = 0; k < bad.size(); ++k) comp[k] = find(k);
+    }
+    std::vector<uint32_t> comp_size(bad.size(), 0);
+    for (uint32_t k = 0; k < bad.size(); ++k) ++comp_size[comp[k]];
+    std::vector<uint32_t> single; // positions in `bad` of the elements that stay element patches
+    std::vector<std::vector<uint32_t>> multi; // per cluster component: positions in `bad`, ascending
+    {
+        std::vector<int32_t> slot(bad.size(), -1);
+        for (uint32_t k = 0; k < bad.size(); ++k) {
+            if (!use_clusters || comp_size[comp[k]] == 1) { single.push_back(k); continue; }
+            if (slot[comp[k]] < 0) slot[comp[k]] = int32_t(multi.size()), multi.emplace_back();
+            multi[size_t(slot[comp[k]])].push_back(k);
+        }
+    }
+    const auto fill = [&](PatchSet &ps, const std::vector<uint32_t> &elem, uint32_t npe, uint32_t n_level_nodes) {
+        const uint32_t np = uint32_t(single.size());
         std::vector<uint32_t> nodes(size_t(np) * npe);
         std::vector<std::pair<uint32_t, uint32_t>> inc; // (node, patch * npe + local)
         for (uint32_t p = 0; p < np; ++p)
             for (uint32_t a = 0; a < npe; ++a) {
-                nodes[size_t(p) * npe + a] = elem[size_t(bad[p]) * npe + a];
+                nodes[size_t(p) * npe + a] = elem[size_t(bad[single[p]]) * npe + a];
                 inc.emplace_back(nodes[size_t(p) * npe + a], p * npe + a);
             }
         std::sort(inc.begin(), inc.end());
@@ -222,57 +426,183 @@ void mh_select_patches(mh_system *sys, float threshold) {
             std::vector<uint32_t> worst(np, 1);
             for (size_t t = 0; t + 1 < ptr.size(); ++t)
                 for (uint32_t l = ptr[t]; l < ptr[t + 1]; ++l) worst[tp[l]] = std::max(worst[tp[l]], cover[t]);
-            for (uint32_t p = 0; p < np; ++p) weight[p] = std::pow(double(worst[p]), overlap_exponent);
+            for (uint32_t p = 0; p < np; ++p) weight[p] = std::pow(double(worst[p]), overlap_exponent); // (1 with clusters: single components share no node)
         }
-        ps.weight.reset(ctx, np);
-        ps.weight.upload(weight.data(), np);
         ps.n_patches = np;
+        ps.n_bad_elements = uint32_t(bad.size());
         ps.n_touched = uint32_t(touched.size());
-        ps.nodes.reset(ctx, nodes.size());
-        ps.touched.reset(ctx, touched.size());
-        ps.t_ptr.reset(ctx, ptr.size());
-        ps.t_patch.reset(ctx, tp.size());
-        ps.t_local.reset(ctx, tl.size());
-        ps.nodes.upload(nodes.data(), nodes.size());
-        ps.touched.upload(touched.data(), touched.size());
-        ps.t_ptr.upload(ptr.data(), ptr.size());
-        ps.t_patch.upload(tp.data(), tp.size());
-        ps.t_local.upload(tl.data(), tl.size());
+        if (np) {
+            ps.weight.reset(ctx, np);
+            ps.weight.upload(weight.data(), np);
+            ps.nodes.reset(ctx, nodes.size());
+            ps.touched.reset(ctx, touched.size());
+            ps.t_ptr.reset(ctx, ptr.size());
+            ps.t_patch.reset(ctx, tp.size());
+            ps.t_local.reset(ctx, tl.size());
+            ps.nodes.upload(nodes.data(), nodes.size());
+            ps.touched.upload(touched.data(), touched.size());
+            ps.t_ptr.upload(ptr.data(), ptr.size());
+            ps.t_patch.upload(tp.data(), tp.size());
+            ps.t_local.upload(tl.data(), tl.size());
+        }
+        // clusters: the union of each component's nodes on this level, first come first kept; a component with more than cluster_cap nodes is
+        // cut into pieces of that many (node-disjoint: block Jacobi over the pieces)
+        std::vector<uint32_t> crow, cptr{0};
+        std::vector<uint64_t> iptr{0};
+        std::vector<uint32_t> tile_cluster, tile_row0;
+        std::vector<uint8_t> seen(n_level_nodes, 0);
+        uint32_t largest = 0;
+        const auto close_piece = [&](std::vector<uint32_t> &piece) {
+            if (piece.empty()) return;
+            std::sort(piece.begin(), piece.end());
+            for (const uint32_t v : piece)
+                for (uint32_t k = 0; k < 3; ++k) crow.push_back(3 * v + k);
+            const uint32_t order = uint32_t(3 * piece.size());
+            const uint32_t c = uint32_t(cptr.size() - 1);
+            for (uint32_t r0 = 0; r0 < order; r0 += 64) tile_cluster.push_back(c), tile_row0.push_back(r0);
+            cptr.push_back(uint32_t(crow.size()));
+            iptr.push_back(iptr.back() + uint64_t(order) * order);
+            largest = std::max(largest, uint32_t(piece.size()));
+            piece.clear();
+        };
+        for (const auto &members : multi) {
+            std::vector<uint32_t> piece;
+            for (const uint32_t k : members)
+                for (uint32_t a = 0; a < npe; ++a) {
+                    const uint32_t v = elem[size_t(bad[k]) * npe + a];
+                    if (seen[v]) continue;
+                    seen[v] = 1;
+                    piece.push_back(v);
+                    if (piece.size() >= cluster_cap) close_piece(piece);
+                }
+            close_piece(piece);
+        }
+        ps.n_clusters = uint32_t(cptr.size() - 1);
+        ps.cluster_rows = uint32_t(crow.size());
+        ps.cluster_tiles = uint32_t(tile_cluster.size());
+        ps.largest_cluster = largest;
+        ps.h_cluster_ptr = cptr;
+        if (ps.n_clusters) {
+            ps.cluster_row.reset(ctx, crow.size());
+            ps.cluster_ptr.reset(ctx, cptr.size());
+            ps.cluster_inv_ptr.reset(ctx, iptr.size());
+            ps.tile_cluster.reset(ctx, tile_cluster.size());
+            ps.tile_row0.reset(ctx, tile_row0.size());
+            ps.cluster_row.upload(crow.data(), crow.size());
+            ps.cluster_ptr.upload(cptr.data(), cptr.size());
+            ps.cluster_inv_ptr.upload(iptr.data(), iptr.size());
+            ps.tile_cluster.upload(tile_cluster.data(), tile_cluster.size());
+            ps.tile_row0.upload(tile_row0.data(), tile_row0.size());
+            ps.cinv64.reset(ctx, iptr.back());
+            ps.cinv32.reset(ctx, iptr.back());
+        }
         HIP_CHECK(hipStreamSynchronize(st));
     };
-    fill(sys->patches2, en, 10);
-    fill(sys->patches1, ep, 4);
+    fill(sys->patches2, en, 10, sys->n_nodes);
+    fill(sys->patches1, ep, 4, sys->n_points);
+}
+
+// SPD inverse in place, order n (column-major = row-major: symmetric), by the block Gauss-Jordan elimination of the coarse level
+// (mh_eigs.hip: mh_build_hierarchy), 128 columns per step: P = A_kk^-1 (one workgroup), C = A(:, k), R = P A(k, :), A -= C R, A(k, :) = R,
+// A(:, k) = -C P, A_kk = P.  Returns the first pivot block's failure (0: fine).
+static int spd_inverse_in_place(mh_context *ctx, double *a, uint32_t n) {
+    const uint32_t nb = 128;
+    DevArray<double> cblk(ctx, size_t(n) * nb), rblk(ctx, size_t(n) * nb), pinv(ctx, size_t(nb) * nb);
+    DevArray<int> info(ctx, 1);
+    info.zero();
+    const double one = 1, zero = 0, mone = -1;
+    const rocblas_int ld = rocblas_int(n);
+    for (uint32_t k0 = 0; k0 < n; k0 += nb) { // (ctx->blas is bound to ctx->stream: mh_context)
+        const rocblas_int w = rocblas_int(std::min(nb, n - k0));
+        mh_spd_inverse_small(ctx, a + size_t(k0) * n + k0, n, uint32_t(w), pinv, uint32_t(w), info);
+        HIP_CHECK(hipMemcpyAsync(cblk, a + size_t(k0) * n, size_t(n) * size_t(w) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, w, ld, w, &one, pinv, w, a + k0, ld, &zero, rblk, w));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, ld, w, &mone, cblk, ld, rblk, w, &one, a, ld));
+        HIP_CHECK(hipMemcpy2DAsync(a + k0, size_t(n) * sizeof(double), rblk.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), n, hipMemcpyDeviceToDevice, ctx->stream));
+        ROCBLAS_CHECK(rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, ld, w, w, &mone, cblk, ld, pinv, w, &zero, a + size_t(k0) * n, ld));
+        HIP_CHECK(hipMemcpy2DAsync(a + size_t(k0) * n + k0, size_t(n) * sizeof(double), pinv.get(), size_t(w) * sizeof(double), size_t(w) * sizeof(double), size_t(w), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    k_symmetrize<<<div_up(size_t(n) * n, TB), TB, 0, ctx->stream>>>(a, n);
+    KERNEL_CHECK();
+    int h = 0;
+    info.download(&h, 1); // (synchronises: the workspaces go back to the pool after the last kernel that reads them)
+    return h;
 }
 
 // The patch inverses of one level from its shifted operator (after k_shift_values).
 void mh_build_patch_inverses(mh_context *ctx, const BsrLevel &lvl, PatchSet &ps) {
-    if (!ps.n_patches) return;
-    const size_t n = size_t(3) * ps.npe;
-    ps.inv64.reset(ctx, size_t(ps.n_patches) * n * n);
-    ps.inv32.reset(ctx, size_t(ps.n_patches) * n * n);
+    if (!ps.any()) return;
     ps.dropped.reset(ctx, 2); // read back by mh_finish_hierarchy, with the set-up's next synchronising download
     ps.dropped.zero();
-    if (ps.npe == 10) k_patch_inverse<10><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, ps.dropped);
-    else k_patch_inverse<4><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, ps.dropped);
+    if (ps.n_patches) {
+        const size_t n = size_t(3) * ps.npe;
+        ps.inv64.reset(ctx, size_t(ps.n_patches) * n * n);
+        ps.inv32.reset(ctx, size_t(ps.n_patches) * n * n);
+        if (ps.npe == 10) k_patch_inverse<10><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, ps.dropped);
+        else k_patch_inverse<4><<<ps.n_patches, 64, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.nodes, ps.weight, ps.n_patches, ps.inv64, ps.inv32, ps.dropped);
+        KERNEL_CHECK();
+    }
+    if (!ps.n_clusters) return;
+    k_cluster_block<<<dim3(ps.n_clusters, 64), TB, 0, ctx->stream>>>(lvl.row_ptr, lvl.col, lvl.aval, ps.cluster_row, ps.cluster_ptr, ps.cluster_inv_ptr, ps.cinv64);
+    KERNEL_CHECK();
+    // orders up to 128 in one launch (Gauss-Jordan in LDS, a workgroup each); the larger ones one after the other by the blocked elimination
+    std::vector<uint32_t> small, large;
+    for (uint32_t c = 0; c < ps.n_clusters; ++c) (ps.h_cluster_ptr[c + 1] - ps.h_cluster_ptr[c] <= 128 ? small : large).push_back(c);
+    if (!small.empty()) {
+        DevArray<uint32_t> list(ctx, small.size());
+        list.upload(small.data(), small.size());
+        static PerDeviceOnce attr;
+        attr.run(ctx->device, [] { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_inverse_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); });
+        k_cluster_inverse_lds<<<uint32_t(small.size()), 128, size_t(128) * 129 * sizeof(double), ctx->stream>>>(list, ps.cluster_ptr, ps.cluster_inv_ptr, ps.cinv64, ps.dropped);
+        KERNEL_CHECK();
+        HIP_CHECK(hipStreamSynchronize(ctx->stream)); // (`list` returns to the pool)
+    }
+    if (!large.empty()) {
+        std::vector<uint64_t> iptr(ps.n_clusters + 1);
+        ps.cluster_inv_ptr.download(iptr.data(), iptr.size());
+        for (const uint32_t c : large) {
+            const uint32_t order = ps.h_cluster_ptr[c + 1] - ps.h_cluster_ptr[c];
+            if (spd_inverse_in_place(ctx, ps.cinv64.get() + iptr[c], order) != 0) { // not safely positive definite: the cluster contributes nothing
+                HIP_CHECK(hipMemsetAsync(ps.cinv64.get() + iptr[c], 0, size_t(order) * order * sizeof(double), ctx->stream));
+                const int report[2] = {1, int(c) + 1000001};
+                int have[2] = {0, 0};
+                ps.dropped.download(have, 2);
+                have[0] += report[0], have[1] = std::max(have[1], report[1]);
+                ps.dropped.upload(have, 2);
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
+    k_f64_to_f32<<<div_up(ps.cinv64.count, TB), TB, 0, ctx->stream>>>(ps.cinv64, ps.cinv32, ps.cinv64.count);
     KERNEL_CHECK();
 }
 
 template<typename T>
 void mh_apply_patches(mh_context *ctx, const PatchSet &ps, const T *in, const T *minus, uint32_t w, T coef, T *d, T *x, double *z, uint32_t wz, T *scratch) {
-    if (!ps.n_patches) return;
-    const T *inv;
-    if constexpr (std::is_same<T, double>::value) inv = ps.inv64.get();
-    else inv = ps.inv32.get();
-    const dim3 grid(ps.n_patches, div_up(w, 64));
-    const size_t rows = size_t(ps.n_touched) * 3 * w;
-    if (ps.npe == 10) {
-        k_patch_solve<T, 10><<<grid, 64, 0, ctx->stream>>>(in, minus, w, ps.nodes, inv, scratch);
-        k_patch_gather<T, 10><<<div_up(rows, TB), TB, 0, ctx->stream>>>(scratch, w, ps.touched, ps.t_ptr, ps.t_patch, ps.t_local, ps.n_touched, coef, d, x, z, wz);
-    } else {
-        k_patch_solve<T, 4><<<grid, 64, 0, ctx->stream>>>(in, minus, w, ps.nodes, inv, scratch);
-        k_patch_gather<T, 4><<<div_up(rows, TB), TB, 0, ctx->stream>>>(scratch, w, ps.touched, ps.t_ptr, ps.t_patch, ps.t_local, ps.n_touched, coef, d, x, z, wz);
+    if (ps.n_patches) {
+        const T *inv;
+        if constexpr (std::is_same<T, double>::value) inv = ps.inv64.get();
+        else inv = ps.inv32.get();
+        const dim3 grid(ps.n_patches, div_up(w, 64));
+        const size_t rows = size_t(ps.n_touched) * 3 * w;
+        if (ps.npe == 10) {
+            k_patch_solve<T, 10><<<grid, 64, 0, ctx->stream>>>(in, minus, w, ps.nodes, inv, scratch);
+            k_patch_gather<T, 10><<<div_up(rows, TB), TB, 0, ctx->stream>>>(scratch, w, ps.touched, ps.t_ptr, ps.t_patch, ps.t_local, ps.n_touched, coef, d, x, z, wz);
+        } else {
+            k_patch_solve<T, 4><<<grid, 64, 0, ctx->stream>>>(in, minus, w, ps.nodes, inv, scratch);
+            k_patch_gather<T, 4><<<div_up(rows, TB), TB, 0, ctx->stream>>>(scratch, w, ps.touched, ps.t_ptr, ps.t_patch, ps.t_local, ps.n_touched, coef, d, x, z, wz);
+        }
+        KERNEL_CHECK();
     }
-    KERNEL_CHECK();
+    if (ps.n_clusters) { // (rows disjoint from the element patches' and from one another: the order of the two parts does not matter)
+        const T *cinv;
+        if constexpr (std::is_same<T, double>::value) cinv = ps.cinv64.get();
+        else cinv = ps.cinv32.get();
+        T *y = scratch + size_t(ps.n_patches) * 3 * ps.npe * w;
+        k_cluster_apply<T><<<dim3(ps.cluster_tiles, div_up(w, 64)), 256, 0, ctx->stream>>>(in, minus, w, ps.cluster_row, ps.cluster_ptr, ps.cluster_inv_ptr, ps.tile_cluster, ps.tile_row0, cinv, y);
+        k_cluster_scatter<T><<<div_up(size_t(ps.cluster_rows) * w, TB), TB, 0, ctx->stream>>>(y, w, ps.cluster_row, ps.cluster_rows, coef, d, x, z, wz);
+        KERNEL_CHECK();
+    }
 }
 template void mh_apply_patches<float>(mh_context *, const PatchSet &, const float *, const float *, uint32_t, float, float *, float *, double *, uint32_t, float *);
 template void mh_apply_patches<double>(mh_context *, const PatchSet &, const double *, const double *, uint32_t, double, double *, double *, double *, uint32_t, double *);

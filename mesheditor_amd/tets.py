@@ -21,7 +21,7 @@ def _lib():
     return L
 
 
-def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repair_slivers=True, interior_shell="when_flat", quality=False, max_volume=0.0):
+def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repair_slivers=True, interior_shell="when_flat", quality=False, max_volume=0.0, break_flat_cells=True):
     """(points float64 [V', 3], tets uint32 [T, 4], boundary_steiner_count): input vertex i keeps index i, added points follow.
     interior_steiner (tetra::Options::InteriorSteiner): the recovery's points are moved off the surface afterwards, so that every
     input triangle is a boundary face (the count returned is what had to stay on it; 0 = the reference's contract holds).
@@ -31,12 +31,14 @@ def tetrahedralize(points, triangles, max_steiner=0, interior_steiner=True, repa
     with flat cells at the surface), "never", "always".
     quality / max_volume: the reference's tetra::Options::Quality / MaxVolume (src/mesh/Tetrahedralize.h:17-27): interior points until the
     radius-edge ratio is at most 2 where the fixed surface allows / until no tetrahedron is larger than max_volume.
+    break_flat_cells (tetra::Options::BreakFlatCells): the always-on last pass that leaves no cell below a shape measure of 1e-2 where an
+    interior point beside it helps; False leaves the flat cells of a fine UV sphere's fill in (tests of the solver on such a mesh).
     Raises RuntimeError with the tetrahedraliser's message for open / self-intersecting / unrecoverable surfaces."""
     L = _lib()
     pts = np.ascontiguousarray(points, dtype=np.float64)
     tri = np.ascontiguousarray(triangles, dtype=np.uint32)
     h = L.mhx_tetrahedralize2(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), len(tri), int(max_steiner),
-                              int(bool(interior_steiner)) | (2 if repair_slivers else 0) | {"when_flat": 0, "never": 4, "always": 8}[interior_shell] | (16 if quality else 0),
+                              int(bool(interior_steiner)) | (2 if repair_slivers else 0) | {"when_flat": 0, "never": 4, "always": 8}[interior_shell] | (16 if quality else 0) | (0 if break_flat_cells else 32),
                               float(max_volume))
     try:
         err = L.mhx_tets_error(h).decode()

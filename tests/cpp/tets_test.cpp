@@ -752,4 +752,72 @@ CASE(an_obj_file_loads_welded_and_fanned) {
     EXPECT(!LoadObj("/nonexistent/file.obj"));
 }
 
+// Round 6: the DEFAULT fill leaves no flat cell.  UV spheres -- planar latitude-longitude quads, needle fans at
+// the poles: without the last pass (Options::BreakFlatCells) the fine ones keep hundreds of cells flat to 1e-9, on which no iterative
+// eigensolver converges -- come back with every shape measure above 1e-3 (measured: 0.16 at 24 x 12 ... 0.023 at 128 x 64), interior points
+// only, the boundary the input triangulation.  The reference repairs and optimises "either way" (src/mesh/Tetrahedralize.h:19-20).
+CASE(the_default_fill_of_uv_spheres_has_no_flat_cell) {
+    const auto uv_sphere = [](int segments, int rings) {
+        Surface s;
+        const double radius = 0.15, pi = 3.14159265358979323846;
+        const auto f32 = [](double v) { return double(float(v)); }; // (an .obj round trip, as the reference's generator writes)
+        s.P.push_back({0, f32(radius), 0});
+        for (int i = 1; i < rings; ++i)
+            for (int j = 0; j < segments; ++j) {
+                const double th = pi * i / rings, ph = 2 * pi * j / segments;
+                s.P.push_back({f32(radius * std::sin(th) * std::cos(ph)), f32(radius * std::cos(th)), f32(radius * std::sin(th) * std::sin(ph))});
+            }
+        s.P.push_back({0, f32(-radius), 0});
+        const auto tri = [&](uint32_t a, uint32_t b, uint32_t c) { s.T.insert(s.T.end(), {a, b, c}); };
+        for (int j = 0; j < segments; ++j) tri(0, uint32_t(1 + j), uint32_t(1 + (j + 1) % segments));
+        for (int i = 0; i + 2 < rings; ++i) {
+            const uint32_t a = uint32_t(1 + i * segments), b = uint32_t(1 + (i + 1) * segments);
+            for (int j = 0; j < segments; ++j) {
+                const uint32_t k = uint32_t((j + 1) % segments);
+                tri(a + uint32_t(j), b + uint32_t(j), b + k);
+                tri(a + uint32_t(j), b + k, a + k);
+            }
+        }
+        const uint32_t last = uint32_t(s.P.size() - 1), a = uint32_t(1 + (rings - 2) * segments);
+        for (int j = 0; j < segments; ++j) tri(last, a + uint32_t((j + 1) % segments), a + uint32_t(j));
+        return s;
+    };
+    const auto worst_shape = [](const TetMesh &m) {
+        double worst = 1e300;
+        for (const auto &t : m.Tets) {
+            const dvec3 u = m.Points[t[1]] - m.Points[t[0]], v = m.Points[t[2]] - m.Points[t[0]], w = m.Points[t[3]] - m.Points[t[0]];
+            const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+            double l2 = 0;
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j) {
+                    const dvec3 e = m.Points[t[size_t(i)]] - m.Points[t[size_t(j)]];
+                    l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+                }
+            const double lrms = std::sqrt(l2 / 6);
+            worst = std::min(worst, lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0);
+        }
+        return worst;
+    };
+    for (const auto &[segments, rings] : {std::pair{24, 12}, std::pair{64, 32}, std::pair{96, 48}}) {
+        const Surface s = uv_sphere(segments, rings);
+        const auto r = tetra::Tetrahedralize(s.P, s.T);
+        EXPECT_NOTE(bool(r), ErrorOf(r));
+        if (!r) continue;
+        const std::string defect = ValidateGeneral(s, r->Mesh);
+        EXPECT_NOTE(defect.empty(), defect);
+        const double worst = worst_shape(r->Mesh);
+        std::printf("        UV sphere %3d x %2d: %zu tets, %u added points (%u beside flat cells), worst shape %.3g\n", segments, rings, r->Mesh.Tets.size(), r->Profile.SteinerCount,
+                    r->Profile.FlatCellPointCount, worst);
+        EXPECT(worst >= 1e-3);
+        EXPECT(r->Profile.BdrySteinerCount == 0);
+        if (segments == 96) {
+            EXPECT(r->Profile.FlatCellPointCount > 0); // (this one needs the pass: 172 cells flat to 1e-8 without it)
+            tetra::Options as_before;
+            as_before.BreakFlatCells = false;
+            const auto flat = tetra::Tetrahedralize(s.P, s.T, as_before);
+            EXPECT(bool(flat) && worst_shape(flat->Mesh) < 1e-6 && flat->Profile.FlatCellPointCount == 0);
+        }
+    }
+}
+
 int main() { return check::run_all(); }

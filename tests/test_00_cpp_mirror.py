@@ -25,7 +25,7 @@ def _run(name, timeout=600):
 
 def test_cpp_tests_compile_against_the_mirror():
     _build()
-    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test", "tets_test", "batch_test"):
+    for name in ("modal_solver_test", "modal_render_test", "contact_model_test", "model_io_test", "tets_test", "tet_caller_test", "batch_test"):
         assert os.path.exists(os.path.join(CPP, "bin", name))
 
 
@@ -46,6 +46,14 @@ def test_star_shaped_tet_fill_and_obj_loader():
     tests/ValidateTetMesh.h (host code, no GPU)."""
     _build()
     assert "0 failure(s)" in _run("tets_test")
+
+
+def test_tet_front_end_binds_as_the_reference_declares_it():
+    """SURVEY section 8f row N3, the drop-in half: tests/cpp/tet_caller_test.cpp restates the reference's two callers of GenerateTets /
+    tetra::Tetrahedralize (tests/ModalSolveTool.cpp:72-77, tests/ModalSolverBench.cpp:285-327) against the mirror's mesh/Tets.h and
+    mesh/Tetrahedralize.h -- expected-shaped return, tetra::Profile -- and checks the Profile's arithmetic (host code, no GPU)."""
+    _build()
+    assert "0 failure(s)" in _run("tet_caller_test")
 
 
 @pytest.mark.gpu

@@ -246,13 +246,19 @@ def test_tet_front_end_quality_and_max_volume_options():
         uniq, counts = np.unique(faces, axis=0, return_counts=True)
         return counts.max() <= 2 and {tuple(r) for r in uniq[counts == 1]} == {tuple(sorted(r)) for r in f.tolist()}
 
-    p0, t0, _ = tets.tetrahedralize(v, f, interior_shell="never")
+    p0, t0, _ = tets.tetrahedralize(v, f, interior_shell="never", break_flat_cells=False)
     p1, t1, left1 = tets.tetrahedralize(v, f, quality=True)
     vol0, q0 = shapes(p0, t0)
     vol1, q1 = shapes(p1, t1)
     assert left1 == 0 and np.array_equal(p1[: len(v)], v) and len(p1) > len(v)
     assert vol1.min() > 0 and boundary_is_the_input(p1, t1)
     assert (q0 < 1e-3).sum() > 0 and (q1 < 1e-3).sum() == 0, ((q0 < 1e-3).sum(), (q1 < 1e-3).sum())
+    # round 6: the flat-cell pass is always on (tetra::Options::BreakFlatCells) -- the same fill without the quality arm and without
+    # the shell has no cell below 1e-3 either, with interior points only
+    p2, t2, left2 = tets.tetrahedralize(v, f, interior_shell="never")
+    vol2, q2 = shapes(p2, t2)
+    assert left2 == 0 and np.array_equal(p2[: len(v)], v) and len(p0) < len(p2) < len(p1)
+    assert vol2.min() > 0 and boundary_is_the_input(p2, t2) and (q2 < 1e-3).sum() == 0, q2.min()
     assert abs(vol1.sum() - vol0.sum()) < 1e-12 * vol0.sum()
     bound = vol0.sum() / 6 / 4000
     p2, t2, left2 = tets.tetrahedralize(v, f, max_volume=bound)

@@ -1346,6 +1346,34 @@ def test_a_fine_uv_sphere_solves_through_the_quality_arm(api):
         c.close()
 
 
+@pytest.mark.parametrize("seg,rings", [(96, 48), (128, 64)])
+def test_a_fine_uv_sphere_solves_through_the_default_options(api, seg, rings):
+    """no valid mesh may come back empty.  The 128 x 64 UV sphere through the front end's DEFAULT options
+    returned nothing in round 5 (346 cells flat to 1e-9 in its fill: `profiles/r05_quality_sphere.txt`), the 96 x 48 one took 57
+    iterations.  With the always-on flat-cell pass (tetra::Options::BreakFlatCells, round 6) the fill has no cell below a shape measure
+    of 1e-3 and the solve returns all 65 pairs within 40 iterations (measured: 22 and 23, `profiles/r06_quality_sphere.txt`); the
+    fundamental is the ball's (8.89 kHz for ceramic at r = 0.15 m; the quality-arm fill of the same surface: 8 885-8 887 Hz)."""
+    from mesheditor_amd import tets as front_end
+    P, F = meshes.uv_sphere_surface(0.15, seg, rings)
+    pts, tets, left = front_end.tetrahedralize(P, F)
+    assert left == 0 and np.array_equal(pts[: len(P)], P)
+    q = pts[tets.astype(np.int64)]
+    vol6 = np.abs(np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0]))
+    e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+    assert (vol6 * np.sqrt(2) / e2 ** 1.5).min() >= 1e-3
+    c = api.Context(0)
+    try:
+        m = meshes.MATERIALS["Ceramic"]
+        ex = pts[(np.arange(10) * len(P)) // 10].astype(np.float32)
+        r = api.mesh2modes(c, pts, tets, api.material(*m), ex, config=api.default_config(num_modes=50, num_fem_modes=65))
+        assert len(r.eigenvalues) == 65
+        assert r.profile["restarts"] <= 40, r.profile["restarts"]
+        f7 = np.sqrt(r.eigenvalues[6]) / (2 * np.pi)
+        assert abs(f7 - 8888.0) < 6.0, f7
+    finally:
+        c.close()
+
+
 def test_the_shift_invert_operator_as_an_operation(api, ctx):
     """SURVEY 8a row A8's interface (src/audio/CholeskyShiftInvert.h:11-30: set_shift, perform_op, solve_panel): x = (K - sigma M)^-1 b through the
     C ABI (preconditioned conjugate gradients on the device: there is no factorisation) against a sparse direct solve of the exported

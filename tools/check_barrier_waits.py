@@ -118,8 +118,16 @@ def main():
             sources += sorted(glob.glob(os.path.join(root, "mesheditor_amd", "csrc", "lab", "*.hip")))
         for src in sources:
             out = os.path.join(tmp, os.path.basename(src)[:-4] + ".s")
+            # the flags of mesheditor_amd/csrc/Makefile (CXXFLAGS incl. $(EXTRA) from the environment, STRICT for the two bit-exact files): the
+            # assembly checked is the assembly shipped
             strict = ["-ffp-contract=off"] if os.path.basename(src) in ("mh_pipeline.hip", "mh_bank.hip") else []
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", *strict, "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+            extra = os.environ.get("EXTRA", "").split()
+            p = subprocess.run(["/opt/rocm/bin/hipcc", *extra, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-S", *strict, "-o", out, src],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if p.returncode != 0:
+                sys.stderr.write(p.stdout)
+                sys.stderr.write(f"check_barrier_waits: hipcc failed on {src} (exit {p.returncode})\n")
+                return 2
             files.append(out)
     total, bad = 0, 0
     for f in files:
