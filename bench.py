@@ -511,7 +511,7 @@ def main():
         step()
     sync(ctxs)
     dt_instrumented = time.perf_counter() - t1
-    stats = [{k: sum(c.kernel_stats(cls)[k] for c in ctxs) for k in ("launches", "total_ms", "total_bytes")} for cls in (0, 1, 3, 4)]
+    stats = [{k: sum(c.kernel_stats(cls)[k] for c in ctxs) for k in ("launches", "total_ms", "total_bytes")} for cls in (0, 1, 3, 4, 5)]
     for c in ctxs:
         c.time_kernels(False)
 
@@ -555,7 +555,7 @@ def main():
         line["gathered_records"] = {"count": len(records), "words_per_record": sharding.record_length(NEV_MAX, POS_MAX),
                                     "fields": "eigenvalues, freqs, t60s, positions, shapes, mass properties, solve profile",
                                     "collective": "ncclAllGather from C++ (modal::SolveBatch)" if comm is not None else "torch.distributed all_gather (%s)" % ("gloo" if share_gpu else "nccl")}
-    spmm, asm, comb, comb_bytes = stats
+    spmm, asm, comb, comb_bytes, comb_full = stats
     if spmm["launches"]:
         achieved = spmm["total_bytes"] / (spmm["total_ms"] * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm",
@@ -580,6 +580,13 @@ def main():
                                     "algorithmic_bytes_per_launch": comb_bytes["total_bytes"] / max(1, comb_bytes["launches"]),
                                     "hbm_GBps_at_that_time": comb_bytes["total_bytes"] / (comb["total_ms"] * 1e-3) / 1e9,
                                     "ms_per_step": comb["total_ms"] / args.steps / max(1, len(ctxs)),
+                                    # the iteration's full-size update alone (>= 200 basis columns into >= 128 output columns: X and P together,
+                                    # 240 -> 160 on the 65-pair solve); the class average above also holds the HBM-bound projections (80 -> 80,
+                                    # accumulate: 13 flop per byte) and the coarse solve's short products
+                                    "full_size_update": ({"launches": comb_full["launches"], "avg_launch_us": 1e3 * comb_full["total_ms"] / comb_full["launches"],
+                                                          "algorithmic_flops_per_launch": comb_full["total_bytes"] / comb_full["launches"],
+                                                          "achieved": comb_full["total_bytes"] / (comb_full["total_ms"] * 1e-3) / 1e12,
+                                                          "frac": comb_full["total_bytes"] / (comb_full["total_ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS} if comb_full["launches"] else None),
                                     "peak_note": "78.6 TFLOP/s: the MI355X data sheet's fp64 matrix figure (the microarchitecture guide lists none); the device holds 2.0-2.1 GHz under these kernels, 65 TFLOP/s there"}
     if not batch:
         line["profile"] = {k: last.profile.get(k) for k in ("assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract", "restarts", "op_applications", "sytrd_redos", "rr_selfcheck")}

@@ -93,8 +93,10 @@ void mh_default_config(mh_solver_config *);
  *   MH_KERNEL_COMBINE  the basis updates out = [X | W | P] C of the eigensolver (k_combine, fp64 MFMA; the vendor dgemm for blocks of
  *                      >= 400 basis columns); flops: 2 n (basis columns) (output columns) per launch.  MH_KERNEL_COMBINE_BYTES carries
  *                      the same launches' algorithmic bytes (8 n (basis + output columns)) as its work, no time of its own.
+ *                      MH_KERNEL_COMBINE_FULL: the subset of those launches with >= 200 basis and >= 128 output columns (an iteration's
+ *                      full-size update of X and P together: 240 -> 160 columns on the 65-pair solve), same work unit.
  * Stats are the totals since the last enable: launches, summed device milliseconds, summed work. */
-enum { MH_KERNEL_SPMM = 0, MH_KERNEL_ASSEMBLY = 1, MH_KERNEL_BANK = 2, MH_KERNEL_COMBINE = 3, MH_KERNEL_COMBINE_BYTES = 4, MH_KERNEL_CLASSES = 5 };
+enum { MH_KERNEL_SPMM = 0, MH_KERNEL_ASSEMBLY = 1, MH_KERNEL_BANK = 2, MH_KERNEL_COMBINE = 3, MH_KERNEL_COMBINE_BYTES = 4, MH_KERNEL_COMBINE_FULL = 5, MH_KERNEL_CLASSES = 6 };
 int mh_context_time_kernels(mh_context *, int enable);
 int mh_context_kernel_stats(mh_context *, uint64_t *launches, double *total_ms, double *total_bytes); /* MH_KERNEL_SPMM */
 int mh_context_kernel_class_stats(mh_context *, int kernel_class, uint64_t *launches, double *total_ms, double *total_work);

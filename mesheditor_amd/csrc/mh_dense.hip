@@ -8,6 +8,8 @@
 //   result is bit-reproducible.  Roofline: max(8 n (wa + wb) bytes / HBM, 2 n wa wb flops / fp64 MFMA peak).
 #include "mh_common.h"
 
+#include <optional>
+
 #include <map>
 
 // hipFuncSetAttribute once per (kernel, device): function attributes are per device, and first calls may race between the host
@@ -545,6 +547,8 @@ void mh_combine(mh_context *ctx, size_t n, const double *x, uint32_t wx, const d
     const uint32_t m_total = wx + ww + wp;
     // (bench.py's roofline_combine: one timed span and one work figure per call, whichever path it takes)
     TimedLaunch timed(ctx, MH_KERNEL_COMBINE, 2.0 * double(n) * double(m_total) * double(col_count));
+    std::optional<TimedLaunch> timed_full; // (the same span once more for the class of full-size updates: X and P of an iteration together)
+    if (m_total >= 200 && col_count >= 128) timed_full.emplace(ctx, MH_KERNEL_COMBINE_FULL, 2.0 * double(n) * double(m_total) * double(col_count));
     if (ctx->time_kernels) ctx->totals[MH_KERNEL_COMBINE_BYTES].work += 8.0 * double(n) * (double(m_total) + double(col_count)), ctx->totals[MH_KERNEL_COMBINE_BYTES].launches += 1;
     if (wide_blas && !mh_test_own_gemm() && m_total >= 400 && col_count >= 128 && !caller_omap && out1 != x && out2 != x && n >= 65536) {
         const uint32_t px = ldx ? ldx : wx; // physical columns of the X panel

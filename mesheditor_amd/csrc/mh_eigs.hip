@@ -74,6 +74,7 @@ struct Switches {
     double cheb_ratio = 0.0, cheb_ratio1 = 0.0; // (ratio1: the P1 level's own interval, optional fifth value of MH_CYCLE)
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
+    bool test_last_resort = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "last_resort"); // every solve of more than 12 288 unknowns goes straight to the last resort
     bool test_selfcheck_fail = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "selfcheck_fail"); // the first solve's Rayleigh-Ritz self-check reports a failure
     bool no_poly_start = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_poly_start"); // (A/B hook of round 5: the cold start block as rounds 1-4 had it)
     Switches() {
@@ -1364,6 +1365,84 @@ void dense_eigs(mh_system *sys, uint32_t nev, double sigma, double *eigenvalues,
 } // namespace
 
 namespace {
+__global__ void k_axpy_panel(double *__restrict__ y, const double *__restrict__ b, size_t count) { // y <- b - y
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) y[i] = b[i] - y[i];
+}
+__global__ void k_coldot_partial(const double *__restrict__ x, const double *__restrict__ y, size_t rows, uint32_t w, double *__restrict__ partial, uint32_t rows_per_block) {
+    const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= w) return;
+    const size_t r0 = size_t(blockIdx.x) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    double s = 0;
+    for (size_t r = r0; r < r1; ++r) s += x[r * w + c] * y[r * w + c];
+    partial[size_t(blockIdx.x) * w + c] = s;
+}
+// x += alpha p, r -= alpha ap with alpha_c = rz_c / pap_c (0 for a column that has converged exactly)
+__global__ void k_cg_advance(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ p, const double *__restrict__ ap, const double *__restrict__ rz, const double *__restrict__ pap,
+                             size_t count, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t c = uint32_t(i % w);
+    const double alpha = pap[c] > 0 ? rz[c] / pap[c] : 0.0;
+    x[i] += alpha * p[i];
+    r[i] -= alpha * ap[i];
+}
+// p = z + beta p with beta_c = rz_new_c / rz_old_c
+__global__ void k_cg_direction(double *__restrict__ p, const double *__restrict__ z, const double *__restrict__ rz_new, const double *__restrict__ rz_old, size_t count, uint32_t w) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t c = uint32_t(i % w);
+    const double beta = rz_old[c] > 0 ? rz_new[c] / rz_old[c] : 0.0;
+    p[i] = z[i] + beta * p[i];
+}
+} // namespace
+
+namespace {
+// z ~= A^-1 r for an n x w panel by `iters` steps of conjugate gradients preconditioned with the cycle, the columns independent runs in
+// lockstep (no convergence test: no read-back).  The LAST RESORT's preconditioner (eigs_impl): where the cycle alone leaves the block
+// iteration unstable -- a mesh with cells flat to 1e-9: what the cycle returns carries components along the flat cells' stiff directions
+// that the Rayleigh-Ritz step cannot digest -- a few CG steps around it hand the eigensolver (nearly) the shift-invert direction A^-1 r of
+// the reference's own method (src/audio/mesh2modes.cpp:441-512), at ten times the cost per iteration.
+struct PanelCg {
+    mh_system *sys;
+    mh_context *ctx;
+    size_t n;
+    uint32_t wmax;
+    DevArray<double> rr, zz, p, ap, rz, rz_new, pap, scratch;
+    static constexpr uint32_t rpb = 256;
+    PanelCg(mh_system *s, uint32_t w) : sys(s), ctx(s->ctx), n(size_t(3) * s->n_nodes), wmax(w), rr(s->ctx, n * w), zz(s->ctx, n * w), p(s->ctx, n * w), ap(s->ctx, n * w), rz(s->ctx, w), rz_new(s->ctx, w),
+                                        pap(s->ctx, w), scratch(s->ctx, size_t(div_up(n, rpb)) * w) {}
+    void dot(const double *u, const double *v, double *out, uint32_t w) {
+        const uint32_t nb = uint32_t(div_up(n, rpb));
+        k_coldot_partial<<<dim3(nb, div_up(w, 64)), 64, 0, ctx->stream>>>(u, v, n, w, scratch, rpb);
+        KERNEL_CHECK();
+        k_colsumsq_final<<<w, 256, 0, ctx->stream>>>(scratch, nb, w, out);
+        KERNEL_CHECK();
+    }
+    template<typename Prec> void solve(Prec &prec, const double *r, double *z, uint32_t w, int iters) {
+        hipStream_t st = ctx->stream;
+        HIP_CHECK(hipMemsetAsync(z, 0, n * w * sizeof(double), st));
+        HIP_CHECK(hipMemcpyAsync(rr.get(), r, n * w * sizeof(double), hipMemcpyDeviceToDevice, st));
+        prec.apply(rr, zz, w);
+        HIP_CHECK(hipMemcpyAsync(p.get(), zz.get(), n * w * sizeof(double), hipMemcpyDeviceToDevice, st));
+        dot(rr, zz, rz, w);
+        for (int k = 0; k < iters; ++k) {
+            mh_spmm(ctx, sys->L2, sys->L2.aval, p, ap, nullptr, nullptr, w);
+            dot(p, ap, pap, w);
+            k_cg_advance<<<grid1(n * w), TB, 0, st>>>(z, rr, p, ap, rz, pap, n * w, w);
+            KERNEL_CHECK();
+            if (k + 1 == iters) break;
+            prec.apply(rr, zz, w);
+            dot(rr, zz, rz_new, w);
+            k_cg_direction<<<grid1(n * w), TB, 0, st>>>(p, zz, rz_new, rz, n * w, w);
+            KERNEL_CHECK();
+            HIP_CHECK(hipMemcpyAsync(rz.get(), rz_new.get(), w * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+    }
+};
+} // namespace
+
+namespace {
 // Block LOBPCG on the pencil (A, M) = (K - sigma M, M) with hard locking: one object per solve; the
 // stages of an iteration are its member functions, in the order run() calls them.
 struct BlockLobpcg {
@@ -1402,8 +1481,10 @@ struct BlockLobpcg {
     uint32_t res_pitch = 0;
     bool res_ready = false, rw_from_rr = false;
     DevArray<int> info; // [1]: conditioning report of mh_potrf_small
+    int inner_cg = 0; // > 0: the preconditioner is that many CG steps around the (double-precision) cycle -- the last resort (eigs_impl)
     std::unique_ptr<Precond<float>> prec32;
     std::unique_ptr<Precond<double>> prec64;
+    std::unique_ptr<PanelCg> panel_cg;
     // ---- switches (read once) and what follows from them
     const bool verbose = switches().verbose, fp32_prec = switches().fp32_prec;
     // W is orthogonalised against P in coefficient space (no M P panel, no tall projection against P) for blocks of up to 128 columns
@@ -1433,11 +1514,12 @@ struct BlockLobpcg {
     uint32_t w = 0, wa = 0, m = 0, wp_new = 0; // active columns (= width of W), their count as the X part, order of the small problem, width of the next P
 
     BlockLobpcg(mh_system *system, uint32_t nev_, uint32_t block, double sigma_, double residual_tol_, uint32_t max_iters_, const float *seed_basis_, uint32_t seed_rows_,
-                uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_)
+                uint32_t seed_cols_, const volatile unsigned char *cancel_, volatile float *progress_, mh_profile &prof_, mh_profile *profile_, int inner_cg_ = 0)
         : sys(system), ctx(system->ctx), st(system->ctx->stream), n(size_t(3) * system->n_nodes), nev(nev_), b(block), mmax(3 * block), sigma(sigma_), residual_tol(residual_tol_),
           max_iters(max_iters_), seed_basis(seed_basis_), seed_rows(seed_rows_), seed_cols(seed_cols_), cancel(cancel_), progress(progress_), prof(prof_), profile(profile_),
           iterating(system->ctx->device, true), t_iter(system->ctx), pproj_ok(block <= 128), scaled_norms(system->patches2.any()), theta(block), rn(block), mn(block), xn(block), norms(3 * size_t(block)),
           theta_act(block), order(block), locked(block, 0) {
+        inner_cg = inner_cg_;
         for (DevArray<double> *panel : {&X, &AX, &MX, &Xn, &AXn, &MXn, &W, &AW, &MW, &P, &Pn, &R, &Rw}) panel->reset(ctx, n * b);
         if (!pproj_ok) // M P is only kept for blocks wider than 128 columns (the narrower ones project against P in coefficient space)
             for (DevArray<double> *panel : {&MP, &MPn}) panel->reset(ctx, n * b);
@@ -1465,8 +1547,9 @@ struct BlockLobpcg {
         // Single-precision smoothers unless the mesh has FLAT cells (round 6): an element of shape 1e-9 puts entries 1e9 times its neighbours'
         // into the operator, and the residuals of its rows -- differences of such entries -- have no correct digit in fp32; the clusters'
         // inverses (condition number ~ 1 / shape) then turn that noise into the iterate.  Such a mesh starts in double precision.
-        if (fp32_prec && !(sys->worst_quality < kFlatShape)) prec32 = std::make_unique<Precond<float>>(sys, std::min(b, kPrecondColumns));
+        if (fp32_prec && !(sys->worst_quality < kFlatShape) && !inner_cg) prec32 = std::make_unique<Precond<float>>(sys, std::min(b, kPrecondColumns));
         else prec64 = std::make_unique<Precond<double>>(sys, std::min(b, kPrecondColumns));
+        if (inner_cg) panel_cg = std::make_unique<PanelCg>(sys, std::min(b, kPrecondColumns));
         auto hd = sys->L2.dinv.to_host();
         double dmin = 1e300;
         for (double v : hd) dmin = std::min(dmin, v);
@@ -1546,7 +1629,8 @@ struct BlockLobpcg {
     // gathered into a compact panel and scattered back (two extra passes over the slab, a few per cent of the cycle's own traffic).
     void precondition(const double *r, double *z, uint32_t w) {
         auto one = [&](const double *rp, double *zp, uint32_t wc) {
-            if (prec32) prec32->apply(rp, zp, wc);
+            if (panel_cg) panel_cg->solve(*prec64, rp, zp, wc, inner_cg);
+            else if (prec32) prec32->apply(rp, zp, wc);
             else prec64->apply(rp, zp, wc);
         };
         if (w <= kPrecondColumns) return one(r, z, w);
@@ -2180,6 +2264,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             try {
                 try {
                     try {
+                        if (switches().test_last_resort) mh_throw(MH_ENOTCONVERGED, "MH_TEST=last_resort");
                         BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
                         solver.run(eigenvalues);
                     } catch (const MhError &e) {
@@ -2200,7 +2285,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     // T_deg(1 + 2 x overshoot): twelve-fold per smoothing at degree 16 for 2 %.  The bound is a power-iteration estimate times 1.1
                     // (measured margin on the workloads: 6-9 %); should it fall short on some mesh, the iteration stalls or loses rank.  One retry
                     // with both levels' bounds widened by a quarter (costs the smoothers a few per cent of their efficiency, nothing else).
-                    if (e.code != MH_ENOTCONVERGED || max_iters < 50 || sys->lmax_widened) throw;
+                    // (not for a mesh with flat cells: what fails there is not the bound -- the last resort below is next)
+                    if (e.code != MH_ENOTCONVERGED || max_iters < 50 || sys->lmax_widened || switches().test_last_resort || sys->worst_quality < kFlatShape) throw;
                     if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- once more with the smoothers' spectral bounds widened by 25 %%\n", e.what());
                     sys->L1.lmax *= 1.25;
                     sys->L2.lmax *= 1.25;
@@ -2209,6 +2295,19 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     solver.run(eigenvalues);
                 }
             } catch (const MhError &e) {
+                // Last resort of a LARGER system (round 6): the block iteration once more with (nearly) the reference's own search directions --
+                // A^-1 r by eight conjugate-gradient steps around the double-precision cycle instead of the cycle alone (PanelCg).  Ten times
+                // the cost per iteration, a handful of iterations; reached only by meshes the two attempts above gave up on (cells flat to
+                // 1e-9 in a caller's own mesh: the front end's fills have none since round 6).  MH_ENOTCONVERGED is what is left when this
+                // fails too.  MH_TEST=last_resort sends every solve here (tests).
+                if (e.code == MH_ENOTCONVERGED && n > kDenseLastResort && max_iters >= 50) {
+                    if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- last resort: conjugate-gradient search directions\n", e.what());
+                    prof = sys->profile;
+                    prof.dofs = uint32_t(n);
+                    BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, 8);
+                    solver.run(eigenvalues);
+                    return;
+                }
                 // Last resort of a SMALL system whose iteration stalled (measured: a UV sphere's surface filled without interior
                 // points -- a quarter of the tetrahedra flat to 1e-8, ||A|| / theta ~ 1e13): one dense eigensolve in the inverse
                 // form.  O(n^3), seconds at the size limit: better than no modes for an editor primitive.
@@ -2234,38 +2333,6 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
 // gradients on the panel -- w independent runs in lockstep, the eigensolver's three-level cycle (double-precision smoothers) as the
 // preconditioner -- to a relative residual rel_tol per column.  A caller that drives its own Lanczos through this pays a full iterative
 // solve per application (~25 cycle applications for 1e-11): it exists for interface completeness, mh_eigs is the fast path.
-namespace {
-__global__ void k_axpy_panel(double *__restrict__ y, const double *__restrict__ b, size_t count) { // y <- b - y
-    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < count) y[i] = b[i] - y[i];
-}
-__global__ void k_coldot_partial(const double *__restrict__ x, const double *__restrict__ y, size_t rows, uint32_t w, double *__restrict__ partial, uint32_t rows_per_block) {
-    const uint32_t c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= w) return;
-    const size_t r0 = size_t(blockIdx.x) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    double s = 0;
-    for (size_t r = r0; r < r1; ++r) s += x[r * w + c] * y[r * w + c];
-    partial[size_t(blockIdx.x) * w + c] = s;
-}
-// x += alpha p, r -= alpha ap with alpha_c = rz_c / pap_c (0 for a column that has converged exactly)
-__global__ void k_cg_advance(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ p, const double *__restrict__ ap, const double *__restrict__ rz, const double *__restrict__ pap,
-                             size_t count, uint32_t w) {
-    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t c = uint32_t(i % w);
-    const double alpha = pap[c] > 0 ? rz[c] / pap[c] : 0.0;
-    x[i] += alpha * p[i];
-    r[i] -= alpha * ap[i];
-}
-// p = z + beta p with beta_c = rz_new_c / rz_old_c
-__global__ void k_cg_direction(double *__restrict__ p, const double *__restrict__ z, const double *__restrict__ rz_new, const double *__restrict__ rz_old, size_t count, uint32_t w) {
-    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t c = uint32_t(i % w);
-    const double beta = rz_old[c] > 0 ? rz_new[c] / rz_old[c] : 0.0;
-    p[i] = z[i] + beta * p[i];
-}
-} // namespace
 
 // b, x: n x w row-major panels in the internal numbering.  Returns the iterations taken; *worst_rel = the worst column's ||b - A x|| / ||b||.
 uint32_t mh_shift_invert_panel(mh_system *sys, double sigma, const double *b, double *x, uint32_t w, double rel_tol, uint32_t max_iters, double *worst_rel) {
