@@ -1464,8 +1464,6 @@ struct BlockLobpcg {
     Timer t_iter;
     double precond_seconds = 0;
     double best_worst_active = 1e300; // smallest worst relative residual of the active columns seen so far
-    double restart_best = 1e300, last_worst_active = 0; // the same since the last restart; the previous iteration's
-    uint32_t growth_run = 0, restarts = 0, drop_p_until = 0; // iterations of growth in a row; restarts made; no conjugate directions before this iteration
     int floor_strikes = 0;            // consecutive iterations in which the worst active residual sat 1e3 above it
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
@@ -1854,20 +1852,6 @@ struct BlockLobpcg {
                 if (!locked[i]) worst_active = std::max(worst_active, std::sqrt(rn[i]) / (std::abs(theta[i]) * std::sqrt(mn[i])));
             }
             best_worst_active = std::min(best_worst_active, worst_active);
-            // ... and before it comes to that: residuals of the active columns that have GROWN for two iterations running, to four times their best,
-            // with nothing newly converged, are the onset of that loss of rank -- on a mesh with flat cells (||A|| / theta ~ 1e8 and up) it sets in long
-            // before the wanted pairs are done (128 x 64 UV sphere with 346 cells flat to 5e-10: 57 of 65 pairs at iteration 60, residuals then 9e-5
-            // -> 1e-3 -> 1e+1 in twenty iterations).  The cure is the textbook one: drop the conjugate directions for two iterations (a restart on
-            // [X W]) and measure growth afresh; at most eight times per solve.
-            growth_run = (h > 1 && worst_active > last_worst_active && hist_nconv[h - 2] == nconv) ? growth_run + 1 : 0;
-            last_worst_active = worst_active;
-            if (it >= 12 && growth_run >= 2 && worst_active > 4 * restart_best && restarts < 8) {
-                if (verbose) fprintf(stderr, "[lobpcg] it %3u residuals growing (%.1e from %.1e): two iterations without conjugate directions\n", it, worst_active, restart_best);
-                drop_p_until = it + 2;
-                ++restarts;
-                growth_run = 0;
-                restart_best = worst_active;
-            } else restart_best = std::min(restart_best, worst_active);
             // (three iterations in a row: one step's jump is also what a guard column looks like when its Ritz value drops into the
             // wanted range late -- a missed member of a multiplet arrives with a residual of 1e-2 .. 1e-1 beside pairs just above the tolerance)
             floor_strikes = it >= 20 && worst_active > 1e3 * best_worst_active ? floor_strikes + 1 : 0;
@@ -2090,7 +2074,6 @@ struct BlockLobpcg {
         // count is the same without it (18 and 18 at S100k) -- and an iteration on [X W] costs a third less
         // (Rayleigh-Ritz of order 2w, no P Grams, narrower updates): 224 -> 213 ms per solve.
         if (!warm && it < kSkipP && !hist_worst.empty() && hist_worst.back() > 0.5) wp_new = 0;
-        if (it < drop_p_until) wp_new = 0; // (a restart: converged_or_locked saw the residuals grow)
         if (wp_new) { // App = Cp^T gA_prev Cp for the next iteration's P-P block
             small_dgemm(ctx, rocblas_operation_none, rocblas_operation_none, m, wp_new, m, &one, gA0, m, Cp, m, &zero, T1, m);
             small_dgemm(ctx, rocblas_operation_transpose, rocblas_operation_none, wp_new, wp_new, m, &one, Cp, m, T1, m, &zero, App, wp_new);
@@ -2304,8 +2287,13 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- last resort: conjugate-gradient search directions\n", e.what());
                     prof = sys->profile;
                     prof.dofs = uint32_t(n);
-                    BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, 8);
-                    solver.run(eigenvalues);
+                    try {
+                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, 8);
+                        solver.run(eigenvalues);
+                    } catch (const MhError &again) {
+                        if (again.code != MH_ENOTCONVERGED) throw;
+                        mh_throw(MH_ENOTCONVERGED, "%s (the last resort too: %s)", e.what(), again.what()); // what the caller reads first is why the solve itself stopped
+                    }
                     return;
                 }
                 // Last resort of a SMALL system whose iteration stalled (measured: a UV sphere's surface filled without interior

@@ -365,8 +365,10 @@ void mh_select_patches(mh_system *sys, float threshold) {
     // the rims in components of up to 163 elements) they save 4-7 iterations of 41 and cost twice the time in dense products: element patches
     // there, as before.  MH_CLUSTERS=1 forces them, =0 forbids.
     static const int cluster_switch = getenv("MH_CLUSTERS") ? atoi(getenv("MH_CLUSTERS")) : -1;
-    const bool use_clusters = cluster_switch == 1 || (cluster_switch != 0 && sys->worst_quality < 1e-4f);
+    const bool flat_cells = sys->worst_quality < 1e-4f;
+    bool use_clusters = cluster_switch == 1 || (cluster_switch != 0 && cluster_switch != 2 && flat_cells); // (2, experiment: the P1 level only)
     static const uint32_t cluster_cap = getenv("MH_CLUSTER_CAP") ? uint32_t(std::max(16, atoi(getenv("MH_CLUSTER_CAP")))) : 2048u; // nodes: an inverse of order 6 144 at most
+    if (getenv("MH_DEBUG_PATCH")) fprintf(stderr, "[patch] bad %zu of %u, n_nodes %u n_points %u worst %.2e clusters %d\n", bad.size(), nt, sys->n_nodes, sys->n_points, double(sys->worst_quality), int(use_clusters));
     std::vector<uint32_t> comp(bad.size());
     {
         std::vector<uint32_t> parent(bad.size());
@@ -391,14 +393,6 @@ void mh_select_patches(mh_system *sys, float threshold) {
     for (uint32_t k = 0; k < bad.size(); ++k) ++comp_size[comp[k]];
     std::vector<uint32_t> single; // positions in `bad` of the elements that stay element patches
     std::vector<std::vector<uint32_t>> multi; // per cluster component: positions in `bad`, ascending
-    {
-        std::vector<int32_t> slot(bad.size(), -1);
-        for (uint32_t k = 0; k < bad.size(); ++k) {
-            if (!use_clusters || comp_size[comp[k]] == 1) { single.push_back(k); continue; }
-            if (slot[comp[k]] < 0) slot[comp[k]] = int32_t(multi.size()), multi.emplace_back();
-            multi[size_t(slot[comp[k]])].push_back(k);
-        }
-    }
     const auto fill = [&](PatchSet &ps, const std::vector<uint32_t> &elem, uint32_t npe, uint32_t n_level_nodes) {
         const uint32_t np = uint32_t(single.size());
         std::vector<uint32_t> nodes(size_t(np) * npe);
@@ -420,7 +414,7 @@ void mh_select_patches(mh_system *sys, float threshold) {
         }
         ptr.push_back(uint32_t(inc.size()));
         std::vector<double> weight(np, 1.0);
-        {
+        if (np) {
             std::vector<uint32_t> cover(touched.size(), 0);
             for (size_t t = 0; t + 1 < ptr.size(); ++t) cover[t] = ptr[t + 1] - ptr[t];
             std::vector<uint32_t> worst(np, 1);
@@ -498,8 +492,23 @@ void mh_select_patches(mh_system *sys, float threshold) {
         }
         HIP_CHECK(hipStreamSynchronize(st));
     };
+    const auto regroup = [&](bool clusters) { // which elements stay element patches, which hang together as clusters
+        single.clear();
+        multi.clear();
+        std::vector<int32_t> slot(bad.size(), -1);
+        for (uint32_t k = 0; k < bad.size(); ++k) {
+            if (!clusters || comp_size[comp[k]] == 1) { single.push_back(k); continue; }
+            if (slot[comp[k]] < 0) slot[comp[k]] = int32_t(multi.size()), multi.emplace_back();
+            multi[size_t(slot[comp[k]])].push_back(k);
+        }
+    };
+    regroup(use_clusters);
+    if (getenv("MH_DEBUG_PATCH")) fprintf(stderr, "[patch] single %zu multi %zu\n", single.size(), multi.size());
     fill(sys->patches2, en, 10, sys->n_nodes);
+    if (getenv("MH_DEBUG_PATCH")) fprintf(stderr, "[patch] P2 filled: clusters %u rows %u largest %u\n", sys->patches2.n_clusters, sys->patches2.cluster_rows, sys->patches2.largest_cluster);
+    if (cluster_switch == 2) regroup(true);
     fill(sys->patches1, ep, 4, sys->n_points);
+    if (getenv("MH_DEBUG_PATCH")) fprintf(stderr, "[patch] P1 filled: clusters %u rows %u largest %u\n", sys->patches1.n_clusters, sys->patches1.cluster_rows, sys->patches1.largest_cluster);
 }
 
 // SPD inverse in place, order n (column-major = row-major: symmetric), by the block Gauss-Jordan elimination of the coarse level
