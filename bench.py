@@ -51,7 +51,7 @@ def pmc_traffic(family="spmm_family", workload=PMC_WORKLOAD):
     those passes measured (a per-launch figure of the cube says nothing about a batch of 30k-tet meshes)."""
     if workload != PMC_WORKLOAD:
         return None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)[family]["hbm_bytes_per_launch"])
