@@ -2287,6 +2287,14 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- last resort: conjugate-gradient search directions\n", e.what());
                     prof = sys->profile;
                     prof.dofs = uint32_t(n);
+                    // (with the smoothers' bounds a quarter wider, if they are not already: the conjugate gradients around the cycle need it to be
+                    // positive definite, i.e. no end of the spectrum above the bound -- on the 128 x 64 sphere's flat fill 19 iterations with the
+                    // wider bounds against 59 without)
+                    if (!sys->lmax_widened) {
+                        sys->L1.lmax *= 1.25;
+                        sys->L2.lmax *= 1.25;
+                        sys->lmax_widened = true;
+                    }
                     try {
                         BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, 8);
                         solver.run(eigenvalues);
