@@ -5,6 +5,7 @@
 #include "modalhip.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <chrono>
 #include <cmath>
 #include <stdexcept>
@@ -197,7 +198,7 @@ ModalResult mesh2modes(const TetMesh &tets, const AcousticMaterialProperties &ma
     const auto *seed = reuse.SeedBasis;
     const bool warm = seed && seed->rows() == std::ptrdiff_t(n) && seed->cols() >= std::ptrdiff_t(nev);
     // The reference's tolerances bound Ritz-value errors; a relative residual r leaves an eigenvalue error ~ r^2.
-    const double residual_tol = warm ? std::clamp(std::sqrt(config.WarmTolerance) * 1e-2, 1e-8, 1e-2) : std::clamp(0.1 * std::sqrt(config.Tolerance), 1e-8, 1e-4);
+    const double residual_tol = warm ? std::clamp(std::sqrt(config.WarmTolerance) * 1e-2, 1e-8, 1e-2) : std::clamp(std::sqrt(config.Tolerance), 1e-8, 1e-4); // (eigenvalue error ~ residual^2 = Tolerance: mesheditor_amd/api.py, residual_tolerance)
     if (cancelled()) return result; // empty Modes, the rest as computed so far
     std::vector<double> eigenvalues(nev);
     mh_profile dev{};

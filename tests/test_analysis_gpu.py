@@ -679,7 +679,7 @@ def test_batch64_config4_through_solve_batch(api, oracle):
         i = r["index"]
         assert len(r["eigenvalues"]) == 45 and r["dofs"] == 128625 and 0 < len(r["freqs"]) <= 30
         assert (np.abs(r["eigenvalues"][:6]) < 1e-6 * r["eigenvalues"][6]).all()
-        assert worst[i][0] < 1.5e-5 and worst[i][1] < 1e-7, (i, worst[i])
+        assert worst[i][0] < 1.5e-4 and worst[i][1] < 1e-7, (i, worst[i])  # (the default config's residual tolerance: sqrt(Tolerance) = 1e-4, api.residual_tolerance)
         rho = items[i][2][0]
         p = items[i][0]
         assert abs(r["mass"] - rho * np.prod(p.max(0) - p.min(0))) < 2e-6 * r["mass"]  # float (1.f / 6.f) in the reference's volume, SURVEY App. A
