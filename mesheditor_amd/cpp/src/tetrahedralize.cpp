@@ -936,6 +936,21 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
 // Boundary faces are untouched (an edge on the boundary has an open ring and is skipped), no point is added or moved, every new
 // tetrahedron is positively oriented (exact), and an exchange is made only if the worst shape among the new tetrahedra exceeds
 // the worst among the old ones -- so the pass terminates and can only improve the mesh's worst elements.
+// MH_TET_DEBUG: every face on at most two tetrahedra, every tetrahedron positively oriented -- said per stage, so that a defect names its origin
+static void DebugValidate(const TetMesh &mesh, const char *stage) {
+    static const bool on = std::getenv("MH_TET_DEBUG") != nullptr;
+    if (!on) return;
+    std::map<Tri, int> count;
+    size_t inverted = 0;
+    for (const auto &t : mesh.Tets) {
+        if (exact::Orient3D(mesh.Points[t[0]], mesh.Points[t[1]], mesh.Points[t[2]], mesh.Points[t[3]]) <= 0) ++inverted;
+        for (int i = 0; i < 4; ++i) ++count[Sorted(t[size_t(i + 1) & 3], t[size_t(i + 2) & 3], t[size_t(i + 3) & 3])];
+    }
+    size_t over = 0;
+    for (const auto &[f, c] : count) over += c > 2;
+    std::fprintf(stderr, "[tets] %-28s %zu tets, %zu points: %zu faces on more than two tetrahedra, %zu tetrahedra not positively oriented\n", stage, mesh.Tets.size(), mesh.Points.size(), over, inverted);
+}
+
 static uint32_t RepairSlivers(TetMesh &mesh, double target, const std::set<Tri> *walls = nullptr) { // walls: faces INSIDE the mesh that must stay (non-manifold input)
     auto &P = mesh.Points;
     auto &T = mesh.Tets;
@@ -954,6 +969,7 @@ static uint32_t RepairSlivers(TetMesh &mesh, double target, const std::set<Tri> 
                 if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
             } else {
                 auto it = faces.find(key);
+                if (it == faces.end()) continue;
                 if (it->second[0] == t) it->second[0] = it->second[1];
                 it->second[1] = -1;
                 if (it->second[0] < 0) faces.erase(it);
@@ -1447,7 +1463,10 @@ public:
     // (the long cells of a bare surface's Delaunay fill all hold an interior point in their circumspheres: the full cavity of an early
     // point is most of the mesh, and a local one serves as well -- the exchanges of the sliver repair afterwards do not need a Delaunay
     // mesh).  Returns the cells to be replaced; empty when the containing cell itself cannot see p through one of its hull faces.
-    std::vector<int32_t> Cavity(const dvec3 &p, int32_t at) {
+    // `also`: a cell that joins the cavity whatever the insphere test says, if it shares a face with it (a FLAT cell's circumsphere is a
+    // half-space whose side is decided by the last bits of its vertices: a point just under a cap may lie outside it) -- the star-shape
+    // test below still has the last word on it.
+    std::vector<int32_t> Cavity(const dvec3 &p, int32_t at, int32_t also = -1) {
         if (Mark.size() < T.size()) Mark.resize(T.size() + T.size() / 2, 0);
         ++Stamp;
         std::vector<int32_t> cavity{at};
@@ -1457,7 +1476,7 @@ public:
                 const int32_t o = Across(cavity[head], i);
                 if (o < 0 || Mark[size_t(o)] == Stamp) continue;
                 const auto &ov = T[size_t(o)];
-                if (exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0) Mark[size_t(o)] = Stamp, cavity.push_back(o);
+                if (o == also || exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0) Mark[size_t(o)] = Stamp, cavity.push_back(o);
             }
         // star-shaped hull: every hull face must see p strictly from the inside; a cell whose face does not leaves the cavity
         bool ok = true;
@@ -1674,13 +1693,91 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
 // flat neighbours fall into the cavity together and are replaced by cells of the new point's height.  A position is taken only when the
 // flat cell goes and the WORST cell of the fan is better than the worst cell it replaces; the best of the candidate positions wins.
 // Points are strictly interior; the boundary and the walls are untouched.  Returns the number of points added.
-static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> *walls, size_t budget) {
+static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> *walls, size_t budget, uint32_t n_input, uint32_t *moved_out = nullptr) {
     FillEditor ed(mesh, walls);
     auto &P = mesh.Points;
     auto &T = mesh.Tets;
     const auto cross = [](const dvec3 &p, const dvec3 &q) { return dvec3{p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x}; };
     const auto dot = [](const dvec3 &p, const dvec3 &q) { return p.x * q.x + p.y * q.y + p.z * q.z; };
-    uint32_t added = 0;
+    uint32_t added = 0, moved = 0;
+    // A flat cell that holds an ADDED interior point is flat because that point sits almost in the plane of the other three (a recovery point
+    // lifted only a hair off the surface): the cure is to move the point, not to add another beside it.  Candidates along the cell's normal
+    // (both ways) and towards the centroid of the point's neighbours; taken where every tetrahedron at the point stays positively oriented
+    // (exact) and the worst of them improves; the best candidate wins.  Input vertices, points on the boundary and on walls never move.
+    const auto relocate = [&](int32_t t0) -> bool {
+        const auto cell = T[size_t(t0)];
+        for (int vi = 0; vi < 4; ++vi) {
+            const uint32_t v = cell[size_t(vi)];
+            if (v < n_input) continue;
+            std::vector<int32_t> star;
+            bool fixed = false;
+            dvec3 centre{0, 0, 0};
+            double weight = 0;
+            for (size_t t = 0; t < T.size() && !fixed; ++t) {
+                if (ed.IsDead(t)) continue;
+                const auto &c = T[t];
+                int at = -1;
+                for (int i = 0; i < 4; ++i)
+                    if (c[size_t(i)] == v) at = i;
+                if (at < 0) continue;
+                star.push_back(int32_t(t));
+                for (int i = 0; i < 4; ++i) {
+                    if (i == at) { // the faces that hold v are the other three: none may be a boundary or wall face
+                        continue;
+                    }
+                    if (ed.Across(int32_t(t), i) < 0) fixed = true; // face i is opposite vertex i, i.e. it holds v when i != at
+                    centre = centre + P[c[size_t(i)]];
+                    weight += 1;
+                }
+            }
+            if (fixed || star.empty()) continue;
+            centre = centre * (1.0 / weight);
+            const dvec3 &a = P[cell[size_t(vi + 1) & 3]], &b = P[cell[size_t(vi + 2) & 3]], &c3 = P[cell[size_t(vi + 3) & 3]];
+            dvec3 n = cross(b - a, c3 - a);
+            const double nl = std::sqrt(dot(n, n));
+            if (!(nl > 0)) continue;
+            n = n * (1.0 / nl);
+            const double scale = std::sqrt(nl); // ~ the opposite face's edge length
+            const auto worst_at = [&](const dvec3 &x, bool &valid) {
+                double worst = 1e300;
+                valid = true;
+                for (const int32_t t : star) {
+                    dvec3 q[4];
+                    for (int i = 0; i < 4; ++i) q[i] = T[size_t(t)][size_t(i)] == v ? x : P[T[size_t(t)][size_t(i)]];
+                    if (exact::Orient3D(q[0], q[1], q[2], q[3]) <= 0) { valid = false; return 0.0; }
+                    const dvec3 u = q[1] - q[0], w = q[2] - q[0], z = q[3] - q[0];
+                    const double vol6 = std::fabs(dot(u, cross(w, z)));
+                    double l2 = 0;
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = i + 1; j < 4; ++j) l2 += dot(q[i] - q[j], q[i] - q[j]);
+                    const double lrms = std::sqrt(l2 / 6);
+                    worst = std::min(worst, lrms > 0 ? 1.4142135623730951 * vol6 / (lrms * lrms * lrms) : 0.0);
+                }
+                return worst;
+            };
+            bool ok = false;
+            double best = worst_at(P[v], ok);
+            if (!ok) continue;
+            dvec3 best_x = P[v];
+            bool found = false;
+            std::vector<dvec3> candidates;
+            for (const double step : {0.15, 0.3, 0.5, 0.8}) {
+                candidates.push_back(P[v] + n * (step * scale));
+                candidates.push_back(P[v] - n * (step * scale));
+            }
+            for (const double step : {0.25, 0.5, 0.75, 1.0}) candidates.push_back(P[v] + (centre - P[v]) * step);
+            for (const dvec3 &x : candidates) {
+                bool valid = false;
+                const double w = worst_at(x, valid);
+                if (valid && w > best * 1.5) best = w, best_x = x, found = true;
+            }
+            if (found) {
+                P[v] = best_x;
+                return true;
+            }
+        }
+        return false;
+    };
     for (int pass = 0; pass < 6 && added < budget; ++pass) {
         std::vector<std::pair<double, int32_t>> work; // flattest first
         for (size_t t = 0; t < T.size(); ++t)
@@ -1694,6 +1791,8 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
         for (const auto &[q0, t0] : work) {
             if (added >= budget) break;
             if (ed.IsDead(size_t(t0))) continue;
+            if (ShapeOf(P, T[size_t(t0)]) >= floor) continue; // (a neighbour's point has moved meanwhile)
+            if (relocate(t0)) { ++moved; ++added_this_pass; continue; }
             const auto cell = T[size_t(t0)];
             // candidate positions
             std::vector<dvec3> candidates;
@@ -1752,7 +1851,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             for (const dvec3 &p : candidates) {
                 const int32_t at = ed.Locate(p, t0);
                 if (at < 0) continue;
-                const std::vector<int32_t> in = ed.Cavity(p, at);
+                const std::vector<int32_t> in = ed.Cavity(p, at, t0);
                 if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) continue;
                 double worst_old = 1e300, worst_new = 1e300;
                 for (const int32_t c : in) worst_old = std::min(worst_old, ShapeOf(P, T[size_t(c)]));
@@ -1769,10 +1868,11 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                 ++added, ++added_this_pass;
             }
         }
-        if (std::getenv("MH_TET_DEBUG")) std::fprintf(stderr, "BreakFlatCells pass %d: %zu below %.0e (flattest %.1e), %u points\n", pass, work.size(), floor, work.front().first, added_this_pass);
+        if (std::getenv("MH_TET_DEBUG")) std::fprintf(stderr, "BreakFlatCells pass %d: %zu below %.0e (flattest %.1e), %u points added or moved (%u moved so far)\n", pass, work.size(), floor, work.front().first, added_this_pass, moved);
         if (!added_this_pass) break;
     }
     if (added) ed.Compact();
+    if (moved_out) *moved_out = moved;
     return added;
 }
 
@@ -2160,6 +2260,16 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
     out.Profile.CarveSeconds = seconds_since(stage_start);
     stage_start = Clock::now();
     const auto refine_start = stage_start; // everything from here on is the last stage
+    DebugValidate(out.Mesh, "after the carve");
+    // The recovery's points are exact midpoints (expansions) while it runs and ROUNDED on the way out: a tetrahedron between several of them
+    // on one thin wall can come out flat or turned over in the rounded coordinates (found by the round-6 soak: a 13 mm scan wall at a 13 mm
+    // lattice, 2 080 recovery points, 15 such tetrahedra -- and a crash in the sliver repair behind them).  Such a fill is not handed on:
+    // the attempt reports that the refinement did not converge, and the constrained recovery (a handful of points) takes over.
+    {
+        size_t turned = 0;
+        for (const auto &t : out.Mesh.Tets) turned += exact::Orient3D(out.Mesh.Points[t[0]], out.Mesh.Points[t[1]], out.Mesh.Points[t[2]], out.Mesh.Points[t[3]]) <= 0;
+        if (turned) return out.Error = "boundary recovery did not converge: " + std::to_string(turned) + " tetrahedra flat or inverted once the recovery's points are rounded", out;
+    }
     if (options.InteriorSteiner && out.BoundarySteinerCount) {
         for (auto &e : split_edge) e = {final_id(e[0]), final_id(e[1])};
         const uint32_t on_surface = out.BoundarySteinerCount;
@@ -2167,6 +2277,7 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
         out.Profile.VolSteinerCount = on_surface - out.BoundarySteinerCount;
         out.Profile.SuppressSeconds = seconds_since(stage_start);
     }
+    DebugValidate(out.Mesh, "after lifting");
     if (options.RepairSlivers) {
         std::set<Tri> walls; // non-manifold input: the surface pieces that ended up between two tetrahedra
         if (!manifold)
@@ -2283,8 +2394,9 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
         };
         constexpr double kShapeFloor = 1e-2; // cells below it are worked on; what the pass guarantees where it succeeds is 1e-3 (tests)
         for (int round = 0; round < 4 && options.BreakFlatCells && worst_shape(out.Mesh) < kShapeFloor; ++round) {
-            const uint32_t points = BreakFlatCells(out.Mesh, kShapeFloor, keep, std::max<size_t>(4096, out.Mesh.Points.size() / 4));
-            if (!points) break;
+            uint32_t moved = 0;
+            const uint32_t points = BreakFlatCells(out.Mesh, kShapeFloor, keep, std::max<size_t>(4096, out.Mesh.Points.size() / 4), n_input, &moved);
+            if (!points && !moved) break;
             out.FlatCellPoints += points;
             for (int sweep = 0; sweep < 2; ++sweep) {
                 out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
@@ -2294,6 +2406,11 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
         }
     }
     out.Profile.RefineSeconds = seconds_since(refine_start);
+    DebugValidate(out.Mesh, "at the end");
+    // never hand on a mesh with a tetrahedron that is not positively oriented (the reference's validator, tests/ValidateTetMesh.h:47-140, rejects it)
+    for (const auto &t : out.Mesh.Tets)
+        if (exact::Orient3D(out.Mesh.Points[t[0]], out.Mesh.Points[t[1]], out.Mesh.Points[t[2]], out.Mesh.Points[t[3]]) <= 0)
+            return out.Error = "boundary recovery did not converge: the finished fill holds a tetrahedron that is not positively oriented", out;
     return out;
 }
 

@@ -1,0 +1,88 @@
+"""Round-6 robustness soak of the whole path with the DEFAULT settings (residual tolerance sqrt(Tolerance), front end's default options incl. the flat-cell pass):
+(1) random jittered Kuhn boxes as tools/probe/random_bodies_soak.py; (2) random closed surfaces through tetra::Tetrahedralize -- UV spheres of random resolution stretched
+into ellipsoids (needle triangles at the poles, planar quads), tori, scan-like skillets -- then mesh2modes.  Every solve must return all its pairs without the spectral-bound
+retry, the dense redo or the last resort (MH_VERBOSE lines are searched for them); every fill must have a worst shape >= 1e-3.   python tools/probe/r06_soak.py [boxes] [surfaces]"""
+import sys, os, time, io
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import numpy as np
+from mesheditor_amd import api, meshes, tets as front_end
+
+def shape_min(p, t):
+    q = p[t.astype(np.int64)]
+    vol6 = np.abs(np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0]))
+    e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+    return float((vol6 * np.sqrt(2) / e2 ** 1.5).min())
+
+def torus(R, r, nu, nv):
+    u = np.arange(nu) * 2 * np.pi / nu
+    v = np.arange(nv) * 2 * np.pi / nv
+    P = np.array([[(R + r * np.cos(b)) * np.cos(a), (R + r * np.cos(b)) * np.sin(a), r * np.sin(b)] for a in u for b in v], np.float32).astype(np.float64)
+    F = []
+    for i in range(nu):
+        for j in range(nv):
+            a, b, c, d = i * nv + j, ((i + 1) % nu) * nv + j, ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv
+            F += [(a, b, c), (a, c, d)]
+    return P, np.array(F, np.uint32)
+
+ctx = api.Context(0)
+rng = np.random.default_rng(606)
+mats = [meshes.MATERIALS[k] for k in meshes.MATERIAL_ORDER]
+n_boxes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+n_surf = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+fails, its = [], []
+for trial in range(n_boxes):
+    nx, ny, nz = (int(v) for v in rng.integers(2, 15, 3))
+    if nx * ny * nz < 24: continue
+    lx, ly, lz = 0.02 * nx * rng.uniform(0.6, 1.6), 0.02 * ny * rng.uniform(0.6, 1.6), 0.02 * nz * rng.uniform(0.6, 1.6)
+    pts, tets = meshes.kuhn_box(nx, ny, nz, lx, ly, lz)
+    jitter = rng.uniform(0.0, 0.3)
+    pts = pts + rng.uniform(-1, 1, pts.shape) * jitter * min(lx / nx, ly / ny, lz / nz) * 0.5
+    m = mats[trial % len(mats)]
+    pairs = int(rng.choice([20, 45, 65]))
+    ex = pts[:: max(1, len(pts) // 10)][:10].astype(np.float32)
+    r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(num_modes=max(5, pairs - 15), num_fem_modes=pairs))
+    ok = len(r.eigenvalues) == min(pairs, 3 * 0 + pairs)
+    its.append(r.profile.get("restarts", 0))
+    print(f"box {trial:3d} {nx}x{ny}x{nz} jitter {jitter:.2f} tets {len(tets)} pairs {pairs}: {len(r.eigenvalues)} pairs, {r.profile.get('restarts')} iterations", flush=True)
+    if not ok: fails.append(("box", trial, nx, ny, nz))
+for trial in range(n_surf):
+    kind = trial % 3
+    t0 = time.time()
+    if kind == 0:
+        seg = int(rng.choice([16, 24, 32, 48, 64, 80]))
+        P, F = meshes.uv_sphere_surface(0.1, seg, max(6, seg // 2))
+        P = P * rng.uniform(0.4, 1.6, 3)
+        name = f"ellipsoid {seg}x{max(6, seg // 2)}"
+    elif kind == 1:
+        nu, nv = int(rng.integers(12, 48)), int(rng.integers(6, 20))
+        P, F = torus(0.1, 0.1 * rng.uniform(0.15, 0.5), nu, nv)
+        P = P * rng.uniform(0.6, 1.4, 3)
+        name = f"torus {nu}x{nv}"
+    else:
+        h = float(rng.choice([0.02, 0.016, 0.013]))
+        P, F = meshes.skillet_scan_surface(h, h * rng.uniform(1.1, 1.6), noise_seed=int(rng.integers(1, 1000)))
+        name = f"scan h={h}"
+    try:
+        pts, tets, left = front_end.tetrahedralize(P, F)
+    except RuntimeError as e:
+        print(f"surf {trial:3d} {name}: front end: {str(e)[:120]}", flush=True)
+        fails.append(("fill", trial, name, str(e)[:80]))
+        continue
+    smin = shape_min(pts, tets)
+    m = mats[trial % len(mats)]
+    pairs = int(rng.choice([30, 45, 65]))
+    ex = pts[(np.arange(10) * len(P)) // 10].astype(np.float32)
+    t1 = time.time()
+    try:
+        r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(num_modes=pairs - 15, num_fem_modes=pairs))
+    except Exception as e:  # noqa: BLE001
+        print(f"surf {trial:3d} {name}: {len(P)} -> {len(pts)} points {len(tets)} tets, worst shape {smin:.1e}: EXCEPTION {e!r} <- {e.__cause__!r}"[:400], flush=True)
+        fails.append(("exception", trial, name, repr(e.__cause__)[:120]))
+        np.savez("gpurun_out/r06_soak_fail_%d.npz" % trial, pts=pts, tets=tets, material=np.array(m), pairs=pairs)
+        continue
+    ctx.synchronize()
+    its.append(r.profile.get("restarts", 0))
+    print(f"surf {trial:3d} {name}: {len(P)} -> {len(pts)} points {len(tets)} tets ({left} on the surface, fill {t1 - t0:.1f} s), worst shape {smin:.1e}; {len(r.eigenvalues)} of {pairs} pairs, {r.profile.get('restarts')} iterations, {1e3 * (time.time() - t1):.0f} ms", flush=True)
+    if len(r.eigenvalues) != pairs: fails.append(("solve", trial, name))
+    if smin < 1e-3: fails.append(("shape", trial, name, smin))
+print("solves", len(its), "iterations min / median / max", min(its), int(np.median(its)), max(its), "failures", fails)
