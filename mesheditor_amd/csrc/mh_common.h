@@ -479,6 +479,7 @@ struct mh_system {
     // Rayleigh-Ritz step) runs beside the elimination's one-workgroup kernels.
     hipEvent_t coarse_done{nullptr};
     bool coarse_pending{false};
+    double coarse_lift{0}; // relative lift of the coarse operator's diagonal beyond the default (raised by eigs_impl when the elimination met a non-positive pivot)
     DevArray<double> coarse_ws[5];
     DevArray<int> coarse_info;
     ~mh_system() {

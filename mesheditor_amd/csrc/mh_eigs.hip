@@ -75,6 +75,7 @@ struct Switches {
     bool test_sytrd_giveup = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "sytrd_giveup");
     bool no_tridiag_wide = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_tridiag_wide");
     bool test_last_resort = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "last_resort"); // every solve of more than 12 288 unknowns goes straight to the last resort
+    bool test_coarse_pivot = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "coarse_pivot"); // the first coarse elimination of a system reports a non-positive pivot
     bool test_selfcheck_fail = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "selfcheck_fail"); // the first solve's Rayleigh-Ritz self-check reports a failure
     bool no_poly_start = getenv("MH_TEST") && strstr(getenv("MH_TEST"), "no_poly_start"); // (A/B hook of round 5: the cold start block as rounds 1-4 had it)
     Switches() {
@@ -1154,6 +1155,7 @@ void mh_finish_hierarchy(mh_system *sys) {
             fprintf(stderr, "[lobpcg] %d of %u + %u sliver patches / clusters of the %s level dropped (e.g. patch %d; clusters count from 1000000): their nodes keep the diagonal scaling only\n", dropped[0], ps->n_patches, ps->n_clusters,
                     ps->npe == 10 ? "P2" : "P1", dropped[1] - 1);
     }
+    if (switches().test_coarse_pivot && sys->coarse_lift == 0) hinfo = 1; // (test hook: the first elimination of every system reports a lost pivot)
     if (hinfo != 0) {
         sys->hierarchy_ready = false;
         mh_throw(MH_EFACTOR, "coarse operator not positive definite (pivot %d of a diagonal block): shift must be negative", hinfo);
@@ -1182,7 +1184,10 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
     sys->a0.zero();
     k_coarse_matrix<<<sys->n_agg, 64, 0, ctx->stream>>>(sys->L1.row_ptr, sys->L1.col, sys->L1.aval, sys->agg_t, sys->agg_of, sys->agg_ptr, sys->agg_nodes, sys->n_agg, sys->a0);
     KERNEL_CHECK();
-    k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), 1e-12);
+    // (a mesh with flat cells: the Galerkin product cancels entries of 1e17 down to rigid-body terms of 1e10 and below -- its rounding is
+    // ~1e-9 of the diagonal, enough to cost the coarse operator its definiteness: "coarse operator not positive definite" on one stretched
+    // UV sphere of the round-6 soak.  The diagonal is lifted by that much instead of by 1e-12.)
+    k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), std::max(sys->coarse_lift, sys->worst_quality < kFlatShape ? 1e-8 : 1e-12));
     KERNEL_CHECK();
     DevArray<int> &info = sys->coarse_info;
     info.reset(ctx, 1);
@@ -2238,6 +2243,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // itself but what ran beside it: rocBLAS's LDS-bound dsymm kernel, which only wide blocks call, on the same CU as a workgroup
             // of k_sytrd_multi, whose barrier at the top of the column loop hipcc had left without its LDS wait; mh_common.h:
             // mh_lds_writes_landed, DESIGN.md section 6.  With the wait in place the lock is gone.)
+            const auto build_and_solve = [&] {
             {
                 Timer t(ctx);
                 mh_build_hierarchy(sys, sigma, true); // (the coarse elimination may still run: the first preconditioner application waits for it)
@@ -2318,6 +2324,21 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 prof.restarts = max_iters + 1;
                 sys->profile = prof;
                 if (profile) *profile = prof;
+            }
+            };
+            // The shift is negative (checked above), so K - sigma M IS positive definite and so is every Galerkin coarse operator of it in exact
+            // arithmetic: a coarse elimination that meets a non-positive pivot has lost it to rounding (flat cells: entries of 1e17 cancelling).
+            // That is not the caller's "factorization failed": the diagonal lift of the coarse operator goes up a thousandfold, twice at most.
+            for (int lifted = 0;; ++lifted) {
+                try {
+                    build_and_solve();
+                    break;
+                } catch (const MhError &e) {
+                    if (e.code != MH_EFACTOR || !strstr(e.what(), "coarse operator") || lifted >= 2) throw;
+                    sys->coarse_lift = (sys->coarse_lift > 0 ? sys->coarse_lift : 1e-9) * 1e3;
+                    sys->hierarchy_ready = false;
+                    if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- the coarse operator's diagonal lifted by %.0e, once more\n", e.what(), sys->coarse_lift);
+                }
             }
         }
     }

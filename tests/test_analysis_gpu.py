@@ -1463,6 +1463,35 @@ def test_the_last_resort_reproduces_the_oracle():
     assert "last resort: conjugate-gradient search directions" in p.stderr, p.stderr[-2000:]
 
 
+def test_the_fall_backs_of_a_solve_reproduce_the_oracle():
+    """The redo paths of eigs_impl that no healthy mesh reaches, each forced by its test hook in a fresh interpreter (the switches are read once)
+    and held to the committed oracle eigenvalues of the 10k-tet ball at 1e-6: a coarse elimination that meets a non-positive pivot (rounding on a
+    mesh with flat cells; found by the round-6 soak as a false "factorization failed") is redone with the coarse operator's diagonal lifted;
+    a failed Rayleigh-Ritz self-check is redone without the exchange kernels instead of returning MH_EHIP."""
+    import subprocess
+    import sys
+    code = (
+        "import json, os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from mesheditor_amd import api, meshes\n"
+        "pts, tets, m, kw = meshes.workload('ball_s10k')\n"
+        "fx = json.load(open(os.path.join(%r, 'tests', 'golden', 'oracle_eigs_ball_s10k.json')))\n"
+        "c = api.Context(0)\n"
+        "ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)\n"
+        "r = api.mesh2modes(c, pts, tets, api.material(*m), ex, config=api.default_config(**kw))\n"
+        "ref = np.array(fx['eigenvalues'])\n"
+        "assert len(r.eigenvalues) == len(ref), len(r.eigenvalues)\n"
+        "el = ref > 1e-6 * ref[-1]\n"
+        "rel = np.abs(r.eigenvalues[el] - ref[el]) / ref[el]\n"
+        "assert rel.max() < 1e-6, rel.max()\n"
+        "c.close()\n"
+    ) % (ROOT, ROOT)
+    for hook, said in (("coarse_pivot", "the coarse operator's diagonal lifted"), ("selfcheck_fail", "once more without the exchange kernels")):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MH_TEST=hook, MH_VERBOSE="1"), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (hook, p.stdout[-2000:] + p.stderr[-2000:])
+        assert said in p.stderr, (hook, p.stderr[-2000:])
+
+
 def test_the_shift_invert_operator_as_an_operation(api, ctx):
     """SURVEY 8a row A8's interface (src/audio/CholeskyShiftInvert.h:11-30: set_shift, perform_op, solve_panel): x = (K - sigma M)^-1 b through the
     C ABI (preconditioned conjugate gradients on the device: there is no factorisation) against a sparse direct solve of the exported

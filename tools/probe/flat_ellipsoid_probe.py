@@ -6,9 +6,10 @@ import numpy as np
 from mesheditor_amd import api, meshes, tets as T
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ctx = api.Context(0)
-m = meshes.MATERIALS["Ceramic"]
+mats = [meshes.MATERIALS[k] for k in meshes.MATERIAL_ORDER]
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
-    seg = int(rng.choice([32, 48, 64, 80]))
+    m = mats[trial % len(mats)]
+    seg = int(rng.choice([32, 48, 64, 80] if len(sys.argv) < 4 else [24, 32, 48, 64]))
     P, F = meshes.uv_sphere_surface(0.1, seg, seg // 2)
     s = rng.uniform(0.4, 1.6, 3)
     P = P * s
