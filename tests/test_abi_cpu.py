@@ -294,3 +294,22 @@ def test_decimated_scan_surfaces_fill_with_their_triangulation_as_the_boundary(h
     # the decimation's few per cent of the undecimated solid's (marching-tetrahedra surface filled in round 3: scan_s30k / scan_s100k)
     full = {0.011: 0.00115437750498, 0.006: 0.000646398052489}[h]
     assert abs(vol6.sum() / 6 - full) < 0.03 * full
+
+
+def test_tet_front_end_never_hands_on_an_inverted_tetrahedron():
+    """Found by the round-6 soak (tools/probe/r06_soak.py): a 13 mm scan wall at a 13 mm lattice makes the conforming recovery add 2 080 points on the
+    surface; exact while it runs, ROUNDED on the way out, they left 15 tetrahedra flat or turned over -- and the sliver repair behind them crashed
+    (a face looked up that was not there).  Such an attempt is now reported as not converged, the constrained recovery takes over, and no fill is
+    handed on with a tetrahedron that is not positively oriented (the reference's validator rejects one: tests/ValidateTetMesh.h:47-140)."""
+    from mesheditor_amd import meshes, tets
+    v, f = meshes.skillet_scan_surface(0.013, 0.01782900063536733, noise_seed=814)
+    p, t, left = tets.tetrahedralize(v, f)
+    assert left == 0 and np.array_equal(p[: len(v)], v)
+    q = p[t.astype(np.int64)]
+    vol6 = np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0])
+    assert vol6.min() > 0
+    faces = np.sort(np.concatenate([t[:, [1, 2, 3]], t[:, [0, 2, 3]], t[:, [0, 1, 3]], t[:, [0, 1, 2]]]), axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    assert counts.max() <= 2 and {tuple(r) for r in uniq[counts == 1]} == {tuple(sorted(r)) for r in f.tolist()}
+    e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+    assert (vol6 * np.sqrt(2) / e2 ** 1.5).min() > 1e-3
