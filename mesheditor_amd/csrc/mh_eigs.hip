@@ -1187,7 +1187,7 @@ void mh_build_hierarchy(mh_system *sys, double sigma, bool defer) {
     // (a mesh with flat cells: the Galerkin product cancels entries of 1e17 down to rigid-body terms of 1e10 and below -- its rounding is
     // ~1e-9 of the diagonal, enough to cost the coarse operator its definiteness: "coarse operator not positive definite" on one stretched
     // UV sphere of the round-6 soak.  The diagonal is lifted by that much instead of by 1e-12.)
-    k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), std::max(sys->coarse_lift, sys->worst_quality < kFlatShape ? 1e-8 : 1e-12));
+    k_fix_coarse_diag<<<grid1(n0), TB, 0, ctx->stream>>>(sys->a0, uint32_t(n0), std::max(std::max(sys->coarse_lift, getenv("MH_COARSE_LIFT") ? atof(getenv("MH_COARSE_LIFT")) : 0.0), sys->worst_quality < kFlatShape ? 1e-8 : 1e-12));
     KERNEL_CHECK();
     DevArray<int> &info = sys->coarse_info;
     info.reset(ctx, 1);
