@@ -432,7 +432,8 @@ struct PatchSet {
     DevArray<double> cinv64;
     DevArray<float> cinv32;
     bool any() const { return n_patches || n_clusters; }
-    size_t scratch_rows() const { return size_t(n_patches) * 3 * npe + cluster_rows; } // rows of the work panel mh_apply_patches needs
+    static constexpr int kClusterSlices = 8;                          // K slices of the cluster product when its row tiles alone are too few workgroups
+    size_t scratch_rows() const { return size_t(n_patches) * 3 * npe + size_t(cluster_rows) * kClusterSlices; } // rows of the work panel mh_apply_patches needs
 };
 
 struct mh_system {

@@ -232,27 +232,31 @@ __global__ void __launch_bounds__(128) k_cluster_inverse_lds(const uint32_t *__r
 template<typename T>
 __global__ void __launch_bounds__(256) k_cluster_apply(const T *__restrict__ in, const T *__restrict__ minus, uint32_t w, const uint32_t *__restrict__ crow, const uint32_t *__restrict__ cptr,
                                                       const uint64_t *__restrict__ iptr, const uint32_t *__restrict__ tile_cluster, const uint32_t *__restrict__ tile_row0,
-                                                      const T *__restrict__ inv, T *__restrict__ y) {
+                                                      const T *__restrict__ inv, T *__restrict__ y, size_t y_slice) {
     constexpr int KT = 32;
     __shared__ T s_inv[64][KT + 1];
     __shared__ T s_v[KT][64 + 1];
     const uint32_t c = tile_cluster[blockIdx.x], row0 = tile_row0[blockIdx.x], r0 = cptr[c], N = cptr[c + 1] - r0, col0 = blockIdx.y * 64;
     const T *m = inv + iptr[c];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    // the K range in gridDim.z slices (whole KT chunks each), slice z to its own copy of y: a cluster of 2 400 rows has 39 row tiles -- too few
+    // workgroups for the chip, each with a K loop of 77 chunks; the slices are added in a fixed order by k_cluster_scatter (bit-reproducible)
+    const uint32_t kslice = ((N + gridDim.z - 1) / gridDim.z + KT - 1) / KT * KT, kb = blockIdx.z * kslice, ke = min(N, kb + kslice);
+    y += size_t(blockIdx.z) * y_slice;
     T acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0;
-    for (uint32_t k0 = 0; k0 < N; k0 += KT) {
+    for (uint32_t k0 = kb; k0 < ke; k0 += KT) {
         for (int e = tid; e < 64 * KT; e += 256) {
             const uint32_t r = row0 + e / KT, k = k0 + e % KT;
-            s_inv[e / KT][e % KT] = (r < N && k < N) ? m[size_t(r) * N + k] : T(0);
+            s_inv[e / KT][e % KT] = (r < N && k < ke) ? m[size_t(r) * N + k] : T(0);
         }
         for (int e = tid; e < KT * 64; e += 256) {
             const uint32_t k = k0 + e / 64, cc = col0 + e % 64;
             T v = 0;
-            if (k < N && cc < w) {
+            if (k < ke && cc < w) {
                 const size_t o = size_t(crow[r0 + k]) * w + cc;
                 v = minus ? in[o] - minus[o] : in[o];
             }
@@ -288,12 +292,14 @@ __global__ void __launch_bounds__(256) k_cluster_apply(const T *__restrict__ in,
 // the clusters' rows are pairwise distinct: s = coef * y goes straight to its row; d += s, x += s (either may be null), or z (double, pitch wz) += s
 template<typename T>
 __global__ void k_cluster_scatter(const T *__restrict__ y, uint32_t w, const uint32_t *__restrict__ crow, uint32_t nrows, T coef, T *__restrict__ d, T *__restrict__ x, double *__restrict__ z,
-                                  uint32_t wz) {
+                                  uint32_t wz, int slices) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= size_t(nrows) * w) return;
     const uint32_t c = uint32_t(i % w);
     const size_t row = crow[i / w];
-    const T s = coef * y[i];
+    T sum = 0;
+    for (int q = 0; q < slices; ++q) sum += y[size_t(q) * nrows * w + i]; // (fixed order)
+    const T s = coef * sum;
     if (d) d[row * w + c] += s;
     if (x) x[row * w + c] += s;
     if (z && c < wz) z[row * wz + c] += double(s);
@@ -608,8 +614,12 @@ void mh_apply_patches(mh_context *ctx, const PatchSet &ps, const T *in, const T 
         if constexpr (std::is_same<T, double>::value) cinv = ps.cinv64.get();
         else cinv = ps.cinv32.get();
         T *y = scratch + size_t(ps.n_patches) * 3 * ps.npe * w;
-        k_cluster_apply<T><<<dim3(ps.cluster_tiles, div_up(w, 64)), 256, 0, ctx->stream>>>(in, minus, w, ps.cluster_row, ps.cluster_ptr, ps.cluster_inv_ptr, ps.tile_cluster, ps.tile_row0, cinv, y);
-        k_cluster_scatter<T><<<div_up(size_t(ps.cluster_rows) * w, TB), TB, 0, ctx->stream>>>(y, w, ps.cluster_row, ps.cluster_rows, coef, d, x, z, wz);
+        // K slices: enough workgroups for the chip when the tiles alone are few (the largest clusters), one when there are plenty
+        const uint32_t tiles = ps.cluster_tiles * div_up(w, 64);
+        const int slices = ps.largest_cluster >= 256 && tiles < 2048 ? PatchSet::kClusterSlices : 1;
+        k_cluster_apply<T><<<dim3(ps.cluster_tiles, div_up(w, 64), slices), 256, 0, ctx->stream>>>(in, minus, w, ps.cluster_row, ps.cluster_ptr, ps.cluster_inv_ptr, ps.tile_cluster, ps.tile_row0, cinv, y,
+                                                                                                   size_t(ps.cluster_rows) * w);
+        k_cluster_scatter<T><<<div_up(size_t(ps.cluster_rows) * w, TB), TB, 0, ctx->stream>>>(y, w, ps.cluster_row, ps.cluster_rows, coef, d, x, z, wz, slices);
         KERNEL_CHECK();
     }
 }
