@@ -279,7 +279,7 @@ def test_decimated_scan_surfaces_fill_with_their_triangulation_as_the_boundary(h
     assert len(f2) <= ratio * len(f) * 1.05 + 8
     p, t, left_on_surface = tets.tetrahedralize(v2.astype(np.float64), f2)
     assert left_on_surface == 0 and np.array_equal(p[: len(v2)], v2.astype(np.float64))
-    assert len(p) - len(v2) <= 16  # a handful of points at most, all inside
+    assert len(p) - len(v2) <= 64  # a handful of recovery points (<= 16) and, since round 6, the interior points the flat-cell pass puts beside cells below 1e-2 (27 on the 100k one); all inside
     t64 = t.astype(np.int64)
     vol6 = np.einsum("ij,ij->i", np.cross(p[t64[:, 1]] - p[t64[:, 0]], p[t64[:, 2]] - p[t64[:, 0]]), p[t64[:, 3]] - p[t64[:, 0]])
     assert vol6.min() > 0
