@@ -84,5 +84,7 @@ for trial in range(n_surf):
     its.append(r.profile.get("restarts", 0))
     print(f"surf {trial:3d} {name}: {len(P)} -> {len(pts)} points {len(tets)} tets ({left} on the surface, fill {t1 - t0:.1f} s), worst shape {smin:.1e}; {len(r.eigenvalues)} of {pairs} pairs, {r.profile.get('restarts')} iterations, {1e3 * (time.time() - t1):.0f} ms", flush=True)
     if len(r.eigenvalues) != pairs: fails.append(("solve", trial, name))
-    if smin < 1e-3: fails.append(("shape", trial, name, smin))
+    if smin < 1e-3:
+        fails.append(("shape", trial, name, smin))
+        if left == 0: np.savez("gpurun_out/r06_soak_flat_%d.npz" % trial, P=P, F=F)  # (a fill with a flat cell and NO point left on the surface: one for the front end's to-do list)
 print("solves", len(its), "iterations min / median / max", min(its), int(np.median(its)), max(its), "failures", fails)
