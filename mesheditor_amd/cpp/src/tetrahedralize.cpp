@@ -830,6 +830,7 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
         return u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x);
     };
     uint32_t stuck = 0;
+    size_t why[4] = {0, 0, 0, 0};
     for (size_t k = split_edge.size(); k-- > 0;) {
         const uint32_t m = n_input + uint32_t(k), a = split_edge[k][0], b = split_edge[k][1];
         // the boundary triangles at m: exactly (a, m, c), (m, b, c), (a, m, d), (m, b, d)
@@ -855,11 +856,11 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
                 } else if (!(apex[0] == w || (n_apex == 2 && apex[1] == w))) pattern = false;
             }
         }
-        if (!pattern || n_boundary != 4 || n_apex != 2) { ++stuck; continue; }
+        if (!pattern || n_boundary != 4 || n_apex != 2) { ++stuck; ++why[0]; continue; }
         const uint32_t c = apex[0], d = apex[1];
         for (const auto key : {face_key(a, m, c), face_key(m, b, c), face_key(a, m, d), face_key(m, b, d)})
             if (!faces.count(key) || faces[key].first != 1) pattern = false;
-        if (!pattern) { ++stuck; continue; }
+        if (!pattern) { ++stuck; ++why[1]; continue; }
         // which side of the restored triangles is inside: the side of the fourth vertex of the tet on (a, m, c) / (a, m, d)
         const auto fourth = [&](uint32_t t, uint32_t x, uint32_t y, uint32_t z) {
             for (const uint32_t v : T[t])
@@ -868,7 +869,7 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
         };
         const uint32_t ec = fourth(faces[face_key(a, m, c)].second, a, m, c), ed = fourth(faces[face_key(a, m, d)].second, a, m, d);
         const int in_c = orient(P[a], P[m], P[c], P[ec]), in_d = orient(P[a], P[m], P[d], P[ed]);
-        if (in_c == 0 || in_d == 0) { ++stuck; continue; }
+        if (in_c == 0 || in_d == 0) { ++stuck; ++why[2]; continue; }
         const auto cross = [](const dvec3 &u, const dvec3 &v) { return dvec3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; };
         const auto unit = [](dvec3 v) {
             const double l = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
@@ -912,7 +913,82 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
                 double q;
                 if (valid_quality(x, q) && q > best_q) best_q = q, best = x;
             }
-        if (!(best_q > 0)) { ++stuck; continue; }
+        if (!(best_q > 0)) {
+            // None of the sampled positions is valid: on a finely tessellated smooth surface the tetrahedra at m include caps on nearly coplanar
+            // surface vertices, and the region from which m sees every face of its link AND fits the two new tetrahedra is a sliver of space
+            // the three sampled directions miss.  Every condition above is the sign of a determinant that is AFFINE in the position, so that
+            // region is a polyhedron: its Chebyshev centre (the point farthest inside all the planes) is a small linear programme -- solved
+            // here by enumeration of the vertices of the feasible set of (position, depth), some forty constraints at most -- and the exact
+            // predicates then have the last word on it.
+            struct Plane { dvec3 n; double d; }; // n . x + d >= depth, |n| = 1
+            std::vector<Plane> planes;
+            const double eps_len = h > 0 ? h : 1.0;
+            const auto add_condition = [&](const auto &g, int want) { // g(x): an orientation determinant as a function of the position; want: its required sign
+                if (want == 0) return;
+                const double g0 = g(old);
+                const dvec3 grad{(g(old + dvec3{eps_len, 0, 0}) - g0) / eps_len, (g(old + dvec3{0, eps_len, 0}) - g0) / eps_len, (g(old + dvec3{0, 0, eps_len}) - g0) / eps_len};
+                const double len = std::sqrt(grad.x * grad.x + grad.y * grad.y + grad.z * grad.z);
+                if (!(len > 0)) return;
+                const double sgn = want > 0 ? 1.0 : -1.0;
+                const dvec3 n = grad * (sgn / len);
+                planes.push_back({n, sgn * g0 / len - (n.x * old.x + n.y * old.y + n.z * old.z)});
+            };
+            for (const uint32_t t : star[k]) {
+                const auto tet = T[t];
+                add_condition([&](const dvec3 &x) {
+                    dvec3 q[4];
+                    for (int i = 0; i < 4; ++i) q[i] = tet[size_t(i)] == m ? x : P[tet[size_t(i)]];
+                    return volume6(q[0], q[1], q[2], q[3]);
+                }, 1);
+            }
+            add_condition([&](const dvec3 &x) { return volume6(P[a], P[b], P[c], x); }, in_c);
+            add_condition([&](const dvec3 &x) { return volume6(P[a], P[b], P[d], x); }, in_d);
+            add_condition([&](const dvec3 &x) { return volume6(P[a], x, P[c], P[b]); }, -in_c);
+            add_condition([&](const dvec3 &x) { return volume6(P[a], x, P[d], P[b]); }, -in_d);
+            add_condition([&](const dvec3 &x) { return volume6(x, P[b], P[c], P[a]); }, -orient(P[m], P[b], P[c], P[fourth(faces[face_key(m, b, c)].second, m, b, c)]));
+            add_condition([&](const dvec3 &x) { return volume6(x, P[b], P[d], P[a]); }, -orient(P[m], P[b], P[d], P[fourth(faces[face_key(m, b, d)].second, m, b, d)]));
+            // (c and d on opposite sides of the face (a, b, x): implied for x inside both restored triangles' inner half-spaces near the edge; the exact test below checks it)
+            double best_depth = 0;
+            dvec3 centre = old;
+            const size_t np_ = planes.size();
+            if (np_ >= 4 && np_ <= 64) {
+                for (size_t i0 = 0; i0 < np_; ++i0)
+                    for (size_t i1 = i0 + 1; i1 < np_; ++i1)
+                        for (size_t i2 = i1 + 1; i2 < np_; ++i2)
+                            for (size_t i3 = i2 + 1; i3 < np_; ++i3) {
+                                // n_i . x - depth = -d_i for the four planes: a 4 x 4 system in (x, depth)
+                                const Plane *pl[4] = {&planes[i0], &planes[i1], &planes[i2], &planes[i3]};
+                                double A[4][5];
+                                for (int r = 0; r < 4; ++r) A[r][0] = pl[r]->n.x, A[r][1] = pl[r]->n.y, A[r][2] = pl[r]->n.z, A[r][3] = -1.0, A[r][4] = -pl[r]->d;
+                                bool singular = false;
+                                for (int col = 0; col < 4 && !singular; ++col) {
+                                    int piv = col;
+                                    for (int r = col + 1; r < 4; ++r)
+                                        if (std::fabs(A[r][col]) > std::fabs(A[piv][col])) piv = r;
+                                    if (std::fabs(A[piv][col]) < 1e-12) { singular = true; break; }
+                                    if (piv != col)
+                                        for (int cc = 0; cc < 5; ++cc) std::swap(A[piv][cc], A[col][cc]);
+                                    for (int r = 0; r < 4; ++r) {
+                                        if (r == col) continue;
+                                        const double f = A[r][col] / A[col][col];
+                                        for (int cc = col; cc < 5; ++cc) A[r][cc] -= f * A[col][cc];
+                                    }
+                                }
+                                if (singular) continue;
+                                const dvec3 x{A[0][4] / A[0][0], A[1][4] / A[1][1], A[2][4] / A[2][2]};
+                                const double depth = A[3][4] / A[3][3];
+                                if (!(depth > best_depth)) continue;
+                                const dvec3 move = x - old;
+                                if (move.x * move.x + move.y * move.y + move.z * move.z > 4 * h * h) continue; // (not beyond the edge's own length)
+                                bool feasible = true;
+                                for (size_t j = 0; j < np_ && feasible; ++j) feasible = planes[j].n.x * x.x + planes[j].n.y * x.y + planes[j].n.z * x.z + planes[j].d >= depth * (1 - 1e-9) - 1e-300;
+                                if (feasible) best_depth = depth, centre = x;
+                            }
+            }
+            double q;
+            if (best_depth > 0 && valid_quality(centre, q)) best_q = q, best = centre;
+            if (!(best_q > 0)) { ++stuck; ++why[3]; continue; }
+        }
         // apply: m moves; the four old boundary faces become interior, two tetrahedra restore (a, b, c) and (a, b, d)
         P[m] = best;
         for (const uint32_t w : {c, d}) {
@@ -922,20 +998,10 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
             add_tet(uint32_t(T.size() - 1));
         }
     }
+    if (stuck && std::getenv("MH_TET_DEBUG")) std::fprintf(stderr, "[tets] lifting: %u of %zu points stay on the surface: %zu not the four-triangle pattern, %zu pattern faces not on the boundary, %zu degenerate side, %zu no valid inner position\n", stuck, split_edge.size(), why[0], why[1], why[2], why[3]);
     return stuck;
 }
 
-// Sliver repair (the reference's tetrahedraliser repairs slivers whatever its options say: src/mesh/Tetrahedralize.h:20).  A
-// Delaunay fill of a bare surface leaves flat tetrahedra -- four points of one latitude ring of a UV sphere, the wedges under a
-// recovered edge -- whose stiffness entries dwarf their neighbours' and stall iterative eigensolvers (shape 2e-8 on the reference's
-// sample sphere: ||A|| / theta ~ 1e13).  This pass changes the CONNECTIVITY only, by hill climbing on the worst shape measure of
-// the tetrahedra involved (shape = 6 sqrt 2 V / l_rms^3: 1 for the regular tetrahedron, 0 for a flat one):
-//   * edge removal: the n <= 12 tetrahedra around an interior edge {u, v} are replaced by the best triangulation of their link
-//     polygon coned to u and to v (Klincsek's dynamic programme over the polygon: n = 3 is the 3-2 flip, n = 4 the 4-4 flip);
-//   * the 2-3 flip of an interior face.
-// Boundary faces are untouched (an edge on the boundary has an open ring and is skipped), no point is added or moved, every new
-// tetrahedron is positively oriented (exact), and an exchange is made only if the worst shape among the new tetrahedra exceeds
-// the worst among the old ones -- so the pass terminates and can only improve the mesh's worst elements.
 // MH_TET_DEBUG: every face on at most two tetrahedra, every tetrahedron positively oriented -- said per stage, so that a defect names its origin
 static void DebugValidate(const TetMesh &mesh, const char *stage) {
     static const bool on = std::getenv("MH_TET_DEBUG") != nullptr;
@@ -951,6 +1017,17 @@ static void DebugValidate(const TetMesh &mesh, const char *stage) {
     std::fprintf(stderr, "[tets] %-28s %zu tets, %zu points: %zu faces on more than two tetrahedra, %zu tetrahedra not positively oriented\n", stage, mesh.Tets.size(), mesh.Points.size(), over, inverted);
 }
 
+// Sliver repair (the reference's tetrahedraliser repairs slivers whatever its options say: src/mesh/Tetrahedralize.h:20).  A
+// Delaunay fill of a bare surface leaves flat tetrahedra -- four points of one latitude ring of a UV sphere, the wedges under a
+// recovered edge -- whose stiffness entries dwarf their neighbours' and stall iterative eigensolvers (shape 2e-8 on the reference's
+// sample sphere: ||A|| / theta ~ 1e13).  This pass changes the CONNECTIVITY only, by hill climbing on the worst shape measure of
+// the tetrahedra involved (shape = 6 sqrt 2 V / l_rms^3: 1 for the regular tetrahedron, 0 for a flat one):
+//   * edge removal: the n <= 12 tetrahedra around an interior edge {u, v} are replaced by the best triangulation of their link
+//     polygon coned to u and to v (Klincsek's dynamic programme over the polygon: n = 3 is the 3-2 flip, n = 4 the 4-4 flip);
+//   * the 2-3 flip of an interior face.
+// Boundary faces are untouched (an edge on the boundary has an open ring and is skipped), no point is added or moved, every new
+// tetrahedron is positively oriented (exact), and an exchange is made only if the worst shape among the new tetrahedra exceeds
+// the worst among the old ones -- so the pass terminates and can only improve the mesh's worst elements.
 static uint32_t RepairSlivers(TetMesh &mesh, double target, const std::set<Tri> *walls = nullptr) { // walls: faces INSIDE the mesh that must stay (non-manifold input)
     auto &P = mesh.Points;
     auto &T = mesh.Tets;

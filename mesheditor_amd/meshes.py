@@ -77,6 +77,47 @@ def jittered_scan(i, variants=8):
     return p * rng.uniform(0.8, 1.25, 3), t.copy()
 
 
+def with_flat_cells(points, tets, n_fixed, count=40, eps=1e-8, seed=0):
+    """A caller's own mesh with flat cells, made from a well-shaped one (tests and probes of the solver's handling of such meshes: the front end's own
+    fills have none since round 6): `count` interior points -- index >= n_fixed, on no boundary face, no two of them neighbours -- are each moved almost
+    into the plane of the opposite face of one of their tetrahedra, to `eps` of their height over it (towards that face's centroid).  That tetrahedron's
+    shape measure drops to ~eps; every other tetrahedron at the point keeps its orientation (checked: a move that would turn one over is skipped).
+    Returns (points, number of cells flattened)."""
+    pts = np.array(points, dtype=np.float64)
+    t = np.asarray(tets).astype(np.int64)
+    faces = np.sort(np.concatenate([t[:, [1, 2, 3]], t[:, [0, 2, 3]], t[:, [0, 1, 3]], t[:, [0, 1, 2]]]), axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    on_boundary = np.zeros(len(pts), bool)
+    on_boundary[uniq[counts == 1].ravel()] = True
+    order = np.argsort(t.ravel(), kind="stable")
+    owner = t.ravel()[order]
+    start = np.searchsorted(owner, np.arange(len(pts) + 1))
+    rng = np.random.Generator(np.random.MT19937(seed))
+    blocked = np.zeros(len(pts), bool)
+    done = 0
+
+    def vol6(q):
+        return np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0])
+
+    for v in rng.permutation(np.arange(n_fixed, len(pts))):
+        if done >= count:
+            break
+        if on_boundary[v] or blocked[v]:
+            continue
+        star = order[start[v]:start[v + 1]] // 4
+        cell = t[star[0]]
+        face = cell[cell != v]
+        x = pts[face].mean(0) + eps * (pts[v] - pts[face].mean(0))
+        q = pts[t[star]].copy()
+        q[t[star] == v] = x
+        if vol6(q).min() <= 0:
+            continue
+        pts[v] = x
+        blocked[np.unique(t[star])] = True
+        done += 1
+    return pts, done
+
+
 def workload(name):
     """Named workloads: returns (points, tets, material tuple, solver kwargs)."""
     if name == "bar_square":  # tests/ModalSolverTest.cpp:228-245
