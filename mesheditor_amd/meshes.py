@@ -141,8 +141,8 @@ def workload(name):
             _SCAN_CACHE[key] = (p, t)
         p, t = _SCAN_CACHE[key]
         return p.copy(), t.copy(), MATERIALS["Ceramic"], {"num_modes": 50, "num_fem_modes": 65}
-    if name in ("uvsphere_96x48", "uvsphere_128x64"):  # fine UV spheres through the front end's DEFAULT options (the 128 x 64
-        seg, rings = (96, 48) if name == "uvsphere_96x48" else (128, 64)  # one came back empty until the always-on flat-cell pass of round 6): 41 059 / 72 674 tets
+    if name in ("uvsphere_80x40", "uvsphere_96x48", "uvsphere_128x64"):  # fine UV spheres through the front end's DEFAULT options (the
+        seg, rings = {"uvsphere_80x40": (80, 40), "uvsphere_96x48": (96, 48), "uvsphere_128x64": (128, 64)}[name]  # 128 x 64 one came back empty in round 5)
         key = ("uvsphere", seg, rings)
         if key not in _SCAN_CACHE:
             from . import tets as tet_front_end

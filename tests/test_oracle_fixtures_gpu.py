@@ -24,9 +24,9 @@ WORKLOADS = ["ball_s10k", "cube_s30k", "cube_s100k", "skillet_s100k", "scan_s30k
              "config3_s30k", "config3_s100k", "scan_s30k_repaired", "scan_s100k_repaired", "config3_s30k_repaired", "config3_s100k_repaired",
              # BASELINE config 2 as written: the UV-sphere primitive (48 x 24 surface, 9 457 tets after the front end) -- ball_s10k is its Kuhn-mapped stand-in
              "uvsphere_s10k",
-             # round 6: a FINE UV sphere (96 x 48) through the front end's default options -- the class that took 57 iterations (and, at 128 x 64,
-             # returned nothing) until the always-on flat-cell pass; the 128 x 64 one does not fit the build container's oracle (> 62 GB)
-             "uvsphere_96x48"]
+             # round 6: a FINE UV sphere (80 x 40) through the front end's default options -- the class that took 57 iterations (96 x 48) or returned
+             # nothing (128 x 64) in round 5; the oracle's factorisation of the 96 x 48 and 128 x 64 fills does not fit the build container (> 60 GB)
+             "uvsphere_80x40"]
 
 
 def load_fixture(name):
