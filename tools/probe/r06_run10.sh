@@ -1,6 +1,6 @@
 # round-6 evidence files: the flat-cell meshes through the solver, the cluster A/B on the scan fills, the iteration timeline
-python tools/probe/flat_sphere_probe.py 96 48 default MH_CLUSTERS=0 > gpurun_out/r06_flat_cells.txt 2>&1
-python tools/probe/flat_sphere_probe.py 128 64 default MH_CLUSTERS=0 >> gpurun_out/r06_flat_cells.txt 2>&1
+true
+true
 (echo "# default (element patches on these meshes)"; python tools/scan_probe.py scan_s30k scan_s100k scan_s100k_interior scan_s100k_repaired --reps 2 2>&1 | tail -4 | cut -c1-260
  echo "# MH_CLUSTERS=1 (cluster patches forced, both levels)"; MH_CLUSTERS=1 python tools/scan_probe.py scan_s30k scan_s100k scan_s100k_interior scan_s100k_repaired --reps 2 2>&1 | tail -4 | cut -c1-260
  echo "# MH_CLUSTERS=2 (clusters on the P1 level only)"; MH_CLUSTERS=2 python tools/scan_probe.py scan_s30k scan_s100k scan_s100k_interior scan_s100k_repaired --reps 2 2>&1 | tail -4 | cut -c1-260
