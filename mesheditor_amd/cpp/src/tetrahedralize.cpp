@@ -1517,9 +1517,10 @@ public:
     bool IsDead(size_t t) const { return Dead[t] != 0; }
     // the cell that holds p strictly inside, by a walk from `from` that never crosses the boundary or a wall; -1: the surface cuts p
     // off, or p lies on a face or an edge (not this point)
-    int32_t Locate(const dvec3 &p, int32_t from) const {
+    int32_t Locate(const dvec3 &p, int32_t from, std::vector<int32_t> *path = nullptr) const { // path: the cells the walk went through, `from` first
         int32_t at = from;
         for (int step = 0; step < 400 && at >= 0; ++step) {
+            if (path) path->push_back(at);
             const auto cell = T[size_t(at)];
             int32_t next = -3;
             bool strictly = true;
@@ -1543,17 +1544,22 @@ public:
     // `also`: a cell that joins the cavity whatever the insphere test says, if it shares a face with it (a FLAT cell's circumsphere is a
     // half-space whose side is decided by the last bits of its vertices: a point just under a cap may lie outside it) -- the star-shape
     // test below still has the last word on it.
-    std::vector<int32_t> Cavity(const dvec3 &p, int32_t at, int32_t also = -1) {
+    std::vector<int32_t> Cavity(const dvec3 &p, int32_t at, int32_t also = -1, double flat_below = 0, const std::vector<int32_t> *seeds = nullptr) {
         if (Mark.size() < T.size()) Mark.resize(T.size() + T.size() / 2, 0);
         ++Stamp;
         std::vector<int32_t> cavity{at};
         Mark[size_t(at)] = Stamp;
+        if (seeds) // (the cells the walk from the flat cell to the point's cell went through: they tie the two together; the star-shape test decides)
+            for (const int32_t c : *seeds)
+                if (c >= 0 && Mark[size_t(c)] != Stamp) Mark[size_t(c)] = Stamp, cavity.push_back(c);
         for (size_t head = 0; head < cavity.size() && cavity.size() < 512; ++head)
             for (int i = 0; i < 4; ++i) {
                 const int32_t o = Across(cavity[head], i);
                 if (o < 0 || Mark[size_t(o)] == Stamp) continue;
                 const auto &ov = T[size_t(o)];
-                if (o == also || exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0) Mark[size_t(o)] = Stamp, cavity.push_back(o);
+                // (flat_below: with `also`, every FLAT neighbour of the cavity joins as well -- caps come stacked, and the one next to the cap in hand
+                // decides whether the cap's inner face is a face of the cavity's hull, which the point would have to see from the wrong side)
+                if (o == also || exact::InSphere(P[ov[0]], P[ov[1]], P[ov[2]], P[ov[3]], p) > 0 || (flat_below > 0 && FlatBelow(ov, flat_below))) Mark[size_t(o)] = Stamp, cavity.push_back(o);
             }
         // star-shaped hull: every hull face must see p strictly from the inside; a cell whose face does not leaves the cavity
         bool ok = true;
@@ -1619,6 +1625,18 @@ public:
             Link(int32_t(T.size() - 1), true);
         }
         return first;
+    }
+    bool FlatBelow(const std::array<uint32_t, 4> &t, double bound) const {
+        const dvec3 u = P[t[1]] - P[t[0]], v = P[t[2]] - P[t[0]], w = P[t[3]] - P[t[0]];
+        const double vol6 = std::fabs(u.x * (v.y * w.z - v.z * w.y) - u.y * (v.x * w.z - v.z * w.x) + u.z * (v.x * w.y - v.y * w.x));
+        double l2 = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                const dvec3 e = P[t[size_t(i)]] - P[t[size_t(j)]];
+                l2 += e.x * e.x + e.y * e.y + e.z * e.z;
+            }
+        const double lrms = std::sqrt(l2 / 6);
+        return !(lrms > 0) || 1.4142135623730951 * vol6 / (lrms * lrms * lrms) < bound;
     }
     void Compact() {
         std::vector<std::array<uint32_t, 4>> kept;
@@ -1925,15 +1943,42 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             dvec3 best_p{0, 0, 0};
             std::vector<int32_t> best_in;
             std::vector<std::array<uint32_t, 4>> best_fresh;
+            static const bool dbg2 = std::getenv("MH_TET_DEBUG2") != nullptr;
             for (const dvec3 &p : candidates) {
-                const int32_t at = ed.Locate(p, t0);
+                std::vector<int32_t> path;
+                const int32_t at = ed.Locate(p, t0, &path);
+                if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "  cell %d (%u %u %u %u) shape %.1e n_open %d candidate (%.5f %.5f %.5f): located in %d\n", t0, cell[0], cell[1], cell[2], cell[3], q0, n_open, p.x, p.y, p.z, at);
                 if (at < 0) continue;
-                const std::vector<int32_t> in = ed.Cavity(p, at, t0);
-                if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) continue;
+                std::vector<int32_t> in = ed.Cavity(p, at, t0);
+                if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) { // once more with the cap's flat neighbours taken in
+                    in = ed.Cavity(p, at, t0, 0.05);
+                    if ((in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) && path.size() <= 12) in = ed.Cavity(p, at, t0, 0.05, &path); // ... and with the walk's cells
+                    if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) {
+                        if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "      cavity %s\n", in.empty() ? "empty (the containing cell does not see the point through its hull)" : "without the flat cell");
+                        continue;
+                    }
+                }
                 double worst_old = 1e300, worst_new = 1e300;
                 for (const int32_t c : in) worst_old = std::min(worst_old, ShapeOf(P, T[size_t(c)]));
                 const auto fresh = ed.Fan(in);
                 for (const auto &piece : fresh) worst_new = std::min(worst_new, ShapeOf(P, piece, &p));
+                {
+                    // A cavity that took cells in by adjacency may SWALLOW a vertex (every tetrahedron at an interior point inside it): the fan would
+                    // leave that point belonging to no tetrahedron (the round-6 soak: "mesh point(s) belong to no tetrahedron").  Not this position.
+                    std::vector<uint32_t> before, after;
+                    for (const int32_t c : in)
+                        for (const uint32_t v : T[size_t(c)]) before.push_back(v);
+                    for (const auto &piece : fresh)
+                        for (const uint32_t v : piece) after.push_back(v);
+                    std::sort(before.begin(), before.end());
+                    before.erase(std::unique(before.begin(), before.end()), before.end());
+                    std::sort(after.begin(), after.end());
+                    after.erase(std::unique(after.begin(), after.end()), after.end());
+                    bool swallowed = false;
+                    for (const uint32_t v : before) swallowed = swallowed || !std::binary_search(after.begin(), after.end(), v);
+                    if (swallowed) continue;
+                }
+                if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "      cavity of %zu cells, worst old %.1e, worst new %.1e\n", in.size(), worst_old, worst_new);
                 if (!(worst_new > worst_old)) continue;
                 const double gain = worst_new;
                 if (gain > best_gain) best_gain = gain, best_p = p, best_in = in, best_fresh = fresh;
@@ -2484,6 +2529,13 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
     }
     out.Profile.RefineSeconds = seconds_since(refine_start);
     DebugValidate(out.Mesh, "at the end");
+    {
+        std::vector<uint8_t> used(out.Mesh.Points.size(), 0);
+        for (const auto &t : out.Mesh.Tets)
+            for (const uint32_t v : t) used[v] = 1;
+        for (size_t v = n_input; v < used.size(); ++v) // (an input vertex no triangle uses is the caller's business; an ADDED point must be in the mesh)
+            if (!used[v]) return out.Error = "boundary recovery did not converge: an added point belongs to no tetrahedron", out;
+    }
     // never hand on a mesh with a tetrahedron that is not positively oriented (the reference's validator, tests/ValidateTetMesh.h:47-140, rejects it)
     for (const auto &t : out.Mesh.Tets)
         if (exact::Orient3D(out.Mesh.Points[t[0]], out.Mesh.Points[t[1]], out.Mesh.Points[t[2]], out.Mesh.Points[t[3]]) <= 0)

@@ -25,7 +25,7 @@ def torus(R, r, nu, nv):
     return P, np.array(F, np.uint32)
 
 ctx = api.Context(0)
-rng = np.random.default_rng(606)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 606)
 mats = [meshes.MATERIALS[k] for k in meshes.MATERIAL_ORDER]
 n_boxes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n_surf = int(sys.argv[2]) if len(sys.argv) > 2 else 30
