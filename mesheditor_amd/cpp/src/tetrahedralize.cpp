@@ -1573,6 +1573,7 @@ public:
                     dvec3 q[4];
                     for (int j = 0; j < 4; ++j) q[j] = j == i ? p : P[cv[size_t(j)]];
                     if (exact::Orient3D(q[0], q[1], q[2], q[3]) > 0) continue;
+                    if (Trace) std::fprintf(stderr, "        cell %d (%u %u %u %u) shape %.1e cannot show face %d to the point (%s)\n", c, cv[0], cv[1], cv[2], cv[3], FlatBelow(cv, 0) ? 0.0 : ShapeValue(cv), i, c == at ? "the containing cell" : "dropped");
                     if (c == at) ok = false;
                     else Mark[size_t(c)] = 0, changed = true;
                     break;
@@ -1625,6 +1626,38 @@ public:
             Link(int32_t(T.size() - 1), true);
         }
         return first;
+    }
+    bool Trace{false};
+    // the cells around the edge (u, v), walked from cell t; empty unless the ring closes without meeting the boundary or a wall (an edge of
+    // the surface, or one in a wall, is nobody's to split) and within 64 cells
+    std::vector<int32_t> Ring(int32_t t, uint32_t u, uint32_t v) const {
+        std::vector<int32_t> ring;
+        int32_t at = t;
+        uint32_t from = UINT32_MAX; // the third vertex of the face the walk came in through
+        for (int step = 0; step < 64; ++step) {
+            ring.push_back(at);
+            const auto &c = T[size_t(at)];
+            int others[2], k = 0;
+            for (int i = 0; i < 4; ++i)
+                if (c[size_t(i)] != u && c[size_t(i)] != v) {
+                    if (k == 2) return {};
+                    others[k++] = i;
+                }
+            if (k != 2) return {};
+            const int behind = from == UINT32_MAX || c[size_t(others[0])] == from ? others[0] : others[1];
+            const int ahead = behind == others[0] ? others[1] : others[0];
+            const int32_t next = Across(at, behind); // (the face opposite `behind` holds u, v and `ahead`)
+            if (next < 0) return {};
+            if (next == t) return ring;
+            from = c[size_t(ahead)];
+            at = next;
+        }
+        return {};
+    }
+    double ShapeValue(const std::array<uint32_t, 4> &t) const {
+        double lo = 0, hi = 1;
+        for (int k = 0; k < 40; ++k) (FlatBelow(t, 0.5 * (lo + hi)) ? hi : lo) = 0.5 * (lo + hi);
+        return hi;
     }
     bool FlatBelow(const std::array<uint32_t, 4> &t, double bound) const {
         const dvec3 u = P[t[1]] - P[t[0]], v = P[t[2]] - P[t[0]], w = P[t[3]] - P[t[0]];
@@ -1949,6 +1982,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                 const int32_t at = ed.Locate(p, t0, &path);
                 if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "  cell %d (%u %u %u %u) shape %.1e n_open %d candidate (%.5f %.5f %.5f): located in %d\n", t0, cell[0], cell[1], cell[2], cell[3], q0, n_open, p.x, p.y, p.z, at);
                 if (at < 0) continue;
+                ed.Trace = dbg2 && q0 < 1e-6 && std::getenv("MH_TET_DEBUG3");
                 std::vector<int32_t> in = ed.Cavity(p, at, t0);
                 if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) { // once more with the cap's flat neighbours taken in
                     in = ed.Cavity(p, at, t0, 0.05);
@@ -1988,6 +2022,71 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                 // (Cavity's marks belong to the LAST candidate: commit needs only the lists)
                 ed.Commit(best_p, best_in, best_fresh);
                 ++added, ++added_this_pass;
+                continue;
+            }
+            // No position's cavity keeps the flat cell (caps come in fans round a surface vertex: the cavity unravels cell by cell under the
+            // star-shape test).  Then one of the cell's INTERIOR edges is split instead, at a point pushed off the cell's plane: the cells round
+            // the edge are halved, nothing else changes, and the flat cell's two halves get the point's height.  An edge qualifies when its
+            // ring of cells closes inside the body; a position, when every half is positively oriented (exact) and the worst half is better
+            // than the worst cell of the ring.
+            {
+                std::vector<int32_t> best_ring;
+                uint32_t best_u = 0, best_v = 0;
+                const uint32_t id = uint32_t(P.size());
+                for (int i = 0; i < 4; ++i)
+                    for (int j = i + 1; j < 4; ++j) {
+                        const uint32_t u = cell[size_t(i)], v = cell[size_t(j)];
+                        const std::vector<int32_t> ring = ed.Ring(t0, u, v);
+                        if (ring.empty()) continue;
+                        double worst_old = 1e300;
+                        for (const int32_t c : ring) worst_old = std::min(worst_old, ShapeOf(P, T[size_t(c)]));
+                        const dvec3 mid = (P[u] + P[v]) * 0.5;
+                        // positions: from the edge's midpoint towards the middle of the ring's other vertices (the kernel of the ring is where
+                        // the point may go: the cells round a surface vertex are thin, an offset of the cell's own size leaves them), then the
+                        // offsets of the insertion above
+                        std::vector<dvec3> positions;
+                        {
+                            dvec3 middle{0, 0, 0};
+                            double count = 0;
+                            for (const int32_t c : ring)
+                                for (const uint32_t x : T[size_t(c)])
+                                    if (x != u && x != v) middle = middle + P[x], count += 1;
+                            middle = middle * (1.0 / count);
+                            for (const double step : {0.35, 0.2, 0.5, 0.1, 0.7, 0.05}) positions.push_back(mid + (middle - mid) * step);
+                            for (const dvec3 &full : candidates) positions.push_back(mid + (full - centroid));
+                            for (const dvec3 &full : candidates) positions.push_back(mid + (full - centroid) * 0.2);
+                        }
+                        for (const dvec3 &p : positions) {
+                            double worst_new = 1e300;
+                            bool valid = true;
+                            for (size_t r = 0; r < ring.size() && valid; ++r)
+                                for (const uint32_t gone : {u, v}) {
+                                    std::array<uint32_t, 4> piece = T[size_t(ring[r])];
+                                    dvec3 q[4];
+                                    for (int k = 0; k < 4; ++k) {
+                                        if (piece[size_t(k)] == gone) piece[size_t(k)] = id;
+                                        q[k] = piece[size_t(k)] == id ? p : P[piece[size_t(k)]];
+                                    }
+                                    if (exact::Orient3D(q[0], q[1], q[2], q[3]) <= 0) { valid = false; break; }
+                                    worst_new = std::min(worst_new, ShapeOf(P, piece, &p));
+                                }
+                            if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "      edge (%u %u) ring of %zu, offset position: %s, worst old %.1e, worst new %.1e\n", u, v, ring.size(), valid ? "valid" : "a half is inverted", worst_old, valid ? worst_new : 0.0);
+                            if (!valid || !(worst_new > worst_old) || !(worst_new > best_gain)) continue;
+                            best_gain = worst_new, best_p = p, best_ring = ring, best_u = u, best_v = v;
+                        }
+                    }
+                if (best_gain > 0) {
+                    std::vector<std::array<uint32_t, 4>> halves;
+                    for (const int32_t c : best_ring)
+                        for (const uint32_t gone : {best_u, best_v}) {
+                            std::array<uint32_t, 4> piece = T[size_t(c)];
+                            for (uint32_t &x : piece)
+                                if (x == gone) x = id;
+                            halves.push_back(piece);
+                        }
+                    ed.Commit(best_p, best_ring, halves);
+                    ++added, ++added_this_pass;
+                }
             }
         }
         if (std::getenv("MH_TET_DEBUG")) std::fprintf(stderr, "BreakFlatCells pass %d: %zu below %.0e (flattest %.1e), %u points added or moved (%u moved so far)\n", pass, work.size(), floor, work.front().first, added_this_pass, moved);
