@@ -791,6 +791,52 @@ struct SurfaceEdgeUse {
 };
 } // namespace
 
+// The point farthest inside a set of half-spaces n . x + d >= 0 (|n| = 1), no further than `reach` from `old`: a linear programme in
+// (position, depth), solved by enumeration of the vertices of its feasible set -- four planes at a time, sixty-four planes at most.
+// Returns the depth (0: none found) and the point.  Rounded arithmetic: the caller's exact predicates have the last word.
+struct HalfSpace {
+    dvec3 n;
+    double d;
+};
+static double ChebyshevCentre(const std::vector<HalfSpace> &planes, const dvec3 &old, double reach, dvec3 &centre) {
+    double best_depth = 0;
+    const size_t np_ = planes.size();
+    if (np_ < 4 || np_ > 64) return 0;
+    for (size_t i0 = 0; i0 < np_; ++i0)
+        for (size_t i1 = i0 + 1; i1 < np_; ++i1)
+            for (size_t i2 = i1 + 1; i2 < np_; ++i2)
+                for (size_t i3 = i2 + 1; i3 < np_; ++i3) {
+                    // n_i . x - depth = -d_i for the four planes: a 4 x 4 system in (x, depth)
+                    const HalfSpace *pl[4] = {&planes[i0], &planes[i1], &planes[i2], &planes[i3]};
+                    double A[4][5];
+                    for (int r = 0; r < 4; ++r) A[r][0] = pl[r]->n.x, A[r][1] = pl[r]->n.y, A[r][2] = pl[r]->n.z, A[r][3] = -1.0, A[r][4] = -pl[r]->d;
+                    bool singular = false;
+                    for (int col = 0; col < 4 && !singular; ++col) {
+                        int piv = col;
+                        for (int r = col + 1; r < 4; ++r)
+                            if (std::fabs(A[r][col]) > std::fabs(A[piv][col])) piv = r;
+                        if (std::fabs(A[piv][col]) < 1e-12) { singular = true; break; }
+                        if (piv != col)
+                            for (int cc = 0; cc < 5; ++cc) std::swap(A[piv][cc], A[col][cc]);
+                        for (int r = 0; r < 4; ++r) {
+                            if (r == col) continue;
+                            const double f = A[r][col] / A[col][col];
+                            for (int cc = col; cc < 5; ++cc) A[r][cc] -= f * A[col][cc];
+                        }
+                    }
+                    if (singular) continue;
+                    const dvec3 x{A[0][4] / A[0][0], A[1][4] / A[1][1], A[2][4] / A[2][2]};
+                    const double depth = A[3][4] / A[3][3];
+                    if (!(depth > best_depth)) continue;
+                    const dvec3 move = x - old;
+                    if (move.x * move.x + move.y * move.y + move.z * move.z > reach * reach) continue;
+                    bool feasible = true;
+                    for (size_t j = 0; j < np_ && feasible; ++j) feasible = planes[j].n.x * x.x + planes[j].n.y * x.y + planes[j].n.z * x.z + planes[j].d >= depth * (1 - 1e-9) - 1e-300;
+                    if (feasible) best_depth = depth, centre = x;
+                }
+    return best_depth;
+}
+
 // The recovery above leaves its points ON the surface: the boundary of the mesh refines the input triangulation.  The reference's
 // contract (src/mesh/Tetrahedralize.h:59) wants every input triangle a boundary face and added points strictly inside, so the
 // points are taken off the surface again, last one first.  The last point m bisected a surface edge (a, b) with the apexes c, d
@@ -920,8 +966,7 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
             // region is a polyhedron: its Chebyshev centre (the point farthest inside all the planes) is a small linear programme -- solved
             // here by enumeration of the vertices of the feasible set of (position, depth), some forty constraints at most -- and the exact
             // predicates then have the last word on it.
-            struct Plane { dvec3 n; double d; }; // n . x + d >= depth, |n| = 1
-            std::vector<Plane> planes;
+            std::vector<HalfSpace> planes;
             const double eps_len = h > 0 ? h : 1.0;
             const auto add_condition = [&](const auto &g, int want) { // g(x): an orientation determinant as a function of the position; want: its required sign
                 if (want == 0) return;
@@ -948,43 +993,8 @@ static uint32_t LiftBoundaryPoints(TetMesh &mesh, uint32_t n_input, const std::v
             add_condition([&](const dvec3 &x) { return volume6(x, P[b], P[c], P[a]); }, -orient(P[m], P[b], P[c], P[fourth(faces[face_key(m, b, c)].second, m, b, c)]));
             add_condition([&](const dvec3 &x) { return volume6(x, P[b], P[d], P[a]); }, -orient(P[m], P[b], P[d], P[fourth(faces[face_key(m, b, d)].second, m, b, d)]));
             // (c and d on opposite sides of the face (a, b, x): implied for x inside both restored triangles' inner half-spaces near the edge; the exact test below checks it)
-            double best_depth = 0;
             dvec3 centre = old;
-            const size_t np_ = planes.size();
-            if (np_ >= 4 && np_ <= 64) {
-                for (size_t i0 = 0; i0 < np_; ++i0)
-                    for (size_t i1 = i0 + 1; i1 < np_; ++i1)
-                        for (size_t i2 = i1 + 1; i2 < np_; ++i2)
-                            for (size_t i3 = i2 + 1; i3 < np_; ++i3) {
-                                // n_i . x - depth = -d_i for the four planes: a 4 x 4 system in (x, depth)
-                                const Plane *pl[4] = {&planes[i0], &planes[i1], &planes[i2], &planes[i3]};
-                                double A[4][5];
-                                for (int r = 0; r < 4; ++r) A[r][0] = pl[r]->n.x, A[r][1] = pl[r]->n.y, A[r][2] = pl[r]->n.z, A[r][3] = -1.0, A[r][4] = -pl[r]->d;
-                                bool singular = false;
-                                for (int col = 0; col < 4 && !singular; ++col) {
-                                    int piv = col;
-                                    for (int r = col + 1; r < 4; ++r)
-                                        if (std::fabs(A[r][col]) > std::fabs(A[piv][col])) piv = r;
-                                    if (std::fabs(A[piv][col]) < 1e-12) { singular = true; break; }
-                                    if (piv != col)
-                                        for (int cc = 0; cc < 5; ++cc) std::swap(A[piv][cc], A[col][cc]);
-                                    for (int r = 0; r < 4; ++r) {
-                                        if (r == col) continue;
-                                        const double f = A[r][col] / A[col][col];
-                                        for (int cc = col; cc < 5; ++cc) A[r][cc] -= f * A[col][cc];
-                                    }
-                                }
-                                if (singular) continue;
-                                const dvec3 x{A[0][4] / A[0][0], A[1][4] / A[1][1], A[2][4] / A[2][2]};
-                                const double depth = A[3][4] / A[3][3];
-                                if (!(depth > best_depth)) continue;
-                                const dvec3 move = x - old;
-                                if (move.x * move.x + move.y * move.y + move.z * move.z > 4 * h * h) continue; // (not beyond the edge's own length)
-                                bool feasible = true;
-                                for (size_t j = 0; j < np_ && feasible; ++j) feasible = planes[j].n.x * x.x + planes[j].n.y * x.y + planes[j].n.z * x.z + planes[j].d >= depth * (1 - 1e-9) - 1e-300;
-                                if (feasible) best_depth = depth, centre = x;
-                            }
-            }
+            const double best_depth = ChebyshevCentre(planes, old, 2 * h, centre);
             double q;
             if (best_depth > 0 && valid_quality(centre, q)) best_q = q, best = centre;
             if (!(best_q > 0)) { ++stuck; ++why[3]; continue; }
@@ -1858,6 +1868,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                     weight += 1;
                 }
             }
+            if (std::getenv("MH_TET_DEBUG2")) std::fprintf(stderr, "  relocate: cell %d vertex %u: star of %zu, %s\n", t0, v, star.size(), fixed ? "on the boundary or a wall" : "free");
             if (fixed || star.empty()) continue;
             centre = centre * (1.0 / weight);
             const dvec3 &a = P[cell[size_t(vi + 1) & 3]], &b = P[cell[size_t(vi + 2) & 3]], &c3 = P[cell[size_t(vi + 3) & 3]];
@@ -1897,7 +1908,37 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             for (const dvec3 &x : candidates) {
                 bool valid = false;
                 const double w = worst_at(x, valid);
+                if (std::getenv("MH_TET_DEBUG2")) std::fprintf(stderr, "      position: %s, worst %.1e (now %.1e)\n", valid ? "valid" : "a cell inverts", w, best);
                 if (valid && w > best * 1.5) best = w, best_x = x, found = true;
+            }
+            if (!found && star.size() <= 64) {
+                // No sampled position keeps every cell at the point positive (a point a hair off a surface EDGE has a star of forty cells, some
+                // of them thin: the steps above overshoot them).  The positions that do are a polyhedron -- each cell's volume is affine in
+                // the position -- and the point farthest inside it is ChebyshevCentre's small linear programme.
+                std::vector<HalfSpace> planes;
+                double reach = 0;
+                for (const int32_t t : star) {
+                    const auto &tet = T[size_t(t)];
+                    const auto g = [&](const dvec3 &x) {
+                        dvec3 q[4];
+                        for (int i = 0; i < 4; ++i) q[i] = tet[size_t(i)] == v ? x : P[tet[size_t(i)]];
+                        return dot(q[1] - q[0], cross(q[2] - q[0], q[3] - q[0]));
+                    };
+                    const double g0 = g(P[v]);
+                    const dvec3 grad{(g(P[v] + dvec3{scale, 0, 0}) - g0) / scale, (g(P[v] + dvec3{0, scale, 0}) - g0) / scale, (g(P[v] + dvec3{0, 0, scale}) - g0) / scale};
+                    const double len = std::sqrt(dot(grad, grad));
+                    if (!(len > 0)) continue;
+                    const dvec3 nrm = grad * (1.0 / len);
+                    planes.push_back({nrm, g0 / len - dot(nrm, P[v])});
+                    for (const uint32_t x : tet) reach = std::max(reach, std::sqrt(dot(P[x] - P[v], P[x] - P[v])));
+                }
+                dvec3 x = P[v];
+                if (ChebyshevCentre(planes, P[v], reach, x) > 0) {
+                    bool valid = false;
+                    const double w = worst_at(x, valid);
+                    if (std::getenv("MH_TET_DEBUG2")) std::fprintf(stderr, "      the star's centre: %s, worst %.1e (now %.1e)\n", valid ? "valid" : "a cell inverts", w, best);
+                    if (valid && w > best * 1.5) best = w, best_x = x, found = true;
+                }
             }
             if (found) {
                 P[v] = best_x;
