@@ -337,3 +337,31 @@ def test_the_flat_cell_pass_on_a_repaired_scan_fill():
     faces = np.sort(np.concatenate([t1[:, [1, 2, 3]], t1[:, [0, 2, 3]], t1[:, [0, 1, 3]], t1[:, [0, 1, 2]]]), axis=1)
     uniq, counts = np.unique(faces, axis=0, return_counts=True)
     assert counts.max() <= 2 and {tuple(r) for r in uniq[counts == 1]} == {tuple(sorted(r)) for r in f.tolist()}
+
+
+@pytest.mark.parametrize("name,was", [("torus_sliver", 2e-8), ("torus_edge", 1.4e-5), ("ellipsoid_cap", 3.8e-7)])
+def test_the_soak_s_flat_fills_come_back_without_a_flat_cell(name, was):
+    """Three surfaces of the round-6 soak (tests/golden/make_flat_fill_surfaces.py replays its random stream) whose default fills kept a cell at `was`
+    after the flat-cell pass's insertions: a sliver of four surface vertices across a coarse torus's tube, a recovery point a hair off a surface edge,
+    caps on planar quads over a fan of thin cells round a surface vertex (every insertion cavity unravels under the star-shape test).  The pass now
+    splits an interior edge of such a cell inside the kernel of its ring, or moves the added point to the Chebyshev centre of its star
+    (mesheditor_amd/cpp/src/tetrahedralize.cpp: BreakFlatCells): no cell below 1e-3, the boundary still the input's triangulation, the input
+    vertices untouched, every tetrahedron positively oriented, every added point in one."""
+    from mesheditor_amd import tets
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat_fill_surfaces.npz"))
+    v, f = data[name + "_P"], data[name + "_F"]
+    p, t, left = tets.tetrahedralize(v, f)
+    assert left == 0 and np.array_equal(p[: len(v)], v)
+    q = p[t.astype(np.int64)]
+    vol6 = np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0])
+    assert vol6.min() > 0
+    e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+    assert (vol6 * np.sqrt(2) / e2 ** 1.5).min() > 1e-3
+    assert len(np.unique(t)) == len(p)
+    faces = np.sort(np.concatenate([t[:, [1, 2, 3]], t[:, [0, 2, 3]], t[:, [0, 1, 3]], t[:, [0, 1, 2]]]), axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    assert counts.max() <= 2 and {tuple(r) for r in uniq[counts == 1]} == {tuple(sorted(r)) for r in f.tolist()}
+    # the enclosed volume (divergence theorem over the input triangles) is the fill's
+    a, b, c = v[f[:, 0].astype(np.int64)], v[f[:, 1].astype(np.int64)], v[f[:, 2].astype(np.int64)]
+    enclosed = abs(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6
+    assert abs(vol6.sum() / 6 - enclosed) < 1e-9 * enclosed
