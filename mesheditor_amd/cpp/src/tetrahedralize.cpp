@@ -1828,6 +1828,33 @@ static uint32_t RefineQuality(TetMesh &mesh, bool quality, double ratio_bound, d
             if (!m.ok || !is_bad(m)) continue;
             const bool too_large = max_volume > 0 && m.volume > max_volume;
             bool inserted = false;
+            if (too_large && !quality) {
+                // the volume bound alone (the front end's last word): of the circumcentre, the centroid and the midpoint of the longest edge's
+                // opposite pair -- whichever fan has the best worst cell; a flat cell made here would stay
+                const auto &v = T[size_t(t0)];
+                std::vector<dvec3> tries{m.centre, (P[v[0]] + P[v[1]] + P[v[2]] + P[v[3]]) * 0.25};
+                tries.push_back((tries[0] + tries[1]) * 0.5);
+                double best = -1;
+                dvec3 best_p{0, 0, 0};
+                std::vector<int32_t> best_in;
+                std::vector<std::array<uint32_t, 4>> best_fresh;
+                for (const dvec3 &p : tries) {
+                    const int32_t at = ed.Locate(p, t0);
+                    if (at < 0) continue;
+                    const std::vector<int32_t> in = ed.Cavity(p, at);
+                    if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) continue;
+                    const auto fresh = ed.Fan(in);
+                    double worst = 1e300;
+                    for (const auto &piece : fresh) worst = std::min(worst, ShapeOf(P, piece, &p));
+                    if (worst > best) best = worst, best_p = p, best_in = in, best_fresh = fresh;
+                }
+                if (best > 0) {
+                    ed.Commit(best_p, best_in, best_fresh);
+                    hopeless.resize(T.size(), 0);
+                    ++added, ++added_this_pass;
+                    inserted = true;
+                }
+            }
             for (int attempt = 0; attempt < 2 && !inserted; ++attempt) {
                 // attempt 0: the circumcentre; attempt 1 (a tetrahedron that is too large only): its centroid, which it always contains
                 if (attempt == 1 && !too_large) break;
@@ -2076,18 +2103,19 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             std::vector<int32_t> best_in;
             std::vector<std::array<uint32_t, 4>> best_fresh;
             static const bool dbg2 = std::getenv("MH_TET_DEBUG2") != nullptr;
+            static const double dbg_below = std::getenv("MH_TET_DEBUG_BELOW") ? std::atof(std::getenv("MH_TET_DEBUG_BELOW")) : 1e-6; // (which cells the trace follows)
             for (const dvec3 &p : candidates) {
                 std::vector<int32_t> path;
                 const int32_t at = ed.Locate(p, t0, &path);
-                if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "  cell %d (%u %u %u %u) shape %.1e n_open %d candidate (%.5f %.5f %.5f): located in %d\n", t0, cell[0], cell[1], cell[2], cell[3], q0, n_open, p.x, p.y, p.z, at);
+                if (dbg2 && q0 < dbg_below) std::fprintf(stderr, "  cell %d (%u %u %u %u) shape %.1e n_open %d candidate (%.5f %.5f %.5f): located in %d\n", t0, cell[0], cell[1], cell[2], cell[3], q0, n_open, p.x, p.y, p.z, at);
                 if (at < 0) continue;
-                ed.Trace = dbg2 && q0 < 1e-6 && std::getenv("MH_TET_DEBUG3");
+                ed.Trace = dbg2 && q0 < dbg_below && std::getenv("MH_TET_DEBUG3");
                 std::vector<int32_t> in = ed.Cavity(p, at, t0);
                 if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) { // once more with the cap's flat neighbours taken in
                     in = ed.Cavity(p, at, t0, 0.05);
                     if ((in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) && path.size() <= 12) in = ed.Cavity(p, at, t0, 0.05, &path); // ... and with the walk's cells
                     if (in.empty() || std::find(in.begin(), in.end(), t0) == in.end()) {
-                        if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "      cavity %s\n", in.empty() ? "empty (the containing cell does not see the point through its hull)" : "without the flat cell");
+                        if (dbg2 && q0 < dbg_below) std::fprintf(stderr, "      cavity %s\n", in.empty() ? "empty (the containing cell does not see the point through its hull)" : "without the flat cell");
                         continue;
                     }
                 }
@@ -2111,7 +2139,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                     for (const uint32_t v : before) swallowed = swallowed || !std::binary_search(after.begin(), after.end(), v);
                     if (swallowed) continue;
                 }
-                if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "      cavity of %zu cells, worst old %.1e, worst new %.1e\n", in.size(), worst_old, worst_new);
+                if (dbg2 && q0 < dbg_below) std::fprintf(stderr, "      cavity of %zu cells, worst old %.1e, worst new %.1e\n", in.size(), worst_old, worst_new);
                 if (!(worst_new > worst_old)) continue;
                 const double gain = worst_new;
                 if (gain > best_gain) best_gain = gain, best_p = p, best_in = in, best_fresh = fresh;
@@ -2136,6 +2164,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                     for (int j = i + 1; j < 4; ++j) {
                         const uint32_t u = cell[size_t(i)], v = cell[size_t(j)];
                         const std::vector<int32_t> ring = ed.Ring(t0, u, v);
+                        if (dbg2 && q0 < dbg_below && ring.empty()) std::fprintf(stderr, "      edge (%u %u): its ring of cells is open (a surface or wall edge) or longer than 64\n", u, v);
                         if (ring.empty()) continue;
                         double worst_old = 1e300;
                         for (const int32_t c : ring) worst_old = std::min(worst_old, ShapeOf(P, T[size_t(c)]));
@@ -2154,6 +2183,27 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                             for (const double step : {0.35, 0.2, 0.5, 0.1, 0.7, 0.05}) positions.push_back(mid + (middle - mid) * step);
                             for (const dvec3 &full : candidates) positions.push_back(mid + (full - centroid));
                             for (const dvec3 &full : candidates) positions.push_back(mid + (full - centroid) * 0.2);
+                            // ... and the point farthest inside the region where every half is positive (each half's volume is affine in the
+                            // position: ChebyshevCentre) -- the kernel of a ring that hugs the surface is a sliver the samples miss
+                            std::vector<HalfSpace> planes;
+                            const double span = std::sqrt(dot(P[u] - P[v], P[u] - P[v]));
+                            for (const int32_t c : ring)
+                                for (const uint32_t gone : {u, v}) {
+                                    const auto tet = T[size_t(c)];
+                                    const auto g = [&](const dvec3 &x) {
+                                        dvec3 q[4];
+                                        for (int k = 0; k < 4; ++k) q[k] = tet[size_t(k)] == gone ? x : P[tet[size_t(k)]];
+                                        return dot(q[1] - q[0], cross(q[2] - q[0], q[3] - q[0]));
+                                    };
+                                    const double g0 = g(mid);
+                                    const dvec3 grad{(g(mid + dvec3{span, 0, 0}) - g0) / span, (g(mid + dvec3{0, span, 0}) - g0) / span, (g(mid + dvec3{0, 0, span}) - g0) / span};
+                                    const double len = std::sqrt(dot(grad, grad));
+                                    if (!(len > 0)) continue;
+                                    const dvec3 nrm = grad * (1.0 / len);
+                                    planes.push_back({nrm, g0 / len - dot(nrm, mid)});
+                                }
+                            dvec3 deepest = mid;
+                            if (ChebyshevCentre(planes, mid, span, deepest) > 0) positions.push_back(deepest);
                         }
                         for (const dvec3 &p : positions) {
                             double worst_new = 1e300;
@@ -2169,7 +2219,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                                     if (exact::Orient3D(q[0], q[1], q[2], q[3]) <= 0) { valid = false; break; }
                                     worst_new = std::min(worst_new, ShapeOf(P, piece, &p));
                                 }
-                            if (dbg2 && q0 < 1e-6) std::fprintf(stderr, "      edge (%u %u) ring of %zu, offset position: %s, worst old %.1e, worst new %.1e\n", u, v, ring.size(), valid ? "valid" : "a half is inverted", worst_old, valid ? worst_new : 0.0);
+                            if (dbg2 && q0 < dbg_below) std::fprintf(stderr, "      edge (%u %u) ring of %zu, offset position: %s, worst old %.1e, worst new %.1e\n", u, v, ring.size(), valid ? "valid" : "a half is inverted", worst_old, valid ? worst_new : 0.0);
                             if (!valid || !(worst_new > worst_old) || !(worst_new > best_gain)) continue;
                             best_gain = worst_new, best_p = p, best_ring = ring, best_u = u, best_v = v;
                         }
@@ -2723,6 +2773,28 @@ static Attempt TetrahedralizeOnce(std::span<const dvec3> points, std::span<const
                 if (!SmoothAddedPoints(out.Mesh, n_input, keep)) break;
             }
             out.SliverExchanges += RepairSlivers(out.Mesh, options.SliverTarget, keep);
+        }
+    }
+    // MaxVolume has the last word: the exchanges, the smoothing and the flat-cell pass that followed the quality arm merge and move cells, and a
+    // tetrahedron may have grown past the bound again (the round-6 options fuzz: up to twice the bound on one fill in five); without
+    // RepairSlivers the arm above has not run at all.  Points only from here on -- nothing after this changes a volume.
+    if (options.MaxVolume > 0) {
+        std::set<Tri> walls;
+        if (!manifold)
+            for (const Tri &t : surface) walls.insert(Sorted(final_id(t[0]), final_id(t[1]), final_id(t[2])));
+        const std::set<Tri> *keep = manifold ? nullptr : &walls;
+        const size_t cap = options.MaxRefinePoints ? options.MaxRefinePoints : std::max<size_t>(20000, 40 * out.Mesh.Points.size());
+        for (int round = 0; round < 4; ++round) {
+            if (out.QualityPoints < cap) out.QualityPoints += RefineQuality(out.Mesh, false, 2.0, options.MaxVolume, keep, cap - out.QualityPoints);
+            // (a point that bounds a volume may leave a sliver between interior points: the flat-cell pass beside it -- points and moves only,
+            // no exchange -- and the bound once more, which ends the loop)
+            double worst = 1e300;
+            for (const auto &t : out.Mesh.Tets) worst = std::min(worst, ShapeOf(out.Mesh.Points, t));
+            if (round == 3 || !options.BreakFlatCells || !options.RepairSlivers || worst >= 1e-3) break;
+            uint32_t moved = 0;
+            const uint32_t points = BreakFlatCells(out.Mesh, 2e-3, keep, 4096, n_input, &moved);
+            out.FlatCellPoints += points;
+            if (!points && !moved) break;
         }
     }
     out.Profile.RefineSeconds = seconds_since(refine_start);

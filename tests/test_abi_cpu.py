@@ -365,3 +365,33 @@ def test_the_soak_s_flat_fills_come_back_without_a_flat_cell(name, was):
     a, b, c = v[f[:, 0].astype(np.int64)], v[f[:, 1].astype(np.int64)], v[f[:, 2].astype(np.int64)]
     enclosed = abs(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6
     assert abs(vol6.sum() / 6 - enclosed) < 1e-9 * enclosed
+
+
+def test_max_volume_has_the_last_word():
+    """Found by the round-6 options fuzz (tools/probe/r06_front_end_fuzz.py): the quality arm bounded every volume, and the exchanges, the smoothing
+    and the flat-cell pass that FOLLOW it merged and moved cells past the bound again (up to twice MaxVolume on one fill in five).  The bound is
+    now enforced once more at the very end -- points only, the best-shaped of circumcentre / centroid / their midpoint, the flat-cell pass (no
+    exchanges) in turn with it -- on the fuzz's first case: a 47 x 17 torus, InteriorShell::Always, MaxVolume = enclosed volume / 14 681."""
+    import importlib.util
+    from mesheditor_amd import tets
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_flat_fill_surfaces.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    v, f, name = mk.soak_surface(11, 1)
+    assert name == "torus 47x17"
+    bound = 7.35120153672187e-08
+    p, t, left = tets.tetrahedralize(v, f, interior_shell="always", max_volume=bound)
+    q = p[t.astype(np.int64)]
+    vol6 = np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0])
+    assert left == 0 and np.array_equal(p[: len(v)], v) and vol6.min() > 0
+    assert vol6.max() / 6 <= bound * (1 + 1e-12), vol6.max() / 6 / bound
+    e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+    assert (vol6 * np.sqrt(2) / e2 ** 1.5).min() > 1e-3
+    a, b, c = v[f[:, 0].astype(np.int64)], v[f[:, 1].astype(np.int64)], v[f[:, 2].astype(np.int64)]
+    enclosed = abs(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6
+    assert abs(vol6.sum() / 6 - enclosed) < 1e-9 * enclosed
+    # without RepairSlivers the quality arm used not to run at all: the bound holds there too
+    p, t, _ = tets.tetrahedralize(v, f, repair_slivers=False, max_volume=4 * bound)
+    q = p[t.astype(np.int64)]
+    vol6 = np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0])
+    assert vol6.max() / 6 <= 4 * bound * (1 + 1e-12)
