@@ -794,7 +794,7 @@ struct SurfaceEdgeUse {
 } // namespace
 
 // The point farthest inside a set of half-spaces n . x + d >= 0 (|n| = 1), no further than `reach` from `old`: a linear programme in
-// (position, depth), solved by enumeration of the vertices of its feasible set -- four planes at a time, sixty-four planes at most.
+// (position, depth), solved by enumeration of the vertices of its feasible set -- four planes at a time -- over a growing subset of the planes.
 // Returns the depth (0: none found) and the point.  Rounded arithmetic: the caller's exact predicates have the last word.
 struct HalfSpace {
     dvec3 n;
@@ -843,7 +843,7 @@ static double ChebyshevVertex(const std::vector<HalfSpace> &planes, const std::v
 }
 static double ChebyshevCentre(const std::vector<HalfSpace> &planes, const dvec3 &old, double reach, dvec3 &centre) {
     const size_t np_ = planes.size();
-    if (np_ < 4 || np_ > 64) return 0;
+    if (np_ < 4 || np_ > 4096) return 0;
     // Cutting planes: the optimum hangs on four of the planes, nearly always among those nearest to the point as it stands.  Start from the
     // sixteen nearest, solve, take in the planes the answer violates, solve again; with none violated the answer is the whole set's (and,
     // the active planes kept in their own order, the same four systems in the same arithmetic as the enumeration of all C(n, 4) would
@@ -879,6 +879,7 @@ static double ChebyshevCentre(const std::vector<HalfSpace> &planes, const dvec3 
         std::sort(violated.begin(), violated.end());
         for (size_t k = 0; k < std::min<size_t>(violated.size(), 8); ++k) in[violated[k].second] = 1;
     }
+    if (np_ > 64) return 0; // (sixteen rounds of cuts did not settle it: the full enumeration is C(n, 4) systems, affordable for a few dozen planes only)
     active.clear();
     for (uint32_t i = 0; i < np_; ++i) active.push_back(i);
     return ChebyshevVertex(planes, active, old, reach, centre);
@@ -1996,7 +1997,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                         std::memcpy(bits, &P[x], sizeof bits);
                         for (const uint64_t word : {uint64_t(x), bits[0], bits[1], bits[2]}) signature = (signature ^ word) * 0x100000001b3ull;
                     }
-            if (!found && star.size() <= 64 && centre_tried.insert(signature).second) {
+            if (!found && star.size() <= 512 && centre_tried.insert(signature).second) {
                 // No sampled position keeps every cell at the point positive (a point a hair off a surface EDGE has a star of forty cells, some
                 // of them thin: the steps above overshoot them).  The positions that do are a polyhedron -- each cell's volume is affine in
                 // the position -- and the point farthest inside it is ChebyshevCentre's small linear programme.
