@@ -22,7 +22,7 @@ class SolverConfig(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("mass_props", "quad_mesh", "assemble", "sample_excite", "factorize", "iterate", "op_solve", "extract")] + \
-               [(n, C.c_uint32) for n in ("dofs", "stiffness_nonzeros", "op_applications", "restarts", "sytrd_redos", "reserved")] + [("rr_selfcheck", C.c_double)]
+               [(n, C.c_uint32) for n in ("dofs", "stiffness_nonzeros", "op_applications", "restarts", "sytrd_redos", "pairs_at_floor")] + [("rr_selfcheck", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1470,6 +1470,8 @@ struct BlockLobpcg {
     double precond_seconds = 0;
     double best_worst_active = 1e300; // smallest worst relative residual of the active columns seen so far
     int floor_strikes = 0;            // consecutive iterations in which the worst active residual sat 1e3 above it
+    std::vector<double> hist_active;  // the worst active residual per iteration (the last resort's stall test)
+    uint32_t pairs_at_floor = 0;      // wanted pairs handed on although their residual stayed above the tolerance (the last resort only; see converged_or_locked)
     // ---- panels (n x b) and small matrices
     DevArray<double> X, AX, MX, Xn, AXn, MXn, W, AW, MW, P, MP, Pn, MPn, R, Rw;
     DevArray<double> gA, gM, gM0, gA0, App, evals, ework, Cp, T1, H, H2, G, dscale, Linv, theta_d, rn_d, mn_d, scratch, Ct, norms_d, theta_act_d, Hp, Up, Vp, T1p;
@@ -1811,7 +1813,12 @@ struct BlockLobpcg {
             // 1-4) whether those pairs ever locked was decided by the rounding of the Rayleigh-Ritz step: 32 iterations with one
             // tridiagonalisation kernel, no convergence with the other two (tools/probe/sphere_iters_probe.py, profiles/r05_rigid_floor.txt).
             // A pair accepted here has an eigenvector error of 256 eps ||A|| / (lambda_7 - sigma) ~ 1e-7 at worst and an eigenvalue error of its square.
-            const bool ok = rel < residual_tol || (near_shift && std::sqrt(rn[i]) < 256 * 2.2e-16 * floor_norm);
+            // (it 0 of a cold start: the pairs near the shift ARE the exact rigid-body vectors of the start block -- null vectors of K whatever the
+            // mesh -- and what they measure is the rounding of forming A x alone: 1 000 ... 3 000 times eps ||A|| ||x|| on a raw Delaunay fill with
+            // cells at 3e-11, whose rows cancel entries of 1e18.  Left active they only collect noise from the search directions and the solve
+            // never ends; the reference's factorisation hands the same six back at +-1e2 beside elastic values of 2e7)
+            const double floor_factor = it == 0 && !warm && sys->worst_quality < kFlatShape ? 65536.0 : 256.0;
+            const bool ok = rel < residual_tol || (near_shift && std::sqrt(rn[i]) < floor_factor * 2.2e-16 * floor_norm);
             if (ok) locked[i] = 1;
             if (!locked[i]) act.push_back(i);
         }
@@ -1859,6 +1866,21 @@ struct BlockLobpcg {
             best_worst_active = std::min(best_worst_active, worst_active);
             // (three iterations in a row: one step's jump is also what a guard column looks like when its Ritz value drops into the
             // wanted range late -- a missed member of a multiplet arrives with a residual of 1e-2 .. 1e-1 beside pairs just above the tolerance)
+            // The last resort on a mesh at the edge of double precision (raw Delaunay fills, cells at 1e-8 .. 1e-9, ||A|| / theta ~ 1e9): the last
+            // few pairs stop a factor below ten above the tolerance and stay there -- the floor of forming A x.  The reference's factorisation
+            // returns its pairs on such a mesh whatever their residuals are; an empty result for a residual of 1.8e-4 against 1e-4 (eigenvalue error
+            // ~ its square) would be the worse answer.  Thirty iterations without a newly converged pair and without a tenth off the worst
+            // residual, that residual within ten times the tolerance: the pairs are handed on, counted in mh_profile.pairs_at_floor and said so.
+            hist_active.push_back(worst_active);
+            if (inner_cg > 0 && it >= 40) {
+                const size_t h = hist_active.size();
+                if (h > 30 && hist_nconv[h - 31] == nconv && worst_active > 0.9 * hist_active[h - 31] && worst_active <= 10.0 * residual_tol) {
+                    pairs_at_floor = nev > nconv ? nev - nconv : 0;
+                    if (verbose) fprintf(stderr, "[lobpcg] it %3u: %u pairs have sat at a residual of %.2e (tolerance %.1e) for thirty iterations -- the rounding floor of this mesh; handed on as they are\n", it, pairs_at_floor, worst_active, residual_tol);
+                    converged = true;
+                    return true;
+                }
+            }
             floor_strikes = it >= 20 && worst_active > 1e3 * best_worst_active ? floor_strikes + 1 : 0;
             if (floor_strikes >= 3)
                 mh_throw(MH_ENOTCONVERGED, "LOBPCG: %u of %u pairs converged; the others sit at the rounding floor (residual %.1e and growing, best %.1e, tolerance %.1e)", nconv, nev,
@@ -2183,7 +2205,7 @@ struct BlockLobpcg {
     // the solve's health counters: redone Rayleigh-Ritz steps and the worst sampled self-check residual (k_rr_selfcheck) since start()
     void read_health() {
         prof.sytrd_redos = ctx->sytrd_redos - redos_at_start;
-        prof.reserved = 0;
+        prof.pairs_at_floor = pairs_at_floor;
         prof.rr_selfcheck = 0.0;
         if (ctx->rr_check) {
             unsigned long long bits = 0;
@@ -2301,12 +2323,24 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         sys->L2.lmax *= 1.25;
                         sys->lmax_widened = true;
                     }
-                    try {
-                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, 8);
-                        solver.run(eigenvalues);
-                    } catch (const MhError &again) {
-                        if (again.code != MH_ENOTCONVERGED) throw;
-                        mh_throw(MH_ENOTCONVERGED, "%s (the last resort too: %s)", e.what(), again.what()); // what the caller reads first is why the solve itself stopped
+                    // (eight steps first; a mesh they do not do -- ||A|| / theta ~ 1e11: the cycle is a poor preconditioner of the flat cells' rows -- gets
+                    // forty: each outer iteration is then nearly an exact inverse iteration, at fifty cycles' cost)
+                    static const int first_steps = getenv("MH_LAST_RESORT_CG") ? std::max(1, atoi(getenv("MH_LAST_RESORT_CG"))) : 8;
+                    for (const int steps : {first_steps, 5 * first_steps}) {
+                        try {
+                            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, steps == first_steps ? max_iters : std::min<uint32_t>(max_iters, 120), seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, steps);
+                            solver.run(eigenvalues);
+                            return;
+                        } catch (const MhError &again) {
+                            if (again.code != MH_ENOTCONVERGED) throw;
+                            if (steps == first_steps) {
+                                if (switches().verbose) fprintf(stderr, "[lobpcg] the last resort with %d conjugate-gradient steps: %s -- once more with %d\n", steps, again.what(), 5 * steps);
+                                prof = sys->profile;
+                                prof.dofs = uint32_t(n);
+                                continue;
+                            }
+                            mh_throw(MH_ENOTCONVERGED, "%s (the last resort too: %s)", e.what(), again.what()); // what the caller reads first is why the solve itself stopped
+                        }
                     }
                     return;
                 }

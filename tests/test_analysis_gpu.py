@@ -1591,3 +1591,54 @@ def test_random_closed_surfaces_through_front_end_and_solve_against_the_oracle(a
     assert rel.max() < 1e-6, (name, rel.max())
     assert np.abs(r.eigenvalues[~elastic]).max() < 1e-6 * evo[elastic][0]
     assert r.profile["restarts"] <= 40, (name, r.profile["restarts"])
+
+
+def _option_made_mesh(seed, index):
+    """the mesh tools/probe/r06_soak_options.py makes for (seed, index): the soak's surface through the front end with that script's random options"""
+    from mesheditor_amd import tets as front_end
+    rng = np.random.default_rng(700000 * seed + index)
+    P, F, name = _soak_surface(seed, index)
+    opts = dict(quality=bool(rng.random() < 0.2), max_volume=0.0, interior_shell=str(rng.choice(["when_flat", "never", "always"])), repair_slivers=bool(rng.random() < 0.65),
+                break_flat_cells=bool(rng.random() < 0.7))
+    if rng.random() < 0.2:
+        a, b, c = P[F[:, 0].astype(np.int64)], P[F[:, 1].astype(np.int64)], P[F[:, 2].astype(np.int64)]
+        opts["max_volume"] = float(abs(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6 / rng.integers(2000, 12000))
+    pts, tets, _ = front_end.tetrahedralize(P, F, **opts)
+    return pts, tets, len(P), int(rng.choice([30, 45, 65])), opts, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,index,flattest,bound", [(31, 3, 1e-8, 1e-6), (33, 31, 1e-10, 1e-4)])
+def test_raw_fills_at_the_edge_of_double_precision_return_the_oracles_pairs(api, ctx, oracle, seed, index, flattest, bound):
+    """Found by tools/probe/r06_soak_options.py (the solver on whatever the front end's OPTIONS can make): two raw Delaunay fills -- RepairSlivers off, the
+    shell's points added -- with cells at 5.8e-9 (||A|| = 7e16) and 2.7e-11 (||A|| = 1.3e18) came back EMPTY, while the oracle (the reference's
+    factorisation) returns every pair on both.  (i) The six exact rigid-body vectors of a cold start measure 1 000 - 3 000 eps ||A|| ||x|| on such rows and
+    never locked; they lock at iteration 0 now.  (ii) The last pairs of the last resort stop within ten times the tolerance and stay: after thirty
+    iterations without change they are handed on and counted (mh_profile.pairs_at_floor).  Eigenvalues against the oracle: 1e-6 at 5.8e-9, 1e-4 at
+    2.7e-11 -- where eps ||A|| / theta_7 = 7e-6 is what double precision leaves of ANY method's answer (the oracle's own rigid-body values sit at 4e-5 of theta_7)."""
+    pts, tets, n_surface, pairs, opts, name = _option_made_mesh(seed, index)
+    assert not opts["repair_slivers"], opts
+    q = pts[tets.astype(np.int64)]
+    vol6 = np.abs(np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0]))
+    e2 = sum(((q[:, i] - q[:, j]) ** 2).sum(1) for i in range(4) for j in range(i + 1, 4)) / 6
+    assert (vol6 * np.sqrt(2) / e2 ** 1.5).min() < flattest, name
+    m = meshes.MATERIALS[meshes.MATERIAL_ORDER[index % len(meshes.MATERIAL_ORDER)]]
+    mg, mo = _mats(api, oracle, m)
+    ex = pts[(np.arange(10) * n_surface) // 10].astype(np.float32)
+    r = api.mesh2modes(ctx, pts, tets, mg, ex, config=api.default_config(num_modes=pairs - 15, num_fem_modes=pairs))
+    assert len(r.eigenvalues) == pairs, (name, r.profile)
+    assert 0 < r.profile["pairs_at_floor"] <= 6, r.profile
+    evo, _, _ = oracle.System(pts, tets, mo).eigs(pairs)
+    elastic = evo > 1e-3 * evo[-1]
+    assert elastic.sum() == pairs - 6
+    rel = np.abs(r.eigenvalues[elastic] - evo[elastic]) / evo[elastic]
+    assert rel.max() < bound, (name, rel.max())
+    assert np.abs(r.eigenvalues[~elastic]).max() < 1e-4 * evo[elastic][0]
+
+
+@pytest.mark.gpu
+def test_a_healthy_solve_reports_no_pair_at_the_floor(api, ctx):
+    pts, tets, m, kw = meshes.workload("cube_s10k")
+    ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
+    r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(**kw))
+    assert r.profile["pairs_at_floor"] == 0 and r.profile["sytrd_redos"] == 0

@@ -1,7 +1,7 @@
 """Round-6 soak of the SOLVER on whatever the front end's options can make (GPU): the surfaces of tools/probe/r06_soak.py (tests/golden/make_flat_fill_surfaces.py: soak_surface),
 filled with random Quality / MaxVolume / InteriorShell / RepairSlivers / BreakFlatCells -- a third of them with the sliver repair OFF, i.e. raw Delaunay fills with cells flat to
 rounding, the worst a caller's own TetMesh can look like -- then mesh2modes with the default config.  Every solve must return all its pairs; the log says which fall-back, if any,
-each one needed.     python tools/probe/r06_soak_options.py <seed> <count>"""
+each one needed.     python tools/probe/r06_soak_options.py <seed> <count> [first]"""
 import importlib.util
 import os
 import sys
@@ -18,10 +18,11 @@ mk = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(mk)
 
 seed, count = int(sys.argv[1]), int(sys.argv[2])
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = api.Context(0)
 mats = [meshes.MATERIALS[k] for k in meshes.MATERIAL_ORDER]
 fails, its = [], []
-for index in range(count):
+for index in range(first, first + count):
     rng = np.random.default_rng(700000 * seed + index)
     P, F, name = mk.soak_surface(seed, index)
     if len(P) > 1300:
@@ -54,6 +55,6 @@ for index in range(count):
         continue
     ctx.synchronize()
     its.append(r.profile.get("restarts", 0))
-    print(f"{tag}; {len(r.eigenvalues)} of {pairs} pairs, {r.profile.get('restarts')} iterations, {1e3 * (time.time() - t1):.0f} ms", flush=True)
+    print(f"{tag}; {len(r.eigenvalues)} of {pairs} pairs, {r.profile.get('restarts')} iterations, {1e3 * (time.time() - t1):.0f} ms{', %d pairs at the rounding floor' % r.profile['pairs_at_floor'] if r.profile.get('pairs_at_floor') else ''}", flush=True)
     if len(r.eigenvalues) != pairs: fails.append((index, "pairs", len(r.eigenvalues)))
 print("solves", len(its), "iterations min / median / max", min(its), int(np.median(its)), max(its), "failures", fails)
