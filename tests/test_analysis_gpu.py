@@ -1642,3 +1642,31 @@ def test_a_healthy_solve_reports_no_pair_at_the_floor(api, ctx):
     ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
     r = api.mesh2modes(ctx, pts, tets, api.material(*m), ex, config=api.default_config(**kw))
     assert r.profile["pairs_at_floor"] == 0 and r.profile["sytrd_redos"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bodies", [2, 3])
+def test_a_tet_mesh_of_several_disjoint_bodies(api, ctx, oracle, bodies):
+    """mesh2modes takes any TetMesh (src/audio/mesh2modes.h:77) -- also one of several disjoint bodies: 6 rigid-body modes EACH, of which the cold start's
+    block holds the six global ones only; the others are found by the iteration at eigenvalue 0 like any pair.  Against the oracle: the count of
+    rigid-body values, the elastic eigenvalues to 1e-6, the modes PostprocessModes keeps."""
+    parts = [meshes.kuhn_box(6, 5, 4, 0.12, 0.1, 0.08), meshes.kuhn_box(4, 4, 7, 0.05, 0.05, 0.09, origin=(5.0, 2.0, -3.0)), meshes.kuhn_box(3, 3, 3, 0.04, 0.04, 0.04, origin=(0.0, 0.4, 0.0))][:bodies]
+    rng = np.random.default_rng(5)
+    pts, tets, off = [], [], 0
+    for p, t in parts:
+        pts.append(p + rng.uniform(-1, 1, p.shape) * 0.002)
+        tets.append(t + off)
+        off += len(p)
+    pts, tets = np.concatenate(pts), np.concatenate(tets).astype(np.uint32)
+    m = meshes.MATERIALS["Ceramic"]
+    mg, mo = _mats(api, oracle, m)
+    pairs = 45
+    ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
+    r = api.mesh2modes(ctx, pts, tets, mg, ex, config=api.default_config(num_modes=pairs - 15, num_fem_modes=pairs))
+    evo, _, _ = oracle.System(pts, tets, mo).eigs(pairs)
+    assert len(r.eigenvalues) == pairs
+    elastic = evo > 1e-6 * evo[-1]
+    assert (~elastic).sum() == 6 * bodies
+    assert (np.abs(r.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    assert np.abs(r.eigenvalues[~elastic]).max() < 1e-6 * evo[elastic][0]
+    assert r.profile["restarts"] <= 20 and r.profile["pairs_at_floor"] == 0
