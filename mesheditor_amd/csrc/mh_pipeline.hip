@@ -133,21 +133,23 @@ __global__ void k_assign_nodes(const uint32_t *__restrict__ tets, const uint32_t
 
 // Coordinates of every P2 node in the reference numbering (midside = edge midpoint) and its Morton key.
 __global__ void k_node_xyz_keys(const double *__restrict__ pts, uint32_t npts, const uint64_t *__restrict__ edge_key, const uint32_t *__restrict__ rank_of,
-                                uint32_t ne, double3 lo, double inv_extent, double *__restrict__ xyz_ref, uint64_t *__restrict__ mkey, uint32_t *__restrict__ ids) {
+                                uint32_t ne, double3 lo, double inv_extent, double3 origin, double *__restrict__ xyz_ref, uint64_t *__restrict__ mkey, uint32_t *__restrict__ ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npts + ne) return;
     double x, y, z;
     uint32_t node;
+    // (origin: zero, or the bounding box's corner for a body far from the origin -- mh_build_system.  A point minus the corner is exact where the
+    // two are within a factor of two, and rounds to eps of the DIFFERENCE otherwise: the node coordinates keep the digits the caller's own carry)
     if (i < npts) {
         node = i;
-        x = pts[3 * size_t(i)]; y = pts[3 * size_t(i) + 1]; z = pts[3 * size_t(i) + 2];
+        x = pts[3 * size_t(i)] - origin.x; y = pts[3 * size_t(i) + 1] - origin.y; z = pts[3 * size_t(i) + 2] - origin.z;
     } else {
         const uint32_t u = i - npts;
         node = npts + rank_of[u];
         const uint32_t a = uint32_t(edge_key[u] >> 32), b = uint32_t(edge_key[u]);
-        x = 0.5 * (pts[3 * size_t(a)] + pts[3 * size_t(b)]);
-        y = 0.5 * (pts[3 * size_t(a) + 1] + pts[3 * size_t(b) + 1]);
-        z = 0.5 * (pts[3 * size_t(a) + 2] + pts[3 * size_t(b) + 2]);
+        x = 0.5 * ((pts[3 * size_t(a)] - origin.x) + (pts[3 * size_t(b)] - origin.x));
+        y = 0.5 * ((pts[3 * size_t(a) + 1] - origin.y) + (pts[3 * size_t(b) + 1] - origin.y));
+        z = 0.5 * ((pts[3 * size_t(a) + 2] - origin.z) + (pts[3 * size_t(b) + 2] - origin.z));
     }
     xyz_ref[3 * size_t(node)] = x; xyz_ref[3 * size_t(node) + 1] = y; xyz_ref[3 * size_t(node) + 2] = z;
     auto quant = [&](double v, double l) {
@@ -235,13 +237,17 @@ template<typename K> __global__ void k_segment_ptr(const K *__restrict__ keys, s
 }
 
 // ---- ComputeElementBases ----------------------------------------------------------------------------------
-__global__ void k_element_basis(const double *__restrict__ pts, const uint32_t *__restrict__ tets, uint32_t nt, double *__restrict__ basis) {
+__global__ void k_element_basis(const double *__restrict__ pts, const uint32_t *__restrict__ tets, uint32_t nt, double3 origin, double *__restrict__ basis) {
     const uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nt) return;
     double v[4][3];
+    // (origin: zero unless the body is far from the origin of its coordinates -- mh_build_system.  The cofactors below are sums of PRODUCTS of
+    // coordinates, as the reference forms them: at 100 m they cancel eight digits and the gradients no longer sum to zero -- K then has no exact
+    // rigid-body null space, which a factorisation does not notice and the block iteration's rigid-body columns do)
+    const double o[3] = {origin.x, origin.y, origin.z};
     for (int a = 0; a < 4; ++a) {
         const uint32_t id = tets[4 * size_t(el) + a];
-        for (int d = 0; d < 3; ++d) v[a][d] = pts[3 * size_t(id) + d];
+        for (int d = 0; d < 3; ++d) v[a][d] = pts[3 * size_t(id) + d] - o[d];
     }
     // det = dot(d - a, cross(b - a, c - a))  (GetTetDeterminant, mesh2modes.cpp:64-66)
     const double bx = v[1][0] - v[0][0], by = v[1][1] - v[0][1], bz = v[1][2] - v[0][2];
@@ -859,7 +865,18 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
     DevArray<uint32_t> ids(ctx, nn);
     sys->perm.reset(ctx, nn);
     sys->inv_perm.reset(ctx, nn);
-    k_node_xyz_keys<<<div_up(nn, TB), TB, 0, st>>>(mesh->points, npts, edge_key, rank_of, ne, double3{lo[0], lo[1], lo[2]}, 1.0 / extent, xyz_ref, mkey, ids);
+    // A body far from the origin (a scene's object at its world position: found by tools/probe/r06_odd_meshes_probe.py -- 100 m away the solve
+    // ended on a failed self-check, 1 km away it returned nothing, the oracle's factorisation does not care): every use of the node coordinates
+    // downstream is a DIFFERENCE (rigid-body vectors about a centroid, aggregates about theirs, the start block's box, the Morton keys), and a
+    // coordinate of 1e3 carries an absolute rounding of 1e-13 into differences of 1e-2 -- a thousand times the floor the iteration's clauses
+    // assume.  Farther than four extents from the origin the coordinates are kept relative to the bounding box's corner instead.  (Nearer: as
+    // they come, bit for bit what rounds 1-5 computed.)  The element bases are formed from the same relative coordinates (k_element_basis).
+    double far = 0;
+    for (int d = 0; d < 3; ++d) far = std::max({far, std::fabs(lo[d]), std::fabs(hi[d])});
+    const bool relative = far > 4.0 * extent;
+    const double3 origin = relative ? double3{lo[0], lo[1], lo[2]} : double3{0, 0, 0};
+    const double3 key_lo = relative ? double3{0, 0, 0} : double3{lo[0], lo[1], lo[2]};
+    k_node_xyz_keys<<<div_up(nn, TB), TB, 0, st>>>(mesh->points, npts, edge_key, rank_of, ne, key_lo, 1.0 / extent, origin, xyz_ref, mkey, ids);
     KERNEL_CHECK();
     sort_pairs(ctx, tmp, mkey.get(), mkey_s.get(), ids.get(), sys->perm.get(), nn, 63);
     DevArray<uint32_t> is_corner(ctx, nn), corner_incl(ctx, nn);
@@ -893,7 +910,7 @@ void mh_build_system(mh_context *ctx, const mh_mesh *mesh, const mh_material &ma
 
     // --- element bases, tables, patterns, assembly (P2 and its Galerkin P1 coarse operator)
     sys->elem_basis.reset(ctx, size_t(nt) * EB);
-    k_element_basis<<<div_up(nt, TB), TB, 0, st>>>(mesh->points, tets, nt, sys->elem_basis);
+    k_element_basis<<<div_up(nt, TB), TB, 0, st>>>(mesh->points, tets, nt, origin, sys->elem_basis);
     KERNEL_CHECK();
     std::vector<double> tq, tl;
     quad_tables(tq);

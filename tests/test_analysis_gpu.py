@@ -1670,3 +1670,33 @@ def test_a_tet_mesh_of_several_disjoint_bodies(api, ctx, oracle, bodies):
     assert (np.abs(r.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
     assert np.abs(r.eigenvalues[~elastic]).max() < 1e-6 * evo[elastic][0]
     assert r.profile["restarts"] <= 20 and r.profile["pairs_at_floor"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distance", [100.0, 1000.0])
+def test_a_body_far_from_the_origin_of_its_coordinates(api, ctx, oracle, distance):
+    """Found by tools/probe/r06_odd_meshes_probe.py: a jittered box 100 m from the origin ended on a failed Rayleigh-Ritz self-check, 1 km away the solve
+    returned nothing -- the oracle's factorisation returns every pair.  The element bases are cofactor sums of PRODUCTS of coordinates (as the reference
+    forms them, mesh2modes.cpp:144-161): at 100 m they cancel eight digits, the gradients no longer sum to zero, and K loses its exact rigid-body null
+    space -- which a Cholesky factorisation does not notice and the block iteration's rigid-body columns do.  Farther than four extents from the origin
+    the device forms element bases and node coordinates relative to the bounding box's corner (exact differences): same 9 iterations as at the origin,
+    eigenvalues 5e-10 from the body's own at the origin -- where the oracle's drift to 3e-8 at 1 km (3e-4 at 100 km: tools/probe/r06_far_and_small_probe.py)."""
+    pts, tets = meshes.kuhn_box(7, 6, 5, 0.14, 0.12, 0.1)
+    pts = pts + np.random.default_rng(9).uniform(-1, 1, pts.shape) * 0.003
+    m = meshes.MATERIALS["Ceramic"]
+    mg, mo = _mats(api, oracle, m)
+    pairs = 45
+    cfg = api.default_config(num_modes=30, num_fem_modes=pairs)
+    ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
+    home = api.mesh2modes(ctx, pts, tets, mg, ex, config=cfg)
+    far_pts = pts + np.array([distance, -0.5 * distance, 0.25 * distance])
+    far = api.mesh2modes(ctx, far_pts, tets, mg, far_pts[(np.arange(10) * len(pts)) // 10].astype(np.float32), config=cfg)
+    assert len(far.eigenvalues) == pairs == len(home.eigenvalues), far.profile
+    assert far.profile["restarts"] <= home.profile["restarts"] + 2 and far.profile["pairs_at_floor"] == 0
+    elastic = home.eigenvalues > 1e-6 * home.eigenvalues[-1]
+    assert elastic.sum() == pairs - 6
+    assert (np.abs(far.eigenvalues[elastic] - home.eigenvalues[elastic]) / home.eigenvalues[elastic]).max() < 1e-8
+    evo, _, _ = oracle.System(far_pts, tets, mo).eigs(pairs)
+    assert (np.abs(far.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    assert np.array_equal(far.sample_point_of_excitation, home.sample_point_of_excitation)
+    assert abs(far.mass - home.mass) < 1e-9 * home.mass and len(far.freqs) == len(home.freqs)
