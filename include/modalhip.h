@@ -59,7 +59,7 @@ typedef struct {
     /* health of the device solve (no reference counterpart; zero / rounding level on a healthy run): Rayleigh-Ritz steps that were redone by a
      * fall-back because the multi-workgroup tridiagonalisation timed out, and the worst sampled residual of the steps' self-check against the
      * saved Rayleigh-Ritz matrix, max_i |A z - theta z|_i over max_i (sum_c |a_ic z_c| + |theta z_i|) -- 1e-13 ... 3e-12 measured; a solve
-     * whose check exceeds 1e-8 fails with MH_EHIP */
+     * whose check exceeds 1e-6 fails with MH_EHIP */
     uint32_t sytrd_redos;
     /* wanted pairs that the LAST RESORT handed on with a residual still above the tolerance (below ten times it, unchanged for thirty iterations: the
      * rounding floor of a mesh at the edge of double precision -- raw Delaunay fills with cells at 1e-8); 0 on every solve that converged */

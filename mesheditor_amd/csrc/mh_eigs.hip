@@ -2199,7 +2199,10 @@ struct BlockLobpcg {
         sys->profile = prof;
         if (profile) *profile = prof;
         if (switches().test_selfcheck_fail && !ctx->exchange_disabled) prof.rr_selfcheck = 1.0; // (test hook: the redo in eigs_impl)
-        if (!(prof.rr_selfcheck < 1e-8))
+        // (1e-6, not the 1e-8 of round 5: a step whose matrix spans |sigma| .. ||A|| with an ill-conditioned block -- the first steps on two bodies joined at
+        // ONE vertex, whose smoothed columns all lean on the same three hinge modes -- leaves 2e-8 honestly, and the pairs a solve returns are accepted
+        // on their TRUE residuals, not on the step's; what the check is for, a wrong launch of an exchange kernel, leaves 1e-3 and more)
+        if (!(prof.rr_selfcheck < 1e-6))
             mh_throw(MH_EHIP, "Rayleigh-Ritz self-check failed: a step's eigenpairs leave a relative residual of %.2e against the step's own matrix", prof.rr_selfcheck);
     }
     // the solve's health counters: redone Rayleigh-Ritz steps and the worst sampled self-check residual (k_rr_selfcheck) since start()

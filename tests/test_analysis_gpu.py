@@ -1700,3 +1700,31 @@ def test_a_body_far_from_the_origin_of_its_coordinates(api, ctx, oracle, distanc
     assert (np.abs(far.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
     assert np.array_equal(far.sample_point_of_excitation, home.sample_point_of_excitation)
     assert abs(far.mass - home.mass) < 1e-9 * home.mass and len(far.freqs) == len(home.freqs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("joint,zero_modes", [("vertex", 9), ("edge", 7)])
+def test_two_bodies_joined_at_one_vertex_or_along_one_edge(api, ctx, oracle, joint, zero_modes):
+    """Mechanisms: two cubes sharing ONE vertex (three hinge rotations) or ONE edge (one) have zero-energy modes beyond the six rigid-body ones, which no
+    start block holds.  Found by tools/probe/r06_hinge_probe.py: the vertex case returned nothing -- its first Rayleigh-Ritz steps work on a block whose
+    smoothed columns all lean on the same three hinge modes, the step's self-check read 2e-8 against a failure threshold of 1e-8, and the solve, which had
+    converged on its true residuals in 8 iterations, was thrown away twice.  The threshold is 1e-6 now (a wrong launch, what the check is for, leaves 1e-3)."""
+    a = meshes.kuhn_box(4, 4, 4, 0.08, 0.08, 0.08)
+    b = meshes.kuhn_box(4, 4, 4, 0.08, 0.08, 0.08, origin=(0.08, 0.08, 0.08) if joint == "vertex" else (0.08, 0.08, 0.0))
+    pts = np.concatenate([a[0], b[0]])
+    tets = np.concatenate([a[1], b[1] + len(a[0])]).astype(np.uint32)
+    _, first, inv = np.unique(np.round(pts * 1e9).astype(np.int64), axis=0, return_index=True, return_inverse=True)
+    pts, tets = pts[first], inv.reshape(-1)[tets].astype(np.uint32)
+    assert len(pts) == 2 * len(a[0]) - (1 if joint == "vertex" else 5)
+    m = meshes.MATERIALS["Ceramic"]
+    mg, mo = _mats(api, oracle, m)
+    pairs = 45
+    ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
+    r = api.mesh2modes(ctx, pts, tets, mg, ex, config=api.default_config(num_modes=30, num_fem_modes=pairs))
+    evo, _, _ = oracle.System(pts, tets, mo).eigs(pairs)
+    assert len(r.eigenvalues) == pairs, r.profile
+    elastic = evo > 1e-6 * evo[-1]
+    assert (~elastic).sum() == zero_modes
+    assert (np.abs(r.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
+    assert np.abs(r.eigenvalues[~elastic]).max() < 1e-6 * evo[elastic][0]
+    assert r.profile["restarts"] <= 15 and r.profile["rr_selfcheck"] < 1e-6
