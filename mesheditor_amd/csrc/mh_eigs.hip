@@ -2268,6 +2268,8 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
             // itself but what ran beside it: rocBLAS's LDS-bound dsymm kernel, which only wide blocks call, on the same CU as a workgroup
             // of k_sytrd_multi, whose barrier at the top of the column loop hipcc had left without its LDS wait; mh_common.h:
             // mh_lds_writes_landed, DESIGN.md section 6.  With the wait in place the lock is gone.)
+            const float *seed = seed_basis; // (a warm start that fails is retried cold: build_and_solve)
+            uint32_t srows = seed_rows, scols = seed_cols;
             const auto build_and_solve = [&] {
             {
                 Timer t(ctx);
@@ -2279,8 +2281,22 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                 try {
                     try {
                         if (switches().test_last_resort) mh_throw(MH_ENOTCONVERGED, "MH_TEST=last_resort");
-                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
-                        solver.run(eigenvalues);
+                        try {
+                            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed, srows, scols, cancel, progress, prof, profile);
+                            solver.run(eigenvalues);
+                        } catch (const MhError &e) {
+                            // A seeded basis that does not serve -- its columns in another order than the solve left them (the exact rigid-body vectors
+                            // then stand beside their seeded copies: a rank-deficient block), zeros, a NaN, one column forty-five times -- is no
+                            // reason to go through the fall-backs below with it, or to return nothing: the reference's SubspaceIterate takes what
+                            // it is given.  Once more from a cold start, and the fall-backs after that are cold as well.
+                            if (!seed || e.code != MH_ENOTCONVERGED || max_iters < 50) throw;
+                            if (switches().verbose) fprintf(stderr, "[lobpcg] %s -- the seeded basis did not serve: once more from a cold start\n", e.what());
+                            seed = nullptr, srows = 0, scols = 0;
+                            prof = sys->profile;
+                            prof.dofs = uint32_t(n);
+                            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed, srows, scols, cancel, progress, prof, profile);
+                            solver.run(eigenvalues);
+                        }
                     } catch (const MhError &e) {
                         // A Rayleigh-Ritz step whose eigenpairs do not fit the step's own matrix (k_rr_selfcheck: sampled per step, read once at
                         // the end) means a dense kernel delivered wrong numbers -- in rounds 2-4 the tagged exchange beside an LDS-bound
@@ -2291,7 +2307,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                         ctx->exchange_disabled = true;
                         prof = sys->profile;
                         prof.dofs = uint32_t(n);
-                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
+                        BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed, srows, scols, cancel, progress, prof, profile);
                         solver.run(eigenvalues);
                     }
                 } catch (const MhError &e) {
@@ -2305,7 +2321,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     sys->L1.lmax *= 1.25;
                     sys->L2.lmax *= 1.25;
                     sys->lmax_widened = true;
-                    BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile);
+                    BlockLobpcg solver(sys, nev, b, sigma, residual_tol, max_iters, seed, srows, scols, cancel, progress, prof, profile);
                     solver.run(eigenvalues);
                 }
             } catch (const MhError &e) {
@@ -2331,7 +2347,7 @@ static void eigs_impl(mh_system *sys, uint32_t nev, double sigma, double residua
                     static const int first_steps = getenv("MH_LAST_RESORT_CG") ? std::max(1, atoi(getenv("MH_LAST_RESORT_CG"))) : 8;
                     for (const int steps : {first_steps, 5 * first_steps}) {
                         try {
-                            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, steps == first_steps ? max_iters : std::min<uint32_t>(max_iters, 120), seed_basis, seed_rows, seed_cols, cancel, progress, prof, profile, steps);
+                            BlockLobpcg solver(sys, nev, b, sigma, residual_tol, steps == first_steps ? max_iters : std::min<uint32_t>(max_iters, 120), seed, srows, scols, cancel, progress, prof, profile, steps);
                             solver.run(eigenvalues);
                             return;
                         } catch (const MhError &again) {

@@ -1728,3 +1728,28 @@ def test_two_bodies_joined_at_one_vertex_or_along_one_edge(api, ctx, oracle, joi
     assert (np.abs(r.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6
     assert np.abs(r.eigenvalues[~elastic]).max() < 1e-6 * evo[elastic][0]
     assert r.profile["restarts"] <= 15 and r.profile["rr_selfcheck"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_a_seeded_basis_that_does_not_serve_is_retried_cold(api, ctx, oracle):
+    """The reference's warm branch (SubspaceIterate, mesh2modes.cpp) takes the previous basis as it is given.  Found by tools/probe/r06_odd_seeds_probe.py: the
+    solve's own basis with its columns REVERSED, zeros, a NaN, one column forty-five times all ended in a rank-deficient start block (the exact rigid-body
+    vectors beside their seeded copies) -- 301 'iterations' through the dense redo on this small mesh, nothing at all above 12 288 unknowns.  A warm start
+    that fails is now retried from a cold start before any other fall-back: the cold solve's iteration count, the oracle's eigenvalues."""
+    pts, tets = meshes.kuhn_box(6, 5, 4, 0.3, 0.25, 0.2)
+    pts = pts + np.random.default_rng(3).uniform(-1, 1, pts.shape) * 0.004
+    m = meshes.MATERIALS["Ceramic"]
+    mg, mo = _mats(api, oracle, m)
+    ex = pts[(np.arange(10) * len(pts)) // 10].astype(np.float32)
+    cfg = api.default_config(num_modes=30, num_fem_modes=45)
+    cold = api.mesh2modes(ctx, pts, tets, mg, ex, config=cfg, keep_basis=True)
+    basis = np.array(cold.basis, np.float32)
+    evo, _, _ = oracle.System(pts, tets, mo).eigs(45)
+    elastic = evo > 1e-6 * evo[-1]
+    seeds = {"own": basis, "reversed": basis[:, ::-1], "zeros": np.zeros_like(basis), "nan": np.where(np.arange(basis.size).reshape(basis.shape) == 12345, np.nan, basis).astype(np.float32),
+             "equal": np.repeat(basis[:, 7:8], basis.shape[1], 1), "noise": np.random.default_rng(1).standard_normal(basis.shape).astype(np.float32)}
+    for name, seed in seeds.items():
+        r = api.mesh2modes(ctx, pts, tets, mg, ex, config=cfg, seed_basis=seed)
+        assert len(r.eigenvalues) == 45, name
+        assert (np.abs(r.eigenvalues[elastic] - evo[elastic]) / evo[elastic]).max() < 1e-6, name
+        assert r.profile["restarts"] <= (1 if name == "own" else cold.profile["restarts"] + 4), (name, r.profile["restarts"])
