@@ -489,6 +489,13 @@ template<typename Audio, typename Real> void RenderBlock(Audio &m, Real *out, ui
     const uint32_t impact_cap = m.MaxImpacts.load(std::memory_order_relaxed);
     RingConsume(m, [&](const ModalEvent &e) {
         if (e.Object >= b.Entities.size()) return; // addressed to a slot this bank does not have
+        // (an excitation position the object does not have: the reference reads past the object's shapes there -- undefined, NaN in the oracle's run
+        // of tools/probe/r06_odd_bank_probe.py; on the device that read may leave the shape buffer altogether.  Such an impact is dropped.)
+        if (e.Kind == ModalEventKind::Impact && b.ModeCount[e.Object] > 0) {
+            const uint32_t first = b.ShapeOffset[e.Object];
+            const uint32_t last = size_t(e.Object) + 1 < b.ShapeOffset.size() ? b.ShapeOffset[e.Object + 1] : uint32_t(b.ShapeX.size());
+            if (uint64_t(e.ExPos) * b.ModeCount[e.Object] + b.ModeCount[e.Object] > uint64_t(last - first)) return;
+        }
         if (e.Kind == ModalEventKind::Silence) Quiet(m, b, e.Object, false);
         else if (e.Kind == ModalEventKind::Impact && e.PulseStep > 0) StartImpact(b, e, impact_cap);
     });
