@@ -1918,6 +1918,21 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
     // (both ways) and towards the centroid of the point's neighbours; taken where every tetrahedron at the point stays positively oriented
     // (exact) and the worst of them improves; the best candidate wins.  Input vertices, points on the boundary and on walls never move.
     std::unordered_set<uint64_t> centre_tried;
+    // the cells at every ADDED point (relocate's stars; a scan of all cells per point was a fifth of a fine ellipsoid's fill): built per pass, kept up by note_new_cells
+    std::vector<std::vector<int32_t>> incident;
+    const auto index_cells = [&] {
+        incident.assign(P.size(), {});
+        for (size_t t = 0; t < T.size(); ++t)
+            if (!ed.IsDead(t))
+                for (const uint32_t v : T[t])
+                    if (v >= n_input) incident[v].push_back(int32_t(t));
+    };
+    const auto note_new_cells = [&](size_t first) {
+        incident.resize(P.size());
+        for (size_t t = first; t < T.size(); ++t)
+            for (const uint32_t v : T[t])
+                if (v >= n_input) incident[v].push_back(int32_t(t));
+    };
     const auto relocate = [&](int32_t t0) -> bool {
         const auto cell = T[size_t(t0)];
         for (int vi = 0; vi < 4; ++vi) {
@@ -1927,7 +1942,9 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             bool fixed = false;
             dvec3 centre{0, 0, 0};
             double weight = 0;
-            for (size_t t = 0; t < T.size() && !fixed; ++t) {
+            for (const int32_t listed : incident[v]) { // (ascending, as a scan of all cells would meet them)
+                if (fixed) break;
+                const size_t t = size_t(listed);
                 if (ed.IsDead(t)) continue;
                 const auto &c = T[t];
                 int at = -1;
@@ -2042,6 +2059,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             }
         if (work.empty()) break;
         std::sort(work.begin(), work.end());
+        index_cells();
         uint32_t added_this_pass = 0;
         for (const auto &[q0, t0] : work) {
             if (added >= budget) break;
@@ -2148,7 +2166,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
             }
             if (best_gain > 0) {
                 // (Cavity's marks belong to the LAST candidate: commit needs only the lists)
-                ed.Commit(best_p, best_in, best_fresh);
+                note_new_cells(ed.Commit(best_p, best_in, best_fresh));
                 ++added, ++added_this_pass;
                 continue;
             }
@@ -2234,7 +2252,7 @@ static uint32_t BreakFlatCells(TetMesh &mesh, double floor, const std::set<Tri> 
                                 if (x == gone) x = id;
                             halves.push_back(piece);
                         }
-                    ed.Commit(best_p, best_ring, halves);
+                    note_new_cells(ed.Commit(best_p, best_ring, halves));
                     ++added, ++added_this_pass;
                 }
             }
