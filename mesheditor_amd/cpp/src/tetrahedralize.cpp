@@ -1559,19 +1559,14 @@ public:
     struct FaceHash {
         size_t operator()(const Tri &f) const { return (size_t(f[0]) * 0x9E3779B97F4A7C15ull) ^ (size_t(f[1]) * 0xC2B2AE3D27D4EB4Full) ^ (size_t(f[2]) * 0x165667B19E3779F9ull); }
     };
-    FillEditor(TetMesh &mesh, const std::set<Tri> *walls) : P(mesh.Points), T(mesh.Tets), Walls(walls), Dead(mesh.Tets.size(), 0), Mark(mesh.Tets.size(), 0) {
+    FillEditor(TetMesh &mesh, const std::set<Tri> *walls) : P(mesh.Points), T(mesh.Tets), Walls(walls), Dead(mesh.Tets.size(), 0), Mark(mesh.Tets.size(), 0),
+                                                           Neighbour(mesh.Tets.size(), std::array<int32_t, 4>{-1, -1, -1, -1}) {
         CellsOn.reserve(T.size() * 2);
         for (size_t t = 0; t < T.size(); ++t) Link(int32_t(t), true);
     }
     static Tri FaceOf(const std::array<uint32_t, 4> &v, int i) { return Sorted(v[size_t(i + 1) & 3], v[size_t(i + 2) & 3], v[size_t(i + 3) & 3]); }
     // the cell across face i of cell t, or -1 at the boundary, -2 behind a wall
-    int32_t Across(int32_t t, int i) const {
-        const Tri key = FaceOf(T[size_t(t)], i);
-        if (Walls && Walls->count(key)) return -2;
-        const auto it = CellsOn.find(key);
-        if (it == CellsOn.end()) return -1;
-        return it->second[0] == t ? it->second[1] : it->second[0];
-    }
+    int32_t Across(int32_t t, int i) const { return Neighbour[size_t(t)][size_t(i)]; } // (kept by Link: the face map's answer, without the look-up -- half a fine ellipsoid's fill was that look-up)
     bool IsDead(size_t t) const { return Dead[t] != 0; }
     // the cell that holds p strictly inside, by a walk from `from` that never crosses the boundary or a wall; -1: the surface cuts p
     // off, or p lies on a face or an edge (not this point)
@@ -1681,6 +1676,7 @@ public:
         for (const auto &piece : fresh) {
             T.push_back(piece);
             Dead.push_back(0);
+            Neighbour.push_back({-1, -1, -1, -1});
             Link(int32_t(T.size() - 1), true);
         }
         return first;
@@ -1741,17 +1737,29 @@ public:
 
 private:
     bool Inside(int32_t c) const { return c >= 0 && Mark[size_t(c)] == Stamp; }
+    // the index of the face `key` in cell o (the vertex of o that the face does not hold)
+    int FaceIndexIn(int32_t o, const Tri &key) const {
+        const auto &v = T[size_t(o)];
+        for (int j = 0; j < 4; ++j)
+            if (v[size_t(j)] != key[0] && v[size_t(j)] != key[1] && v[size_t(j)] != key[2]) return j;
+        return 0;
+    }
     void Link(int32_t t, bool add) {
         for (int i = 0; i < 4; ++i) {
             const Tri key = FaceOf(T[size_t(t)], i);
+            const bool wall = Walls && Walls->count(key);
             if (add) {
                 auto [it, fresh] = CellsOn.try_emplace(key, std::array<int32_t, 2>{t, -1});
                 if (!fresh) (it->second[0] < 0 ? it->second[0] : it->second[1]) = t;
+                const int32_t other = it->second[0] == t ? it->second[1] : it->second[0];
+                Neighbour[size_t(t)][size_t(i)] = wall ? -2 : other;
+                if (other >= 0) Neighbour[size_t(other)][size_t(FaceIndexIn(other, key))] = wall ? -2 : t;
             } else {
                 auto it = CellsOn.find(key);
                 if (it == CellsOn.end()) continue;
                 if (it->second[0] == t) it->second[0] = it->second[1];
                 it->second[1] = -1;
+                if (it->second[0] >= 0) Neighbour[size_t(it->second[0])][size_t(FaceIndexIn(it->second[0], key))] = wall ? -2 : -1;
                 if (it->second[0] < 0) CellsOn.erase(it);
             }
         }
@@ -1760,6 +1768,7 @@ private:
     std::unordered_map<Tri, std::array<int32_t, 2>, FaceHash> CellsOn;
     std::vector<uint8_t> Dead;
     std::vector<uint32_t> Mark; // cavity membership by stamp
+    std::vector<std::array<int32_t, 4>> Neighbour; // per live cell and face: the cell across, -1 at the boundary, -2 behind a wall
     uint32_t Stamp{0};
 };
 
